@@ -1,0 +1,73 @@
+"""ctypes binding of libgeotr_hip.so (the C ABI declared in include/geotr.h).
+
+The product path has NO fallback: if the HIP library is missing, or a call fails, a RuntimeError is
+raised.  Nothing here imports or calls anything under oracle/.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgeotr_hip.so')
+
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+c_ptr = ctypes.c_void_p
+c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/geotr.h declares (tests check this)
+SIGNATURES = {
+    'geotr_last_error': (ctypes.c_char_p, []),
+    'geotr_abi_version': (ctypes.c_int, []),
+    'geotr_grid_subsample_workspace_bytes': (c_size, [c_i64, c_i64]),
+    'geotr_grid_subsample': (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    'geotr_radius_grid_workspace_bytes': (c_size, [c_i64, c_i64]),
+    'geotr_radius_grid_build': (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_f32, c_ptr, c_size, c_ptr]),
+    'geotr_radius_count': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_f32, c_ptr, c_ptr, c_ptr]),
+    'geotr_radius_query': (ctypes.c_int,
+                           [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_f32, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library or fail loudly (no CPU / eager fallback exists by design)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'or `make -C geotransformer_amd/csrc`. geotransformer_amd has no fallback path.')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().geotr_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'{what} failed (code {code}): {msg}')
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError('geotransformer_amd needs a HIP device (MI355X / gfx950); no CPU fallback exists.')

@@ -1,0 +1,95 @@
+// Shared host/device helpers for libgeotr_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/geotr.h"
+
+namespace geotr {
+
+constexpr int kWave = 64;
+
+// thread-local error string behind geotr_last_error()
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+#define GEOTR_CHECK_ARG(cond, ...) \
+  do {                             \
+    if (!(cond)) return geotr::fail(GEOTR_E_INVALID, __VA_ARGS__); \
+  } while (0)
+
+#define GEOTR_CHECK_LAUNCH(what)                                                              \
+  do {                                                                                        \
+    hipError_t e__ = hipGetLastError();                                                       \
+    if (e__ != hipSuccess) return geotr::fail(GEOTR_E_LAUNCH, "%s: %s", what, hipGetErrorString(e__)); \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// carve typed arrays out of a caller-provided workspace
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(reinterpret_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off += align_up(count * sizeof(T));
+    return p;
+  }
+};
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// Exclusive scan across a block of NT threads (NT multiple of 64, <= 1024).
+// `smem` needs NT/64 + 1 ints.  Returns the exclusive prefix of v; total = block sum.
+template <int NT>
+__device__ __forceinline__ int block_exclusive_scan(int v, int* smem, int& total) {
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  int inc = wave_inclusive_scan(v);
+  if (lane == 63) smem[wid] = inc;
+  __syncthreads();
+  if (wid == 0) {
+    int s = lane < NT / 64 ? smem[lane] : 0;
+    int si = wave_inclusive_scan(s);
+    if (lane < NT / 64) smem[lane] = si - s;
+    if (lane == NT / 64 - 1) smem[NT / 64] = si;
+  }
+  __syncthreads();
+  int res = smem[wid] + inc - v;
+  total = smem[NT / 64];
+  __syncthreads();
+  return res;
+}
+
+// cloud index of stacked row i given device lengths; also returns the cloud's first row.
+__device__ __forceinline__ int cloud_of(const int64_t* len, int batch, int64_t i, int64_t& start) {
+  int64_t s = 0;
+  for (int b = 0; b < batch; ++b) {
+    int64_t l = len[b];
+    if (i < s + l) {
+      start = s;
+      return b;
+    }
+    s += l;
+  }
+  start = s;
+  return batch;  // past the end
+}
+#endif
+
+}  // namespace geotr

@@ -1,0 +1,802 @@
+// neighbors.hip -- N1 (grid subsampling) and N2 (radius search) for gfx950, behind the C ABI of
+// include/geotr.h.  Hand-written HIP; wave = 64; no CUDA paths.
+//
+// Reference semantics reproduced (file:line relative to /root/reference):
+//   grid subsampling : geotransformer/extensions/cpu/grid_subsampling/grid_subsampling_cpu.cpp:3-75
+//   radius search    : geotransformer/extensions/cpu/radius_neighbors/radius_neighbors_cpu.cpp:3-91
+//                      geotransformer/extensions/extra/nanoflann/nanoflann.hpp:249-253,432-440,1280-1289
+//
+// Exactness rules: every fp32 op that feeds a comparison, a voxel key or a
+// barycentre is a single IEEE round-to-nearest operation (__fmul_rn/__fadd_rn/__fsub_rn/__fdiv_rn),
+// never contracted into an FMA: the x86-64 reference build has no FMA.
+#include <algorithm>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace geotr {
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+char* error_buffer() {
+  static thread_local char buf[512] = "";
+  return buf;
+}
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ================================================================================================
+// N2 radius search
+// ================================================================================================
+constexpr int kMaxBatch = 256;
+constexpr int kScanTile = 2048;  // elements per block in the cell-count scan (256 threads x 8)
+
+struct CloudGrid {
+  float mn[3];
+  float cs;        // cell size (>= radius * 1.001, doubled until the cloud fits its cell budget)
+  int dim[3];
+  int cell_base;   // first cell of this cloud in cell_start[]
+  int64_t s_start; // first support row of this cloud
+  int64_t s_len;
+};
+
+struct GridLayout {
+  int64_t ns, batch, cells, cells_per_cloud, scan_blocks;
+  CloudGrid* hdr;
+  int* cell_cnt;    // [cells]      counts, then consumed by the scatter
+  int* cell_start;  // [cells + 1]  exclusive prefix
+  int* block_sums;  // [scan_blocks + 1]
+  int* cid;         // [ns] cell of each support point
+  float4* sorted;   // [ns] cell-ordered {x, y, z, bits(local index)}
+  size_t bytes;
+};
+
+static GridLayout grid_layout(void* ws, int64_t ns, int64_t batch) {
+  GridLayout L;
+  L.ns = ns;
+  L.batch = batch;
+  int64_t budget = std::min<int64_t>(std::max<int64_t>(32 * ns, 1 << 18), 1 << 26);
+  L.cells_per_cloud = std::max<int64_t>(budget / std::max<int64_t>(batch, 1), 64);
+  L.cells = L.cells_per_cloud * std::max<int64_t>(batch, 1);
+  L.scan_blocks = (L.cells + kScanTile - 1) / kScanTile;
+  Carver c(ws);
+  L.hdr = c.take<CloudGrid>(kMaxBatch);
+  L.cell_cnt = c.take<int>(L.cells);
+  L.cell_start = c.take<int>(L.cells + 1);
+  L.block_sums = c.take<int>(L.scan_blocks + 1);
+  L.cid = c.take<int>(std::max<int64_t>(ns, 1));
+  L.sorted = c.take<float4>(std::max<int64_t>(ns, 1));
+  L.bytes = c.off;
+  return L;
+}
+
+__device__ __forceinline__ int cell_coord(float v, float mn, float cs) {
+  return (int)floorf(__fdiv_rn(__fsub_rn(v, mn), cs));
+}
+
+// one block per cloud: bounding box + grid geometry
+__global__ __launch_bounds__(1024) void rg_bbox_kernel(const float* __restrict__ s, const int64_t* __restrict__ s_len,
+                                                       int batch, float radius, int cells_per_cloud,
+                                                       CloudGrid* __restrict__ hdr) {
+  __shared__ float red[6][16];
+  const int b = blockIdx.x;
+  int64_t start = 0;
+  for (int i = 0; i < b; ++i) start += s_len[i];
+  const int64_t n = s_len[b];
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float* p = s + 3 * (start + i);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      mn[c] = fminf(mn[c], p[c]);
+      mx[c] = fmaxf(mx[c], p[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
+      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
+    }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0)
+    for (int c = 0; c < 3; ++c) {
+      red[c][w] = mn[c];
+      red[3 + c][w] = mx[c];
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < 3; ++c)
+      for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
+        red[c][0] = fminf(red[c][0], red[c][k]);
+        red[3 + c][0] = fmaxf(red[3 + c][0], red[3 + c][k]);
+      }
+    CloudGrid g;
+    g.s_start = start;
+    g.s_len = n;
+    g.cell_base = b * cells_per_cloud;
+    g.cs = radius * 1.001f;  // conservative: points within r are always within +-1 cell
+    if (n > 0) {
+      for (int c = 0; c < 3; ++c) g.mn[c] = red[c][0];
+      for (;;) {
+        double prod = 1.0;
+        for (int c = 0; c < 3; ++c) {
+          g.dim[c] = cell_coord(red[3 + c][0], g.mn[c], g.cs) + 1;
+          prod *= (double)g.dim[c];
+        }
+        if (prod <= (double)cells_per_cloud) break;
+        g.cs *= 2.0f;
+      }
+    } else {
+      for (int c = 0; c < 3; ++c) {
+        g.mn[c] = 0.f;
+        g.dim[c] = 0;
+      }
+    }
+    hdr[b] = g;
+  }
+}
+
+__global__ void rg_count_kernel(const float* __restrict__ s, int64_t ns, int batch, const CloudGrid* __restrict__ hdr,
+                                int* __restrict__ cell_cnt, int* __restrict__ cid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  int b = 0;
+  while (b < batch - 1 && i >= hdr[b].s_start + hdr[b].s_len) ++b;
+  const CloudGrid g = hdr[b];
+  const float* p = s + 3 * i;
+  const int cx = cell_coord(p[0], g.mn[0], g.cs), cy = cell_coord(p[1], g.mn[1], g.cs),
+            cz = cell_coord(p[2], g.mn[2], g.cs);
+  const int c = g.cell_base + cx + g.dim[0] * (cy + g.dim[1] * cz);
+  cid[i] = c;
+  atomicAdd(&cell_cnt[c], 1);
+}
+
+// 3-kernel exclusive scan of cell_cnt -> cell_start
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const int* __restrict__ in, int64_t n, int* __restrict__ sums) {
+  __shared__ int sm[8];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  int v = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int64_t i = base + threadIdx.x * 8 + k;
+    v += i < n ? in[i] : 0;
+  }
+  int tot;
+  block_exclusive_scan<256>(v, sm, tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void scan_sums_kernel(int* __restrict__ sums, int64_t nb) {
+  __shared__ int sm[20];
+  int running = 0;
+  for (int64_t base = 0; base < nb; base += 1024) {
+    int64_t i = base + threadIdx.x;
+    int v = i < nb ? sums[i] : 0, tot;
+    int ex = block_exclusive_scan<1024>(v, sm, tot);
+    if (i < nb) sums[i] = running + ex;
+    running += tot;
+  }
+  if (threadIdx.x == 0) sums[nb] = running;
+}
+__global__ __launch_bounds__(256) void scan_down_kernel(const int* __restrict__ in, int64_t n, const int* __restrict__ sums,
+                                                        int* __restrict__ out) {
+  __shared__ int sm[8];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * 8;
+  int v[8], s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = base + k < n ? in[base + k] : 0;
+    s += v[k];
+  }
+  int tot;
+  int ex = block_exclusive_scan<256>(s, sm, tot) + sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (base + k < n) out[base + k] = ex;
+    ex += v[k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = sums[gridDim.x];
+}
+
+__global__ void rg_scatter_kernel(const float* __restrict__ s, int64_t ns, int batch, const CloudGrid* __restrict__ hdr,
+                                  const int* __restrict__ cid, const int* __restrict__ cell_start,
+                                  int* __restrict__ cell_cnt, float4* __restrict__ sorted) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  int b = 0;
+  while (b < batch - 1 && i >= hdr[b].s_start + hdr[b].s_len) ++b;
+  const int c = cid[i];
+  const int pos = cell_start[c] + atomicSub(&cell_cnt[c], 1) - 1;
+  const float* p = s + 3 * i;
+  sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float((int)(i - hdr[b].s_start)));
+}
+
+// One wave per query.  Candidates = the 3x3x3 cell neighbourhood, visited as 9 x-contiguous runs that
+// are flattened into one index space so all 64 lanes stay busy.  Accepted (d, idx) keys are compacted
+// into an LDS row with ballot + popcount, then ranked (keys are distinct) and written out.
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
+                                                       const float4* __restrict__ sorted, const float* __restrict__ q,
+                                                       const int64_t* __restrict__ q_len, int batch, int64_t nq,
+                                                       float r2, int width, int cap, int64_t ns_total,
+                                                       int64_t* __restrict__ out, int* __restrict__ counts,
+                                                       int* __restrict__ max_count, int* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + w;
+  if (qi >= nq) return;  // whole wave exits; no block-level barrier is used below
+  int64_t qstart;
+  const int b = cloud_of(q_len, batch, qi, qstart);
+  const CloudGrid g = hdr[b < batch ? b : batch - 1];
+  const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
+  unsigned long long* keys = lds_keys + (size_t)w * cap;
+
+  // --- the 9 runs (lane k < 9 owns run k) ---
+  int seg_start = 0, seg_len = 0;
+  if (lane < 9 && g.s_len > 0) {
+    const int cx = cell_coord(qx, g.mn[0], g.cs), cy = cell_coord(qy, g.mn[1], g.cs) + (lane % 3) - 1,
+              cz = cell_coord(qz, g.mn[2], g.cs) + (lane / 3) - 1;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+    if (cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2] && x0 <= x1) {
+      const int row = g.cell_base + g.dim[0] * (cy + g.dim[1] * cz);
+      seg_start = cell_start[row + x0];
+      seg_len = cell_start[row + x1 + 1] - seg_start;
+    }
+  }
+  const int inc = wave_inclusive_scan(seg_len);
+  const int total = __shfl(inc, 8, 64);
+  int pre[9], st[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    pre[k] = __shfl(inc - seg_len, k, 64);
+    st[k] = __shfl(seg_start, k, 64);
+  }
+
+  int base = 0;
+  for (int t0 = 0; t0 < total; t0 += 64) {
+    const int t = t0 + lane;
+    bool accept = false;
+    unsigned long long key = 0;
+    if (t < total) {
+      int k = 0;
+#pragma unroll
+      for (int j = 1; j < 9; ++j) k = (t >= pre[j]) ? j : k;
+      const float4 p = sorted[st[k] + (t - pre[k])];
+      // L2_Simple_Adaptor::evalMetric (nanoflann.hpp:432-440): ((dx*dx) + dy*dy) + dz*dz, no FMA
+      const float dx = __fsub_rn(qx, p.x), dy = __fsub_rn(qy, p.y), dz = __fsub_rn(qz, p.z);
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      accept = d < r2;  // strict (nanoflann.hpp:249-253)
+      key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+    }
+    const unsigned long long ballot = __ballot(accept);
+    if (!COUNT_ONLY) {
+      const int rank = base + __popcll(ballot & ((1ull << lane) - 1ull));
+      if (accept && rank < cap) keys[rank] = key;
+    }
+    base += __popcll(ballot);
+  }
+  int count = base;
+  if (COUNT_ONLY) {
+    if (lane == 0) {
+      counts[qi] = count;
+      atomicMax(max_count, count);
+    }
+    return;
+  }
+  if (count > cap) {
+    if (lane == 0 && overflow) atomicMax(overflow, count);
+    count = cap;
+  }
+  // make this wave's LDS writes visible to all of its lanes (wave-local; other waves never touch this row)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int64_t* row = out + qi * (int64_t)width;
+  for (int e = lane; e < count; e += 64) {
+    const unsigned long long mine = keys[e];
+    int rank = 0;
+    for (int j = 0; j < count; ++j) rank += keys[j] < mine;  // broadcast LDS reads
+    if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
+  }
+  for (int j = count + lane; j < width; j += 64) row[j] = ns_total;  // pad (radius_neighbors_cpu.cpp:85)
+}
+
+// ================================================================================================
+// N1 grid subsampling
+// ================================================================================================
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+// Table words that other lanes update with global atomics (performed at L2) inside the same launch are
+// read back with agent-scope relaxed loads (sc1: served by L2), never through a possibly stale L1 line.
+__device__ __forceinline__ int ld_l2(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int kMaxEpochs = 40;
+
+struct BucketSchedule {  // libstdc++ unordered_map growth: before inserting element number at[e]
+  int n;                 // (0-based count of elements present), the table is rehashed to bk[e] buckets
+  int at[kMaxEpochs];
+  int bk[kMaxEpochs];
+};
+
+// Probe the real container once (host): the schedule is a property of the libstdc++ this library
+// is linked against, exactly like the reference extension.
+static const BucketSchedule& bucket_schedule(int64_t upto) {
+  static std::mutex mu;
+  static BucketSchedule sch;
+  static int64_t probed = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (upto <= probed) return sch;
+  std::unordered_map<size_t, char> m;
+  size_t last = m.bucket_count();
+  int64_t target = std::max<int64_t>(upto, 1 << 16) * 2;
+  sch.n = 0;
+  for (int64_t i = 0; i < target; ++i) {
+    m.emplace((size_t)i, 0);
+    if (m.bucket_count() != last) {
+      last = m.bucket_count();
+      if (sch.n < kMaxEpochs) {
+        sch.at[sch.n] = (int)i;
+        sch.bk[sch.n] = (int)last;
+        ++sch.n;
+      }
+    }
+  }
+  probed = target;
+  return sch;
+}
+
+struct GsCloud {
+  float org[3];
+  unsigned long long nx, nxy;
+  int64_t start, len;
+  int m;  // number of voxels (output points) of this cloud
+};
+
+struct GsLayout {
+  GsCloud* hdr;
+  unsigned long long* keys;  // [2n] open-addressing table, region of cloud b = [2*start, 2*start + 2*len)
+  int* first;                // [2n] smallest point index (cloud-local) of the voxel in this slot
+  int* cnt;                  // [2n] points in the voxel
+  int* rank_of_slot;         // [2n]
+  int* slot_of_point;        // [n]
+  int* slot_of_rank;         // [n]   (cloud region = [start, start+len))
+  int* csr_off;              // [n]
+  int* cursor;               // [n]
+  int* members;              // [n]
+  float* bary;               // [3n]
+  unsigned long long* vkey;  // [n]
+  int* list_a;               // [n]
+  int* list_b;               // [n]
+  int* nxt;                  // [n]
+  int* off;                  // [n]
+  int* bfirst;               // [3n + 64 batch]
+  int* bcnt;
+  int* bhead;
+  size_t bytes;
+};
+
+static GsLayout gs_layout(void* ws, int64_t n, int64_t batch) {
+  GsLayout L;
+  Carver c(ws);
+  const size_t N = (size_t)std::max<int64_t>(n, 1), TB = 3 * N + 64 * (size_t)std::max<int64_t>(batch, 1);
+  L.hdr = c.take<GsCloud>(kMaxBatch);
+  L.keys = c.take<unsigned long long>(2 * N);
+  L.first = c.take<int>(2 * N);
+  L.cnt = c.take<int>(2 * N);
+  L.rank_of_slot = c.take<int>(2 * N);
+  L.slot_of_point = c.take<int>(N);
+  L.slot_of_rank = c.take<int>(N);
+  L.csr_off = c.take<int>(N);
+  L.cursor = c.take<int>(N);
+  L.members = c.take<int>(N);
+  L.bary = c.take<float>(3 * N);
+  L.vkey = c.take<unsigned long long>(N);
+  L.list_a = c.take<int>(N);
+  L.list_b = c.take<int>(N);
+  L.nxt = c.take<int>(N);
+  L.off = c.take<int>(N);
+  L.bfirst = c.take<int>(TB);
+  L.bcnt = c.take<int>(TB);
+  L.bhead = c.take<int>(TB);
+  L.bytes = c.off;
+  return L;
+}
+
+__global__ void gs_init_kernel(GsLayout L, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += stride) {
+    L.keys[i] = kEmptyKey;
+    L.first[i] = 0x7fffffff;
+    L.cnt[i] = 0;
+    if (i < n) L.cursor[i] = 0;
+  }
+}
+
+// one block per cloud: min/max corner -> origin, NX, NY  (grid_subsampling_cpu.cpp:9-20, cloud.cpp:4-37)
+__global__ __launch_bounds__(1024) void gs_bbox_kernel(const float* __restrict__ pts, const int64_t* __restrict__ len,
+                                                       int batch, float voxel, float inv_voxel, GsCloud* __restrict__ hdr) {
+  __shared__ float red[6][16];
+  const int b = blockIdx.x;
+  int64_t start = 0;
+  for (int i = 0; i < b; ++i) start += len[i];
+  const int64_t n = len[b];
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float* p = pts + 3 * (start + i);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      mn[c] = fminf(mn[c], p[c]);
+      mx[c] = fmaxf(mx[c], p[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
+      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
+    }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0)
+    for (int c = 0; c < 3; ++c) {
+      red[c][w] = mn[c];
+      red[3 + c][w] = mx[c];
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < 3; ++c)
+      for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
+        red[c][0] = fminf(red[c][0], red[c][k]);
+        red[3 + c][0] = fmaxf(red[3 + c][0], red[3 + c][k]);
+      }
+    GsCloud g;
+    g.start = start;
+    g.len = n;
+    g.m = 0;
+    // originCorner = floor(minCorner * (float)(1. / voxel)) * voxel      (:11, cloud.h:84)
+    for (int c = 0; c < 3; ++c) g.org[c] = n > 0 ? __fmul_rn(floorf(__fmul_rn(red[c][0], inv_voxel)), voxel) : 0.f;
+    unsigned long long nx = 1, ny = 1;
+    if (n > 0) {
+      nx = (unsigned long long)(floor((double)__fdiv_rn(__fsub_rn(red[3][0], g.org[0]), voxel)) + 1.0);
+      ny = (unsigned long long)(floor((double)__fdiv_rn(__fsub_rn(red[4][0], g.org[1]), voxel)) + 1.0);
+    }
+    g.nx = nx;
+    g.nxy = nx * ny;
+    hdr[b] = g;
+  }
+}
+
+__device__ __forceinline__ int gs_cloud_of_point(const GsCloud* hdr, int batch, int64_t i) {
+  int b = 0;
+  while (b < batch - 1 && i >= hdr[b].start + hdr[b].len) ++b;
+  return b;
+}
+
+// thread per point: voxel key (:32-35) -> open-addressing insert; first index & count per voxel
+__global__ void gs_insert_kernel(const float* __restrict__ pts, int64_t n, int batch, float voxel, GsLayout L) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = gs_cloud_of_point(L.hdr, batch, i);
+  const GsCloud g = L.hdr[b];
+  const float* p = pts + 3 * i;
+  const unsigned long long ix = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(p[0], g.org[0]), voxel));
+  const unsigned long long iy = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(p[1], g.org[1]), voxel));
+  const unsigned long long iz = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(p[2], g.org[2]), voxel));
+  const unsigned long long key = ix + g.nx * iy + g.nxy * iz;
+  const unsigned long long size = 2ull * (unsigned long long)g.len;
+  unsigned long long slot = ((key * 0x9E3779B97F4A7C15ull) >> 24) % size;
+  const unsigned long long base = 2ull * (unsigned long long)g.start;
+  for (;;) {
+    const unsigned long long prev = atomicCAS(&L.keys[base + slot], kEmptyKey, key);
+    if (prev == kEmptyKey || prev == key) break;
+    slot = slot + 1 == size ? 0 : slot + 1;
+  }
+  const int s = (int)(base + slot);
+  atomicMin(&L.first[s], (int)(i - g.start));
+  atomicAdd(&L.cnt[s], 1);
+  L.slot_of_point[i] = s;
+}
+
+// one block per cloud: number voxels by first occurrence (= unordered_map insertion order) and build
+// the CSR offsets of their member lists.
+__global__ __launch_bounds__(1024) void gs_rank_kernel(int batch, GsLayout L) {
+  __shared__ int sm[20];
+  const int b = blockIdx.x;
+  GsCloud g = L.hdr[b];
+  const int n = (int)g.len;
+  int running = 0;
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    int slot = -1, flag = 0;
+    if (i < n) {
+      slot = L.slot_of_point[g.start + i];
+      flag = L.first[slot] == i;
+    }
+    int tot;
+    const int r = running + block_exclusive_scan<1024>(flag, sm, tot);
+    if (flag) {
+      L.rank_of_slot[slot] = r;
+      L.slot_of_rank[g.start + r] = slot;
+    }
+    running += tot;
+  }
+  const int m = running;
+  __syncthreads();
+  running = 0;
+  for (int base = 0; base < m; base += 1024) {
+    const int r = base + threadIdx.x;
+    const int c = r < m ? L.cnt[L.slot_of_rank[g.start + r]] : 0;
+    int tot;
+    const int ex = running + block_exclusive_scan<1024>(c, sm, tot);
+    if (r < m) L.csr_off[g.start + r] = ex;
+    running += tot;
+  }
+  if (threadIdx.x == 0) L.hdr[b].m = m;
+}
+
+__global__ void gs_fill_kernel(int64_t n, int batch, GsLayout L) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = gs_cloud_of_point(L.hdr, batch, i);
+  const int64_t start = L.hdr[b].start;
+  const int slot = L.slot_of_point[i];
+  const int r = L.rank_of_slot[slot];
+  const int pos = L.csr_off[start + r] + atomicAdd(&L.cursor[start + r], 1);
+  L.members[start + pos] = (int)(i - start);
+}
+
+// thread per voxel: members in ascending input order -> sequential fp32 sums (grid_subsampling_cpu.h:17-20),
+// barycentre = sum * (float)(1.0 / count)  (grid_subsampling_cpu.cpp:46)
+__global__ void gs_bary_kernel(const float* __restrict__ pts, int64_t n, int batch, GsLayout L) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int b = gs_cloud_of_point(L.hdr, batch, t);
+  const GsCloud g = L.hdr[b];
+  const int r = (int)(t - g.start);
+  if (r >= g.m) return;
+  const int slot = L.slot_of_rank[g.start + r];
+  const int c = L.cnt[slot];
+  int* mem = L.members + g.start + L.csr_off[g.start + r];
+  for (int i = 1; i < c; ++i) {  // insertion sort: voxels hold a handful of points
+    const int v = mem[i];
+    int j = i - 1;
+    while (j >= 0 && mem[j] > v) {
+      mem[j + 1] = mem[j];
+      --j;
+    }
+    mem[j + 1] = v;
+  }
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int i = 0; i < c; ++i) {
+    const float* p = pts + 3 * (g.start + mem[i]);
+    sx = __fadd_rn(sx, p[0]);
+    sy = __fadd_rn(sy, p[1]);
+    sz = __fadd_rn(sz, p[2]);
+  }
+  const float w = (float)(1.0 / (double)c);
+  float* o = L.bary + 3 * (g.start + r);
+  o[0] = __fmul_rn(sx, w);
+  o[1] = __fmul_rn(sy, w);
+  o[2] = __fmul_rn(sz, w);
+  L.vkey[g.start + r] = L.keys[slot];
+}
+
+// one block per cloud: replay of the libstdc++ hashtable order.
+// Within an epoch (constant bucket count B) the container's list order equals: buckets by first
+// appearance in `proc` DESCENDING, inside a bucket by position in `proc` DESCENDING, where
+// proc = (list order at the end of the previous epoch) ++ (keys first inserted in this epoch).
+// A rehash replays the list as insertions into an empty table, hence the recursion over epochs.
+__global__ __launch_bounds__(1024) void gs_replay_kernel(int batch, GsLayout L, BucketSchedule sch,
+                                                         float* __restrict__ s_points, int64_t* __restrict__ s_len) {
+  __shared__ int sm[20];
+  const int b = blockIdx.x;
+  const GsCloud g = L.hdr[b];
+  const int m = g.m;
+  int64_t out_base = 0;
+  for (int i = 0; i < b; ++i) out_base += L.hdr[i].m;
+  if (threadIdx.x == 0) s_len[b] = m;
+  if (m == 0) return;
+  const int64_t tb = 3 * g.start + 64 * (int64_t)b;
+  int* bfirst = L.bfirst + tb;
+  int* bcnt = L.bcnt + tb;
+  int* bhead = L.bhead + tb;
+  int* cur = L.list_a + g.start;
+  int* nxt_list = L.list_b + g.start;
+  int* chain = L.nxt + g.start;
+  int* off = L.off + g.start;
+  const unsigned long long* vkey = L.vkey + g.start;
+  int n_prev = 0;
+  for (int e = 0; e < sch.n; ++e) {
+    if (sch.at[e] >= m) break;
+    const int B = sch.bk[e];
+    const int n = (e + 1 < sch.n) ? min(m, sch.at[e + 1]) : m;
+    for (int k = threadIdx.x; k < B; k += 1024) {
+      bfirst[k] = 0x7fffffff;
+      bcnt[k] = 0;
+      bhead[k] = -1;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n; p += 1024) {
+      const int id = p < n_prev ? cur[p] : p;
+      const int k = (int)(vkey[id] % (unsigned long long)B);
+      atomicMin(&bfirst[k], p);
+      atomicAdd(&bcnt[k], 1);
+      chain[p] = atomicExch(&bhead[k], p);
+    }
+    __syncthreads();
+    // off[p] = number of elements in buckets that first appear after position p (suffix scan)
+    int running = 0;
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+      const int t = t0 + threadIdx.x;
+      const int p = n - 1 - t;
+      int wgt = 0;
+      if (t < n) {
+        const int id = p < n_prev ? cur[p] : p;
+        const int k = (int)(vkey[id] % (unsigned long long)B);
+        wgt = ld_l2(&bfirst[k]) == p ? ld_l2(&bcnt[k]) : 0;
+      }
+      int tot;
+      const int ex = running + block_exclusive_scan<1024>(wgt, sm, tot);
+      if (t < n) off[p] = ex;
+      running += tot;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n; p += 1024) {
+      const int id = p < n_prev ? cur[p] : p;
+      const int k = (int)(vkey[id] % (unsigned long long)B);
+      int r = 0;
+      for (int j = ld_l2(&bhead[k]); j >= 0; j = chain[j]) r += j > p;
+      nxt_list[off[ld_l2(&bfirst[k])] + r] = id;
+    }
+    __syncthreads();
+    int* tmp = cur;
+    cur = nxt_list;
+    nxt_list = tmp;
+    n_prev = n;
+  }
+  for (int j = threadIdx.x; j < m; j += 1024) {
+    const float* src = L.bary + 3 * (g.start + cur[j]);
+    float* dst = s_points + 3 * (out_base + j);
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+  }
+}
+
+}  // namespace geotr
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+using namespace geotr;
+
+extern "C" {
+
+const char* geotr_last_error(void) { return error_buffer(); }
+int geotr_abi_version(void) { return 1; }
+
+size_t geotr_radius_grid_workspace_bytes(int64_t ns, int64_t batch) {
+  return grid_layout(nullptr, ns, batch).bytes;
+}
+
+int geotr_radius_grid_build(const float* s_points, const int64_t* s_len, int64_t batch, int64_t ns, float radius,
+                            void* grid_ws, size_t grid_ws_bytes, void* stream_) {
+  GEOTR_CHECK_ARG(s_len && grid_ws && (s_points || ns == 0), "radius_grid_build: null pointer");
+  GEOTR_CHECK_ARG(batch >= 1 && batch <= kMaxBatch, "radius_grid_build: batch %lld outside [1, %d]", (long long)batch,
+                  kMaxBatch);
+  GEOTR_CHECK_ARG(ns >= 0 && ns < (1ll << 31), "radius_grid_build: ns %lld out of range", (long long)ns);
+  GEOTR_CHECK_ARG(radius > 0.f, "radius_grid_build: radius must be positive");
+  hipStream_t stream = (hipStream_t)stream_;
+  GridLayout L = grid_layout(grid_ws, ns, batch);
+  if (grid_ws_bytes < L.bytes)
+    return fail(GEOTR_E_WORKSPACE, "radius_grid_build: workspace %zu < required %zu", grid_ws_bytes, L.bytes);
+  if (hipMemsetAsync(L.cell_cnt, 0, sizeof(int) * (size_t)L.cells, stream) != hipSuccess)
+    return fail(GEOTR_E_LAUNCH, "radius_grid_build: memset failed");
+  rg_bbox_kernel<<<dim3((unsigned)batch), dim3(1024), 0, stream>>>(s_points, s_len, (int)batch, radius,
+                                                                    (int)L.cells_per_cloud, L.hdr);
+  if (ns > 0) {
+    const unsigned nb = (unsigned)((ns + 255) / 256);
+    rg_count_kernel<<<dim3(nb), dim3(256), 0, stream>>>(s_points, ns, (int)batch, L.hdr, L.cell_cnt, L.cid);
+  }
+  scan_reduce_kernel<<<dim3((unsigned)L.scan_blocks), dim3(256), 0, stream>>>(L.cell_cnt, L.cells, L.block_sums);
+  scan_sums_kernel<<<dim3(1), dim3(1024), 0, stream>>>(L.block_sums, L.scan_blocks);
+  scan_down_kernel<<<dim3((unsigned)L.scan_blocks), dim3(256), 0, stream>>>(L.cell_cnt, L.cells, L.block_sums,
+                                                                            L.cell_start);
+  if (ns > 0) {
+    const unsigned nb = (unsigned)((ns + 255) / 256);
+    rg_scatter_kernel<<<dim3(nb), dim3(256), 0, stream>>>(s_points, ns, (int)batch, L.hdr, L.cid, L.cell_start,
+                                                          L.cell_cnt, L.sorted);
+  }
+  GEOTR_CHECK_LAUNCH("radius_grid_build");
+  return GEOTR_OK;
+}
+
+static int radius_query_common(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
+                               int64_t batch, int64_t nq, int64_t ns, float radius, int64_t width, int64_t cap,
+                               int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns, batch);
+  if (nq == 0) return GEOTR_OK;
+  const float r2 = radius * radius;  // fp32 product, as radius_neighbors_cpu.cpp:12
+  const unsigned nb = (unsigned)((nq + 3) / 4);
+  if (count_only) {
+    rg_query_kernel<true><<<dim3(nb), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
+                                                             r2, 0, 0, ns, nullptr, counts, max_count, nullptr);
+  } else {
+    const size_t lds = (size_t)cap * 4 * sizeof(unsigned long long);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rg_query_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(GEOTR_E_LAUNCH, "radius_query: cannot reserve %zu B of LDS", lds);
+    }
+    rg_query_kernel<false><<<dim3(nb), dim3(256), lds, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch,
+                                                                nq, r2, (int)width, (int)cap, ns, out, nullptr,
+                                                                nullptr, overflow);
+  }
+  GEOTR_CHECK_LAUNCH("radius_query");
+  return GEOTR_OK;
+}
+
+int geotr_radius_count(const void* grid_ws, int64_t ns, const float* q_points, const int64_t* q_len, int64_t batch,
+                       int64_t nq, float radius, int32_t* counts, int32_t* max_count, void* stream) {
+  GEOTR_CHECK_ARG(grid_ws && q_len && counts && max_count && (q_points || nq == 0), "radius_count: null pointer");
+  GEOTR_CHECK_ARG(batch >= 1 && batch <= kMaxBatch && nq >= 0 && ns >= 0, "radius_count: bad sizes");
+  return radius_query_common(true, grid_ws, q_points, q_len, batch, nq, ns, radius, 0, 0, nullptr, counts, max_count,
+                             nullptr, stream);
+}
+
+int geotr_radius_query(const void* grid_ws, int64_t ns, const float* q_points, const int64_t* q_len, int64_t batch,
+                       int64_t nq, float radius, int64_t width, int64_t row_capacity, int64_t* out, int32_t* overflow,
+                       void* stream) {
+  GEOTR_CHECK_ARG(grid_ws && q_len && (q_points || nq == 0) && (out || nq * width == 0), "radius_query: null pointer");
+  GEOTR_CHECK_ARG(batch >= 1 && batch <= kMaxBatch && nq >= 0 && ns >= 0, "radius_query: bad sizes");
+  GEOTR_CHECK_ARG(width >= 0 && width < (1 << 20), "radius_query: bad width %lld", (long long)width);
+  int64_t cap = row_capacity > 0 ? row_capacity : 256;
+  cap = (cap + 63) / 64 * 64;
+  if (cap > 4096) return fail(GEOTR_E_CAPACITY, "radius_query: row_capacity %lld > 4096", (long long)row_capacity);
+  if (width == 0) return GEOTR_OK;
+  return radius_query_common(false, grid_ws, q_points, q_len, batch, nq, ns, radius, width, cap, out, nullptr, nullptr,
+                             overflow, stream);
+}
+
+size_t geotr_grid_subsample_workspace_bytes(int64_t n, int64_t batch) { return gs_layout(nullptr, n, batch).bytes; }
+
+int geotr_grid_subsample(const float* points, const int64_t* len, int64_t batch, int64_t n, float voxel,
+                         float* s_points, int64_t* s_len, void* ws, size_t ws_bytes, void* stream_) {
+  GEOTR_CHECK_ARG(len && s_len && ws && (points || n == 0) && (s_points || n == 0), "grid_subsample: null pointer");
+  GEOTR_CHECK_ARG(batch >= 1 && batch <= kMaxBatch, "grid_subsample: batch %lld outside [1, %d]", (long long)batch,
+                  kMaxBatch);
+  GEOTR_CHECK_ARG(n >= 0 && n < (1ll << 30), "grid_subsample: n %lld out of range", (long long)n);
+  GEOTR_CHECK_ARG(voxel > 0.f, "grid_subsample: voxel size must be positive");
+  hipStream_t stream = (hipStream_t)stream_;
+  GsLayout L = gs_layout(ws, n, batch);
+  if (ws_bytes < L.bytes)
+    return fail(GEOTR_E_WORKSPACE, "grid_subsample: workspace %zu < required %zu", ws_bytes, L.bytes);
+  const BucketSchedule& sch = bucket_schedule(n);
+  for (int e = 0; e < sch.n; ++e)  // the bucket tables are carved as 3*len + 64 entries per cloud
+    if ((int64_t)sch.bk[e] > 3 * ((int64_t)sch.at[e] + 1) + 64)
+      return fail(GEOTR_E_CAPACITY, "grid_subsample: unexpected libstdc++ bucket growth %d at %d", sch.bk[e], sch.at[e]);
+  const float inv_voxel = (float)(1.0 / (double)voxel);  // `1. / voxel_size` narrowed by operator*(PointXYZ, float)
+  const unsigned nb = (unsigned)std::max<int64_t>((n + 255) / 256, 1);
+  gs_init_kernel<<<dim3(std::min(nb * 2, 4096u)), dim3(256), 0, stream>>>(L, n);
+  gs_bbox_kernel<<<dim3((unsigned)batch), dim3(1024), 0, stream>>>(points, len, (int)batch, voxel, inv_voxel, L.hdr);
+  if (n > 0) gs_insert_kernel<<<dim3(nb), dim3(256), 0, stream>>>(points, n, (int)batch, voxel, L);
+  gs_rank_kernel<<<dim3((unsigned)batch), dim3(1024), 0, stream>>>((int)batch, L);
+  if (n > 0) {
+    gs_fill_kernel<<<dim3(nb), dim3(256), 0, stream>>>(n, (int)batch, L);
+    gs_bary_kernel<<<dim3(nb), dim3(256), 0, stream>>>(points, n, (int)batch, L);
+  }
+  gs_replay_kernel<<<dim3((unsigned)batch), dim3(1024), 0, stream>>>((int)batch, L, sch, s_points, s_len);
+  GEOTR_CHECK_LAUNCH("grid_subsample");
+  return GEOTR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+"""Mirror of geotransformer/utils/data.py:13-189 (stack-mode pyramid + registration collate), device resident.
+
+`precompute_data_stack_mode` keeps the reference's signature and output schema
+({'points','lengths','neighbors','subsampling','upsampling'}: lists of tensors) but runs every
+grid-subsample and radius search on the GPU.  One uniform grid is built per stage and reused by the
+three searches that target that stage (self / sub-sampling / up-sampling all use radius r_i against
+stage i), instead of the reference's ten independent kd-tree builds.
+"""
+import numpy as np
+import torch
+
+from .. import _lib, ext
+
+
+def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits, exact_width=True):
+    """Pyramid of points + neighbour index tensors (data.py:13-77).
+
+    Args mirror the reference.  ``points``/``lengths`` may be CPU or device tensors; outputs live on the
+    same device.  ``exact_width=True`` reproduces the reference's column count
+    ``min(max_count, neighbor_limit)`` (needs one host read per search); ``exact_width=False`` always
+    emits ``neighbor_limit`` columns (extra columns hold the pad index, which every consumer treats as
+    "no neighbour") and never synchronises on the search results.
+    """
+    assert num_stages == len(neighbor_limits)
+    _lib.require_gpu()
+    home = points.device
+    dev = home if home.type == 'cuda' else torch.device('cuda', torch.cuda.current_device())
+    points = points.to(dev).contiguous()
+    lengths = lengths.to(dev).contiguous()
+
+    points_list, lengths_list = [], []
+    for i in range(num_stages):
+        if i > 0:
+            buf, lengths = ext.grid_subsample_device(points, lengths, voxel_size)
+            points = buf[: int(lengths.sum().item())]  # row count is data dependent (one sync per stage)
+        points_list.append(points)
+        lengths_list.append(lengths)
+        voxel_size *= 2
+
+    grids = []
+    r = radius
+    for i in range(num_stages):
+        grids.append(ext.RadiusGrid(points_list[i], lengths_list[i], r))
+        r *= 2
+
+    def search(grid, q_points, q_lengths, limit):
+        if exact_width or limit <= 0:
+            _, max_count = grid.count(q_points, q_lengths)
+            max_count = int(max_count.item())
+            width = max_count if limit <= 0 else min(max_count, limit)
+            return grid.query(q_points, q_lengths, width, row_capacity=max(max_count, 64))
+        return grid.query(q_points, q_lengths, limit, overflow=overflow)
+
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    neighbors_list, subsampling_list, upsampling_list = [], [], []
+    for i in range(num_stages):
+        neighbors_list.append(search(grids[i], points_list[i], lengths_list[i], neighbor_limits[i]))
+        if i < num_stages - 1:
+            subsampling_list.append(search(grids[i], points_list[i + 1], lengths_list[i + 1], neighbor_limits[i]))
+            upsampling_list.append(search(grids[i + 1], points_list[i], lengths_list[i], neighbor_limits[i + 1]))
+    if not exact_width:
+        worst = int(overflow.item())
+        if worst > 0:
+            raise RuntimeError(f'radius search row capacity exceeded ({worst} neighbours in one ball); '
+                               f'use exact_width=True for such dense clouds')
+
+    def back(ts):
+        return [t.to(home) for t in ts]
+
+    return {
+        'points': back(points_list),
+        'lengths': back(lengths_list),
+        'neighbors': back(neighbors_list),
+        'subsampling': back(subsampling_list),
+        'upsampling': back(upsampling_list),
+    }
+
+
+def registration_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits,
+                                       precompute_data=True, device=None, exact_width=True):
+    """Registration collate in stack mode (data.py:139-189): [ref_1..ref_B, src_1..src_B] stacking.
+
+    ``device`` (optional): place the stacked cloud on that device before the pyramid is built, so the
+    returned dict is already device resident (the reference does this afterwards with ``to_cuda``).
+    """
+    batch_size = len(data_dicts)
+    collated = {}
+    for data_dict in data_dicts:
+        for key, value in data_dict.items():
+            if isinstance(value, np.ndarray):
+                value = torch.from_numpy(value)
+            collated.setdefault(key, []).append(value)
+
+    feats = torch.cat(collated.pop('ref_feats') + collated.pop('src_feats'), dim=0)
+    points_list = collated.pop('ref_points') + collated.pop('src_points')
+    lengths = torch.LongTensor([p.shape[0] for p in points_list])
+    points = torch.cat(points_list, dim=0)
+    if device is not None:
+        feats, points, lengths = feats.to(device), points.to(device), lengths.to(device)
+
+    if batch_size == 1:
+        for key, value in collated.items():
+            collated[key] = value[0].to(device) if device is not None and torch.is_tensor(value[0]) else value[0]
+
+    collated['features'] = feats
+    if precompute_data:
+        collated.update(precompute_data_stack_mode(points, lengths, num_stages, voxel_size, search_radius,
+                                                   neighbor_limits, exact_width=exact_width))
+    else:
+        collated['points'] = points
+        collated['lengths'] = lengths
+    collated['batch_size'] = batch_size
+    return collated

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def oracle_lib():
+    """The CPU restatement (oracle/libneighbors_oracle.so), built on demand."""
+    from oracle import neighbors
+    return neighbors.restated()
+
+
+@pytest.fixture(scope='session')
+def reference_lib():
+    """The real reference cores (oracle/_ref/libgeoref.so) or skip when never built."""
+    from oracle import neighbors
+    lib = neighbors.reference()
+    if lib is None:
+        pytest.skip('oracle/_ref/libgeoref.so not built (needs /root/reference)')
+    return lib

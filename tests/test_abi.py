@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library loads and exports every symbol include/geotr.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'geotr.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(geotr_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_something():
+    names = _declared()
+    assert 'geotr_radius_query' in names and 'geotr_grid_subsample' in names
+
+
+def test_library_exports_every_declared_symbol():
+    from geotransformer_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f'{name} declared in include/geotr.h but not exported'
+
+
+def test_python_binding_covers_header():
+    from geotransformer_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    lib = _lib.load()
+    assert lib.geotr_abi_version() >= 1
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any HIP call, with a message from geotr_last_error()."""
+    from geotransformer_amd import _lib
+    lib = _lib.load()
+    code = lib.geotr_radius_grid_build(None, None, 1, 0, 0.1, None, 0, None)
+    assert code == -1
+    assert b'null pointer' in lib.geotr_last_error()
+    assert lib.geotr_radius_grid_workspace_bytes(1000, 2) > 0
+    assert lib.geotr_grid_subsample_workspace_bytes(1000, 2) > 0
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under geotransformer_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'geotransformer_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert 'libneighbors_oracle' not in src and 'libgeoref' not in src, f
+
+
+def test_ext_rejects_bad_inputs_like_the_reference():
+    import torch
+    from geotransformer_amd import ext
+    pts = torch.zeros(4, 3)
+    lens = torch.tensor([4])
+    with pytest.raises(RuntimeError, match='must be a float tensor'):
+        ext.radius_neighbors(pts.double(), pts, lens, lens, 0.1)
+    with pytest.raises(RuntimeError, match='must be an long tensor'):
+        ext.radius_neighbors(pts, pts, lens.int(), lens, 0.1)
+    with pytest.raises(RuntimeError, match='must be contiguous'):
+        ext.grid_subsampling(torch.zeros(3, 4).t(), lens, 0.1)
+    if not torch.cuda.is_available():  # the product path must fail loudly, never fall back to CPU
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            ext.radius_neighbors(pts, pts, lens, lens, 0.1)

@@ -1,0 +1,112 @@
+"""GPU: HIP neighbour ops (through the C ABI) vs the oracle and the committed reference goldens."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLDEN, canonicalise_rows
+
+pytestmark = pytest.mark.gpu
+GOLDENS = sorted(glob.glob(os.path.join(GOLDEN, 'neighbors_*.npz')))
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+@pytest.mark.parametrize('path', GOLDENS, ids=[os.path.basename(p)[:-4] for p in GOLDENS])
+def test_pyramid_matches_reference_golden(path):
+    """Whole pyramid on the GPU vs the real reference's outputs: points bit-exact (values and order),
+    neighbour indices exact (tie groups canonicalised)."""
+    from geotransformer_amd.utils.data import precompute_data_stack_mode
+    g = np.load(path)
+    S = int(g['num_stages'])
+    limits = [int(x) for x in g['limits']]
+    for exact in (True, False):
+        out = precompute_data_stack_mode(_dev(g['points0']), _dev(g['lengths0']), S, float(g['voxel']),
+                                         float(g['radius']), limits, exact_width=exact)
+        for i in range(S):
+            assert out['points'][i].cpu().numpy().tobytes() == g[f'points{i}'].tobytes(), f'points{i}'
+            assert np.array_equal(out['lengths'][i].cpu().numpy(), g[f'lengths{i}'])
+        for key, qs in (('neighbors', lambda i: (i, i)), ('subsampling', lambda i: (i + 1, i)), ('upsampling', lambda i: (i, i + 1))):
+            for i in range(S if key == 'neighbors' else S - 1):
+                qi, si = qs(i)
+                lim = limits[i + 1] if key == 'upsampling' else limits[i]
+                want = canonicalise_rows(g[f'{key}{i}'].astype(np.int64), g[f'points{qi}'], g[f'points{si}'], lim)
+                got = out[key][i].cpu().numpy()
+                if not exact:  # fixed width: extra columns are pad
+                    assert got.shape[1] == lim
+                    pad = g[f'points{si}'].shape[0]
+                    assert (got[:, want.shape[1]:] == pad).all()
+                    got = got[:, : want.shape[1]]
+                assert np.array_equal(got, want), f'{key}{i} exact={exact}'
+
+
+def test_ext_api_matches_oracle_cpu_tensors(oracle_lib):
+    """Drop-in ext API with CPU tensors in / CPU tensors out (what the reference collate passes)."""
+    from geotransformer_amd import ext
+    from geotransformer_amd.synthetic import make_pair
+    item = make_pair(5, 'modelnet', n_points=900)
+    pts = np.concatenate([item['ref_points'], item['src_points']])
+    lens = np.array([len(item['ref_points']), len(item['src_points'])], dtype=np.int64)
+    s_pts, s_len = ext.grid_subsampling(torch.from_numpy(pts), torch.from_numpy(lens), 0.05)
+    o_pts, o_len = oracle_lib.grid_subsampling(pts, lens, 0.05)
+    assert s_pts.device.type == 'cpu' and s_pts.dtype == torch.float32 and s_len.dtype == torch.int64
+    assert s_pts.numpy().tobytes() == o_pts.tobytes() and np.array_equal(s_len.numpy(), o_len)
+    nb = ext.radius_neighbors(s_pts, torch.from_numpy(pts), s_len, torch.from_numpy(lens), 0.125)
+    assert nb.dtype == torch.int64 and nb.device.type == 'cpu'
+    assert np.array_equal(nb.numpy(), oracle_lib.radius_neighbors(o_pts, pts, o_len, lens, 0.125))
+
+
+def test_edge_cases_gpu():
+    from geotransformer_amd import ext
+    one = torch.tensor([1])
+    p = torch.tensor([[0.1, 0.2, 0.3]])
+    pts, lens = ext.grid_subsampling(p, one, 0.05)
+    assert pts.numpy().tobytes() == p.numpy().tobytes() and lens.tolist() == [1]
+    assert ext.radius_neighbors(p, p, one, one, 0.1).tolist() == [[0]]
+    q = torch.tensor([[5.0, 5.0, 5.0]])
+    assert tuple(ext.radius_neighbors(q, p, one, one, 0.1).shape) == (1, 0)
+    s = torch.tensor([[0, 0, 0], [1, 0, 0], [10, 0, 0], [10.05, 0, 0], [10.2, 0, 0]], dtype=torch.float32)
+    qq = torch.tensor([[0, 0, 0], [10, 0, 0]], dtype=torch.float32)
+    nb = ext.radius_neighbors(qq, s, torch.tensor([1, 1]), torch.tensor([2, 3]), 0.3)
+    assert nb.tolist() == [[0, 5, 5], [2, 3, 4]]
+    s2 = torch.tensor([[0, 0, 0], [0.5, 0, 0]], dtype=torch.float32)
+    assert ext.radius_neighbors(s2[:1].contiguous(), s2, one, torch.tensor([2]), 0.5).tolist() == [[0]]
+
+
+def test_full_size_3dmatch_pair_properties(oracle_lib):
+    """BASELINE config 2 size (20k+20k points): GPU pyramid == oracle exactly, plus size-independent
+    properties (sorted rows, self first, symmetry of the neighbour relation)."""
+    from geotransformer_amd.synthetic import CONFIGS, make_pair
+    from geotransformer_amd.utils.data import precompute_data_stack_mode
+    from oracle import neighbors as on
+    from util import fp32_sqdist
+    cfg = CONFIGS['3dmatch']
+    item = make_pair(0, '3dmatch')
+    pts = np.concatenate([item['ref_points'], item['src_points']])
+    lens = np.array([len(item['ref_points']), len(item['src_points'])], dtype=np.int64)
+    out = precompute_data_stack_mode(_dev(pts), _dev(lens), cfg['num_stages'], cfg['voxel'], cfg['radius'],
+                                     cfg['limits'], exact_width=True)
+    want = on.precompute_pyramid(oracle_lib, pts, lens, cfg['num_stages'], cfg['voxel'], cfg['radius'], cfg['limits'])
+    for k in want:
+        for i, w in enumerate(want[k]):
+            got = out[k][i].cpu().numpy()
+            assert got.shape == w.shape and got.tobytes() == w.tobytes(), (k, i)
+    # properties at stage 0 (self search)
+    nb = out['neighbors'][0].cpu().numpy()
+    n = pts.shape[0]
+    assert (nb[:, 0] == np.arange(n)).all()  # self is the nearest neighbour (d = 0)
+    r2 = np.float32(cfg['radius']) * np.float32(cfg['radius'])
+    rows = np.random.default_rng(0).choice(n, 512, replace=False)
+    for i in rows:
+        v = nb[i][nb[i] < n]
+        d = fp32_sqdist(pts[i][None], pts[v])
+        assert (np.diff(d) >= 0).all() and (d < r2).all()
+        same_cloud = (v < lens[0]) == (i < lens[0])
+        assert same_cloud.all()  # never crosses clouds

@@ -1,0 +1,105 @@
+"""CPU: pin the oracle restatement (oracle/neighbors_oracle.cpp) against the golden vectors produced by the
+real reference cores, and against the live reference library when it is present."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from util import GOLDEN, canonicalise_rows, count_tie_rows
+
+GOLDENS = sorted(glob.glob(os.path.join(GOLDEN, 'neighbors_*.npz')))
+
+
+def _stage_searches(g, i):
+    """(name, queries, q_len, supports, s_len, radius) of geotransformer/utils/data.py:31-69 at stage i."""
+    r = float(g['radius']) * 2 ** i
+    out = [(f'neighbors{i}', g[f'points{i}'], g[f'lengths{i}'], g[f'points{i}'], g[f'lengths{i}'], r)]
+    if i < int(g['num_stages']) - 1:
+        out.append((f'subsampling{i}', g[f'points{i+1}'], g[f'lengths{i+1}'], g[f'points{i}'], g[f'lengths{i}'], r))
+        out.append((f'upsampling{i}', g[f'points{i}'], g[f'lengths{i}'], g[f'points{i+1}'], g[f'lengths{i+1}'], 2 * r))
+    return out
+
+
+@pytest.mark.parametrize('path', GOLDENS, ids=[os.path.basename(p)[:-4] for p in GOLDENS])
+def test_grid_subsample_matches_golden(oracle_lib, path):
+    g = np.load(path)
+    v = float(g['voxel'])
+    for i in range(1, int(g['num_stages'])):
+        pts, lens = oracle_lib.grid_subsampling(g[f'points{i-1}'], g[f'lengths{i-1}'], v * 2 ** i)
+        # values AND order bit-identical to the reference (std::unordered_map iteration order)
+        assert np.array_equal(lens, g[f'lengths{i}'])
+        assert pts.tobytes() == g[f'points{i}'].tobytes()
+
+
+@pytest.mark.parametrize('path', GOLDENS, ids=[os.path.basename(p)[:-4] for p in GOLDENS])
+def test_radius_search_matches_golden(oracle_lib, path):
+    g = np.load(path)
+    for i in range(int(g['num_stages'])):
+        for name, q, ql, s, sl, r in _stage_searches(g, i):
+            ref_full = g[name].astype(np.int64)
+            got = oracle_lib.radius_neighbors(q, s, ql, sl, r)
+            assert got.shape == ref_full.shape, name
+            # same neighbour sets; order identical up to exact-distance ties (canonical = (d, idx))
+            assert np.array_equal(got, canonicalise_rows(ref_full, q, s)), name
+            limit = int(g['limits'][i])
+            got_l = oracle_lib.radius_neighbors(q, s, ql, sl, r, limit)
+            assert np.array_equal(got_l, canonicalise_rows(ref_full, q, s, limit)), name
+
+
+def test_quantised_golden_is_tie_heavy():
+    g = np.load(os.path.join(GOLDEN, 'neighbors_modelnet_quantised_s1.npz'))
+    ties = count_tie_rows(g['neighbors0'].astype(np.int64), g['points0'], g['points0'])
+    assert ties > 100  # the tie-aware comparison above is actually exercised
+
+
+def test_continuous_golden_self_search_is_tie_free():
+    g = np.load(os.path.join(GOLDEN, 'neighbors_modelnet_s0.npz'))
+    assert count_tie_rows(g['neighbors0'].astype(np.int64), g['points0'], g['points0']) == 0
+    # tie-free => the reference's own order must be reproduced exactly, no canonicalisation needed
+    from oracle import neighbors
+    got = neighbors.restated().radius_neighbors(g['points0'], g['points0'], g['lengths0'], g['lengths0'], float(g['radius']))
+    assert np.array_equal(got, g['neighbors0'].astype(np.int64))
+
+
+def test_oracle_against_live_reference(oracle_lib, reference_lib):
+    """Fresh seeds, full pyramid, live reference library (only where oracle/_ref was built)."""
+    from geotransformer_amd.synthetic import CONFIGS, make_pair
+    from oracle import neighbors
+    for seed, config, n in [(11, 'modelnet', 700), (12, '3dmatch', 2500)]:
+        cfg = CONFIGS[config]
+        item = make_pair(seed, config, n_points=n)
+        pts = np.concatenate([item['ref_points'], item['src_points']])
+        lens = np.array([len(item['ref_points']), len(item['src_points'])])
+        zero = [0] * cfg['num_stages']
+        a = neighbors.precompute_pyramid(reference_lib, pts, lens, cfg['num_stages'], cfg['voxel'], cfg['radius'], zero)
+        b = neighbors.precompute_pyramid(oracle_lib, pts, lens, cfg['num_stages'], cfg['voxel'], cfg['radius'], zero)
+        for i in range(cfg['num_stages']):
+            assert a['points'][i].tobytes() == b['points'][i].tobytes()
+            assert np.array_equal(a['lengths'][i], b['lengths'][i])
+            assert np.array_equal(b['neighbors'][i], canonicalise_rows(a['neighbors'][i], a['points'][i], a['points'][i]))
+        for i in range(cfg['num_stages'] - 1):
+            assert np.array_equal(b['subsampling'][i], canonicalise_rows(a['subsampling'][i], a['points'][i + 1], a['points'][i]))
+            assert np.array_equal(b['upsampling'][i], canonicalise_rows(a['upsampling'][i], a['points'][i], a['points'][i + 1]))
+
+
+def test_edge_cases(oracle_lib):
+    # single point, single cloud
+    p = np.array([[0.1, 0.2, 0.3]], dtype=np.float32)
+    pts, lens = oracle_lib.grid_subsampling(p, np.array([1]), 0.05)
+    assert pts.tobytes() == p.tobytes() and lens.tolist() == [1]
+    nb = oracle_lib.radius_neighbors(p, p, np.array([1]), np.array([1]), 0.1)
+    assert nb.tolist() == [[0]]
+    # no neighbour at all => width 0 (radius_neighbors.cpp:54: max_neighbors = 0)
+    q = np.array([[5.0, 5.0, 5.0]], dtype=np.float32)
+    nb = oracle_lib.radius_neighbors(q, p, np.array([1]), np.array([1]), 0.1)
+    assert nb.shape == (1, 0)
+    # ragged batch: second cloud's indices are offset by the first cloud's size; pad = total supports
+    s = np.array([[0, 0, 0], [1, 0, 0], [10, 0, 0], [10.05, 0, 0], [10.2, 0, 0]], dtype=np.float32)
+    qq = np.array([[0, 0, 0], [10, 0, 0]], dtype=np.float32)
+    nb = oracle_lib.radius_neighbors(qq, s, np.array([1, 1]), np.array([2, 3]), 0.3)
+    assert nb.tolist() == [[0, 5, 5], [2, 3, 4]]
+    # strict inequality d < r^2: a point at exactly r is excluded
+    s2 = np.array([[0, 0, 0], [0.5, 0, 0]], dtype=np.float32)
+    nb = oracle_lib.radius_neighbors(s2[:1], s2, np.array([1]), np.array([2]), 0.5)
+    assert nb.tolist() == [[0]]
