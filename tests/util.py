@@ -45,3 +45,33 @@ def count_tie_rows(rows, q, s):
         d = fp32_sqdist(q[i][None, :], s[v])
         n += int(np.unique(d).size != d.size)
     return n
+
+
+def load_model_golden(name):
+    """tests/golden/model_*.npz -> (cfg, state_dict, data, out, mids) as torch CPU tensors."""
+    import torch
+    from geotransformer_amd.config import make_cfg
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    cfg = make_cfg(str(g['cfg/experiment']), str(g['cfg/overrides']))
+    sd, data, out, mids = {}, {}, {}, {}
+    lists = {}
+    for key in g.files:
+        kind, rest = key.split('/', 1)
+        a = g[key]
+        if kind == 'sd':
+            sd[rest] = torch.from_numpy(a)
+        elif kind == 'out':
+            out[rest] = torch.from_numpy(a)
+        elif kind == 'mid':
+            mids[rest] = torch.from_numpy(a)
+        elif kind == 'in':
+            if '/' in rest:
+                k, i = rest.split('/')
+                t = torch.from_numpy(a.astype(np.int64) if a.dtype == np.int32 else a)
+                lists.setdefault(k, {})[int(i)] = t
+            else:
+                data[rest] = torch.from_numpy(a)
+    for k, d in lists.items():
+        data[k] = [d[i] for i in range(len(d))]
+    data['batch_size'] = 1
+    return cfg, sd, data, out, mids
