@@ -15,6 +15,7 @@ c_i64 = ctypes.c_int64
 c_f32 = ctypes.c_float
 c_ptr = ctypes.c_void_p
 c_size = ctypes.c_size_t
+c_int = ctypes.c_int
 
 # name -> (restype, argtypes); must list every symbol include/geotr.h declares (tests check this)
 SIGNATURES = {
@@ -27,6 +28,15 @@ SIGNATURES = {
     'geotr_radius_count': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_f32, c_ptr, c_ptr, c_ptr]),
     'geotr_radius_query': (ctypes.c_int,
                            [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_f32, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    'geotr_gemm': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                           c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
+    'geotr_row_positive': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'geotr_kpconv_gather': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
+                                    c_ptr, c_ptr, c_ptr]),
+    'geotr_maxpool': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    'geotr_upsample_concat': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'geotr_group_norm': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
+    'geotr_layer_norm': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_ptr]),
 }
 
 _lib = None

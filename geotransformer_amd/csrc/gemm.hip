@@ -1,0 +1,234 @@
+// gemm.hip -- exact fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate,
+// bitwise an fmaf chain) with a fused epilogue.  It backs every dense contraction of the hot path:
+//   nn.Linear                       (geotransformer/modules/kpconv/modules.py:68,98; transformer/*.py proj_*, expand, ...)
+//   KPConv's sum_k (M,C_in)x(C_in,C_out) (geotransformer/modules/kpconv/kpconv.py:108-110) as one (M,15*C_in)x(15*C_in,C_out)
+//   attention QK^T and PV           (transformer/rpe_transformer.py:57,68; vanilla_transformer.py:55,66)
+//
+//   C[b] = act( alpha * A[b] * op(B[b]) / row_div + bias + residual )
+//
+// Tiling: block tile BM x BN, K-step 32 staged through LDS (rows padded to 33 floats: conflict-free
+// ds_read_b32 for the 32x32x2 fragment layout A[i=lane&31][k=lane>>5]); each wave owns a (WM*32)x(WN*32)
+// sub-tile = WM*WN accumulators of 16 VGPRs.  Next tile's global loads are issued before the MFMAs of the
+// current one.  Two instances: 128x128 (4 waves, 2x2 tiles per wave) for tall operands, 64x64 (4 waves, 1 tile
+// per wave) for the few-hundred-row superpoint matrices.
+#include "common.h"
+
+namespace geotr {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kBK = 32;
+constexpr int kLdsStride = kBK + 1;
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const int32_t* row_div;
+  const float* residual;
+  int64_t lda, ldb, ldc, ldr;
+  int64_t strideA, strideB, strideC;
+  int M, N, K;
+  int b_is_kn;
+  float alpha;
+  int act;  // 0 none, 1 relu, 2 leaky relu (0.1)
+};
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int WAVES_N = BN / (32 * WN);
+  constexpr int T = 256;
+  static_assert((BM / (32 * WM)) * WAVES_N == 4, "4 waves per block");
+  __shared__ float As[BM * kLdsStride];
+  __shared__ float Bs[BN * kLdsStride];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const float* A = g.A + (int64_t)blockIdx.z * g.strideA;
+  const float* B = g.B + (int64_t)blockIdx.z * g.strideB;
+  float* C = g.C + (int64_t)blockIdx.z * g.strideC;
+  const int wrow = (wave / WAVES_N) * 32 * WM, wcol = (wave % WAVES_N) * 32 * WN;
+
+  constexpr int A_V4 = BM * kBK / 4 / T;  // float4 per thread
+  constexpr int B_V4 = BN * kBK / 4 / T;
+  float4 ra[A_V4], rb[B_V4];
+
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int s = 0; s < A_V4; ++s) {
+      const int f = tid + s * T, row = f >> 3, kq = (f & 7) * 4;
+      const int gm = m0 + row, gk = k0 + kq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gm < g.M) {
+        const float* p = A + (int64_t)gm * g.lda + gk;
+        if (VEC && gk + 3 < g.K) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gk < g.K) v.x = p[0];
+          if (gk + 1 < g.K) v.y = p[1];
+          if (gk + 2 < g.K) v.z = p[2];
+          if (gk + 3 < g.K) v.w = p[3];
+        }
+      }
+      ra[s] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < B_V4; ++s) {
+      const int f = tid + s * T;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!g.b_is_kn) {  // B is (N, K) row-major (nn.Linear weight): float4 along K
+        const int row = f >> 3, kq = (f & 7) * 4;
+        const int gn = n0 + row, gk = k0 + kq;
+        if (gn < g.N) {
+          const float* p = B + (int64_t)gn * g.ldb + gk;
+          if (VEC && gk + 3 < g.K) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            if (gk < g.K) v.x = p[0];
+            if (gk + 1 < g.K) v.y = p[1];
+            if (gk + 2 < g.K) v.z = p[2];
+            if (gk + 3 < g.K) v.w = p[3];
+          }
+        }
+      } else {  // B is (K, N) row-major: float4 along N
+        const int kk = f / (BN / 4), nq = (f % (BN / 4)) * 4;
+        const int gk = k0 + kk, gn = n0 + nq;
+        if (gk < g.K) {
+          const float* p = B + (int64_t)gk * g.ldb + gn;
+          if (VEC && gn + 3 < g.N) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            if (gn < g.N) v.x = p[0];
+            if (gn + 1 < g.N) v.y = p[1];
+            if (gn + 2 < g.N) v.z = p[2];
+            if (gn + 3 < g.N) v.w = p[3];
+          }
+        }
+      }
+      rb[s] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int s = 0; s < A_V4; ++s) {
+      const int f = tid + s * T, row = f >> 3, kq = (f & 7) * 4;
+      float* d = As + row * kLdsStride + kq;
+      d[0] = ra[s].x;
+      d[1] = ra[s].y;
+      d[2] = ra[s].z;
+      d[3] = ra[s].w;
+    }
+#pragma unroll
+    for (int s = 0; s < B_V4; ++s) {
+      const int f = tid + s * T;
+      if (!g.b_is_kn) {
+        const int row = f >> 3, kq = (f & 7) * 4;
+        float* d = Bs + row * kLdsStride + kq;
+        d[0] = rb[s].x;
+        d[1] = rb[s].y;
+        d[2] = rb[s].z;
+        d[3] = rb[s].w;
+      } else {
+        const int kk = f / (BN / 4), nq = (f % (BN / 4)) * 4;
+        Bs[(nq + 0) * kLdsStride + kk] = rb[s].x;
+        Bs[(nq + 1) * kLdsStride + kk] = rb[s].y;
+        Bs[(nq + 2) * kLdsStride + kk] = rb[s].z;
+        Bs[(nq + 3) * kLdsStride + kk] = rb[s].w;
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt = (g.K + kBK - 1) / kBK;
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  const int fr = lane & 31, fk = lane >> 5;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load_tile((kt + 1) * kBK);
+#pragma unroll
+    for (int ks = 0; ks < kBK / 2; ++ks) {
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = As[(wrow + 32 * i + fr) * kLdsStride + 2 * ks + fk];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = Bs[(wcol + 32 * j + fr) * kLdsStride + 2 * ks + fk];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int gn = n0 + wcol + 32 * j + fr;
+      if (gn >= g.N) continue;
+      const float bias = g.bias ? g.bias[gn] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wrow + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (gm >= g.M) continue;
+        float v = acc[i][j][r] * g.alpha;
+        if (g.row_div) v = v / (float)max(g.row_div[gm], 1);
+        v += bias;
+        if (g.residual) v += g.residual[(int64_t)blockIdx.z * g.strideC + (int64_t)gm * g.ldr + gn];
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+        C[(int64_t)gm * g.ldc + gn] = v;
+      }
+    }
+}
+
+}  // namespace geotr
+
+using namespace geotr;
+
+extern "C" int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, int b_is_kn, float* C, int64_t ldc,
+                          int64_t M, int64_t N, int64_t K, int64_t batch, int64_t strideA, int64_t strideB,
+                          int64_t strideC, const float* bias, const int32_t* row_div, const float* residual,
+                          int64_t ldr, float alpha, int act, void* stream_) {
+  GEOTR_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "gemm: negative size");
+  if (M == 0 || N == 0 || batch == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(A && B && C, "gemm: null pointer");
+  GEOTR_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) && batch < 65536, "gemm: size out of range");
+  GEOTR_CHECK_ARG(act >= 0 && act <= 2, "gemm: unknown activation %d", act);
+  hipStream_t stream = (hipStream_t)stream_;
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.row_div = row_div; g.residual = residual;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = residual ? ldr : 0;
+  g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.b_is_kn = b_is_kn; g.alpha = alpha; g.act = act;
+  auto aligned = [](const void* p, int64_t ld, int64_t st) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0 && (st & 3) == 0;
+  };
+  const bool vec = aligned(A, lda, strideA) && aligned(B, ldb, strideB);
+  const bool big = M >= 2048 && N >= 96;
+  if (big) {
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)batch);
+    if (vec) gemm_kernel<128, 128, 2, 2, true><<<grid, dim3(256), 0, stream>>>(g);
+    else gemm_kernel<128, 128, 2, 2, false><<<grid, dim3(256), 0, stream>>>(g);
+  } else {
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)batch);
+    if (vec) gemm_kernel<64, 64, 1, 1, true><<<grid, dim3(256), 0, stream>>>(g);
+    else gemm_kernel<64, 64, 1, 1, false><<<grid, dim3(256), 0, stream>>>(g);
+  }
+  GEOTR_CHECK_LAUNCH("gemm");
+  return GEOTR_OK;
+}

@@ -1,0 +1,399 @@
+// kpconv.hip -- KPConv backbone kernels for gfx950 (K1/K2 of SURVEY.md section 8a).
+//
+//   geotr_kpconv_gather : gather H neighbours, kernel-point influences, weighted feature sums
+//                         (geotransformer/modules/kpconv/kpconv.py:91-105) -> (M, 15*C_in) operand of the
+//                         MFMA contraction in gemm.hip, plus the "neighbours with positive feature sum" count (:113-116)
+//   geotr_row_positive  : flag[j] = sum_c feats[j, c] > 0 (the per-support-row part of :113-114)
+//   geotr_maxpool       : kpconv/functional.py:53-67
+//   geotr_upsample_concat: nearest_upsample (functional.py:6-22) fused with the torch.cat of backbone.py:71-78
+//   geotr_group_norm    : kpconv/modules.py:33-50 (+ fused LeakyReLU / residual add of modules.py:142-147,204-224)
+//   geotr_layer_norm    : LayerNorm(x + residual) of transformer/rpe_transformer.py:102, output_layer.py:20
+#include <algorithm>
+
+#include "common.h"
+
+namespace geotr {
+
+constexpr int kKP = 15;       // kernel points (the only size the reference ships: k_015_center_3D.ply)
+constexpr int kWStride = 16;  // influence rows padded to 16 floats: four broadcast ds_read_b128 per neighbour
+constexpr int kSlotCap = 256; // (points per wave) * H <= 256
+
+__global__ __launch_bounds__(256) void row_positive_kernel(const float* __restrict__ x, int64_t n, int c,
+                                                           unsigned char* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float s = 0.f;
+  for (int j = lane; j < c; j += 64) s += x[row * c + j];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) flag[row] = s > 0.f;
+}
+
+// C_in == 1 (first layer): one thread per query point.
+__global__ __launch_bounds__(256) void kpconv_gather_c1_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
+                                                               const float* __restrict__ sp, const int64_t* __restrict__ nb,
+                                                               const float* __restrict__ kp, int64_t M, int64_t Ns, int H,
+                                                               float sigma, float* __restrict__ out, int* __restrict__ nnum) {
+  __shared__ float kps[kKP * 3];
+  if (threadIdx.x < kKP * 3) kps[threadIdx.x] = kp[threadIdx.x];
+  __syncthreads();
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float qx = qp[3 * m], qy = qp[3 * m + 1], qz = qp[3 * m + 2];
+  float acc[kKP];
+#pragma unroll
+  for (int k = 0; k < kKP; ++k) acc[k] = 0.f;
+  int cnt = 0;
+  for (int h = 0; h < H; ++h) {
+    const int64_t idx = nb[m * H + h];
+    if (idx >= Ns) continue;
+    const float f = feats[idx];
+    cnt += f > 0.f;
+    const float rx = sp[3 * idx] - qx, ry = sp[3 * idx + 1] - qy, rz = sp[3 * idx + 2] - qz;
+#pragma unroll
+    for (int k = 0; k < kKP; ++k) {
+      const float dx = rx - kps[3 * k], dy = ry - kps[3 * k + 1], dz = rz - kps[3 * k + 2];
+      const float w = fmaxf(1.f - sqrtf((dx * dx + dy * dy) + dz * dz) / sigma, 0.f);
+      acc[k] = fmaf(w, f, acc[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kKP; ++k) out[m * kKP + k] = acc[k];
+  nnum[m] = cnt;
+}
+
+// General case.  A wave processes PPW points at a time; LPP = min(C, 64) lanes per point, CPL = C / LPP channels
+// per lane.  Influence weights of the group live in LDS and are read back as wave-wide broadcasts.
+template <int CPL>
+__global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
+                                                            const float* __restrict__ sp, const int64_t* __restrict__ nb,
+                                                            const float* __restrict__ kp,
+                                                            const unsigned char* __restrict__ pos, int64_t M, int64_t Ns,
+                                                            int H, int C, int ppw, float sigma,
+                                                            float* __restrict__ out, int* __restrict__ nnum) {
+  __shared__ __attribute__((aligned(16))) float w_s[4][kSlotCap * kWStride];
+  __shared__ float rel_s[4][kSlotCap * 3];
+  __shared__ int idx_s[4][kSlotCap];
+  __shared__ int cnt_s[4][64];
+  __shared__ float kps[kKP * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < kKP * 3) kps[threadIdx.x] = kp[threadIdx.x];
+  __syncthreads();
+  const int lpp = C < 64 ? C : 64;
+  const int slot = lane / lpp, cl = lane % lpp;
+  const int64_t groups = (M + ppw - 1) / ppw;
+  float* w = w_s[wave];
+  float* rel = rel_s[wave];
+  int* idx = idx_s[wave];
+  int* cnt = cnt_s[wave];
+  for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < groups; g += (int64_t)gridDim.x * 4) {
+    const int64_t m0 = g * ppw;
+    const int total = ppw * H;
+    if (lane < ppw) cnt[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (1) neighbour indices, relative positions, positive-feature count
+    for (int e = lane; e < total; e += 64) {
+      const int s = e / H, h = e - s * H;
+      const int64_t m = m0 + s;
+      int id = -1;
+      if (m < M) {
+        const int64_t j = nb[m * H + h];
+        if (j < Ns) {
+          id = (int)j;
+          rel[3 * e] = sp[3 * j] - qp[3 * m];
+          rel[3 * e + 1] = sp[3 * j + 1] - qp[3 * m + 1];
+          rel[3 * e + 2] = sp[3 * j + 2] - qp[3 * m + 2];
+          if (pos[j]) atomicAdd(&cnt[s], 1);
+        }
+      }
+      idx[e] = id;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (2) influences  w = max(0, 1 - |rel - kp| / sigma)   (kpconv.py:96-99)
+    for (int e = lane; e < total * kWStride; e += 64) {
+      const int n = e >> 4, k = e & 15;
+      float v = 0.f;
+      if (k < kKP && idx[n] >= 0) {
+        const float dx = rel[3 * n] - kps[3 * k], dy = rel[3 * n + 1] - kps[3 * k + 1], dz = rel[3 * n + 2] - kps[3 * k + 2];
+        v = fmaxf(1.f - sqrtf((dx * dx + dy * dy) + dz * dz) / sigma, 0.f);
+      }
+      w[e] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (3) weighted feature sums: acc[k][c] = sum_h w[h][k] * f[h][c]   (kpconv.py:102-105)
+    const int64_t m = m0 + slot;
+    if (slot < ppw && m < M) {
+      float acc[CPL][kKP];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j)
+#pragma unroll
+        for (int k = 0; k < kKP; ++k) acc[j][k] = 0.f;
+      for (int h = 0; h < H; ++h) {
+        const int n = slot * H + h;
+        const int id = idx[n];
+        if (id < 0) continue;
+        const float4* wr = reinterpret_cast<const float4*>(w + n * kWStride);
+        const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+        const float wk[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+        const float* fr = feats + (int64_t)id * C + cl;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const float f = fr[64 * j];
+#pragma unroll
+          for (int k = 0; k < kKP; ++k) acc[j][k] = fmaf(wk[k], f, acc[j][k]);
+        }
+      }
+      float* o = out + m * (int64_t)(kKP * C) + cl;
+#pragma unroll
+      for (int k = 0; k < kKP; ++k)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) o[k * C + 64 * j] = acc[j][k];
+      if (cl == 0) nnum[m] = cnt[slot];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ void maxpool_kernel(const float* __restrict__ x, const int64_t* __restrict__ nb, int64_t M, int64_t Ns, int H, int C,
+                               float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * C) return;
+  const int64_t m = e / C;
+  const int c = (int)(e - m * C);
+  float best = -3.4e38f;
+  for (int h = 0; h < H; ++h) {
+    const int64_t j = nb[m * H + h];
+    best = fmaxf(best, j < Ns ? x[j * C + c] : 0.f);  // the shadow row is all zeros and takes part in the max
+  }
+  out[e] = best;
+}
+
+__global__ void upsample_concat_kernel(const float* __restrict__ coarse, int64_t nc, int c1, const int64_t* __restrict__ up,
+                                       int64_t ld_up, const float* __restrict__ skip, int c2, int64_t M,
+                                       float* __restrict__ out) {
+  const int ct = c1 + c2;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * ct) return;
+  const int64_t m = e / ct;
+  const int c = (int)(e - m * ct);
+  float v;
+  if (c < c1) {
+    const int64_t j = up[m * ld_up];  // column 0 only (functional.py:21)
+    v = j < nc ? coarse[j * c1 + c] : 0.f;
+  } else {
+    v = skip[m * c2 + (c - c1)];
+  }
+  out[e] = v;
+}
+
+// ---- GroupNorm over (N, C): statistics span all N stacked points (modules.py:47-50) -------------------------
+constexpr int kGnRows = 256;  // rows per block in the statistics pass
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int64_t N, int C, double* __restrict__ stats) {
+  extern __shared__ float red[];  // [2][C]
+  const int64_t r0 = (int64_t)blockIdx.x * kGnRows;
+  const int64_t r1 = r0 + kGnRows < N ? r0 + kGnRows : N;
+  if (C >= 256) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s = 0.f, ss = 0.f;
+      for (int64_t r = r0; r < r1; ++r) {
+        const float v = x[r * C + c];
+        s += v;
+        ss = fmaf(v, v, ss);
+      }
+      atomicAdd(&stats[c], (double)s);
+      atomicAdd(&stats[C + c], (double)ss);
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  // thread -> (row phase, channel): consecutive threads read consecutive channels (coalesced)
+  const int per = 256 / C > 0 ? 256 / C : 1;  // C is < 256 here; if it does not divide 256 the tail threads idle
+  const int c = threadIdx.x % C, ph = threadIdx.x / C;
+  if (ph < per) {
+    float s = 0.f, ss = 0.f;
+    for (int64_t r = r0 + ph; r < r1; r += per) {
+      const float v = x[r * C + c];
+      s += v;
+      ss = fmaf(v, v, ss);
+    }
+    atomicAdd(&red[c], s);
+    atomicAdd(&red[C + c], ss);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&stats[i], (double)red[i]);
+}
+
+__global__ void gn_apply_kernel(const float* __restrict__ x, int64_t N, int C, int groups, const double* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                const float* __restrict__ residual, int act, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * C) return;
+  const int c = (int)(e % C);
+  const int cpg = C / groups, g0 = (c / cpg) * cpg;
+  double s = 0.0, ss = 0.0;
+  for (int j = 0; j < cpg; ++j) {
+    s += stats[g0 + j];
+    ss += stats[C + g0 + j];
+  }
+  const double cnt = (double)N * cpg;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  float v = (x[e] - (float)mean) * rstd * gamma[c] + beta[c];
+  if (residual) v += residual[e];
+  if (act == 2) v = v > 0.f ? v : 0.1f * v;
+  if (act == 1) v = fmaxf(v, 0.f);
+  out[e] = v;
+}
+
+// ---- LayerNorm(x + residual), one wave per row ------------------------------------------------------------
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ residual,
+                                                         int64_t N, int C, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float v[16];  // C <= 1024; statically indexed so it stays in registers
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + 64 * i;
+    float t = 0.f;
+    if (c < C) {
+      t = x[row * C + c];
+      if (residual) t += residual[row * C + c];
+    }
+    v[i] = t;
+    s += t;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float d = (lane + 64 * i < C) ? v[i] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.f / sqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) out[row * C + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+  }
+}
+
+}  // namespace geotr
+
+using namespace geotr;
+
+extern "C" {
+
+int geotr_row_positive(const float* x, int64_t n, int64_t c, uint8_t* flag, void* stream) {
+  GEOTR_CHECK_ARG(n >= 0 && c >= 1, "row_positive: bad sizes");
+  if (n == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(x && flag, "row_positive: null pointer");
+  row_positive_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(x, n, (int)c, flag);
+  GEOTR_CHECK_LAUNCH("row_positive");
+  return GEOTR_OK;
+}
+
+int geotr_kpconv_gather(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
+                        const float* kernel_points, const uint8_t* pos_flag, int64_t m, int64_t ns, int64_t h,
+                        int64_t c, int64_t num_kernel_points, float sigma, float* weighted, int32_t* nnum,
+                        void* stream_) {
+  GEOTR_CHECK_ARG(m >= 0 && ns >= 0 && h >= 1 && c >= 1, "kpconv_gather: bad sizes");
+  GEOTR_CHECK_ARG(num_kernel_points == kKP, "kpconv_gather: only %d kernel points are supported (got %lld)", kKP,
+                  (long long)num_kernel_points);
+  if (m == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(s_feats && q_points && s_points && neighbors && kernel_points && weighted && nnum,
+                  "kpconv_gather: null pointer");
+  GEOTR_CHECK_ARG(h <= kSlotCap, "kpconv_gather: neighbour limit %lld > %d", (long long)h, kSlotCap);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (c == 1) {
+    kpconv_gather_c1_kernel<<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream>>>(
+        s_feats, q_points, s_points, neighbors, kernel_points, m, ns, (int)h, sigma, weighted, nnum);
+  } else {
+    GEOTR_CHECK_ARG((c & (c - 1)) == 0 && c <= 512, "kpconv_gather: channels must be a power of two <= 512 (got %lld)",
+                    (long long)c);
+    GEOTR_CHECK_ARG(pos_flag, "kpconv_gather: pos_flag is required for c > 1");
+    const int lpp = c < 64 ? (int)c : 64;
+    int ppw = 64 / lpp;
+    while (ppw > 1 && ppw * h > kSlotCap) ppw >>= 1;
+    const int64_t groups = (m + ppw - 1) / ppw;
+    const unsigned nb = (unsigned)std::min<int64_t>((groups + 3) / 4, 8192);
+    const int cpl = c <= 64 ? 1 : (int)(c / 64);
+#define LAUNCH(CPL)                                                                                                  \
+  kpconv_gather_kernel<CPL><<<dim3(nb), dim3(256), 0, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points, \
+                                                               pos_flag, m, ns, (int)h, (int)c, ppw, sigma, weighted, nnum)
+    if (cpl == 1) LAUNCH(1);
+    else if (cpl == 2) LAUNCH(2);
+    else if (cpl == 4) LAUNCH(4);
+    else LAUNCH(8);
+#undef LAUNCH
+  }
+  GEOTR_CHECK_LAUNCH("kpconv_gather");
+  return GEOTR_OK;
+}
+
+int geotr_maxpool(const float* x, const int64_t* neighbors, int64_t m, int64_t ns, int64_t h, int64_t c, float* out,
+                  void* stream) {
+  GEOTR_CHECK_ARG(m >= 0 && h >= 1 && c >= 1, "maxpool: bad sizes");
+  if (m == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(x && neighbors && out, "maxpool: null pointer");
+  maxpool_kernel<<<dim3((unsigned)((m * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, neighbors, m, ns, (int)h,
+                                                                                              (int)c, out);
+  GEOTR_CHECK_LAUNCH("maxpool");
+  return GEOTR_OK;
+}
+
+int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int64_t* up_idx, int64_t ld_idx,
+                          const float* skip, int64_t c2, int64_t m, float* out, void* stream) {
+  GEOTR_CHECK_ARG(m >= 0 && c1 >= 1 && c2 >= 0 && ld_idx >= 1, "upsample_concat: bad sizes");
+  if (m == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(coarse && up_idx && out && (skip || c2 == 0), "upsample_concat: null pointer");
+  const int64_t tot = m * (c1 + c2);
+  upsample_concat_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      coarse, nc, (int)c1, up_idx, ld_idx, skip, (int)c2, m, out);
+  GEOTR_CHECK_LAUNCH("upsample_concat");
+  return GEOTR_OK;
+}
+
+int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
+                     float eps, const float* residual, int act, float* out, double* stats_ws, void* stream_) {
+  GEOTR_CHECK_ARG(n >= 0 && c >= 1 && groups >= 1 && c % groups == 0, "group_norm: %lld channels / %lld groups",
+                  (long long)c, (long long)groups);
+  if (n == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(x && gamma && beta && out && stats_ws, "group_norm: null pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)c, stream) != hipSuccess)
+    return fail(GEOTR_E_LAUNCH, "group_norm: memset failed");
+  const unsigned nb = (unsigned)((n + kGnRows - 1) / kGnRows);
+  gn_stats_kernel<<<dim3(nb), dim3(256), c < 256 ? sizeof(float) * 2 * (size_t)c : 0, stream>>>(x, n, (int)c, stats_ws);
+  gn_apply_kernel<<<dim3((unsigned)((n * c + 255) / 256)), dim3(256), 0, stream>>>(x, n, (int)c, (int)groups, stats_ws, gamma,
+                                                                                 beta, eps, residual, act, out);
+  GEOTR_CHECK_LAUNCH("group_norm");
+  return GEOTR_OK;
+}
+
+int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c, const float* gamma, const float* beta,
+                     float eps, float* out, void* stream) {
+  GEOTR_CHECK_ARG(n >= 0 && c >= 1 && c <= 1024, "layer_norm: bad sizes (c <= 1024)");
+  if (n == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(x && gamma && beta && out, "layer_norm: null pointer");
+  layer_norm_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(x, residual, n, (int)c, gamma, beta,
+                                                                                         eps, out);
+  GEOTR_CHECK_LAUNCH("layer_norm");
+  return GEOTR_OK;
+}
+
+}  // extern "C"

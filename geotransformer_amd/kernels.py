@@ -1,0 +1,136 @@
+"""Thin torch-facing wrappers over the C ABI (include/geotr.h).  Device tensors in, new device tensors out;
+every call is asynchronous on the current torch stream.  No eager/PyTorch fallback exists: a missing library
+or a failing call raises RuntimeError."""
+import torch
+
+from . import _lib
+
+ACT = {None: 0, 'none': 0, 'relu': 1, 'leaky': 2}
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_cuda, 'expected a float32 device tensor'
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def gemm(a, b, b_is_kn=False, bias=None, row_div=None, residual=None, alpha=1.0, act=None, out=None):
+    """out = act(alpha * a @ op(b) / row_div + bias + residual).
+
+    a: (M,K) or (B,M,K); b: (N,K) [b_is_kn=False, nn.Linear weight] or (K,N) [b_is_kn=True], optionally batched.
+    Rows may be strided views (last dim contiguous)."""
+    lib = _lib.load()
+    batched = a.dim() == 3
+    if not batched:
+        a3, b3 = a.unsqueeze(0), b.unsqueeze(0)
+    else:
+        a3, b3 = a, (b if b.dim() == 3 else b.unsqueeze(0).expand(a.shape[0], -1, -1))
+    assert a3.stride(-1) == 1 and b3.stride(-1) == 1
+    B, M, K = a3.shape
+    N = b3.shape[2] if b_is_kn else b3.shape[1]
+    assert (b3.shape[1] if b_is_kn else b3.shape[2]) == K, 'inner dimensions differ'
+    if out is None:
+        out = torch.empty((B, M, N) if batched else (M, N), dtype=torch.float32, device=a.device)
+    o3 = out if batched else out.unsqueeze(0)
+    assert o3.stride(-1) == 1
+    ldr = 0
+    if residual is not None:
+        assert residual.stride(-1) == 1 and not batched
+        ldr = residual.stride(0)
+    _lib.check(lib.geotr_gemm(_lib.ptr(a3), a3.stride(1), _lib.ptr(b3), b3.stride(1), int(b_is_kn), _lib.ptr(o3),
+                              o3.stride(1), M, N, K, B, a3.stride(0) if B > 1 else 0, b3.stride(0) if B > 1 else 0,
+                              o3.stride(0) if B > 1 else 0, _lib.ptr(bias), _lib.ptr(row_div), _lib.ptr(residual), ldr,
+                              float(alpha), ACT[act], _lib.stream_ptr()), 'geotr_gemm')
+    return out
+
+
+def linear(x, weight, bias=None, act=None, residual=None):
+    """F.linear(x, weight, bias) on the matrix cores; x may have leading batch dims."""
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    res2 = residual.reshape(-1, weight.shape[0]) if residual is not None else None
+    y = gemm(x2, weight, bias=bias, act=act, residual=res2)
+    return y.view(*shape[:-1], weight.shape[0])
+
+
+def row_positive(feats):
+    lib = _lib.load()
+    feats = _f32c(feats)
+    flag = torch.empty(feats.shape[0], dtype=torch.uint8, device=feats.device)
+    _lib.check(lib.geotr_row_positive(_lib.ptr(feats), feats.shape[0], feats.shape[1], _lib.ptr(flag), _lib.stream_ptr()),
+               'geotr_row_positive')
+    return flag
+
+
+def kpconv_gather(s_feats, q_points, s_points, neighbor_indices, kernel_points, sigma):
+    """-> weighted (M, 15*C) fp32, nnum (M,) int32."""
+    lib = _lib.load()
+    s_feats, q_points, s_points = _f32c(s_feats), _f32c(q_points), _f32c(s_points)
+    nb = neighbor_indices if neighbor_indices.is_contiguous() else neighbor_indices.contiguous()
+    assert nb.dtype == torch.int64
+    M, H = nb.shape
+    Ns, C = s_feats.shape
+    K = kernel_points.shape[0]
+    flag = row_positive(s_feats) if C > 1 else None
+    weighted = torch.empty((M, K * C), dtype=torch.float32, device=s_feats.device)
+    nnum = torch.empty(M, dtype=torch.int32, device=s_feats.device)
+    _lib.check(lib.geotr_kpconv_gather(_lib.ptr(s_feats), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(nb),
+                                       _lib.ptr(_f32c(kernel_points)), _lib.ptr(flag), M, Ns, H, C, K, float(sigma),
+                                       _lib.ptr(weighted), _lib.ptr(nnum), _lib.stream_ptr()), 'geotr_kpconv_gather')
+    return weighted, nnum
+
+
+def maxpool(x, neighbor_indices):
+    lib = _lib.load()
+    x = _f32c(x)
+    nb = neighbor_indices if neighbor_indices.is_contiguous() else neighbor_indices.contiguous()
+    M, H = nb.shape
+    out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(lib.geotr_maxpool(_lib.ptr(x), _lib.ptr(nb), M, x.shape[0], H, x.shape[1], _lib.ptr(out), _lib.stream_ptr()),
+               'geotr_maxpool')
+    return out
+
+
+def upsample_concat(coarse, upsample_indices, skip=None):
+    """[nearest_upsample(coarse, upsample_indices), skip] along channels; only column 0 of the indices is read."""
+    lib = _lib.load()
+    coarse = _f32c(coarse)
+    assert upsample_indices.dtype == torch.int64
+    if upsample_indices.dim() == 1:
+        upsample_indices = upsample_indices.unsqueeze(1)
+    M = upsample_indices.shape[0]
+    c1 = coarse.shape[1]
+    c2 = 0 if skip is None else skip.shape[1]
+    if skip is not None:
+        skip = _f32c(skip)
+    out = torch.empty((M, c1 + c2), dtype=torch.float32, device=coarse.device)
+    _lib.check(lib.geotr_upsample_concat(_lib.ptr(coarse), coarse.shape[0], c1, _lib.ptr(upsample_indices),
+                                         upsample_indices.stride(0), _lib.ptr(skip), c2, M, _lib.ptr(out),
+                                         _lib.stream_ptr()), 'geotr_upsample_concat')
+    return out
+
+
+def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, act=None):
+    lib = _lib.load()
+    x = _f32c(x)
+    N, C = x.shape
+    out = torch.empty_like(x)
+    stats = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    if residual is not None:
+        residual = _f32c(residual)
+    _lib.check(lib.geotr_group_norm(_lib.ptr(x), N, C, groups, _lib.ptr(weight), _lib.ptr(bias), float(eps),
+                                    _lib.ptr(residual), ACT[act], _lib.ptr(out), _lib.ptr(stats), _lib.stream_ptr()),
+               'geotr_group_norm')
+    return out
+
+
+def layer_norm(x, weight, bias, eps=1e-5, residual=None):
+    lib = _lib.load()
+    shape = x.shape
+    x2 = _f32c(x.reshape(-1, shape[-1]))
+    r2 = _f32c(residual.reshape(-1, shape[-1])) if residual is not None else None
+    out = torch.empty_like(x2)
+    _lib.check(lib.geotr_layer_norm(_lib.ptr(x2), _lib.ptr(r2), x2.shape[0], x2.shape[1], _lib.ptr(weight), _lib.ptr(bias),
+                                    float(eps), _lib.ptr(out), _lib.stream_ptr()), 'geotr_layer_norm')
+    return out.view(shape)

@@ -80,6 +80,50 @@ int geotr_radius_query(const void* grid_ws, int64_t ns, const float* q_points, c
                        int64_t nq, float radius, int64_t width, int64_t row_capacity, int64_t* out, int32_t* overflow,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Dense contraction on the matrix cores (exact fp32: v_mfma_f32_32x32x2_f32).
+ *   C[b] = act( alpha * A[b] (M,K) * op(B[b]) / max(row_div,1) + bias + residual ),  b < batch
+ *   b_is_kn = 0: B is (N,K) row-major -- an nn.Linear weight (y = x W^T + b), replaces every nn.Linear of
+ *                geotransformer/modules/kpconv/modules.py:68,98, transformer/rpe_transformer.py:27-30,79,
+ *                vanilla_transformer.py:25-27,76, output_layer.py:9-11, geotransformer/geotransformer.py:109-113
+ *   b_is_kn = 1: B is (K,N) row-major -- KPConv.weights viewed (15*C_in, C_out) (kpconv/kpconv.py:108-110),
+ *                the V operand of attention (rpe_transformer.py:68)
+ *   row_div (M, int32, optional): KPConv's neighbour-count normaliser (kpconv.py:113-117), applied before bias.
+ *   residual (M,N) with leading dimension ldr, optional.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.1).
+ * ---------------------------------------------------------------------------------------------- */
+int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, int b_is_kn, float* C, int64_t ldc, int64_t M,
+               int64_t N, int64_t K, int64_t batch, int64_t strideA, int64_t strideB, int64_t strideC,
+               const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
+               void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1/K2  KPConv backbone pieces
+ *   geotr_row_positive   : flag[j] = (sum_c feats[j,c] > 0)                     kpconv/kpconv.py:113-114
+ *   geotr_kpconv_gather  : weighted[m, k*C + c] = sum_h max(0, 1 - |s[nb[m,h]] - q[m] - kp[k]| / sigma) * feats[nb[m,h], c]
+ *                          nnum[m] = #{h : nb[m,h] < ns and flag[nb[m,h]]}      kpconv/kpconv.py:91-105,113-116
+ *                          (pad index ns = the reference's shadow point at 1e6 with zero features)
+ *                          c must be 1 or a power of two <= 512; 15 kernel points; h <= 256.
+ *   geotr_maxpool        : out[m,c] = max_h x_pad[nb[m,h], c]                   kpconv/functional.py:53-67
+ *   geotr_upsample_concat: out[m] = [ coarse_pad[up_idx[m*ld_idx], :c1] , skip[m, :c2] ]
+ *                                                    kpconv/functional.py:6-22 + experiments/.../backbone.py:71-78
+ *   geotr_group_norm     : GroupNorm over the stacked (N,C) matrix (statistics over ALL points),
+ *                          out = act(gn(x) + residual); stats_ws = 2*c doubles   kpconv/modules.py:33-50,142-147,204-224
+ *   geotr_layer_norm     : out = LayerNorm(x + residual)       transformer/rpe_transformer.py:102, output_layer.py:20
+ * ---------------------------------------------------------------------------------------------- */
+int geotr_row_positive(const float* x, int64_t n, int64_t c, uint8_t* flag, void* stream);
+int geotr_kpconv_gather(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
+                        const float* kernel_points, const uint8_t* pos_flag, int64_t m, int64_t ns, int64_t h,
+                        int64_t c, int64_t num_kernel_points, float sigma, float* weighted, int32_t* nnum,
+                        void* stream);
+int geotr_maxpool(const float* x, const int64_t* neighbors, int64_t m, int64_t ns, int64_t h, int64_t c, float* out,
+                  void* stream);
+int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int64_t* up_idx, int64_t ld_idx,
+                          const float* skip, int64_t c2, int64_t m, float* out, void* stream);
+int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
+                     float eps, const float* residual, int act, float* out, double* stats_ws, void* stream);
+int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c, const float* gamma, const float* beta,
+                     float eps, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,7 +48,8 @@ def _read_ply(path):
         while not header.endswith(b'end_header\n'):
             header += f.readline()
         n = int([l for l in header.decode().split('\n') if l.startswith('element vertex')][0].split()[-1])
-        dtype = '<f8' if 'property double x' in header.decode() else '<f4'
+        h = header.decode()
+        dtype = '<f8' if ('property double x' in h or 'property float64 x' in h) else '<f4'
         pts = np.frombuffer(f.read(), dtype=dtype, count=3 * n).reshape(n, 3).astype(np.float64)
     return types.SimpleNamespace(points=pts)
 

@@ -1,0 +1,125 @@
+"""GPU: KPConv backbone kernels (gemm.hip, kpconv.hip) vs the torch-fp32 oracle and the reference goldens."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import load_model_golden
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=2e-4, rtol=2e-4)  # fp32 kernels vs fp32 CPU reference; differences are summation-order only
+
+
+def _mse(a, b):
+    return float(((a - b) ** 2).mean())
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (37, 19, 5), (64, 64, 32), (300, 130, 77), (2500, 128, 480), (4100, 256, 96)])
+@pytest.mark.parametrize('b_is_kn', [False, True])
+def test_gemm_matches_fp64(M, N, K, b_is_kn):
+    from geotransformer_amd import kernels
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g) if b_is_kn else torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    want = (a.double() @ (b.double() if b_is_kn else b.double().t()) + bias.double())
+    got = kernels.gemm(a.cuda(), b.cuda(), b_is_kn=b_is_kn, bias=bias.cuda()).cpu()
+    assert torch.allclose(got.double(), want, atol=1e-5 * max(K, 1) ** 0.5 * 4, rtol=1e-5)
+
+
+def test_gemm_epilogue_and_batch_and_strides():
+    from geotransformer_amd import kernels
+    g = torch.Generator().manual_seed(3)
+    # asymmetric operands: a transposed output or operand would not pass (guide rule 16)
+    a = torch.randn(4, 70, 48, generator=g)
+    b = torch.randn(4, 48, 33, generator=g)
+    got = kernels.gemm(a.cuda(), b.cuda(), b_is_kn=True, alpha=0.5).cpu()
+    assert torch.allclose(got, 0.5 * torch.bmm(a, b), **TOL)
+    # strided A (head slice of a wider matrix), residual, row_div, relu
+    x = torch.randn(90, 256, generator=g)
+    w = torch.randn(40, 64, generator=g)
+    res = torch.randn(90, 40, generator=g)
+    div = torch.randint(0, 5, (90,), generator=g, dtype=torch.int32)
+    xs = x.cuda()[:, 64:128]
+    got = kernels.gemm(xs, w.cuda(), residual=res.cuda(), row_div=div.cuda(), act='relu').cpu()
+    want = F.relu(x[:, 64:128] @ w.t() / div.clamp(min=1).float().unsqueeze(1) + res)
+    assert torch.allclose(got, want, **TOL)
+    got = kernels.linear(x.cuda(), torch.randn(8, 256, generator=torch.Generator().manual_seed(1)).cuda(), act='leaky').cpu()
+    want = F.leaky_relu(x @ torch.randn(8, 256, generator=torch.Generator().manual_seed(1)).t(), 0.1)
+    assert torch.allclose(got, want, **TOL)
+
+
+@pytest.mark.parametrize('C', [1, 8, 16, 32, 64, 128, 256])
+def test_kpconv_layer_matches_oracle(C):
+    """One KPConv layer at several widths (all lane mappings of kpconv_gather) vs oracle/model_oracle.kpconv."""
+    from geotransformer_amd.modules.kpconv import KPConv
+    from oracle import model_oracle as mo
+    g = np.load('tests/golden/neighbors_3dmatch_small_s2.npz')
+    pts = torch.from_numpy(g['points1'])
+    nb = torch.from_numpy(g['neighbors1'].astype(np.int64))[:, :36].contiguous()
+    torch.manual_seed(C)
+    np.random.seed(C)
+    layer = KPConv(C, 2 * C if C > 1 else 16, 15, 0.125, 0.1, bias=True)
+    feats = torch.randn(pts.shape[0], C) if C > 1 else torch.ones(pts.shape[0], 1)
+    if C > 1:
+        feats[::7] = -feats[::7].abs()  # rows with a negative feature sum exercise the neighbour-count rule
+    sd = {'x.' + k: v for k, v in layer.state_dict().items()}
+    want = mo.kpconv(sd, 'x.', feats, pts, pts, nb, 0.1)
+    got = layer.cuda()(feats.cuda(), pts.cuda(), pts.cuda(), nb.cuda()).cpu()
+    assert torch.allclose(got, want, **TOL), float((got - want).abs().max())
+    assert _mse(got, want) <= 1e-8
+
+
+def test_strided_kpconv_and_maxpool_and_upsample():
+    from geotransformer_amd import kernels
+    from oracle import model_oracle as mo
+    g = np.load('tests/golden/neighbors_3dmatch_small_s2.npz')
+    fine, coarse = torch.from_numpy(g['points1']), torch.from_numpy(g['points2'])
+    sub = torch.from_numpy(g['subsampling1'].astype(np.int64))[:, :36].contiguous()
+    up = torch.from_numpy(g['upsampling1'].astype(np.int64))[:, :36].contiguous()
+    x = torch.randn(fine.shape[0], 48)
+    assert torch.equal(kernels.maxpool(x.cuda(), sub.cuda()).cpu(), mo.maxpool(x, sub))
+    y = torch.randn(coarse.shape[0], 40)
+    got = kernels.upsample_concat(y.cuda(), up.cuda(), x.cuda()).cpu()
+    assert torch.equal(got, torch.cat([mo.nearest_upsample(y, up), x], dim=1))
+    # non-contiguous index view (what `neighbors[:, :limit]` is in the reference wrapper)
+    got = kernels.upsample_concat(y.cuda(), up.cuda()[:, :5]).cpu()
+    assert torch.equal(got, mo.nearest_upsample(y, up))
+
+
+@pytest.mark.parametrize('N,C,G', [(1000, 32, 32), (5000, 64, 32), (333, 256, 32), (77, 1024, 32), (2000, 16, 4), (50, 8, 4)])
+def test_group_norm_and_layer_norm(N, C, G):
+    from geotransformer_amd import kernels
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn(N, C, generator=g) * 3 + 1
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    res = torch.randn(N, C, generator=g)
+    want = F.group_norm(x.t().unsqueeze(0), G, w, b, 1e-5).squeeze(0).t()
+    got = kernels.group_norm(x.cuda(), G, w.cuda(), b.cuda()).cpu()
+    assert torch.allclose(got, want, **TOL)
+    got = kernels.group_norm(x.cuda(), G, w.cuda(), b.cuda(), residual=res.cuda(), act='leaky').cpu()
+    assert torch.allclose(got, F.leaky_relu(want + res, 0.1), **TOL)
+    if C <= 1024:
+        want = F.layer_norm(x + res, (C,), w, b)
+        got = kernels.layer_norm(x.cuda(), w.cuda(), b.cuda(), residual=res.cuda()).cpu()
+        assert torch.allclose(got, want, **TOL)
+
+
+@pytest.mark.parametrize('name', ['model_modelnet_small', 'model_3dmatch_small'])
+def test_backbone_matches_reference_golden(name):
+    """Whole KPConv-FPN on the GPU with the reference's weights and collated inputs vs the reference's activations."""
+    from geotransformer_amd.backbone import KPConvFPN
+    cfg, sd, data, out, mids = load_model_golden(name)
+    b = cfg.backbone
+    net = KPConvFPN(b.input_dim, b.output_dim, b.init_dim, b.kernel_size, b.init_radius, b.init_sigma, b.group_norm,
+                    num_stages=b.num_stages)
+    net.load_state_dict({k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')}, strict=True)
+    net = net.cuda().eval()
+    dev = {k: [t.cuda() for t in v] if isinstance(v, list) else v for k, v in data.items()}
+    with torch.no_grad():
+        feats = net(data['features'].cuda(), dev)
+    for got, key in ((feats[-1], 'feats_c_backbone'), (feats[0], 'feats_f_backbone')):
+        want = mids[key]
+        assert got.shape == want.shape
+        assert _mse(got.cpu(), want) <= 1e-6, key  # north_star: feature MSE <= 1e-4
+        assert torch.allclose(got.cpu(), want, atol=2e-3, rtol=2e-3), (key, float((got.cpu() - want).abs().max()))
