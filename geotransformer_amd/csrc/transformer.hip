@@ -1,0 +1,365 @@
+// transformer.hip -- Geometric Structure Embedding and RPE attention kernels for gfx950 (G1/G2/G3 of SURVEY.md 8a).
+//
+//   geotr_gse_knn      : k nearest superpoints per superpoint (geotransformer/modules/geotransformer/geotransformer.py:38-42)
+//   geotr_gse_embed    : embeddings[i,j,:] = proj_d(sinus(d_ij)) + max_x proj_a(sinus(a_ijx))      (:44-70,
+//                        transformer/positional_embedding.py:18-34).  Fused: the sinusoid rows are generated straight
+//                        into the LDS tile that feeds the MFMA A operand; the (N,N,k,D) sinusoid and projected tensors
+//                        of the reference (2 x 201 MB per cloud at N=256, D=256) never exist; max over the k angular
+//                        slots and both biases are applied in the accumulator epilogue.
+//   geotr_attn_softmax : scores = softmax_j((S_e[h,i,j] + e[i,j,:] . qt[i,h,:] + qb[i,h]) * scale) in place, where
+//                        qt = W_p[h]^T q[h] is the algebraic collapse of proj_p over the (N,N,D) embedding
+//                        (transformer/rpe_transformer.py:51-62).  With emb == NULL it is the plain
+//                        scaled softmax of transformer/vanilla_transformer.py:55-63.
+#include "common.h"
+
+namespace geotr {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ---------------------------------------------------------------------------------------------------
+// pairwise squared distance exactly as ops/pairwise_distance.py:23-30 (x2 - 2xy + y2, clamped at 0)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sq_norm3(const float* p) { return (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]; }
+__device__ __forceinline__ float expanded_sqdist(const float* a, const float* b) {
+  const float xy = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+  const float d = (sq_norm3(a) - 2.f * xy) + sq_norm3(b);
+  return fmaxf(d, 0.f);
+}
+
+constexpr int kMaxK = 4;  // angle_k <= 4 (every reference config uses 3)
+
+// one wave per point: (k+1) smallest distances by (distance, index); rank 0 (the presumed self) is dropped
+__global__ __launch_bounds__(256) void gse_knn_kernel(const float* __restrict__ pts, int n, int k, int* __restrict__ knn) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float pi[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  float bd[kMaxK + 1];
+  int bi[kMaxK + 1];
+#pragma unroll
+  for (int r = 0; r <= kMaxK; ++r) {
+    bd[r] = 3.4e38f;
+    bi[r] = 0x7fffffff;
+  }
+  for (int j = lane; j < n; j += 64) {
+    const float pj[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+    float d = sqrtf(expanded_sqdist(pi, pj));
+    int id = j;
+#pragma unroll
+    for (int r = 0; r <= kMaxK; ++r) {  // sorted insert (ascending by (d, idx))
+      const bool less = d < bd[r] || (d == bd[r] && id < bi[r]);
+      const float td = less ? bd[r] : d;
+      const int ti = less ? bi[r] : id;
+      bd[r] = less ? d : bd[r];
+      bi[r] = less ? id : bi[r];
+      d = td;
+      id = ti;
+    }
+  }
+  for (int r = 0; r <= k; ++r) {
+    // wave-wide argmin over the lanes' current heads
+    float d = bd[0];
+    int id = bi[0];
+    for (int o = 32; o > 0; o >>= 1) {
+      const float od = __shfl_xor(d, o, 64);
+      const int oi = __shfl_xor(id, o, 64);
+      if (od < d || (od == d && oi < id)) {
+        d = od;
+        id = oi;
+      }
+    }
+    if (bi[0] == id && bd[0] == d) {  // the winning lane pops its head
+#pragma unroll
+      for (int q = 0; q < kMaxK; ++q) {
+        bd[q] = bd[q + 1];
+        bi[q] = bi[q + 1];
+      }
+      bd[kMaxK] = 3.4e38f;
+      bi[kMaxK] = 0x7fffffff;
+    }
+    if (r > 0 && lane == 0) knn[i * k + (r - 1)] = id;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused GSE.  Block = 64 consecutive (i,j) pairs x all D output channels; wave w owns channels [32w, 32w+32).
+// Per K-chunk of 32: the block generates the sinusoid tile A_s[slot][pair][k] (slot 0 = distance, 1..k = angles) and
+// stages W_d / W_a rows; each wave then issues 16 k-steps x (2 row tiles x (1+k) slots) MFMAs.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kGsePairs = 64;
+constexpr int kGseBK = 32;
+constexpr int kGseStride = kGseBK + 1;
+
+template <int D, int S>  // S = 1 + angle_k slots
+__global__ __launch_bounds__(64 * (D / 32)) void gse_embed_kernel(const float* __restrict__ pts, const int* __restrict__ knn,
+                                                                  int n, const float* __restrict__ div_term,
+                                                                  const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                                  const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                                  float inv_sigma_d, float factor_a,
+                                                                  float* __restrict__ out) {
+  constexpr int T = 64 * (D / 32);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* A_s = smem;                                   // [S][64][33]
+  float* W_s = A_s + S * kGsePairs * kGseStride;       // [2][D][33]
+  float* idx_s = W_s + 2 * D * kGseStride;             // [S][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t total = (int64_t)n * n;
+  const int64_t p0 = (int64_t)blockIdx.x * kGsePairs;
+
+  // ---- embedding indices of the block's pairs (geotransformer.py:36-53) ----
+  for (int e = tid; e < kGsePairs; e += T) {
+    const int64_t p = p0 + e;
+    float vals[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) vals[s] = 0.f;
+    if (p < total) {
+      const int i = (int)(p / n), j = (int)(p - (int64_t)i * n);
+      const float pi[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+      const float pj[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+      vals[0] = sqrtf(expanded_sqdist(pi, pj)) * inv_sigma_d;
+      const float ax = pj[0] - pi[0], ay = pj[1] - pi[1], az = pj[2] - pi[2];  // anchor vector
+#pragma unroll
+      for (int x = 0; x < S - 1; ++x) {
+        const int q = knn[i * (S - 1) + x];
+        const float rx = pts[3 * q] - pi[0], ry = pts[3 * q + 1] - pi[1], rz = pts[3 * q + 2] - pi[2];
+        const float cx = ry * az - rz * ay, cy = rz * ax - rx * az, cz = rx * ay - ry * ax;
+        const float sinv = sqrtf((cx * cx + cy * cy) + cz * cz);
+        // torch.sum starts from +0, so an all-(-0) dot product (anchor == 0 on the diagonal) is +0 there:
+        // keep atan2(+0, +0) = 0 instead of atan2(+0, -0) = pi
+        const float cosv = ((rx * ax + ry * ay) + rz * az) + 0.0f;
+        vals[1 + x] = atan2f(sinv, cosv) * factor_a;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) idx_s[s * kGsePairs + e] = vals[s];
+  }
+
+  f32x16 acc[2][S];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[r][s][q] = 0.f;
+
+  const int fr = lane & 31, fk = lane >> 5;
+  for (int k0 = 0; k0 < D; k0 += kGseBK) {
+    __syncthreads();  // previous chunk's MFMAs are done with A_s / W_s (and idx_s is complete on the first pass)
+    // ---- sinusoid tile: emb[2t] = sin(idx * w_t), emb[2t+1] = cos(idx * w_t)  (positional_embedding.py:28-32) ----
+    for (int e = tid; e < S * kGsePairs * (kGseBK / 2); e += T) {
+      const int t = e % (kGseBK / 2);
+      const int row = e / (kGseBK / 2);  // slot * 64 + pair
+      const float omega = idx_s[row] * div_term[(k0 >> 1) + t];
+      float sv, cv;
+      sincosf(omega, &sv, &cv);
+      A_s[row * kGseStride + 2 * t] = sv;
+      A_s[row * kGseStride + 2 * t + 1] = cv;
+    }
+    // ---- weight rows: W_s[m][col][kk] = W_m[col][k0 + kk] ----
+    for (int e = tid; e < 2 * D * (kGseBK / 4); e += T) {
+      const int kq = (e % (kGseBK / 4)) * 4;
+      const int row = e / (kGseBK / 4);  // m * D + col
+      const float* src = (row < D ? Wd + (int64_t)row * D : Wa + (int64_t)(row - D) * D) + k0 + kq;
+      const float4 v = *reinterpret_cast<const float4*>(src);
+      float* d = W_s + row * kGseStride + kq;
+      d[0] = v.x;
+      d[1] = v.y;
+      d[2] = v.z;
+      d[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int ks = 0; ks < kGseBK / 2; ++ks) {
+      const int kk = 2 * ks + fk;
+      const float b_d = W_s[(32 * wave + fr) * kGseStride + kk];
+      const float b_a = W_s[(D + 32 * wave + fr) * kGseStride + kk];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const float a = A_s[(s * kGsePairs + 32 * r + fr) * kGseStride + kk];
+          acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s == 0 ? b_d : b_a, acc[r][s], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- epilogue: d-part + max over angular slots + both biases (geotransformer.py:60-70) ----
+  const int col = 32 * wave + fr;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int64_t p = p0 + 32 * r + (q & 3) + 8 * (q >> 2) + 4 * fk;
+      if (p >= total) continue;
+      float m = acc[r][1][q];
+#pragma unroll
+      for (int s = 2; s < S; ++s) m = fmaxf(m, acc[r][s][q]);
+      out[p * D + col] = (acc[r][0][q] + bd[col]) + (m + ba[col]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// attention scores: positional term + scale + softmax, one block per query row
+// ---------------------------------------------------------------------------------------------------
+constexpr int kAttTile = 64;  // keys per tile
+
+__global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ scores, const float* __restrict__ emb,
+                                                           const float* __restrict__ qt, const float* __restrict__ qb,
+                                                           int n, int m, int C, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sc_s = smem;                 // [H][m]
+  float* qt_s = sc_s + H * m;         // [C][H]
+  float* part_s = qt_s + C * H;       // [4][H][64]
+  float* e_s = part_s + 4 * H * kAttTile;  // [64][C + 1]
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int es = C + 1;
+  for (int e = tid; e < H * m; e += 256) sc_s[e] = scores[((int64_t)(e / m) * n + i) * m + (e % m)];
+  if (emb) {
+    for (int e = tid; e < C * H; e += 256) {
+      const int c = e / H, h = e % H;
+      qt_s[e] = qt[((int64_t)i * H + h) * C + c];
+    }
+    const float* erow = emb + (int64_t)i * m * C;
+    for (int j0 = 0; j0 < m; j0 += kAttTile) {
+      __syncthreads();
+      const int rows = min(kAttTile, m - j0);
+      for (int e = tid; e < rows * (C / 4); e += 256) {  // coalesced float4 loads of the (rows, C) tile
+        const int r = e / (C / 4), c4 = (e % (C / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(erow + (int64_t)(j0 + r) * C + c4);
+        float* d = e_s + r * es + c4;
+        d[0] = v.x;
+        d[1] = v.y;
+        d[2] = v.z;
+        d[3] = v.w;
+      }
+      __syncthreads();
+      // wave w reduces channels [w*C/4, (w+1)*C/4) for key j0 + lane, all heads
+      float accv[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) accv[h] = 0.f;
+      if (lane < rows) {
+        const int c0 = wave * (C / 4), c1 = c0 + C / 4;
+        for (int c = c0; c < c1; ++c) {
+          const float ev = e_s[lane * es + c];
+#pragma unroll
+          for (int h = 0; h < 8; ++h)
+            if (h < H) accv[h] = fmaf(ev, qt_s[c * H + h], accv[h]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 8; ++h)
+        if (h < H) part_s[(wave * H + h) * kAttTile + lane] = accv[h];
+      __syncthreads();
+      for (int e = tid; e < H * rows; e += 256) {
+        const int h = e / rows, j = e % rows;
+        float p = 0.f;
+        for (int w = 0; w < 4; ++w) p += part_s[(w * H + h) * kAttTile + j];
+        sc_s[h * m + j0 + j] += p + qb[i * H + h];
+      }
+    }
+  }
+  __syncthreads();
+  // softmax over keys, wave per head (heads >= 4 are handled round-robin)
+  for (int h = wave; h < H; h += 4) {
+    float mx = -3.4e38f;
+    for (int j = lane; j < m; j += 64) mx = fmaxf(mx, sc_s[h * m + j] * scale);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = lane; j < m; j += 64) {
+      const float ev = expf(sc_s[h * m + j] * scale - mx);
+      sc_s[h * m + j] = ev;
+      sum += ev;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.f / sum;
+    float* dst = scores + ((int64_t)h * n + i) * m;
+    for (int j = lane; j < m; j += 64) dst[j] = sc_s[h * m + j] * inv;
+  }
+}
+
+}  // namespace geotr
+
+using namespace geotr;
+
+extern "C" {
+
+int geotr_gse_knn(const float* points, int64_t n, int64_t k, int32_t* knn, void* stream) {
+  GEOTR_CHECK_ARG(n >= 0 && k >= 1 && k <= kMaxK, "gse_knn: k must be in [1, %d]", kMaxK);
+  GEOTR_CHECK_ARG(n == 0 || n > k, "gse_knn: need more than k points");
+  if (n == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(points && knn, "gse_knn: null pointer");
+  gse_knn_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(points, (int)n, (int)k, knn);
+  GEOTR_CHECK_LAUNCH("gse_knn");
+  return GEOTR_OK;
+}
+
+}  // extern "C"
+
+template <int D>
+static int launch_gse(int k, const float* pts, const int* knn, int n, const float* div_term, const float* Wd,
+                      const float* bd, const float* Wa, const float* ba, float inv_sigma_d, float factor_a, float* out,
+                      hipStream_t stream) {
+  const int64_t total = (int64_t)n * n;
+  const unsigned nb = (unsigned)((total + kGsePairs - 1) / kGsePairs);
+  const int S = 1 + k;
+  const size_t lds = sizeof(float) * ((size_t)S * kGsePairs * kGseStride + 2 * (size_t)D * kGseStride + (size_t)S * kGsePairs);
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(GEOTR_E_LAUNCH, "gse_embed: cannot reserve %zu B of LDS", lds);
+    kern<<<dim3(nb), dim3(64 * (D / 32)), lds, stream>>>(pts, knn, n, div_term, Wd, bd, Wa, ba, inv_sigma_d, factor_a, out);
+    return GEOTR_OK;
+  };
+  switch (S) {
+    case 2: return go(gse_embed_kernel<D, 2>);
+    case 3: return go(gse_embed_kernel<D, 3>);
+    case 4: return go(gse_embed_kernel<D, 4>);
+    default: return go(gse_embed_kernel<D, 5>);
+  }
+}
+
+extern "C" {
+
+int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t k, int64_t d, const float* div_term,
+                    const float* w_d, const float* b_d, const float* w_a, const float* b_a, float sigma_d, float sigma_a,
+                    float* out, void* stream_) {
+  GEOTR_CHECK_ARG(n >= 0 && k >= 1 && k <= kMaxK, "gse_embed: angle_k must be in [1, %d]", kMaxK);
+  GEOTR_CHECK_ARG(d == 32 || d == 64 || d == 128 || d == 256, "gse_embed: hidden_dim must be 32, 64, 128 or 256 (got %lld)",
+                  (long long)d);
+  if (n == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(points && knn && div_term && w_d && b_d && w_a && b_a && out, "gse_embed: null pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const float inv_sigma_d = 1.0f / sigma_d;
+  const float factor_a = (float)(180.0 / ((double)sigma_a * 3.14159265358979323846));  // geotransformer.py:14
+  int rc;
+  switch (d) {
+    case 32: rc = launch_gse<32>((int)k, points, knn, (int)n, div_term, w_d, b_d, w_a, b_a, inv_sigma_d, factor_a, out, stream); break;
+    case 64: rc = launch_gse<64>((int)k, points, knn, (int)n, div_term, w_d, b_d, w_a, b_a, inv_sigma_d, factor_a, out, stream); break;
+    case 128: rc = launch_gse<128>((int)k, points, knn, (int)n, div_term, w_d, b_d, w_a, b_a, inv_sigma_d, factor_a, out, stream); break;
+    default: rc = launch_gse<256>((int)k, points, knn, (int)n, div_term, w_d, b_d, w_a, b_a, inv_sigma_d, factor_a, out, stream); break;
+  }
+  if (rc != GEOTR_OK) return rc;
+  GEOTR_CHECK_LAUNCH("gse_embed");
+  return GEOTR_OK;
+}
+
+int geotr_attn_softmax(float* scores, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m, int64_t c,
+                       int64_t heads, float scale, void* stream_) {
+  GEOTR_CHECK_ARG(n >= 0 && m >= 1 && heads >= 1 && heads <= 8, "attn_softmax: bad sizes (heads <= 8)");
+  if (n == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(scores && (!emb || (qt && qb)), "attn_softmax: null pointer");
+  GEOTR_CHECK_ARG(!emb || (c % 16 == 0 && c <= 512), "attn_softmax: channels must be a multiple of 16, <= 512");
+  hipStream_t stream = (hipStream_t)stream_;
+  size_t lds = sizeof(float) * (size_t)(heads * m);
+  if (emb) lds += sizeof(float) * (size_t)(c * heads + 4 * heads * kAttTile + kAttTile * (c + 1));
+  if (lds > 160 * 1024) return fail(GEOTR_E_CAPACITY, "attn_softmax: %lld keys need %zu B of LDS", (long long)m, lds);
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_softmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return fail(GEOTR_E_LAUNCH, "attn_softmax: cannot reserve %zu B of LDS", lds);
+  attn_softmax_kernel<<<dim3((unsigned)n), dim3(256), lds, stream>>>(scores, emb, qt, qb, (int)n, (int)m, (int)c, (int)heads, scale);
+  GEOTR_CHECK_LAUNCH("attn_softmax");
+  return GEOTR_OK;
+}
+
+}  // extern "C"

@@ -134,3 +134,38 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None):
     _lib.check(lib.geotr_layer_norm(_lib.ptr(x2), _lib.ptr(r2), x2.shape[0], x2.shape[1], _lib.ptr(weight), _lib.ptr(bias),
                                     float(eps), _lib.ptr(out), _lib.stream_ptr()), 'geotr_layer_norm')
     return out.view(shape)
+
+
+def gse_knn(points, k):
+    """(n, k) int32 indices of the k nearest other points (reference: dist_map.topk(k+1)[..., 1:])."""
+    lib = _lib.load()
+    points = _f32c(points)
+    knn = torch.empty((points.shape[0], k), dtype=torch.int32, device=points.device)
+    _lib.check(lib.geotr_gse_knn(_lib.ptr(points), points.shape[0], k, _lib.ptr(knn), _lib.stream_ptr()), 'geotr_gse_knn')
+    return knn
+
+
+def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a):
+    """(n, n, D) geometric structure embedding of one cloud (n, 3)."""
+    lib = _lib.load()
+    points = _f32c(points)
+    n, d = points.shape[0], w_d.shape[0]
+    out = torch.empty((n, n, d), dtype=torch.float32, device=points.device)
+    _lib.check(lib.geotr_gse_embed(_lib.ptr(points), _lib.ptr(knn), n, knn.shape[1], d, _lib.ptr(_f32c(div_term)),
+                                   _lib.ptr(_f32c(w_d)), _lib.ptr(b_d), _lib.ptr(_f32c(w_a)), _lib.ptr(b_a), float(sigma_d),
+                                   float(sigma_a), _lib.ptr(out), _lib.stream_ptr()), 'geotr_gse_embed')
+    return out
+
+
+def attn_softmax(scores, scale, emb=None, qt=None, qb=None):
+    """In-place softmax over the last dim of scores (H, n, m); with `emb` adds the relative-position term first."""
+    lib = _lib.load()
+    assert scores.is_contiguous()
+    H, n, m = scores.shape
+    c = 0
+    if emb is not None:
+        emb, qt, qb = _f32c(emb), _f32c(qt), _f32c(qb)
+        c = emb.shape[-1]
+    _lib.check(lib.geotr_attn_softmax(_lib.ptr(scores), _lib.ptr(emb), _lib.ptr(qt), _lib.ptr(qb), n, m, c, H, float(scale),
+                                      _lib.stream_ptr()), 'geotr_attn_softmax')
+    return scores

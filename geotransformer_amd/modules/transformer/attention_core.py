@@ -1,0 +1,35 @@
+"""Shared multi-head attention core on the HIP kernels (batch of one cloud, as the reference model uses it)."""
+from ... import kernels
+
+
+def _check_unsupported(**kwargs):
+    for name, value in kwargs.items():
+        if value is not None:
+            raise NotImplementedError(f'{name} is not used by the registration hot path and is not implemented')
+
+
+def multi_head_attention(q, k, v, num_heads, emb=None, w_p=None, b_p=None):
+    """q (n, C), k/v (m, C) already projected.  Returns (hidden (n, C), probabilities (H, n, m)).
+
+    scores = softmax((q_h k_h^T + q_h . (W_p e + b_p)_h) / sqrt(C/H)); the second term is evaluated as
+    e . (W_p[h]^T q_h) + q_h . b_p[h] (exact algebra), so `proj_p` over the (n, m, C)
+    embedding is never computed.
+    """
+    n, C = q.shape
+    m = k.shape[0]
+    H, ch = num_heads, C // num_heads
+    q3 = q.view(n, H, ch).permute(1, 0, 2)  # (H, n, ch) strided views, no copies
+    k3 = k.view(m, H, ch).permute(1, 0, 2)
+    v3 = v.view(m, H, ch).permute(1, 0, 2)
+    scores = kernels.gemm(q3, k3)  # (H, n, m) = q_h k_h^T
+    if emb is not None:
+        qt = q.new_empty((n, H, C))
+        kernels.gemm(q3, w_p.view(H, ch, C), b_is_kn=True, out=qt.permute(1, 0, 2))  # qt[:, h, :] = q_h W_p[h]
+        qb = q.new_empty((n, H))
+        kernels.gemm(q3, b_p.view(H, ch, 1), b_is_kn=True, out=qb.t().unsqueeze(2))   # qb[:, h] = q_h . b_p[h]
+        kernels.attn_softmax(scores, 1.0 / ch ** 0.5, emb=emb, qt=qt, qb=qb)
+    else:
+        kernels.attn_softmax(scores, 1.0 / ch ** 0.5)
+    hidden = q.new_empty((n, C))
+    kernels.gemm(scores, v3, b_is_kn=True, out=hidden.view(n, H, ch).permute(1, 0, 2))
+    return hidden, scores

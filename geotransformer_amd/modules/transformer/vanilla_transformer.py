@@ -1,0 +1,64 @@
+"""Cross-attention layers (mirror of geotransformer/modules/transformer/vanilla_transformer.py:15-135)."""
+import torch.nn as nn
+
+from ... import kernels
+from .attention_core import _check_unsupported, multi_head_attention
+from .output_layer import AttentionOutput
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, d_model, num_heads, dropout=None):
+        super().__init__()
+        if d_model % num_heads != 0:
+            raise ValueError('`d_model` ({}) must be a multiple of `num_heads` ({}).'.format(d_model, num_heads))
+        if dropout is not None:
+            raise NotImplementedError('inference path: dropout=None')
+        self.d_model = d_model
+        self.num_heads = num_heads
+        self.d_model_per_head = d_model // num_heads
+        self.proj_q = nn.Linear(d_model, d_model)
+        self.proj_k = nn.Linear(d_model, d_model)
+        self.proj_v = nn.Linear(d_model, d_model)
+
+    def forward(self, input_q, input_k, input_v, key_weights=None, key_masks=None, attention_factors=None,
+                attention_masks=None):
+        _check_unsupported(key_weights=key_weights, key_masks=key_masks, attention_factors=attention_factors,
+                           attention_masks=attention_masks)
+        if input_q.shape[0] != 1:
+            raise NotImplementedError('batch size 1 (one cloud per call), as in the reference model')
+        q = kernels.linear(input_q[0], self.proj_q.weight, self.proj_q.bias)
+        k = kernels.linear(input_k[0], self.proj_k.weight, self.proj_k.bias)
+        v = kernels.linear(input_v[0], self.proj_v.weight, self.proj_v.bias)
+        hidden, probs = multi_head_attention(q, k, v, self.num_heads)
+        return hidden.unsqueeze(0), probs.unsqueeze(0)
+
+
+class AttentionLayer(nn.Module):
+    def __init__(self, d_model, num_heads, dropout=None):
+        super().__init__()
+        self.attention = MultiHeadAttention(d_model, num_heads, dropout=dropout)
+        self.linear = nn.Linear(d_model, d_model)
+        self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, input_states, memory_states, memory_weights=None, memory_masks=None, attention_factors=None,
+                attention_masks=None):
+        hidden, scores = self.attention(input_states, memory_states, memory_states, key_weights=memory_weights,
+                                        key_masks=memory_masks, attention_factors=attention_factors,
+                                        attention_masks=attention_masks)
+        hidden = kernels.linear(hidden, self.linear.weight, self.linear.bias)
+        out = kernels.layer_norm(hidden, self.norm.weight, self.norm.bias, self.norm.eps, residual=input_states)
+        return out, scores
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, d_model, num_heads, dropout=None, activation_fn='ReLU'):
+        super().__init__()
+        self.attention = AttentionLayer(d_model, num_heads, dropout=dropout)
+        self.output = AttentionOutput(d_model, dropout=dropout, activation_fn=activation_fn)
+
+    def forward(self, input_states, memory_states, memory_weights=None, memory_masks=None, attention_factors=None,
+                attention_masks=None):
+        hidden, scores = self.attention(input_states, memory_states, memory_weights=memory_weights,
+                                        memory_masks=memory_masks, attention_factors=attention_factors,
+                                        attention_masks=attention_masks)
+        return self.output(hidden), scores

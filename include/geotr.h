@@ -124,6 +124,26 @@ int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const
 int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c, const float* gamma, const float* beta,
                      float eps, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * G1/G2/G3  geometric transformer pieces
+ *   geotr_gse_knn      : knn[i, :k] = the k nearest other superpoints of superpoint i, by (distance, index), where
+ *                        distance = sqrt(clamp(|x|^2 - 2xy + |y|^2, 0)); rank 0 (the presumed self) is dropped
+ *                                              geotransformer/modules/geotransformer/geotransformer.py:38-42
+ *   geotr_gse_embed    : out[i,j,:] = W_d sin/cos(d_ij/sigma_d * w) + b_d + max_x (W_a sin/cos(angle_ijx*180/(sigma_a*pi) * w) + b_a)
+ *                        (n,n,d) fp32; div_term (d/2) = the reference's registered buffer exp(-2t ln(1e4)/d)
+ *                                              geotransformer.py:26-72, transformer/positional_embedding.py:8-34
+ *   geotr_attn_softmax : scores (heads,n,m) <- softmax_m((scores + emb[i,j,:] . qt[i,h,:] + qb[i,h]) * scale), in place.
+ *                        qt (n,heads,c) = W_p[h]^T q[h], qb (n,heads) = q[h] . b_p[h]: the exact algebraic collapse of
+ *                        proj_p over the (n,m,c) embedding.  emb == NULL: plain scaled softmax.
+ *                                              transformer/rpe_transformer.py:51-66, vanilla_transformer.py:55-63
+ * ---------------------------------------------------------------------------------------------- */
+int geotr_gse_knn(const float* points, int64_t n, int64_t k, int32_t* knn, void* stream);
+int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t k, int64_t d, const float* div_term,
+                    const float* w_d, const float* b_d, const float* w_a, const float* b_a, float sigma_d, float sigma_a,
+                    float* out, void* stream);
+int geotr_attn_softmax(float* scores, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m, int64_t c,
+                       int64_t heads, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
