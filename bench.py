@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py -- registration pairs/sec of the HIP hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the whole hot path over one synthetic 3DMatch-shape pair (BASELINE config 2: ~20k + 20k points,
+4-stage KPConv-FPN, d = 256): the collate-equivalent pyramid (3 grid subsamples + 10 radius searches) plus the full
+GeoTransformer forward through `estimated_transform`.  Inputs (raw xyz) are resident in HBM when the timed region
+starts; weights are random-init (seed 7351), data synthetic.  At N > 1 every rank processes its own pairs (weak
+scaling, pairs are independent): weights are broadcast once from rank 0 over RCCL and the per-pair transforms are
+all-gathered inside the timed region.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     : dominant kernel (fused GSE embedding, MFMA fp32) -- algorithmic FLOPs / launch over the HIP-event
+                 average launch duration measured live in the timed region, vs the 157.3 TFLOP/s fp32-matrix peak
+  cpu_baseline : the CPU oracle (reference C++ neighbour cores from oracle/_ref when present, else the restatement,
+                 + the torch-fp32 restatement of the model) timed on this box's host cores on ONE pair.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+
+def build_pair(seed, config, n_points):
+    from geotransformer_amd.synthetic import make_pair
+    return make_pair(seed, config, n_points=n_points)
+
+
+def cpu_baseline(cfg, item, model):
+    """Oracle on the host CPU for one pair: neighbour pyramid + model forward (both are checkers, see oracle/)."""
+    from oracle import model_oracle as mo
+    from oracle import neighbors as on
+    lib = on.reference()
+    kind_nb = 'reference C++ cores (oracle/_ref)'
+    if lib is None:
+        lib = on.restated()
+        kind_nb = 'restated C++ (oracle/neighbors_oracle.cpp)'
+    pts = np.concatenate([item['ref_points'], item['src_points']])
+    lens = np.array([len(item['ref_points']), len(item['src_points'])], dtype=np.int64)
+    b = cfg.backbone
+    t0 = time.perf_counter()
+    pyr = on.precompute_pyramid(lib, pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, list(cfg.neighbor_limits))
+    t_collate = time.perf_counter() - t0
+    data = {k: [torch.from_numpy(np.ascontiguousarray(a)) for a in v] for k, v in pyr.items()}
+    data['features'] = torch.ones((pts.shape[0], 1))
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ocfg = mo.config_from_reference(cfg)
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    out = mo.forward(sd, ocfg, data)
+    t_forward = time.perf_counter() - t0
+    return {
+        'value': 1.0 / (t_collate + t_forward), 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+        'sample': f'1 pair of the same workload, no warm-up: collate {t_collate:.2f} s (1 thread, {kind_nb}) + '
+                  f'forward {t_forward:.2f} s (torch fp32 restatement, all cores)',
+        'collate_s': round(t_collate, 3), 'forward_s': round(t_forward, 3),
+    }, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='3dmatch', choices=['3dmatch', 'modelnet', 'kitti'])
+    ap.add_argument('--points', type=int, default=None, help='points per cloud (default: the config\'s)')
+    ap.add_argument('--pairs', type=int, default=4, help='distinct synthetic pairs cycled through per rank')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from geotransformer_amd import _lib, kernels
+    from geotransformer_amd import dist as gd
+    from geotransformer_amd.config import make_cfg
+    from geotransformer_amd.pipeline import RegistrationPipeline
+    from geotransformer_amd.synthetic import CONFIGS
+
+    _lib.require_gpu()
+    _lib.load()
+    rank, world, local = gd.init_from_env()
+    assert world == args.gpus or world == 1, f'launched with WORLD_SIZE={world} but --gpus {args.gpus}'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    cfg = make_cfg(args.config)
+    n_points = args.points or CONFIGS[args.config]['n_points']
+    torch.manual_seed(cfg.seed)
+    np.random.seed(cfg.seed)
+    pipe = RegistrationPipeline(cfg, device=device, exact_width=False)
+    gd.broadcast_module(pipe.model, src=0)  # one RCCL broadcast of the flat parameter buffer
+
+    # synthetic pairs of this rank, resident in HBM before the timed region
+    items = [build_pair(1000 * rank + i, args.config, n_points) for i in range(args.pairs)]
+    pairs = [(torch.from_numpy(it['ref_points']).to(device), torch.from_numpy(it['src_points']).to(device)) for it in items]
+
+    results = torch.zeros((args.steps, 4, 4), dtype=torch.float32, device=device)
+    info = {}
+
+    def step(i, record=None):
+        ref, src = pairs[i % len(pairs)]
+        out = pipe(ref, src)
+        if record is not None:
+            results[record] = out['estimated_transform']
+        return out
+
+    for i in range(args.warmup):
+        out = step(i)
+    info['superpoints'] = [int(out['ref_points_c'].shape[0]), int(out['src_points_c'].shape[0])]
+    info['stage_points'] = None
+
+    kernels.PROFILE['gse_embed'] = []  # HIP-event pairs around the dominant kernel, on the launch stream
+    gd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, record=i)
+    gathered = gd.gather_results(results)  # (world, steps, 4, 4) -- the only collective on the data path
+    gd.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = gd.max_over_ranks(elapsed, device)
+    events = kernels.PROFILE.pop('gse_embed')
+    kernels.PROFILE.clear()
+
+    if rank == 0:
+        assert torch.isfinite(gathered).all()
+        total_pairs = args.steps * world
+        value = total_pairs / elapsed
+        # roofline of the dominant kernel: 2 * n^2 * (1 + k) * D^2 FLOPs per launch (proj_d + k x proj_a)
+        D, k = cfg.geotransformer.hidden_dim, cfg.geotransformer.angle_k
+        durs = [s.elapsed_time(e) * 1e-3 for s, e, _ in events]
+        flops = [2.0 * n * n * (1 + k) * D * D for _, _, n in events]
+        achieved = (sum(flops) / sum(durs)) / 1e12 if durs else None
+        line = {
+            'metric': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)', 'value': round(value, 3), 'unit': 'pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[1]: synthetic {args.config} pair, {n_points}+{n_points} pts, '
+                                   f'{cfg.backbone.num_stages}-stage KPConv-FPN, d={D}, '
+                                   f'{info["superpoints"][0]}+{info["superpoints"][1]} superpoints, '
+                                   f'P={cfg.coarse_matching.num_correspondences}, K={cfg.model.num_points_in_patch}, '
+                                   f'pyramid + full forward per pair',
+                       'pairs_per_step_per_gpu': 1, 'parallelism': f'pairs sharded over {world} GPU(s), no data-path collective',
+                       'weights': 'random init, seed 7351'},
+            'roofline': {'bound': 'mfma', 'kernel': 'gse_embed_kernel<256,4> (fused GSE: sinusoid -> fp32 MFMA -> max_k)',
+                         'achieved': round(achieved, 2) if achieved else None, 'peak': FP32_MATRIX_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4) if achieved else None,
+                         'traffic': None, 'launches': len(durs),
+                         'avg_launch_us': round(1e6 * sum(durs) / len(durs), 1) if durs else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, _ = cpu_baseline(cfg, items[0], pipe.model)
+            line['cpu_baseline'] = base
+            line['speedup_vs_cpu_baseline'] = round(value / base['value'], 1)
+        print(json.dumps(line))
+    gd.barrier()
+
+
+if __name__ == '__main__':
+    main()

@@ -41,6 +41,15 @@ SIGNATURES = {
     'geotr_gse_embed': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_ptr,
                                 c_ptr]),
     'geotr_attn_softmax': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr]),
+    'geotr_point_to_node': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'geotr_superpoint_match': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                       c_ptr, c_ptr]),
+    'geotr_patch_sinkhorn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr,
+                                     c_i64, c_ptr, c_ptr, c_ptr]),
+    'geotr_weighted_procrustes': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'geotr_lgr_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
+    'geotr_lgr': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_int, c_f32, c_i64,
+                          c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
 }
 
 _lib = None

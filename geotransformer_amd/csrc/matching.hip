@@ -1,0 +1,429 @@
+// matching.hip -- superpoint partition, coarse matching, patch scores + log-Sinkhorn (P1/M1/S1/S2 of SURVEY.md 8a).
+//
+//   geotr_point_to_node   : geotransformer/modules/ops/pointcloud_partition.py:61-107
+//   geotr_superpoint_match: geotransformer/modules/geotransformer/superpoint_matching.py:13-50 (scores from a GEMM)
+//   geotr_patch_sinkhorn  : experiments/.../model.py:169-189 (gather + einsum) fused with
+//                           geotransformer/modules/sinkhorn/learnable_sinkhorn.py:13-66 (100 log-domain iterations with
+//                           the (K+1)x(K+1) matrix resident in LDS)
+#include <algorithm>
+
+#include "common.h"
+
+namespace geotr {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float sqn3(const float* p) { return (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]; }
+// ops/pairwise_distance.py:23-30: x2 - 2xy + y2, clamped at 0
+__device__ __forceinline__ float sqdist_expanded(const float* a, const float* b) {
+  const float xy = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+  return fmaxf((sqn3(a) - 2.f * xy) + sqn3(b), 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// P1: point -> nearest node, then per node the K nearest owned points
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void p2n_assign_kernel(const float* __restrict__ pts, int64_t N, const float* __restrict__ nodes,
+                                                         int M, int64_t* __restrict__ point_to_node,
+                                                         unsigned char* __restrict__ node_masks) {
+  extern __shared__ float nd[];  // [M][3]
+  for (int e = threadIdx.x; e < 3 * M; e += blockDim.x) nd[e] = nodes[e];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  float best = 3.4e38f;
+  int bi = 0;
+  for (int m = 0; m < M; ++m) {
+    const float d = sqdist_expanded(nd + 3 * m, p);
+    if (d < best) {  // first minimum wins, like Tensor.min(dim)
+      best = d;
+      bi = m;
+    }
+  }
+  point_to_node[i] = bi;
+  node_masks[bi] = 1;
+}
+
+constexpr int kP2nCap = 4096;  // owned points per node kept in LDS
+
+__global__ __launch_bounds__(256) void p2n_knn_kernel(const float* __restrict__ pts, int64_t N, const float* __restrict__ nodes,
+                                                      const int64_t* __restrict__ point_to_node, int K,
+                                                      int64_t* __restrict__ knn_idx, unsigned char* __restrict__ knn_mask,
+                                                      int* __restrict__ overflow) {
+  __shared__ unsigned long long keys[kP2nCap];
+  __shared__ int cnt;
+  const int node = blockIdx.x;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const float nd[3] = {nodes[3 * node], nodes[3 * node + 1], nodes[3 * node + 2]};
+  for (int64_t i = threadIdx.x; i < N; i += blockDim.x) {
+    if (point_to_node[i] != node) continue;
+    const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    const float d = sqdist_expanded(nd, p);
+    const int pos = atomicAdd(&cnt, 1);
+    if (pos < kP2nCap) keys[pos] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+  }
+  __syncthreads();
+  int c = cnt;
+  if (c > kP2nCap) {
+    if (threadIdx.x == 0) atomicMax(overflow, c);
+    c = kP2nCap;
+  }
+  for (int e = threadIdx.x; e < c; e += blockDim.x) {
+    const unsigned long long mine = keys[e];
+    int rank = 0;
+    for (int j = 0; j < c; ++j) rank += keys[j] < mine;
+    if (rank < K) {
+      knn_idx[(int64_t)node * K + rank] = (int64_t)(unsigned)(mine & 0xffffffffull);
+      knn_mask[(int64_t)node * K + rank] = 1;
+    }
+  }
+  for (int j = c + threadIdx.x; j < K; j += blockDim.x) {  // fewer owned points than K: pad index = N, mask False
+    knn_idx[(int64_t)node * K + j] = N;
+    knn_mask[(int64_t)node * K + j] = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// M1: coarse matching.  xy (n,m) = ref_feats . src_feats^T comes from gemm.hip.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spm_exp_kernel(float* __restrict__ s, int n, int m, const unsigned char* __restrict__ rmask,
+                                                      const unsigned char* __restrict__ cmask, float* __restrict__ rowsum) {
+  __shared__ float red[4];
+  const int i = blockIdx.x;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    float v = 0.f;
+    if (rmask[i] && cmask[j]) v = expf(-fmaxf(2.f - 2.f * s[(int64_t)i * m + j], 0.f));  // exp(-pairwise_distance(normalized))
+    s[(int64_t)i * m + j] = v;
+    acc += v;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) rowsum[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void spm_colsum_kernel(const float* __restrict__ s, int n, int m, float* __restrict__ colsum) {
+  __shared__ float red[4][64];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (j < m)
+    for (int i = part; i < n; i += 4) acc += s[(int64_t)i * m + j];
+  red[part][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (part == 0 && j < m) colsum[j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void spm_dual_kernel(float* __restrict__ s, int n, int m, const float* __restrict__ rowsum, const float* __restrict__ colsum,
+                                const unsigned char* __restrict__ rmask, const unsigned char* __restrict__ cmask, int dual) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)n * m) return;
+  const int i = (int)(e / m), j = (int)(e % m);
+  if (!(rmask[i] && cmask[j])) {
+    s[e] = -1.f;  // excluded from the top-k (valid scores are >= 0)
+    return;
+  }
+  if (dual) s[e] = (s[e] / rowsum[i]) * (s[e] / colsum[j]);
+}
+
+// top-k (largest) of a non-negative score matrix by three radix-histogram passes over the float bits, one block.
+constexpr int kTopkCap = 8192;
+__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ s, int64_t total, int k, int m, int64_t* __restrict__ rows,
+                                                    int64_t* __restrict__ cols, float* __restrict__ vals, int* __restrict__ count_out) {
+  __shared__ unsigned hist[2048];
+  __shared__ unsigned long long cand[kTopkCap];
+  __shared__ unsigned sel_prefix, sel_remaining;
+  __shared__ int ncand, nvalid;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    sel_prefix = 0;
+    ncand = 0;
+    nvalid = 0;
+  }
+  __syncthreads();
+  // number of valid entries (score >= 0) bounds k (superpoint_matching.py:42)
+  int local = 0;
+  for (int64_t e = tid; e < total; e += 1024) local += s[e] >= 0.f;
+  atomicAdd(&nvalid, local);
+  __syncthreads();
+  const int keff = min(k, nvalid);
+  if (tid == 0) {
+    *count_out = keff;
+    sel_remaining = (unsigned)keff;
+  }
+  __syncthreads();
+  if (keff == 0) return;
+  // pass p looks at bits [shift, shift+width) among the elements whose higher bits equal sel_prefix
+  const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+  unsigned maskhi = 0;
+  for (int p = 0; p < 3; ++p) {
+    for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
+    __syncthreads();
+    const unsigned prefix = sel_prefix;
+    for (int64_t e = tid; e < total; e += 1024) {
+      const float v = s[e];
+      if (v < 0.f) continue;
+      const unsigned u = __float_as_uint(v);
+      if ((u & maskhi) == prefix) atomicAdd(&hist[(u >> shifts[p]) & ((1u << widths[p]) - 1u)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {  // walk bins from the top until the k-th largest falls inside one
+      unsigned rem = sel_remaining;
+      int b = (1 << widths[p]) - 1;
+      for (; b > 0; --b) {
+        if (hist[b] >= rem) break;
+        rem -= hist[b];
+      }
+      sel_remaining = rem;
+      sel_prefix = prefix | ((unsigned)b << shifts[p]);
+    }
+    maskhi |= ((1u << widths[p]) - 1u) << shifts[p];
+    __syncthreads();
+  }
+  const unsigned thr = sel_prefix;  // bit pattern of the k-th largest value
+  for (int64_t e = tid; e < total; e += 1024) {
+    const float v = s[e];
+    if (v < 0.f) continue;
+    const unsigned u = __float_as_uint(v);
+    if (u >= thr) {
+      const int pos = atomicAdd(&ncand, 1);
+      // order: larger score first, then smaller flat index
+      if (pos < kTopkCap) cand[pos] = ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)e);
+    }
+  }
+  __syncthreads();
+  const int c = min(ncand, kTopkCap);
+  for (int e = tid; e < c; e += 1024) {
+    const unsigned long long mine = cand[e];
+    int rank = 0;
+    for (int j = 0; j < c; ++j) rank += cand[j] > mine;
+    if (rank < keff) {
+      const unsigned flat = 0xffffffffu - (unsigned)(mine & 0xffffffffull);
+      rows[rank] = flat / (unsigned)m;
+      cols[rank] = flat % (unsigned)m;
+      vals[rank] = __uint_as_float((unsigned)(mine >> 32));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S1 + S2: per patch pair: gather the K x C feature blocks, scores = F_r F_s^T / sqrt(C) on the matrix cores,
+// then the dustbin-augmented log-domain Sinkhorn entirely in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr float kSinkInf = 1e12f;
+
+template <int K>  // points per patch: 32, 64 or 128
+__global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __restrict__ ref_feats, int64_t nr,
+                                                             const float* __restrict__ src_feats, int64_t ns, int C,
+                                                             const int64_t* __restrict__ ref_idx, const int64_t* __restrict__ src_idx,
+                                                             const unsigned char* __restrict__ ref_mask,
+                                                             const unsigned char* __restrict__ src_mask,
+                                                             const float* __restrict__ alpha_p, int iters,
+                                                             const float* __restrict__ scores_in,
+                                                             float* __restrict__ out) {
+  constexpr int K1 = K + 1;
+  constexpr int LD = K1;               // odd leading dimension: bank = (row + col) mod 32
+  constexpr int TILES = K / 32;        // 32x32 MFMA tiles per side
+  constexpr int TPR = K == 32 ? 8 : (K == 64 ? 4 : 2);  // threads per row in the LSE sweeps
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* S = smem;                     // [K1][LD]
+  float* u = S + K1 * LD;              // [K1]
+  float* v = u + K1;                   // [K1]
+  float* lmu = v + K1;                 // [K1]
+  float* lnu = lmu + K1;               // [K1]
+  float* A_s = lnu + K1;               // [K][33]
+  float* B_s = A_s + K * 33;           // [K][33]
+  __shared__ int nvalid[2];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t* ri = ref_idx + (int64_t)p * K;
+  const int64_t* si = src_idx + (int64_t)p * K;
+  const unsigned char* rm = ref_mask + (int64_t)p * K;
+  const unsigned char* sm = src_mask + (int64_t)p * K;
+  if (tid < 2) nvalid[tid] = 0;
+
+  // ---- scores on the matrix cores: wave w owns tiles w, w + 8, ... ----
+  f32x16 acc[(TILES * TILES + 7) / 8];
+#pragma unroll
+  for (int t = 0; t < (TILES * TILES + 7) / 8; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+  const int fr = lane & 31, fk = lane >> 5;
+  for (int k0 = 0; k0 < (scores_in ? 0 : C); k0 += 32) {
+    __syncthreads();
+    for (int e = tid; e < 2 * K * 8; e += 512) {  // gather rows (pad index -> zeros, like the padded feature row)
+      const int side = e / (K * 8), r = (e / 8) % K, kq = (e % 8) * 4;
+      const int64_t row = side == 0 ? ri[r] : si[r];
+      const int64_t lim = side == 0 ? nr : ns;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < lim && k0 + kq < C) {
+        const float* src = (side == 0 ? ref_feats : src_feats) + row * C + k0 + kq;
+        val = *reinterpret_cast<const float4*>(src);
+      }
+      float* d = (side == 0 ? A_s : B_s) + r * 33 + kq;
+      d[0] = val.x;
+      d[1] = val.y;
+      d[2] = val.z;
+      d[3] = val.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < (TILES * TILES + 7) / 8; ++t) {
+      const int tile = wave + 8 * t;
+      if (tile < TILES * TILES) {
+        const int tr = tile / TILES, tc = tile % TILES;
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+          const float a = A_s[(32 * tr + fr) * 33 + 2 * ks + fk];
+          const float b = B_s[(32 * tc + fr) * 33 + 2 * ks + fk];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const float alpha = *alpha_p;
+  __syncthreads();
+  if (scores_in) {  // stand-alone optimal transport: scores were computed by the caller (learnable_sinkhorn.py:20)
+    const float* sp = scores_in + (int64_t)p * K * K;
+    for (int e = tid; e < K * K; e += 512) {
+      const int i = e / K, j = e % K;
+      S[i * LD + j] = (rm[i] && sm[j]) ? sp[e] : -kSinkInf;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < (scores_in ? 0 : (TILES * TILES + 7) / 8); ++t) {
+    const int tile = wave + 8 * t;
+    if (tile < TILES * TILES) {
+      const int tr = tile / TILES, tc = tile % TILES;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = 32 * tr + (q & 3) + 8 * (q >> 2) + 4 * fk, j = 32 * tc + fr;
+        S[i * LD + j] = (rm[i] && sm[j]) ? acc[t][q] / sqrtf((float)C) : -kSinkInf;  // model.py:188
+      }
+    }
+  }
+  // dustbin row / column (learnable_sinkhorn.py:41-48) and marginals (:50-62)
+  for (int e = tid; e < K; e += 512) {
+    S[e * LD + K] = rm[e] ? alpha : -kSinkInf;
+    S[K * LD + e] = sm[e] ? alpha : -kSinkInf;
+    if (rm[e]) atomicAdd(&nvalid[0], 1);
+    if (sm[e]) atomicAdd(&nvalid[1], 1);
+  }
+  if (tid == 0) S[K * LD + K] = alpha;
+  __syncthreads();
+  const float nvr = (float)nvalid[0], nvc = (float)nvalid[1];
+  const float norm = -logf(nvr + nvc);
+  for (int e = tid; e < K1; e += 512) {
+    lmu[e] = e < K ? (rm[e] ? norm : -kSinkInf) : logf(nvc) + norm;
+    lnu[e] = e < K ? (sm[e] ? norm : -kSinkInf) : logf(nvr) + norm;
+    u[e] = 0.f;
+    v[e] = 0.f;
+  }
+  __syncthreads();
+  // ---- 100 x { u = log_mu - LSE_j(S + v);  v = log_nu - LSE_i(S + u) }  (:13-18) ----
+  const int row = tid / TPR, sub = tid % TPR;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (row < K1) {
+        const float* other = half == 0 ? v : u;
+        float mx = -3.4e38f;
+        for (int j = sub; j < K1; j += TPR) {
+          const float x = (half == 0 ? S[row * LD + j] : S[j * LD + row]) + other[j];
+          mx = fmaxf(mx, x);
+        }
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+        for (int j = sub; j < K1; j += TPR) {
+          const float x = (half == 0 ? S[row * LD + j] : S[j * LD + row]) + other[j];
+          sum += expf(x - mx);
+        }
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float lse = mx + logf(sum);
+        if (sub == 0) {
+          if (half == 0) u[row] = lmu[row] - lse;
+          else v[row] = lnu[row] - lse;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* o = out + (int64_t)p * K1 * K1;
+  for (int e = tid; e < K1 * K1; e += 512) {
+    const int i = e / K1, j = e % K1;
+    o[e] = ((S[i * LD + j] + u[i]) + v[j]) - norm;
+  }
+}
+
+}  // namespace geotr
+
+using namespace geotr;
+
+extern "C" {
+
+int geotr_point_to_node(const float* points, int64_t n, const float* nodes, int64_t m, int64_t k, int64_t* point_to_node,
+                        uint8_t* node_masks, int64_t* knn_indices, uint8_t* knn_masks, int32_t* overflow, void* stream_) {
+  GEOTR_CHECK_ARG(n >= 1 && m >= 1 && k >= 1, "point_to_node: bad sizes");
+  GEOTR_CHECK_ARG(points && nodes && point_to_node && node_masks && knn_indices && knn_masks, "point_to_node: null pointer");
+  GEOTR_CHECK_ARG(m <= 12000, "point_to_node: at most 12000 nodes (got %lld)", (long long)m);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hipMemsetAsync(node_masks, 0, (size_t)m, stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "point_to_node: memset failed");
+  const size_t lds = sizeof(float) * 3 * (size_t)m;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(GEOTR_E_LAUNCH, "point_to_node: cannot reserve LDS");
+  p2n_assign_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream>>>(points, n, nodes, (int)m, point_to_node, node_masks);
+  p2n_knn_kernel<<<dim3((unsigned)m), dim3(256), 0, stream>>>(points, n, nodes, point_to_node, (int)k, knn_indices, knn_masks, overflow);
+  GEOTR_CHECK_LAUNCH("point_to_node");
+  return GEOTR_OK;
+}
+
+int geotr_superpoint_match(float* scores, int64_t n, int64_t m, const uint8_t* ref_masks, const uint8_t* src_masks,
+                           int dual_normalization, int64_t k, float* rowsum_ws, float* colsum_ws, int64_t* ref_idx,
+                           int64_t* src_idx, float* corr_scores, int32_t* count, void* stream_) {
+  GEOTR_CHECK_ARG(n >= 1 && m >= 1 && k >= 1 && k <= kTopkCap / 2, "superpoint_match: bad sizes");
+  GEOTR_CHECK_ARG(n * m < (1ll << 31), "superpoint_match: score matrix too large");
+  GEOTR_CHECK_ARG(scores && ref_masks && src_masks && rowsum_ws && colsum_ws && ref_idx && src_idx && corr_scores && count,
+                  "superpoint_match: null pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  spm_exp_kernel<<<dim3((unsigned)n), dim3(256), 0, stream>>>(scores, (int)n, (int)m, ref_masks, src_masks, rowsum_ws);
+  spm_colsum_kernel<<<dim3((unsigned)((m + 63) / 64)), dim3(256), 0, stream>>>(scores, (int)n, (int)m, colsum_ws);
+  spm_dual_kernel<<<dim3((unsigned)((n * m + 255) / 256)), dim3(256), 0, stream>>>(scores, (int)n, (int)m, rowsum_ws, colsum_ws,
+                                                                                 ref_masks, src_masks, dual_normalization);
+  topk_kernel<<<dim3(1), dim3(1024), 0, stream>>>(scores, n * m, (int)k, (int)m, ref_idx, src_idx, corr_scores, count);
+  GEOTR_CHECK_LAUNCH("superpoint_match");
+  return GEOTR_OK;
+}
+
+int geotr_patch_sinkhorn(const float* ref_feats, int64_t nr, const float* src_feats, int64_t ns, int64_t c,
+                         const int64_t* ref_knn_indices, const int64_t* src_knn_indices, const uint8_t* ref_knn_masks,
+                         const uint8_t* src_knn_masks, int64_t p, int64_t k, const float* alpha, int64_t num_iterations,
+                         const float* scores_in, float* matching_scores, void* stream_) {
+  GEOTR_CHECK_ARG(p >= 0 && c >= 4 && c % 4 == 0, "patch_sinkhorn: bad sizes (channels must be a multiple of 4)");
+  GEOTR_CHECK_ARG(k == 32 || k == 64 || k == 128, "patch_sinkhorn: points per patch must be 32, 64 or 128 (got %lld)", (long long)k);
+  if (p == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(ref_knn_masks && src_knn_masks && alpha && matching_scores, "patch_sinkhorn: null pointer");
+  GEOTR_CHECK_ARG(scores_in || (ref_feats && src_feats && ref_knn_indices && src_knn_indices),
+                  "patch_sinkhorn: need either scores_in or features + indices");
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t k1 = (size_t)k + 1;
+  const size_t lds = sizeof(float) * (k1 * k1 + 4 * k1 + 2 * (size_t)k * 33);
+#define LAUNCH(KK)                                                                                                              \
+  do {                                                                                                                          \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sinkhorn_kernel<KK>),                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
+      return fail(GEOTR_E_LAUNCH, "patch_sinkhorn: cannot reserve %zu B of LDS", lds);                                           \
+    patch_sinkhorn_kernel<KK><<<dim3((unsigned)p), dim3(512), lds, stream>>>(ref_feats, nr, src_feats, ns, (int)c, ref_knn_indices, \
+                                                                            src_knn_indices, ref_knn_masks, src_knn_masks, alpha, \
+                                                                            (int)num_iterations, scores_in, matching_scores);    \
+  } while (0)
+  if (k == 32) LAUNCH(32);
+  else if (k == 64) LAUNCH(64);
+  else LAUNCH(128);
+#undef LAUNCH
+  GEOTR_CHECK_LAUNCH("patch_sinkhorn");
+  return GEOTR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+"""Multi-GPU sharding of independent scene pairs: one process per GPU, RCCL over xGMI.
+
+Pairs are independent units, so the data path has no collective.  The only communication is
+  * one broadcast of the flat parameter buffer from rank 0 at start-up (39 MB for the 3DMatch model), and
+  * one all-gather of the fixed-size per-pair results (4x4 transforms) at the end of a batch.
+`backend='nccl'` is RCCL on ROCm; the same code runs under `gloo` on CPU tensors (tests/test_dist.py).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns (rank, world, local)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(num_items, rank, world):
+    """Static round-robin assignment of item indices to ranks (pairs are independent)."""
+    return list(range(rank, num_items, world))
+
+
+@torch.no_grad()
+def broadcast_module(module, src=0):
+    """Make every rank hold rank `src`'s parameters and buffers: ONE broadcast of a flat fp32 buffer."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point()]
+    if not tensors:
+        return
+    flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+    dist.broadcast(flat, src=src)
+    offset = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[offset:offset + n].view_as(t).to(t.dtype))
+        offset += n
+
+
+@torch.no_grad()
+def gather_results(local, world=None):
+    """All-gather a fixed-size per-rank result tensor (e.g. (pairs_per_rank, 4, 4)) -> (world, ...) on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local.unsqueeze(0)
+    world = dist.get_world_size() if world is None else world
+    out = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(out, local.contiguous())
+    return torch.stack(out, dim=0)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    """Max of a python float over all ranks (used for the timed region of bench.py)."""
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

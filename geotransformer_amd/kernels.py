@@ -7,6 +7,10 @@ from . import _lib
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'leaky': 2}
 
+# bench.py sets PROFILE['<kernel>'] = [] to collect (start_event, end_event, problem_size) per launch: HIP events recorded
+# on the stream the kernel is launched on (torch's current stream is the stream passed through the C ABI).
+PROFILE = {}
+
 
 def _f32c(t):
     assert t.dtype == torch.float32 and t.is_cuda, 'expected a float32 device tensor'
@@ -151,9 +155,16 @@ def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a):
     points = _f32c(points)
     n, d = points.shape[0], w_d.shape[0]
     out = torch.empty((n, n, d), dtype=torch.float32, device=points.device)
+    prof = PROFILE.get('gse_embed')
+    if prof is not None:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
     _lib.check(lib.geotr_gse_embed(_lib.ptr(points), _lib.ptr(knn), n, knn.shape[1], d, _lib.ptr(_f32c(div_term)),
                                    _lib.ptr(_f32c(w_d)), _lib.ptr(b_d), _lib.ptr(_f32c(w_a)), _lib.ptr(b_a), float(sigma_d),
                                    float(sigma_a), _lib.ptr(out), _lib.stream_ptr()), 'geotr_gse_embed')
+    if prof is not None:
+        end.record()
+        prof.append((start, end, n))
     return out
 
 
@@ -169,3 +180,102 @@ def attn_softmax(scores, scale, emb=None, qt=None, qb=None):
     _lib.check(lib.geotr_attn_softmax(_lib.ptr(scores), _lib.ptr(emb), _lib.ptr(qt), _lib.ptr(qb), n, m, c, H, float(scale),
                                       _lib.stream_ptr()), 'geotr_attn_softmax')
     return scores
+
+
+def point_to_node(points, nodes, point_limit):
+    """-> point_to_node (N,) int64, node_masks (M,) bool, knn_indices (M,K) int64, knn_masks (M,K) bool."""
+    lib = _lib.load()
+    points, nodes = _f32c(points), _f32c(nodes)
+    N, M, K = points.shape[0], nodes.shape[0], int(point_limit)
+    dev = points.device
+    p2n = torch.empty(N, dtype=torch.int64, device=dev)
+    node_masks = torch.empty(M, dtype=torch.bool, device=dev)
+    knn_idx = torch.empty((M, K), dtype=torch.int64, device=dev)
+    knn_masks = torch.empty((M, K), dtype=torch.bool, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.geotr_point_to_node(_lib.ptr(points), N, _lib.ptr(nodes), M, K, _lib.ptr(p2n), _lib.ptr(node_masks),
+                                       _lib.ptr(knn_idx), _lib.ptr(knn_masks), _lib.ptr(overflow), _lib.stream_ptr()),
+               'geotr_point_to_node')
+    return p2n, node_masks, knn_idx, knn_masks, overflow
+
+
+def superpoint_match(ref_feats, src_feats, ref_masks, src_masks, num_correspondences, dual_normalization=True):
+    """Top-k superpoint correspondences.  Returns (ref_idx (k,), src_idx (k,), scores (k,), count (1,) int32 device);
+    only the first `count` entries are valid (count < k only if fewer than k valid superpoint pairs exist)."""
+    lib = _lib.load()
+    ref_feats, src_feats = _f32c(ref_feats), _f32c(src_feats)
+    n, m, k = ref_feats.shape[0], src_feats.shape[0], int(num_correspondences)
+    dev = ref_feats.device
+    scores = gemm(ref_feats, src_feats)  # (n, m) = <f_r, f_s>
+    rowsum = torch.empty(n, dtype=torch.float32, device=dev)
+    colsum = torch.empty(m, dtype=torch.float32, device=dev)
+    ref_idx = torch.zeros(k, dtype=torch.int64, device=dev)
+    src_idx = torch.zeros(k, dtype=torch.int64, device=dev)
+    vals = torch.zeros(k, dtype=torch.float32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.geotr_superpoint_match(_lib.ptr(scores), n, m, _lib.ptr(ref_masks), _lib.ptr(src_masks),
+                                          int(bool(dual_normalization)), k, _lib.ptr(rowsum), _lib.ptr(colsum),
+                                          _lib.ptr(ref_idx), _lib.ptr(src_idx), _lib.ptr(vals), _lib.ptr(count),
+                                          _lib.stream_ptr()), 'geotr_superpoint_match')
+    return ref_idx, src_idx, vals, count
+
+
+def patch_sinkhorn(alpha, num_iterations, ref_knn_masks, src_knn_masks, scores=None, ref_feats=None, src_feats=None,
+                   ref_knn_indices=None, src_knn_indices=None):
+    """(P, K+1, K+1) log optimal-transport scores; either from `scores` (P,K,K) or fused from features + patch indices."""
+    lib = _lib.load()
+    P, K = ref_knn_masks.shape
+    assert src_knn_masks.shape == (P, K), 'square patches only'
+    dev = ref_knn_masks.device
+    out = torch.empty((P, K + 1, K + 1), dtype=torch.float32, device=dev)
+    rm, sm = ref_knn_masks.contiguous(), src_knn_masks.contiguous()
+    if scores is not None:
+        scores = _f32c(scores)
+        args = (None, 0, None, 0, 4, None, None)
+    else:
+        ref_feats, src_feats = _f32c(ref_feats), _f32c(src_feats)
+        ri, si = ref_knn_indices.contiguous(), src_knn_indices.contiguous()
+        args = (ref_feats, ref_feats.shape[0], src_feats, src_feats.shape[0], ref_feats.shape[1], ri, si)
+    _lib.check(lib.geotr_patch_sinkhorn(_lib.ptr(args[0]), args[1], _lib.ptr(args[2]), args[3], args[4], _lib.ptr(args[5]),
+                                        _lib.ptr(args[6]), _lib.ptr(rm), _lib.ptr(sm), P, K, _lib.ptr(alpha),
+                                        int(num_iterations), _lib.ptr(scores), _lib.ptr(out), _lib.stream_ptr()),
+               'geotr_patch_sinkhorn')
+    return out
+
+
+def weighted_procrustes(src_points, ref_points, weights=None):
+    """(B, 4, 4) rigid transforms aligning src (B,N,3) to ref (B,N,3)."""
+    lib = _lib.load()
+    src_points, ref_points = _f32c(src_points), _f32c(ref_points)
+    B, N, _ = src_points.shape
+    if weights is not None:
+        weights = _f32c(weights)
+    out = torch.empty((B, 4, 4), dtype=torch.float32, device=src_points.device)
+    _lib.check(lib.geotr_weighted_procrustes(_lib.ptr(src_points), _lib.ptr(ref_points), _lib.ptr(weights), B, N,
+                                             _lib.ptr(out), _lib.stream_ptr()), 'geotr_weighted_procrustes')
+    return out
+
+
+def lgr(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, topk, confidence_threshold, mutual,
+        acceptance_radius, correspondence_threshold, num_refinement_steps):
+    """Local-to-global registration.  score_mat (P, R, R) with R >= K: the leading (K, K) block is used (drops dustbins).
+    Returns (ref_corr (cap,3), src_corr (cap,3), scores (cap,), num_corr (1,) int32 device, transform (4,4))."""
+    lib = _lib.load()
+    ref_knn_points, src_knn_points = _f32c(ref_knn_points), _f32c(src_knn_points)
+    P, K, _ = ref_knn_points.shape
+    assert score_mat.stride(2) == 1
+    dev = ref_knn_points.device
+    cap = P * K * int(topk)
+    ref_corr = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+    src_corr = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+    scores = torch.empty(cap, dtype=torch.float32, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    T = torch.empty((4, 4), dtype=torch.float32, device=dev)
+    ws = _lib.workspace(lib.geotr_lgr_workspace_bytes(P, K, int(topk)), dev)
+    _lib.check(lib.geotr_lgr(_lib.ptr(ref_knn_points), _lib.ptr(src_knn_points), _lib.ptr(ref_knn_masks.contiguous()),
+                             _lib.ptr(src_knn_masks.contiguous()), _lib.ptr(score_mat), score_mat.stride(0), score_mat.stride(1),
+                             P, K, int(topk), float(confidence_threshold), int(bool(mutual)), float(acceptance_radius),
+                             int(correspondence_threshold), int(num_refinement_steps), _lib.ptr(ref_corr), _lib.ptr(src_corr),
+                             _lib.ptr(scores), _lib.ptr(num), _lib.ptr(T), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+               'geotr_lgr')
+    return ref_corr, src_corr, scores, num, T

@@ -1,0 +1,36 @@
+"""Local-to-global registration (mirror of geotransformer/modules/geotransformer/local_global_registration.py:11-235).
+
+One C-ABI call (csrc/lgr.hip) replaces the reference's nonzero / python chunk list / 6 host SVD round trips.
+"""
+import torch.nn as nn
+
+from ... import kernels
+from ..registration import WeightedProcrustes
+
+
+class LocalGlobalRegistration(nn.Module):
+    def __init__(self, k, acceptance_radius, mutual=True, confidence_threshold=0.05, use_dustbin=False,
+                 use_global_score=False, correspondence_threshold=3, correspondence_limit=None, num_refinement_steps=5):
+        super().__init__()
+        if use_dustbin or use_global_score or correspondence_limit is not None:
+            raise NotImplementedError('use_dustbin / use_global_score / correspondence_limit are off in every reference '
+                                      'config and are not implemented on the HIP path')
+        self.k = k
+        self.acceptance_radius = acceptance_radius
+        self.mutual = mutual
+        self.confidence_threshold = confidence_threshold
+        self.use_dustbin = use_dustbin
+        self.use_global_score = use_global_score
+        self.correspondence_threshold = correspondence_threshold
+        self.correspondence_limit = correspondence_limit
+        self.num_refinement_steps = num_refinement_steps
+        self.procrustes = WeightedProcrustes(return_transform=True)
+
+    def forward(self, ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, global_scores=None):
+        """(B,K,3) x2, (B,K) bool x2, score_mat (B,K,K) log-likelihoods (may be a [:, :-1, :-1] view) ->
+        ref_corr_points (C,3), src_corr_points (C,3), corr_scores (C,), estimated_transform (4,4)."""
+        ref_corr, src_corr, scores, num, transform = kernels.lgr(
+            ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, self.k, self.confidence_threshold,
+            self.mutual, self.acceptance_radius, self.correspondence_threshold, self.num_refinement_steps)
+        c = int(num.item())  # data-dependent output length: the only host read, after all kernels are queued
+        return ref_corr[:c], src_corr[:c], scores[:c], transform

@@ -144,6 +144,49 @@ int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t 
 int geotr_attn_softmax(float* scores, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m, int64_t c,
                        int64_t heads, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * P1/M1/S1/S2  matching heads
+ *   geotr_point_to_node   : point_to_node[i] = nearest node; node_masks[m] = node owns a point; knn_indices[m,:k] = the k
+ *                           nearest OWNED points by (distance, index), pad = n with knn_masks False
+ *                                                    geotransformer/modules/ops/pointcloud_partition.py:61-107
+ *   geotr_superpoint_match: in: scores (n,m) = ref_feats . src_feats^T of L2-normalised features (overwritten);
+ *                           exp(-(2-2xy)), dual normalisation over valid nodes, global top-k -> indices, scores, count
+ *                                                    geotransformer/modules/geotransformer/superpoint_matching.py:13-50
+ *   geotr_patch_sinkhorn  : per patch pair: scores = F_r F_s^T / sqrt(c) (gathered rows, pad index -> zero row) or
+ *                           `scores_in` (p,k,k); dustbin alpha; masks -> -1e12; num_iterations log-Sinkhorn sweeps;
+ *                           out (p,k+1,k+1).  k in {32,64,128}.
+ *                                experiments/.../model.py:169-189, geotransformer/modules/sinkhorn/learnable_sinkhorn.py:13-66
+ * ---------------------------------------------------------------------------------------------- */
+int geotr_point_to_node(const float* points, int64_t n, const float* nodes, int64_t m, int64_t k, int64_t* point_to_node,
+                        uint8_t* node_masks, int64_t* knn_indices, uint8_t* knn_masks, int32_t* overflow, void* stream);
+int geotr_superpoint_match(float* scores, int64_t n, int64_t m, const uint8_t* ref_masks, const uint8_t* src_masks,
+                           int dual_normalization, int64_t k, float* rowsum_ws, float* colsum_ws, int64_t* ref_idx,
+                           int64_t* src_idx, float* corr_scores, int32_t* count, void* stream);
+int geotr_patch_sinkhorn(const float* ref_feats, int64_t nr, const float* src_feats, int64_t ns, int64_t c,
+                         const int64_t* ref_knn_indices, const int64_t* src_knn_indices, const uint8_t* ref_knn_masks,
+                         const uint8_t* src_knn_masks, int64_t p, int64_t k, const float* alpha, int64_t num_iterations,
+                         const float* scores_in, float* matching_scores, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * L1/L2  local-to-global registration, entirely on the device (the reference does its SVDs on the host)
+ *   geotr_weighted_procrustes: transforms[b] (4x4 row-major) aligning src[b] (n,3) to ref[b] (n,3) with weights[b] (n) or
+ *                              unit weights: w/(sum w + 1e-5), centroids, H, SVD, R = V diag(1,1,det) U^T, t
+ *                                                    geotransformer/modules/registration/procrustes.py:6-73
+ *   geotr_lgr: score_mat[p, i*ld_row + j] (log scores, patch stride ld_patch) -> exp -> mutual top-k & > threshold & masks ->
+ *              stacked correspondences in torch.nonzero order (ref/src_corr_points, corr_scores: capacity p*k*topk rows;
+ *              *num_corr = rows used) -> per-patch hypotheses (>= correspondence_threshold rows) -> best by inlier count ->
+ *              num_refinement_steps re-weighted Procrustes -> estimated_transform (4x4 row-major)
+ *                                       geotransformer/modules/geotransformer/local_global_registration.py:49-83,137-235
+ * ---------------------------------------------------------------------------------------------- */
+int geotr_weighted_procrustes(const float* src_points, const float* ref_points, const float* weights, int64_t batch, int64_t n,
+                              float* transforms, void* stream);
+size_t geotr_lgr_workspace_bytes(int64_t p, int64_t k, int64_t topk);
+int geotr_lgr(const float* ref_knn_points, const float* src_knn_points, const uint8_t* ref_knn_masks,
+              const uint8_t* src_knn_masks, const float* score_mat, int64_t ld_patch, int64_t ld_row, int64_t p, int64_t k,
+              int64_t topk, float confidence_threshold, int mutual, float acceptance_radius, int64_t correspondence_threshold,
+              int64_t num_refinement_steps, float* ref_corr_points, float* src_corr_points, float* corr_scores,
+              int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,56 @@
+"""CPU, world_size 2 over gloo: the multi-GPU path's sharding / weight broadcast / result gather logic."""
+import os
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from geotransformer_amd import dist as gd
+    r, w, _ = gd.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)  # different weights on every rank before the broadcast
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.LayerNorm(7))
+    net.register_buffer('kp', torch.randn(15, 3))
+    gd.broadcast_module(net, src=0)
+    checksum = sum(float(t.double().sum()) for t in list(net.parameters()) + list(net.buffers()))
+    mine = gd.shard_indices(7, rank, world)
+    local = torch.zeros(4, 4, 4)
+    for slot, item in enumerate(mine):
+        local[slot] = float(item)  # stand-in for the pair's estimated transform
+    allres = gd.gather_results(local)
+    gd.barrier()
+    t = gd.max_over_ranks(1.0 + rank, 'cpu')
+    ret[rank] = (checksum, mine, allres.clone(), t)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_broadcast_shard_gather():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    c0, s0, g0, t0 = ret[0]
+    c1, s1, g1, t1 = ret[1]
+    assert abs(c0 - c1) < 1e-9                      # identical weights after one broadcast
+    assert s0 == [0, 2, 4, 6] and s1 == [1, 3, 5]   # round-robin shards cover every pair exactly once
+    assert torch.equal(g0, g1) and g0.shape == (2, 4, 4, 4)
+    assert float(g0[1, 2, 0, 0]) == 5.0             # rank 1's third pair is item 5
+    assert t0 == t1 == 2.0                          # max over ranks
+
+
+def test_single_process_fast_path():
+    sys.path.insert(0, ROOT)
+    from geotransformer_amd import dist as gd
+    assert gd.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+    x = torch.arange(6.).view(2, 3)
+    assert torch.equal(gd.gather_results(x), x.unsqueeze(0))
+    gd.barrier()
+    assert gd.max_over_ranks(3.5, 'cpu') == 3.5

@@ -1,0 +1,153 @@
+"""GPU: partition, coarse matching, Sinkhorn, Procrustes, LGR and the assembled model vs oracle / reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+from util import load_model_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _rot_err_deg(Ta, Tb):
+    R = Ta[:3, :3].double() @ Tb[:3, :3].double().t()
+    return float(torch.rad2deg(torch.acos(((torch.trace(R) - 1) / 2).clamp(-1, 1))))
+
+
+@pytest.mark.parametrize('name', ['model_modelnet_small', 'model_3dmatch_small'])
+def test_point_to_node_partition_matches_oracle(name):
+    from geotransformer_amd.modules.ops import point_to_node_partition
+    from oracle import model_oracle as mo
+    cfg, sd, data, out, mids = load_model_golden(name)
+    pts, nodes = out['ref_points_f'], out['ref_points_c']
+    K = cfg.model.num_points_in_patch
+    want = mo.point_to_node_partition(pts, nodes, K)
+    got = point_to_node_partition(pts.cuda(), nodes.cuda(), K)
+    for g, w in zip(got, want):
+        assert torch.equal(g.cpu(), w)
+    # return_count variant
+    p2n, sizes, masks, idx, km = point_to_node_partition(pts.cuda(), nodes.cuda(), K, return_count=True)
+    assert int(sizes.sum()) == pts.shape[0] and torch.equal(masks.cpu(), sizes.cpu() > 0)
+
+
+@pytest.mark.parametrize('name', ['model_modelnet_small', 'model_3dmatch_small'])
+def test_superpoint_matching_matches_reference_golden(name):
+    from geotransformer_amd.modules.geotransformer import SuperPointMatching
+    from oracle import model_oracle as mo
+    cfg, sd, data, out, mids = load_model_golden(name)
+    K = cfg.model.num_points_in_patch
+    _, rmask, _, _ = mo.point_to_node_partition(out['ref_points_f'], out['ref_points_c'], K)
+    _, smask, _, _ = mo.point_to_node_partition(out['src_points_f'], out['src_points_c'], K)
+    head = SuperPointMatching(cfg.coarse_matching.num_correspondences, cfg.coarse_matching.dual_normalization)
+    ri, si, sc = head(out['ref_feats_c'].cuda(), out['src_feats_c'].cuda(), rmask.cuda(), smask.cuda())
+    wr, ws, wsc = mo.superpoint_matching(out['ref_feats_c'], out['src_feats_c'], rmask, smask,
+                                         cfg.coarse_matching.num_correspondences, cfg.coarse_matching.dual_normalization)
+    assert torch.allclose(sc.cpu(), wsc, rtol=1e-4, atol=1e-9)
+    assert torch.equal(ri.cpu(), out['ref_node_corr_indices']) and torch.equal(si.cpu(), out['src_node_corr_indices'])
+    assert torch.equal(ri.cpu(), wr) and torch.equal(si.cpu(), ws)
+
+
+def test_superpoint_matching_respects_masks_and_small_k():
+    from geotransformer_amd.modules.geotransformer import SuperPointMatching
+    from oracle import model_oracle as mo
+    g = torch.Generator().manual_seed(0)
+    a = torch.nn.functional.normalize(torch.randn(6, 16, generator=g), dim=1)
+    b = torch.nn.functional.normalize(torch.randn(5, 16, generator=g), dim=1)
+    rm = torch.tensor([1, 0, 1, 1, 0, 1], dtype=torch.bool)
+    sm = torch.tensor([1, 1, 0, 1, 1], dtype=torch.bool)
+    head = SuperPointMatching(256, True)  # k larger than the 16 valid pairs -> 16 rows
+    ri, si, sc = head(a.cuda(), b.cuda(), rm.cuda(), sm.cuda())
+    wr, ws, wsc = mo.superpoint_matching(a, b, rm, sm, 256, True)
+    assert ri.shape[0] == 16 and torch.equal(ri.cpu(), wr) and torch.equal(si.cpu(), ws)
+    assert torch.allclose(sc.cpu(), wsc, rtol=1e-5)
+
+
+@pytest.mark.parametrize('K,C', [(32, 32), (64, 256), (128, 64)])
+def test_sinkhorn_matches_oracle(K, C):
+    from geotransformer_amd.modules.sinkhorn import LearnableLogOptimalTransport
+    from oracle import model_oracle as mo
+    g = torch.Generator().manual_seed(K)
+    P, N = 9, 400
+    rf, sf = torch.randn(N, C, generator=g), torch.randn(N + 7, C, generator=g)
+    ridx = torch.randint(0, N, (P, K), generator=g)
+    sidx = torch.randint(0, N + 7, (P, K), generator=g)
+    rmask = torch.rand(P, K, generator=g) > 0.2
+    smask = torch.rand(P, K, generator=g) > 0.3
+    rmask[3] = False  # a patch with no valid reference point
+    ridx[~rmask] = N
+    sidx[~smask] = N + 7
+    ot = LearnableLogOptimalTransport(100)
+    with torch.no_grad():
+        ot.alpha.fill_(0.7)
+    rk = torch.cat([rf, torch.zeros(1, C)])[ridx]
+    sk = torch.cat([sf, torch.zeros(1, C)])[sidx]
+    scores = torch.einsum('bnd,bmd->bnm', rk, sk) / C ** 0.5
+    want = mo.optimal_transport(scores, rmask, smask, ot.alpha.detach(), 100)
+    ot = ot.cuda()
+    got = ot(scores.cuda(), rmask.cuda(), smask.cuda()).cpu()
+    valid = torch.ones(P, dtype=torch.bool)
+    valid[3] = False  # every entry of that patch is masked: compare the others tightly, this one loosely
+    assert torch.allclose(got[valid], want[valid], atol=2e-3, rtol=1e-4), float((got[valid] - want[valid]).abs().max())
+    fused = ot.forward_fused(rf.cuda(), sf.cuda(), ridx.cuda(), sidx.cuda(), rmask.cuda(), smask.cuda()).cpu()
+    assert torch.allclose(fused[valid], want[valid], atol=2e-3, rtol=1e-4), float((fused[valid] - want[valid]).abs().max())
+    # log-marginals: exp(out) rows of valid points sum to ~1/(nr+nc) * ... -> check row-stochasticity in log space
+    e = torch.exp(got[0] + (-torch.log(rmask[0].float().sum() + smask[0].float().sum())))
+    assert torch.isfinite(got[valid]).all() and float(e.sum()) > 0
+
+
+def test_weighted_procrustes_matches_oracle():
+    from geotransformer_amd.modules.registration import weighted_procrustes
+    from oracle import model_oracle as mo
+    g = torch.Generator().manual_seed(2)
+    B, N = 7, 50
+    src = torch.randn(B, N, 3, generator=g)
+    A = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
+    A = A * torch.sign(torch.det(A)).view(B, 1, 1)
+    ref = src @ A.transpose(1, 2) + torch.randn(B, 1, 3, generator=g) + 0.01 * torch.randn(B, N, 3, generator=g)
+    w = torch.rand(B, N, generator=g)
+    src[5, :, 2] = 0.0  # planar source (rank-2 covariance)
+    ref[5] = src[5] @ A[5].t() + 0.3
+    w[6, 3:] = 0.0      # three effective points
+    want = mo.weighted_procrustes(src, ref, w)
+    got = weighted_procrustes(src.cuda(), ref.cuda(), w.cuda(), return_transform=True).cpu()
+    assert torch.allclose(got, want, atol=2e-4), float((got - want).abs().max())
+    R, t = weighted_procrustes(src[0].cuda(), ref[0].cuda(), w[0].cuda())
+    assert torch.allclose(R.cpu(), want[0, :3, :3], atol=2e-4) and torch.allclose(t.cpu(), want[0, :3, 3], atol=2e-4)
+    assert torch.allclose(torch.det(got[:, :3, :3]), torch.ones(B), atol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['model_modelnet_small', 'model_3dmatch_small'])
+def test_lgr_matches_reference_golden(name):
+    """Teacher-forced from the reference's matching scores: same correspondences, same transform."""
+    from geotransformer_amd.modules.geotransformer import LocalGlobalRegistration
+    cfg, sd, data, out, mids = load_model_golden(name)
+    f = cfg.fine_matching
+    head = LocalGlobalRegistration(f.topk, f.acceptance_radius, mutual=f.mutual, confidence_threshold=f.confidence_threshold,
+                                   correspondence_threshold=f.correspondence_threshold, num_refinement_steps=f.num_refinement_steps)
+    ms = out['matching_scores'].cuda()
+    rc, sc, cs, T = head(out['ref_node_corr_knn_points'].cuda(), out['src_node_corr_knn_points'].cuda(),
+                         out['ref_node_corr_knn_masks'].cuda(), out['src_node_corr_knn_masks'].cuda(), ms[:, :-1, :-1], None)
+    assert rc.shape == out['ref_corr_points'].shape
+    assert torch.equal(rc.cpu(), out['ref_corr_points']) and torch.equal(sc.cpu(), out['src_corr_points'])
+    assert torch.allclose(cs.cpu(), out['corr_scores'], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(T.cpu(), out['estimated_transform'], atol=1e-3), (T.cpu(), out['estimated_transform'])
+
+
+@pytest.mark.parametrize('name', ['model_modelnet_small', 'model_3dmatch_small'])
+def test_model_end_to_end_matches_reference_golden(name):
+    """Reference weights + reference collated input -> whole HIP forward vs the reference's outputs."""
+    from geotransformer_amd.model import create_model
+    cfg, sd, data, out, mids = load_model_golden(name)
+    model = create_model(cfg)
+    missing = model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    dev = {k: ([t.cuda() for t in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in data.items()}
+    got = model(dev)
+    for k in ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f'):
+        mse = float(((got[k].cpu() - out[k]) ** 2).mean())
+        assert mse <= 1e-6, (k, mse)  # north_star bound: 1e-4
+    assert torch.equal(got['ref_node_corr_indices'].cpu(), out['ref_node_corr_indices'])
+    assert torch.equal(got['src_node_corr_indices'].cpu(), out['src_node_corr_indices'])
+    assert torch.allclose(got['matching_scores'].cpu(), out['matching_scores'], atol=5e-3, rtol=1e-3)
+    assert got['corr_scores'].shape == out['corr_scores'].shape
+    T, Tw = got['estimated_transform'].cpu(), out['estimated_transform']
+    assert _rot_err_deg(T, Tw) < 0.05 and float((T[:3, 3] - Tw[:3, 3]).norm()) < 1e-3
