@@ -56,14 +56,15 @@ def cpu_baseline(cfg, item, model):
     data['features'] = torch.ones((pts.shape[0], 1))
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ocfg = mo.config_from_reference(cfg)
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch CPU ops of this size stop scaling (and then thrash) well before a big host's core count: use <= 16 threads
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     t0 = time.perf_counter()
     out = mo.forward(sd, ocfg, data)
     t_forward = time.perf_counter() - t0
     return {
         'value': 1.0 / (t_collate + t_forward), 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
         'sample': f'1 pair of the same workload, no warm-up: collate {t_collate:.2f} s (1 thread, {kind_nb}) + '
-                  f'forward {t_forward:.2f} s (torch fp32 restatement, all cores)',
+                  f'forward {t_forward:.2f} s (torch fp32 restatement, {torch.get_num_threads()} threads of {os.cpu_count()} host cores)',
         'collate_s': round(t_collate, 3), 'forward_s': round(t_forward, 3),
     }, out
 

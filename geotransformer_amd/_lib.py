@@ -35,12 +35,13 @@ SIGNATURES = {
                                     c_ptr, c_ptr, c_ptr]),
     'geotr_maxpool': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_upsample_concat': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'geotr_group_norm_workspace_bytes': (c_size, [c_i64, c_i64]),
     'geotr_group_norm': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
     'geotr_layer_norm': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_ptr]),
     'geotr_gse_knn': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_gse_embed': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_ptr,
                                 c_ptr]),
-    'geotr_attn_softmax': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr]),
+    'geotr_attn_softmax': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr]),
     'geotr_point_to_node': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'geotr_superpoint_match': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                        c_ptr, c_ptr]),

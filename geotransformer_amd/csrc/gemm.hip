@@ -196,6 +196,134 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "Skinny" variant for the few-hundred-row superpoint matrices and the deep-K KPConv contractions at the coarse stages:
+// one 32x32 output tile per block, the block's 4 waves split K (wave w takes K-chunks w, w+4, ...), each wave stages its
+// own 32x32 A and B chunks through a private LDS slab with all its loads in flight at once, and the four partial
+// accumulators are reduced through LDS before the fused epilogue.  Serial depth per wave = K/4, blocks = (M/32)(N/32).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+  __shared__ float slab[4][2 * 32 * kLdsStride];  // per wave: A chunk [32][33], B chunk [32][33]; reused for the reduction
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const float* A = g.A + (int64_t)blockIdx.z * g.strideA;
+  const float* B = g.B + (int64_t)blockIdx.z * g.strideB;
+  float* C = g.C + (int64_t)blockIdx.z * g.strideC;
+  float* As = slab[wave];
+  float* Bs = As + 32 * kLdsStride;
+  float4 ra[4], rb[4];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int f = lane + 64 * s, row = f >> 3, kq = (f & 7) * 4;
+      const int gm = m0 + row, gk = k0 + kq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gm < g.M) {
+        const float* p = A + (int64_t)gm * g.lda + gk;
+        if (VEC && gk + 3 < g.K) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gk < g.K) v.x = p[0];
+          if (gk + 1 < g.K) v.y = p[1];
+          if (gk + 2 < g.K) v.z = p[2];
+          if (gk + 3 < g.K) v.w = p[3];
+        }
+      }
+      ra[s] = v;
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!g.b_is_kn) {
+        const int gn = n0 + row;
+        if (gn < g.N) {
+          const float* p = B + (int64_t)gn * g.ldb + gk;
+          if (VEC && gk + 3 < g.K) {
+            w = *reinterpret_cast<const float4*>(p);
+          } else {
+            if (gk < g.K) w.x = p[0];
+            if (gk + 1 < g.K) w.y = p[1];
+            if (gk + 2 < g.K) w.z = p[2];
+            if (gk + 3 < g.K) w.w = p[3];
+          }
+        }
+      } else {
+        const int kk = f >> 3, nq = (f & 7) * 4;  // 32 k-rows x 8 float4 along n
+        const int gk2 = k0 + kk, gn = n0 + nq;
+        if (gk2 < g.K) {
+          const float* p = B + (int64_t)gk2 * g.ldb + gn;
+          if (VEC && gn + 3 < g.N) {
+            w = *reinterpret_cast<const float4*>(p);
+          } else {
+            if (gn < g.N) w.x = p[0];
+            if (gn + 1 < g.N) w.y = p[1];
+            if (gn + 2 < g.N) w.z = p[2];
+            if (gn + 3 < g.N) w.w = p[3];
+          }
+        }
+      }
+      rb[s] = w;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int f = lane + 64 * s, row = f >> 3, kq = (f & 7) * 4;
+      float* d = As + row * kLdsStride + kq;
+      d[0] = ra[s].x; d[1] = ra[s].y; d[2] = ra[s].z; d[3] = ra[s].w;
+      if (!g.b_is_kn) {
+        float* e = Bs + row * kLdsStride + kq;
+        e[0] = rb[s].x; e[1] = rb[s].y; e[2] = rb[s].z; e[3] = rb[s].w;
+      } else {
+        const int kk = f >> 3, nq = (f & 7) * 4;
+        Bs[(nq + 0) * kLdsStride + kk] = rb[s].x;
+        Bs[(nq + 1) * kLdsStride + kk] = rb[s].y;
+        Bs[(nq + 2) * kLdsStride + kk] = rb[s].z;
+        Bs[(nq + 3) * kLdsStride + kk] = rb[s].w;
+      }
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nchunks = (g.K + kBK - 1) / kBK;
+  const int fr = lane & 31, fk = lane >> 5;
+  int c = wave;
+  if (c < nchunks) load_chunk(c * kBK);
+  for (; c < nchunks; c += 4) {
+    store_chunk();  // wave-private slab: only wave-level ordering is needed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (c + 4 < nchunks) load_chunk((c + 4) * kBK);  // next chunk's loads fly under this chunk's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < kBK / 2; ++ks) {
+      const float a = As[fr * kLdsStride + 2 * ks + fk];
+      const float b = Bs[fr * kLdsStride + 2 * ks + fk];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // reduce the 4 partial tiles: slab[w] holds wave w's 32x32 partial, element (row, col) at row * 33 + col
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) As[((r & 3) + 8 * (r >> 2) + 4 * fk) * kLdsStride + fr] = acc[r];
+  __syncthreads();
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int row = e >> 5, col = e & 31;
+    const int gm = m0 + row, gn = n0 + col;
+    if (gm >= g.M || gn >= g.N) continue;
+    const int o = row * kLdsStride + col;
+    float v = ((slab[0][o] + slab[1][o]) + (slab[2][o] + slab[3][o])) * g.alpha;
+    if (g.row_div) v = v / (float)max(g.row_div[gm], 1);
+    if (g.bias) v += g.bias[gn];
+    if (g.residual) v += g.residual[(int64_t)blockIdx.z * g.strideC + (int64_t)gm * g.ldr + gn];
+    if (g.act == 1) v = fmaxf(v, 0.f);
+    if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+    C[(int64_t)gm * g.ldc + gn] = v;
+  }
+}
+
 }  // namespace geotr
 
 using namespace geotr;
@@ -219,15 +347,18 @@ extern "C" int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t l
     return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0 && (st & 3) == 0;
   };
   const bool vec = aligned(A, lda, strideA) && aligned(B, ldb, strideB);
-  const bool big = M >= 2048 && N >= 96;
+  // tall operands with enough 128x128 tiles to fill the chip -> tiled kernel; everything else -> split-K skinny kernel
+  const int64_t big_blocks = ((N + 127) / 128) * ((M + 127) / 128) * batch;
+  const bool big = N >= 96 && big_blocks >= 192 && K <= 1024;
   if (big) {
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)batch);
     if (vec) gemm_kernel<128, 128, 2, 2, true><<<grid, dim3(256), 0, stream>>>(g);
     else gemm_kernel<128, 128, 2, 2, false><<<grid, dim3(256), 0, stream>>>(g);
   } else {
-    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)batch);
-    if (vec) gemm_kernel<64, 64, 1, 1, true><<<grid, dim3(256), 0, stream>>>(g);
-    else gemm_kernel<64, 64, 1, 1, false><<<grid, dim3(256), 0, stream>>>(g);
+    dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32), (unsigned)batch);
+    GEOTR_CHECK_ARG(grid.y <= 65535, "gemm: M too large for the skinny kernel");
+    if (vec) gemm_skinny_kernel<true><<<grid, dim3(256), 0, stream>>>(g);
+    else gemm_skinny_kernel<false><<<grid, dim3(256), 0, stream>>>(g);
   }
   GEOTR_CHECK_LAUNCH("gemm");
   return GEOTR_OK;

@@ -193,42 +193,58 @@ __global__ void upsample_concat_kernel(const float* __restrict__ coarse, int64_t
 }
 
 // ---- GroupNorm over (N, C): statistics span all N stacked points (modules.py:47-50) -------------------------
-constexpr int kGnRows = 256;  // rows per block in the statistics pass
+constexpr int kGnRows = 32;  // rows per block in the statistics pass (many small blocks: the pass is latency-bound)
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int64_t N, int C, double* __restrict__ stats) {
-  extern __shared__ float red[];  // [2][C]
+// pass 1: per-block, per-channel partial (sum, sum of squares) over kGnRows rows -- no atomics
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int64_t N, int C, float* __restrict__ partial) {
+  extern __shared__ float red[];  // [phases][2][C] when C < 256
   const int64_t r0 = (int64_t)blockIdx.x * kGnRows;
   const int64_t r1 = r0 + kGnRows < N ? r0 + kGnRows : N;
+  float* out = partial + (int64_t)blockIdx.x * 2 * C;
   if (C >= 256) {
     for (int c = threadIdx.x; c < C; c += 256) {
       float s = 0.f, ss = 0.f;
+#pragma unroll 8
       for (int64_t r = r0; r < r1; ++r) {
         const float v = x[r * C + c];
         s += v;
         ss = fmaf(v, v, ss);
       }
-      atomicAdd(&stats[c], (double)s);
-      atomicAdd(&stats[C + c], (double)ss);
+      out[c] = s;
+      out[C + c] = ss;
     }
     return;
   }
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-  __syncthreads();
   // thread -> (row phase, channel): consecutive threads read consecutive channels (coalesced)
-  const int per = 256 / C > 0 ? 256 / C : 1;  // C is < 256 here; if it does not divide 256 the tail threads idle
+  const int per = 256 / C;  // C < 256; if it does not divide 256 the tail threads idle
   const int c = threadIdx.x % C, ph = threadIdx.x / C;
   if (ph < per) {
     float s = 0.f, ss = 0.f;
+#pragma unroll 8
     for (int64_t r = r0 + ph; r < r1; r += per) {
       const float v = x[r * C + c];
       s += v;
       ss = fmaf(v, v, ss);
     }
-    atomicAdd(&red[c], s);
-    atomicAdd(&red[C + c], ss);
+    red[(ph * 2) * C + c] = s;
+    red[(ph * 2 + 1) * C + c] = ss;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&stats[i], (double)red[i]);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, cc = i % C;
+    float t = 0.f;
+    for (int q = 0; q < per; ++q) t += red[(q * 2 + which) * C + cc];
+    out[i] = t;
+  }
+}
+// pass 2: one wave per (sum | sumsq, channel): fp64 sum over the blocks
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nb, int C, double* __restrict__ stats) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= 2 * C) return;
+  double t = 0.0;
+  for (int b = lane; b < nb; b += 64) t += (double)partial[(int64_t)b * 2 * C + i];
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  if (lane == 0) stats[i] = t;
 }
 
 __global__ void gn_apply_kernel(const float* __restrict__ x, int64_t N, int C, int groups, const double* __restrict__ stats,
@@ -368,6 +384,11 @@ int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int
   return GEOTR_OK;
 }
 
+size_t geotr_group_norm_workspace_bytes(int64_t n, int64_t c) {
+  const size_t nb = (size_t)((n + kGnRows - 1) / kGnRows);
+  return sizeof(double) * 2 * (size_t)c + sizeof(float) * 2 * (size_t)c * (nb > 0 ? nb : 1);
+}
+
 int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
                      float eps, const float* residual, int act, float* out, double* stats_ws, void* stream_) {
   GEOTR_CHECK_ARG(n >= 0 && c >= 1 && groups >= 1 && c % groups == 0, "group_norm: %lld channels / %lld groups",
@@ -375,10 +396,11 @@ int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const
   if (n == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(x && gamma && beta && out && stats_ws, "group_norm: null pointer");
   hipStream_t stream = (hipStream_t)stream_;
-  if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)c, stream) != hipSuccess)
-    return fail(GEOTR_E_LAUNCH, "group_norm: memset failed");
   const unsigned nb = (unsigned)((n + kGnRows - 1) / kGnRows);
-  gn_stats_kernel<<<dim3(nb), dim3(256), c < 256 ? sizeof(float) * 2 * (size_t)c : 0, stream>>>(x, n, (int)c, stats_ws);
+  float* partial = reinterpret_cast<float*>(stats_ws + 2 * c);
+  const int per = c < 256 ? (int)(256 / c) : 0;
+  gn_partial_kernel<<<dim3(nb), dim3(256), sizeof(float) * 2 * (size_t)c * per, stream>>>(x, n, (int)c, partial);
+  gn_finalize_kernel<<<dim3((unsigned)((2 * c + 3) / 4)), dim3(256), 0, stream>>>(partial, (int)nb, (int)c, stats_ws);
   gn_apply_kernel<<<dim3((unsigned)((n * c + 255) / 256)), dim3(256), 0, stream>>>(x, n, (int)c, (int)groups, stats_ws, gamma,
                                                                                  beta, eps, residual, act, out);
   GEOTR_CHECK_LAUNCH("group_norm");

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(1024) void lgr_refine_kernel(const float* __restric
                                                           float radius, int steps, float* __restrict__ T_final) {
   __shared__ double red[16 * 16];
   __shared__ float T[16];
-  __shared__ int best_p, best_n;
+  __shared__ int best_p;
   const int C = *total;
   if (threadIdx.x == 0) {
     int bp = -1, bn = -1;
@@ -305,7 +305,6 @@ __global__ __launch_bounds__(1024) void lgr_refine_kernel(const float* __restric
         bp = p;
       }
     best_p = bp;
-    best_n = bn;
   }
   __syncthreads();
   if (best_p >= 0) {

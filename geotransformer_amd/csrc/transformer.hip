@@ -205,7 +205,7 @@ constexpr int kAttTile = 64;  // keys per tile
 
 __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ scores, const float* __restrict__ emb,
                                                            const float* __restrict__ qt, const float* __restrict__ qb,
-                                                           int n, int m, int C, int H, float scale) {
+                                                           int n, int m, int ld, int C, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sc_s = smem;                 // [H][m]
   float* qt_s = sc_s + H * m;         // [C][H]
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ s
   float* e_s = part_s + 4 * H * kAttTile;  // [64][C + 1]
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int es = C + 1;
-  for (int e = tid; e < H * m; e += 256) sc_s[e] = scores[((int64_t)(e / m) * n + i) * m + (e % m)];
+  for (int e = tid; e < H * m; e += 256) sc_s[e] = scores[((int64_t)(e / m) * n + i) * ld + (e % m)];
   if (emb) {
     for (int e = tid; e < C * H; e += 256) {
       const int c = e / H, h = e % H;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ s
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float inv = 1.f / sum;
-    float* dst = scores + ((int64_t)h * n + i) * m;
+    float* dst = scores + ((int64_t)h * n + i) * ld;
     for (int j = lane; j < m; j += 64) dst[j] = sc_s[h * m + j] * inv;
   }
 }
@@ -343,9 +343,9 @@ int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t 
   return GEOTR_OK;
 }
 
-int geotr_attn_softmax(float* scores, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m, int64_t c,
-                       int64_t heads, float scale, void* stream_) {
-  GEOTR_CHECK_ARG(n >= 0 && m >= 1 && heads >= 1 && heads <= 8, "attn_softmax: bad sizes (heads <= 8)");
+int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m,
+                       int64_t c, int64_t heads, float scale, void* stream_) {
+  GEOTR_CHECK_ARG(n >= 0 && m >= 1 && ld >= m && heads >= 1 && heads <= 8, "attn_softmax: bad sizes (heads <= 8)");
   if (n == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(scores && (!emb || (qt && qb)), "attn_softmax: null pointer");
   GEOTR_CHECK_ARG(!emb || (c % 16 == 0 && c <= 512), "attn_softmax: channels must be a multiple of 16, <= 512");
@@ -357,7 +357,7 @@ int geotr_attn_softmax(float* scores, const float* emb, const float* qt, const f
       hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_softmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return fail(GEOTR_E_LAUNCH, "attn_softmax: cannot reserve %zu B of LDS", lds);
-  attn_softmax_kernel<<<dim3((unsigned)n), dim3(256), lds, stream>>>(scores, emb, qt, qb, (int)n, (int)m, (int)c, (int)heads, scale);
+  attn_softmax_kernel<<<dim3((unsigned)n), dim3(256), lds, stream>>>(scores, emb, qt, qb, (int)n, (int)m, (int)ld, (int)c, (int)heads, scale);
   GEOTR_CHECK_LAUNCH("attn_softmax");
   return GEOTR_OK;
 }

@@ -120,7 +120,7 @@ def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, act=None):
     x = _f32c(x)
     N, C = x.shape
     out = torch.empty_like(x)
-    stats = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    stats = _lib.workspace(lib.geotr_group_norm_workspace_bytes(N, C), x.device)
     if residual is not None:
         residual = _f32c(residual)
     _lib.check(lib.geotr_group_norm(_lib.ptr(x), N, C, groups, _lib.ptr(weight), _lib.ptr(bias), float(eps),
@@ -171,13 +171,14 @@ def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a):
 def attn_softmax(scores, scale, emb=None, qt=None, qb=None):
     """In-place softmax over the last dim of scores (H, n, m); with `emb` adds the relative-position term first."""
     lib = _lib.load()
-    assert scores.is_contiguous()
     H, n, m = scores.shape
+    ld = scores.stride(1)
+    assert scores.stride(2) == 1 and scores.stride(0) == n * ld, 'scores must be (H, n, m) rows with a common leading dimension'
     c = 0
     if emb is not None:
         emb, qt, qb = _f32c(emb), _f32c(qt), _f32c(qb)
         c = emb.shape[-1]
-    _lib.check(lib.geotr_attn_softmax(_lib.ptr(scores), _lib.ptr(emb), _lib.ptr(qt), _lib.ptr(qb), n, m, c, H, float(scale),
+    _lib.check(lib.geotr_attn_softmax(_lib.ptr(scores), ld, _lib.ptr(emb), _lib.ptr(qt), _lib.ptr(qb), n, m, c, H, float(scale),
                                       _lib.stream_ptr()), 'geotr_attn_softmax')
     return scores
 

@@ -51,7 +51,7 @@ class GeoTransformer(nn.Module):
         fine = self.backbone.fine_stage
         feats = data_dict['features']
         # cloud sizes: taken from the collate (host ints when available, else read back once)
-        lengths = data_dict['lengths']
+        lengths = data_dict.get('lengths_host', data_dict['lengths'])  # host ints from the device collate avoid 3 syncs
         ref_length_c = int(lengths[-1][0])
         ref_length_f = int(lengths[fine][0])
         ref_length = int(lengths[0][0])

@@ -8,6 +8,31 @@ def _check_unsupported(**kwargs):
             raise NotImplementedError(f'{name} is not used by the registration hot path and is not implemented')
 
 
+class FusedProjection:
+    """Concatenated weight/bias of several nn.Linear layers sharing one input: one GEMM instead of several.
+    The concatenation is cached and rebuilt only when a parameter changes (in-place version counters)."""
+
+    def __init__(self, *linears):
+        self.linears = linears
+        self._key = None
+        self._w = self._b = None
+
+    def __call__(self, x):
+        import torch
+        key = tuple((l.weight._version, l.bias._version, l.weight.data_ptr()) for l in self.linears)
+        if key != self._key:
+            self._w = torch.cat([l.weight.detach() for l in self.linears], dim=0).contiguous()
+            self._b = torch.cat([l.bias.detach() for l in self.linears], dim=0).contiguous()
+            self._key = key
+        y = kernels.linear(x, self._w, self._b)
+        sizes = [l.weight.shape[0] for l in self.linears]
+        outs, o = [], 0
+        for sz in sizes:
+            outs.append(y[:, o:o + sz])  # strided views (row stride = total width); consumers accept them
+            o += sz
+        return outs
+
+
 def multi_head_attention(q, k, v, num_heads, emb=None, w_p=None, b_p=None):
     """q (n, C), k/v (m, C) already projected.  Returns (hidden (n, C), probabilities (H, n, m)).
 
@@ -21,7 +46,8 @@ def multi_head_attention(q, k, v, num_heads, emb=None, w_p=None, b_p=None):
     q3 = q.view(n, H, ch).permute(1, 0, 2)  # (H, n, ch) strided views, no copies
     k3 = k.view(m, H, ch).permute(1, 0, 2)
     v3 = v.view(m, H, ch).permute(1, 0, 2)
-    scores = kernels.gemm(q3, k3)  # (H, n, m) = q_h k_h^T
+    mp = (m + 3) // 4 * 4  # leading dimension padded to a multiple of 4: the PV GEMM then takes the float4 load path
+    scores = kernels.gemm(q3, k3, out=q.new_empty((H, n, mp))[:, :, :m])  # (H, n, m) = q_h k_h^T
     if emb is not None:
         qt = q.new_empty((n, H, C))
         kernels.gemm(q3, w_p.view(H, ch, C), b_is_kn=True, out=qt.permute(1, 0, 2))  # qt[:, h, :] = q_h W_p[h]

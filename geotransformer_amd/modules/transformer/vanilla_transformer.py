@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from ... import kernels
-from .attention_core import _check_unsupported, multi_head_attention
+from .attention_core import FusedProjection, _check_unsupported, multi_head_attention
 from .output_layer import AttentionOutput
 
 
@@ -19,6 +19,7 @@ class MultiHeadAttention(nn.Module):
         self.proj_q = nn.Linear(d_model, d_model)
         self.proj_k = nn.Linear(d_model, d_model)
         self.proj_v = nn.Linear(d_model, d_model)
+        self._kv = FusedProjection(self.proj_k, self.proj_v)
 
     def forward(self, input_q, input_k, input_v, key_weights=None, key_masks=None, attention_factors=None,
                 attention_masks=None):
@@ -27,8 +28,11 @@ class MultiHeadAttention(nn.Module):
         if input_q.shape[0] != 1:
             raise NotImplementedError('batch size 1 (one cloud per call), as in the reference model')
         q = kernels.linear(input_q[0], self.proj_q.weight, self.proj_q.bias)
-        k = kernels.linear(input_k[0], self.proj_k.weight, self.proj_k.bias)
-        v = kernels.linear(input_v[0], self.proj_v.weight, self.proj_v.bias)
+        if input_k is input_v:  # the keys and values of cross-attention share their input: one (M, C) x (C, 2C) GEMM
+            k, v = self._kv(input_k[0])
+        else:
+            k = kernels.linear(input_k[0], self.proj_k.weight, self.proj_k.bias)
+            v = kernels.linear(input_v[0], self.proj_v.weight, self.proj_v.bias)
         hidden, probs = multi_head_attention(q, k, v, self.num_heads)
         return hidden.unsqueeze(0), probs.unsqueeze(0)
 

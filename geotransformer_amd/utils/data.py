@@ -28,13 +28,17 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
     points = points.to(dev).contiguous()
     lengths = lengths.to(dev).contiguous()
 
-    points_list, lengths_list = [], []
+    points_list, lengths_list, lengths_host = [], [], []
     for i in range(num_stages):
         if i > 0:
             buf, lengths = ext.grid_subsample_device(points, lengths, voxel_size)
-            points = buf[: int(lengths.sum().item())]  # row count is data dependent (one sync per stage)
+            host = lengths.tolist()  # row counts are data dependent: the one host read per stage
+            points = buf[: sum(host)]
+        else:
+            host = lengths.tolist()
         points_list.append(points)
         lengths_list.append(lengths)
+        lengths_host.append(host)
         voxel_size *= 2
 
     grids = []
@@ -73,6 +77,7 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
         'neighbors': back(neighbors_list),
         'subsampling': back(subsampling_list),
         'upsampling': back(upsampling_list),
+        'lengths_host': lengths_host,  # extra key (python ints): lets the model slice clouds without device reads
     }
 
 

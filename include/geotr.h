@@ -107,7 +107,8 @@ int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, int b_i
  *   geotr_upsample_concat: out[m] = [ coarse_pad[up_idx[m*ld_idx], :c1] , skip[m, :c2] ]
  *                                                    kpconv/functional.py:6-22 + experiments/.../backbone.py:71-78
  *   geotr_group_norm     : GroupNorm over the stacked (N,C) matrix (statistics over ALL points),
- *                          out = act(gn(x) + residual); stats_ws = 2*c doubles   kpconv/modules.py:33-50,142-147,204-224
+ *                          out = act(gn(x) + residual); stats_ws = geotr_group_norm_workspace_bytes(n, c) bytes
+ *                                                                               kpconv/modules.py:33-50,142-147,204-224
  *   geotr_layer_norm     : out = LayerNorm(x + residual)       transformer/rpe_transformer.py:102, output_layer.py:20
  * ---------------------------------------------------------------------------------------------- */
 int geotr_row_positive(const float* x, int64_t n, int64_t c, uint8_t* flag, void* stream);
@@ -119,6 +120,7 @@ int geotr_maxpool(const float* x, const int64_t* neighbors, int64_t m, int64_t n
                   void* stream);
 int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int64_t* up_idx, int64_t ld_idx,
                           const float* skip, int64_t c2, int64_t m, float* out, void* stream);
+size_t geotr_group_norm_workspace_bytes(int64_t n, int64_t c);
 int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
                      float eps, const float* residual, int act, float* out, double* stats_ws, void* stream);
 int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c, const float* gamma, const float* beta,
@@ -132,7 +134,7 @@ int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c
  *   geotr_gse_embed    : out[i,j,:] = W_d sin/cos(d_ij/sigma_d * w) + b_d + max_x (W_a sin/cos(angle_ijx*180/(sigma_a*pi) * w) + b_a)
  *                        (n,n,d) fp32; div_term (d/2) = the reference's registered buffer exp(-2t ln(1e4)/d)
  *                                              geotransformer.py:26-72, transformer/positional_embedding.py:8-34
- *   geotr_attn_softmax : scores (heads,n,m) <- softmax_m((scores + emb[i,j,:] . qt[i,h,:] + qb[i,h]) * scale), in place.
+ *   geotr_attn_softmax : scores (heads,n,m; row stride ld >= m) <- softmax_m((scores + emb[i,j,:] . qt[i,h,:] + qb[i,h]) * scale), in place.
  *                        qt (n,heads,c) = W_p[h]^T q[h], qb (n,heads) = q[h] . b_p[h]: the exact algebraic collapse of
  *                        proj_p over the (n,m,c) embedding.  emb == NULL: plain scaled softmax.
  *                                              transformer/rpe_transformer.py:51-66, vanilla_transformer.py:55-63
@@ -141,8 +143,8 @@ int geotr_gse_knn(const float* points, int64_t n, int64_t k, int32_t* knn, void*
 int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t k, int64_t d, const float* div_term,
                     const float* w_d, const float* b_d, const float* w_a, const float* b_a, float sigma_d, float sigma_a,
                     float* out, void* stream);
-int geotr_attn_softmax(float* scores, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m, int64_t c,
-                       int64_t heads, float scale, void* stream);
+int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m,
+                       int64_t c, int64_t heads, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * P1/M1/S1/S2  matching heads
