@@ -71,21 +71,22 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
                                                             const unsigned char* __restrict__ pos, int64_t M, int64_t Ns,
                                                             int H, int C, int ppw, float sigma,
                                                             float* __restrict__ out, int* __restrict__ nnum) {
-  __shared__ __attribute__((aligned(16))) float w_s[4][kSlotCap * kWStride];
-  __shared__ float rel_s[4][kSlotCap * 3];
-  __shared__ int idx_s[4][kSlotCap];
-  __shared__ int cnt_s[4][64];
+  // dynamic LDS, per wave: w[slots][16] | rel[slots][3] | idx[slots] | cnt[64]  (slots = ppw * H rounded up to 4);
+  // sized to the launch's real need so several blocks fit on a CU (the fixed 256-slot slabs allowed only one)
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
   __shared__ float kps[kKP * 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slots = (ppw * H + 3) & ~3;
+  const int per_wave = slots * (kWStride + 3 + 1) + 64;
   if (threadIdx.x < kKP * 3) kps[threadIdx.x] = kp[threadIdx.x];
   __syncthreads();
   const int lpp = C < 64 ? C : 64;
   const int slot = lane / lpp, cl = lane % lpp;
   const int64_t groups = (M + ppw - 1) / ppw;
-  float* w = w_s[wave];
-  float* rel = rel_s[wave];
-  int* idx = idx_s[wave];
-  int* cnt = cnt_s[wave];
+  float* w = dyn + (size_t)wave * per_wave;
+  float* rel = w + slots * kWStride;
+  int* idx = reinterpret_cast<int*>(rel + slots * 3);
+  int* cnt = idx + slots;
   for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < groups; g += (int64_t)gridDim.x * 4) {
     const int64_t m0 = g * ppw;
     const int total = ppw * H;
@@ -246,6 +247,54 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
   if (lane == 0) stats[i] = t;
 }
+// pass 3: per-channel scale / shift so the apply pass is one fma per element:  y = x * a[c] + b[c]
+__global__ void gn_affine_kernel(const double* __restrict__ stats, int64_t N, int C, int groups, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, float* __restrict__ ab) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int cpg = C / groups, g0 = (c / cpg) * cpg;
+  double s = 0.0, ss = 0.0;
+  for (int j = 0; j < cpg; ++j) {
+    s += stats[g0 + j];
+    ss += stats[C + g0 + j];
+  }
+  const double cnt = (double)N * cpg;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  ab[c] = rstd * gamma[c];
+  ab[C + c] = beta[c] - (float)mean * rstd * gamma[c];
+}
+template <bool VEC4>
+__global__ __launch_bounds__(256) void gn_apply2_kernel(const float* __restrict__ x, int64_t total, int C, const float* __restrict__ ab,
+                                                        const float* __restrict__ residual, int act, float* __restrict__ out) {
+  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (VEC4 ? 4 : 1);
+  if (e >= total) return;
+  if (VEC4) {
+    const int c = (int)(e % C);
+    const float4 v = *reinterpret_cast<const float4*>(x + e);
+    float r[4] = {v.x * ab[c] + ab[C + c], v.y * ab[c + 1] + ab[C + c + 1], v.z * ab[c + 2] + ab[C + c + 2],
+                  v.w * ab[c + 3] + ab[C + c + 3]};
+    if (residual) {
+      const float4 q = *reinterpret_cast<const float4*>(residual + e);
+      r[0] += q.x; r[1] += q.y; r[2] += q.z; r[3] += q.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (act == 2) r[k] = r[k] > 0.f ? r[k] : 0.1f * r[k];
+      if (act == 1) r[k] = fmaxf(r[k], 0.f);
+    }
+    *reinterpret_cast<float4*>(out + e) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+    const int c = (int)(e % C);
+    float v = x[e] * ab[c] + ab[C + c];
+    if (residual) v += residual[e];
+    if (act == 2) v = v > 0.f ? v : 0.1f * v;
+    if (act == 1) v = fmaxf(v, 0.f);
+    out[e] = v;
+  }
+}
 
 __global__ void gn_apply_kernel(const float* __restrict__ x, int64_t N, int C, int groups, const double* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -348,9 +397,11 @@ int geotr_kpconv_gather(const float* s_feats, const float* q_points, const float
     const int64_t groups = (m + ppw - 1) / ppw;
     const unsigned nb = (unsigned)std::min<int64_t>((groups + 3) / 4, 8192);
     const int cpl = c <= 64 ? 1 : (int)(c / 64);
-#define LAUNCH(CPL)                                                                                                  \
-  kpconv_gather_kernel<CPL><<<dim3(nb), dim3(256), 0, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points, \
-                                                               pos_flag, m, ns, (int)h, (int)c, ppw, sigma, weighted, nnum)
+    const int slots = (int)((ppw * h + 3) & ~3ll);
+    const size_t lds = sizeof(float) * 4 * ((size_t)slots * (kWStride + 3 + 1) + 64);
+#define LAUNCH(CPL)                                                                                                    \
+  kpconv_gather_kernel<CPL><<<dim3(nb), dim3(256), lds, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points, \
+                                                                 pos_flag, m, ns, (int)h, (int)c, ppw, sigma, weighted, nnum)
     if (cpl == 1) LAUNCH(1);
     else if (cpl == 2) LAUNCH(2);
     else if (cpl == 4) LAUNCH(4);
@@ -386,7 +437,7 @@ int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int
 
 size_t geotr_group_norm_workspace_bytes(int64_t n, int64_t c) {
   const size_t nb = (size_t)((n + kGnRows - 1) / kGnRows);
-  return sizeof(double) * 2 * (size_t)c + sizeof(float) * 2 * (size_t)c * (nb > 0 ? nb : 1);
+  return sizeof(double) * 2 * (size_t)c + sizeof(float) * 2 * (size_t)c * ((nb > 0 ? nb : 1) + 1);
 }
 
 int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
@@ -401,8 +452,13 @@ int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const
   const int per = c < 256 ? (int)(256 / c) : 0;
   gn_partial_kernel<<<dim3(nb), dim3(256), sizeof(float) * 2 * (size_t)c * per, stream>>>(x, n, (int)c, partial);
   gn_finalize_kernel<<<dim3((unsigned)((2 * c + 3) / 4)), dim3(256), 0, stream>>>(partial, (int)nb, (int)c, stats_ws);
-  gn_apply_kernel<<<dim3((unsigned)((n * c + 255) / 256)), dim3(256), 0, stream>>>(x, n, (int)c, (int)groups, stats_ws, gamma,
-                                                                                 beta, eps, residual, act, out);
+  float* ab = partial + (size_t)nb * 2 * c;
+  gn_affine_kernel<<<dim3((unsigned)((c + 255) / 256)), dim3(256), 0, stream>>>(stats_ws, n, (int)c, (int)groups, gamma, beta, eps, ab);
+  const int64_t total = n * c;
+  if (c % 4 == 0)
+    gn_apply2_kernel<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, residual, act, out);
+  else
+    gn_apply2_kernel<false><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, residual, act, out);
   GEOTR_CHECK_LAUNCH("group_norm");
   return GEOTR_OK;
 }

@@ -203,64 +203,64 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_kernel(const float* _
 // ---------------------------------------------------------------------------------------------------
 constexpr int kAttTile = 64;  // keys per tile
 
-__global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ scores, const float* __restrict__ emb,
-                                                           const float* __restrict__ qt, const float* __restrict__ qb,
-                                                           int n, int m, int ld, int C, int H, float scale) {
+// positional term: one block per (query i, tile of 64 keys):  scores[h,i,j] += e[i,j,:] . qt[i,h,:] + qb[i,h]
+__global__ __launch_bounds__(256) void attn_pos_kernel(float* __restrict__ scores, const float* __restrict__ emb,
+                                                       const float* __restrict__ qt, const float* __restrict__ qb, int n, int m,
+                                                       int ld, int C, int H) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sc_s = smem;                 // [H][m]
-  float* qt_s = sc_s + H * m;         // [C][H]
-  float* part_s = qt_s + C * H;       // [4][H][64]
+  float* qt_s = smem;                      // [C][H]
+  float* part_s = qt_s + C * H;            // [4][H][64]
   float* e_s = part_s + 4 * H * kAttTile;  // [64][C + 1]
-  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x, j0 = blockIdx.y * kAttTile, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int es = C + 1;
-  for (int e = tid; e < H * m; e += 256) sc_s[e] = scores[((int64_t)(e / m) * n + i) * ld + (e % m)];
-  if (emb) {
-    for (int e = tid; e < C * H; e += 256) {
-      const int c = e / H, h = e % H;
-      qt_s[e] = qt[((int64_t)i * H + h) * C + c];
-    }
-    const float* erow = emb + (int64_t)i * m * C;
-    for (int j0 = 0; j0 < m; j0 += kAttTile) {
-      __syncthreads();
-      const int rows = min(kAttTile, m - j0);
-      for (int e = tid; e < rows * (C / 4); e += 256) {  // coalesced float4 loads of the (rows, C) tile
-        const int r = e / (C / 4), c4 = (e % (C / 4)) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(erow + (int64_t)(j0 + r) * C + c4);
-        float* d = e_s + r * es + c4;
-        d[0] = v.x;
-        d[1] = v.y;
-        d[2] = v.z;
-        d[3] = v.w;
-      }
-      __syncthreads();
-      // wave w reduces channels [w*C/4, (w+1)*C/4) for key j0 + lane, all heads
-      float accv[8];
-#pragma unroll
-      for (int h = 0; h < 8; ++h) accv[h] = 0.f;
-      if (lane < rows) {
-        const int c0 = wave * (C / 4), c1 = c0 + C / 4;
-        for (int c = c0; c < c1; ++c) {
-          const float ev = e_s[lane * es + c];
-#pragma unroll
-          for (int h = 0; h < 8; ++h)
-            if (h < H) accv[h] = fmaf(ev, qt_s[c * H + h], accv[h]);
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < 8; ++h)
-        if (h < H) part_s[(wave * H + h) * kAttTile + lane] = accv[h];
-      __syncthreads();
-      for (int e = tid; e < H * rows; e += 256) {
-        const int h = e / rows, j = e % rows;
-        float p = 0.f;
-        for (int w = 0; w < 4; ++w) p += part_s[(w * H + h) * kAttTile + j];
-        sc_s[h * m + j0 + j] += p + qb[i * H + h];
-      }
-    }
+  const int rows = min(kAttTile, m - j0);
+  for (int e = tid; e < C * H; e += 256) {
+    const int c = e / H, h = e % H;
+    qt_s[e] = qt[((int64_t)i * H + h) * C + c];
+  }
+  const float* erow = emb + ((int64_t)i * m + j0) * C;
+  for (int e = tid; e < rows * (C / 4); e += 256) {  // coalesced float4 loads of the (rows, C) tile
+    const int r = e / (C / 4), c4 = (e % (C / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(erow + (int64_t)r * C + c4);
+    float* d = e_s + r * es + c4;
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+    d[3] = v.w;
   }
   __syncthreads();
-  // softmax over keys, wave per head (heads >= 4 are handled round-robin)
-  for (int h = wave; h < H; h += 4) {
+  // wave w reduces channels [w*C/4, (w+1)*C/4) for key j0 + lane, all heads
+  float accv[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) accv[h] = 0.f;
+  if (lane < rows) {
+    const int c0 = wave * (C / 4), c1 = c0 + C / 4;
+    for (int c = c0; c < c1; ++c) {
+      const float ev = e_s[lane * es + c];
+#pragma unroll
+      for (int h = 0; h < 8; ++h)
+        if (h < H) accv[h] = fmaf(ev, qt_s[c * H + h], accv[h]);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 8; ++h)
+    if (h < H) part_s[(wave * H + h) * kAttTile + lane] = accv[h];
+  __syncthreads();
+  for (int e = tid; e < H * rows; e += 256) {
+    const int h = e / rows, j = e % rows;
+    float p = 0.f;
+    for (int w = 0; w < 4; ++w) p += part_s[(w * H + h) * kAttTile + j];
+    scores[((int64_t)h * n + i) * ld + j0 + j] += p + qb[i * H + h];
+  }
+}
+
+// softmax over the keys of one query row, all heads: scores <- softmax(scores * scale)
+__global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ scores, int n, int m, int ld, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sc_s[];  // [H][m]
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < H * m; e += 256) sc_s[e] = scores[((int64_t)(e / m) * n + i) * ld + (e % m)];
+  __syncthreads();
+  for (int h = wave; h < H; h += 4) {  // wave per head
     float mx = -3.4e38f;
     for (int j = lane; j < m; j += 64) mx = fmaxf(mx, sc_s[h * m + j] * scale);
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -350,14 +350,22 @@ int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float*
   GEOTR_CHECK_ARG(scores && (!emb || (qt && qb)), "attn_softmax: null pointer");
   GEOTR_CHECK_ARG(!emb || (c % 16 == 0 && c <= 512), "attn_softmax: channels must be a multiple of 16, <= 512");
   hipStream_t stream = (hipStream_t)stream_;
-  size_t lds = sizeof(float) * (size_t)(heads * m);
-  if (emb) lds += sizeof(float) * (size_t)(c * heads + 4 * heads * kAttTile + kAttTile * (c + 1));
-  if (lds > 160 * 1024) return fail(GEOTR_E_CAPACITY, "attn_softmax: %lld keys need %zu B of LDS", (long long)m, lds);
-  if (lds > 64 * 1024 &&
+  if (emb) {
+    const size_t lds = sizeof(float) * (size_t)(c * heads + 4 * heads * kAttTile + kAttTile * (c + 1));
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_pos_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+      return fail(GEOTR_E_LAUNCH, "attn_softmax: cannot reserve %zu B of LDS", lds);
+    attn_pos_kernel<<<dim3((unsigned)n, (unsigned)((m + kAttTile - 1) / kAttTile)), dim3(256), lds, stream>>>(
+        scores, emb, qt, qb, (int)n, (int)m, (int)ld, (int)c, (int)heads);
+  }
+  const size_t lds2 = sizeof(float) * (size_t)(heads * m);
+  if (lds2 > 160 * 1024) return fail(GEOTR_E_CAPACITY, "attn_softmax: %lld keys need %zu B of LDS", (long long)m, lds2);
+  if (lds2 > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_softmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess)
-    return fail(GEOTR_E_LAUNCH, "attn_softmax: cannot reserve %zu B of LDS", lds);
-  attn_softmax_kernel<<<dim3((unsigned)n), dim3(256), lds, stream>>>(scores, emb, qt, qb, (int)n, (int)m, (int)ld, (int)c, (int)heads, scale);
+                          (int)lds2) != hipSuccess)
+    return fail(GEOTR_E_LAUNCH, "attn_softmax: cannot reserve %zu B of LDS", lds2);
+  attn_softmax_kernel<<<dim3((unsigned)n), dim3(256), lds2, stream>>>(scores, (int)n, (int)m, (int)ld, (int)heads, scale);
   GEOTR_CHECK_LAUNCH("attn_softmax");
   return GEOTR_OK;
 }
