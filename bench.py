@@ -32,6 +32,19 @@ sys.path.insert(0, ROOT)
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 
 
+def pmc_traffic_bytes(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (collected in separate --pmc passes of
+    this same command; bench.py itself cannot run under the counters).  None when no summary is present."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    if not os.path.exists(path):
+        return None
+    data = json.load(open(path))
+    for name, rec in data.items():
+        if kernel_substr in name:
+            return round(rec['hbm_mb_per_launch'] * 1024 * 1024)
+    return None
+
+
 def build_pair(seed, config, n_points):
     from geotransformer_amd.synthetic import make_pair
     return make_pair(seed, config, n_points=n_points)
@@ -156,7 +169,8 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'gse_embed_kernel<256,4> (fused GSE: sinusoid -> fp32 MFMA -> max_k)',
                          'achieved': round(achieved, 2) if achieved else None, 'peak': FP32_MATRIX_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4) if achieved else None,
-                         'traffic': None, 'launches': len(durs),
+                         'traffic': pmc_traffic_bytes('gse_embed_kernel'), 'traffic_unit': 'HBM bytes/launch (rocprofv3 PMC '
+                         'FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/r01_pmc_hbm_traffic.md)', 'launches': len(durs),
                          'avg_launch_us': round(1e6 * sum(durs) / len(durs), 1) if durs else None},
         }
         if world == 1 and not args.no_cpu_baseline:
