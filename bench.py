@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the whole hot path over one synthetic 3DMatch-shape pair (BASELINE config 2: ~20k + 20k points,
+A "step" is one pass of the whole hot path over one batch of `--batch` independent synthetic 3DMatch-shape pairs
+(default 4 per GPU, `--lanes` of them in flight at a time on separate HIP streams; BASELINE config 2: ~20k + 20k points,
 4-stage KPConv-FPN, d = 256): the collate-equivalent pyramid (3 grid subsamples + 10 radius searches) plus the full
 GeoTransformer forward through `estimated_transform`.  Inputs (raw xyz) are resident in HBM when the timed region
 starts; weights are random-init (seed 7351), data synthetic.  At N > 1 every rank processes its own pairs (weak
@@ -90,13 +91,15 @@ def main():
     ap.add_argument('--config', default='3dmatch', choices=['3dmatch', 'modelnet', 'kitti'])
     ap.add_argument('--points', type=int, default=None, help='points per cloud (default: the config\'s)')
     ap.add_argument('--pairs', type=int, default=4, help='distinct synthetic pairs cycled through per rank')
+    ap.add_argument('--batch', type=int, default=4, help='pairs per step per GPU (independent pairs of one batch)')
+    ap.add_argument('--lanes', type=int, default=2, help='pairs kept in flight concurrently (host thread + HIP stream each)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
     from geotransformer_amd import _lib, kernels
     from geotransformer_amd import dist as gd
     from geotransformer_amd.config import make_cfg
-    from geotransformer_amd.pipeline import RegistrationPipeline
+    from geotransformer_amd.pipeline import ConcurrentRegistration, RegistrationPipeline
     from geotransformer_amd.synthetic import CONFIGS
 
     _lib.require_gpu()
@@ -117,20 +120,27 @@ def main():
     items = [build_pair(1000 * rank + i, args.config, n_points) for i in range(args.pairs)]
     pairs = [(torch.from_numpy(it['ref_points']).to(device), torch.from_numpy(it['src_points']).to(device)) for it in items]
 
-    results = torch.zeros((args.steps, 4, 4), dtype=torch.float32, device=device)
+    results = torch.zeros((args.steps, args.batch, 4, 4), dtype=torch.float32, device=device)
     info = {}
+    runner = ConcurrentRegistration(pipe, lanes=args.lanes)
 
     def step(i, record=None):
-        ref, src = pairs[i % len(pairs)]
-        out = pipe(ref, src)
-        if record is not None:
-            results[record] = out['estimated_transform']
-        return out
+        """One step = one batch of `--batch` independent pairs through the whole hot path."""
+        batch = [pairs[(i * args.batch + j) % len(pairs)] for j in range(args.batch)]
+        last = {}
+
+        def sink(j, out):
+            if record is not None:
+                results[record, j] = out['estimated_transform']
+            last[j] = out
+
+        runner.run_batch(batch, sink)
+        return last[0]
 
     for i in range(args.warmup):
         out = step(i)
+    torch.cuda.synchronize()
     info['superpoints'] = [int(out['ref_points_c'].shape[0]), int(out['src_points_c'].shape[0])]
-    info['stage_points'] = None
 
     kernels.PROFILE['gse_embed'] = []  # HIP-event pairs around the dominant kernel, on the launch stream
     gd.barrier()
@@ -148,7 +158,7 @@ def main():
 
     if rank == 0:
         assert torch.isfinite(gathered).all()
-        total_pairs = args.steps * world
+        total_pairs = args.steps * args.batch * world
         value = total_pairs / elapsed
         # roofline of the dominant kernel: 2 * n^2 * (1 + k) * D^2 FLOPs per launch (proj_d + k x proj_a)
         D, k = cfg.geotransformer.hidden_dim, cfg.geotransformer.angle_k
@@ -164,7 +174,8 @@ def main():
                                    f'{info["superpoints"][0]}+{info["superpoints"][1]} superpoints, '
                                    f'P={cfg.coarse_matching.num_correspondences}, K={cfg.model.num_points_in_patch}, '
                                    f'pyramid + full forward per pair',
-                       'pairs_per_step_per_gpu': 1, 'parallelism': f'pairs sharded over {world} GPU(s), no data-path collective',
+                       'pairs_per_step_per_gpu': args.batch, 'pairs_in_flight_per_gpu': args.lanes,
+                       'parallelism': f'pairs sharded over {world} GPU(s), no data-path collective',
                        'weights': 'random init, seed 7351'},
             'roofline': {'bound': 'mfma', 'kernel': 'gse_embed_kernel<256,4> (fused GSE: sinusoid -> fp32 MFMA -> max_k)',
                          'achieved': round(achieved, 2) if achieved else None, 'peak': FP32_MATRIX_PEAK_TFLOPS,

@@ -46,11 +46,16 @@ SIGNATURES = {
     'geotr_superpoint_match': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                        c_ptr, c_ptr]),
     'geotr_patch_sinkhorn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr,
-                                     c_i64, c_ptr, c_ptr, c_ptr]),
+                                     c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'geotr_patch_gather': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr,
+                                   c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'geotr_l2_normalize': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_weighted_procrustes': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_lgr_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
+    'geotr_model_workspace_bytes': (c_size, [c_ptr, c_ptr]),   # struct pointers; typed in geotransformer_amd/native.py
+    'geotr_model_forward': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_lgr': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_int, c_f32, c_i64,
-                          c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+                          c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
 }
 
 _lib = None

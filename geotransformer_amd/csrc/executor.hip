@@ -1,0 +1,370 @@
+// executor.hip -- native (host C++) executor of the whole inference forward (geotr_model_forward, include/geotr.h).
+//
+// Mirrors, launch for launch, what the Python module mirror does (geotransformer_amd/{backbone,model}.py and
+// modules/*): experiments/<exp>/model.py:69-212 -> backbone.py -> modules/kpconv/modules.py, modules/geotransformer/*,
+// modules/transformer/*, modules/sinkhorn, local_global_registration.  Why it exists: one pair is ~260 kernel launches;
+// issued from Python they cost ~5 ms of interpreter time per pair, more than the kernels themselves need.  Here the launch
+// sequence, the intermediates (bump allocator over the caller's workspace) and the data-dependent counts (kept on the
+// device) all stay on the native side: one asynchronous host call per pair, no host<-device read inside.
+#include <cstring>
+
+#include "common.h"
+
+namespace geotr {
+
+struct Ctx {
+  char* base;
+  size_t off = 0, peak = 0, cap;
+  hipStream_t stream;
+  bool dry;  // size-query pass: account for allocations, launch nothing
+  int rc = GEOTR_OK;
+
+  template <typename T>
+  T* alloc(size_t count) {
+    off = align_up(off);
+    T* p = reinterpret_cast<T*>(base + off);
+    off += count * sizeof(T);
+    if (off > peak) peak = off;
+    if (!dry && off > cap && rc == GEOTR_OK) rc = fail(GEOTR_E_WORKSPACE, "model_forward: workspace exhausted (%zu > %zu)", off, cap);
+    return p;
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+  bool live() const { return !dry && rc == GEOTR_OK; }
+  void check(int code) {
+    if (code != GEOTR_OK && rc == GEOTR_OK) rc = code;
+  }
+};
+
+static float* linear(Ctx& c, const geotr_linear& l, const float* x, int64_t lda, int64_t m, int act, const float* residual = nullptr,
+                     int64_t ldr = 0) {
+  float* y = c.alloc<float>((size_t)m * l.out);
+  if (c.live())
+    c.check(geotr_gemm(x, lda, l.w, l.in, 0, y, l.out, m, l.out, l.in, 1, 0, 0, 0, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
+  return y;
+}
+
+// GroupNorm (groups > 0) or LayerNorm (groups == 0) with optional residual / activation; returns a new (n, ch) buffer
+static float* norm(Ctx& c, const geotr_norm& nm, const float* x, int64_t n, int64_t ch, const float* residual, int act) {
+  float* y = c.alloc<float>((size_t)n * ch);
+  if (nm.groups > 0) {
+    const size_t m = c.mark();
+    double* ws = reinterpret_cast<double*>(c.alloc<char>(geotr_group_norm_workspace_bytes(n, ch)));
+    if (c.live()) c.check(geotr_group_norm(x, n, ch, nm.groups, nm.gamma, nm.beta, nm.eps, residual, act, y, ws, c.stream));
+    c.release(m);
+  } else {
+    if (c.live()) c.check(geotr_layer_norm(x, residual, n, ch, nm.gamma, nm.beta, nm.eps, y, c.stream));
+  }
+  return y;
+}
+
+static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64_t ns, const float* q_pts, int64_t m,
+                     const float* s_pts, const int64_t* nb, int64_t h) {
+  float* out = c.alloc<float>((size_t)m * kp.out);
+  const size_t mk = c.mark();
+  uint8_t* flag = kp.in > 1 ? c.alloc<uint8_t>((size_t)ns) : nullptr;
+  float* weighted = c.alloc<float>((size_t)m * kp.num_kernel_points * kp.in);
+  int32_t* nnum = c.alloc<int32_t>((size_t)m);
+  if (c.live()) {
+    if (flag) c.check(geotr_row_positive(s_feats, ns, kp.in, flag, c.stream));
+    c.check(geotr_kpconv_gather(s_feats, q_pts, s_pts, nb, kp.kernel_points, flag, m, ns, h, kp.in, kp.num_kernel_points, kp.sigma,
+                                weighted, nnum, c.stream));
+    const int64_t kdim = kp.num_kernel_points * kp.in;
+    c.check(geotr_gemm(weighted, kdim, kp.weights, kp.out, 1, out, kp.out, m, kp.out, kdim, 1, 0, 0, 0, kp.bias, nnum, nullptr, 0,
+                       1.0f, 0, c.stream));
+  }
+  c.release(mk);
+  return out;
+}
+
+// ConvBlock / ResidualBlock (modules/kpconv/modules.py:105-225); returns (m, out) features
+static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t ns, const float* q_pts, int64_t m, const float* s_pts,
+                    const int64_t* nb, int64_t h) {
+  if (b.is_conv_block) {
+    const size_t mk0 = c.mark();
+    (void)mk0;
+    float* x = kpconv(c, b.conv, s_feats, ns, q_pts, m, s_pts, nb, h);
+    return norm(c, b.conv_norm, x, m, b.conv.out, nullptr, 2);
+  }
+  const float* x = s_feats;
+  if (b.has_unary1) {
+    float* t = linear(c, b.unary1, s_feats, b.unary1.in, ns, 0);
+    x = norm(c, b.unary1_norm, t, ns, b.unary1.out, nullptr, 2);
+  }
+  float* y = kpconv(c, b.conv, x, ns, q_pts, m, s_pts, nb, h);
+  y = norm(c, b.conv_norm, y, m, b.conv.out, nullptr, 2);
+  const float* sc = s_feats;  // shortcut branch
+  const int64_t in_ch = b.has_unary1 ? b.unary1.in : b.conv.in;
+  if (b.strided) {
+    float* pooled = c.alloc<float>((size_t)m * in_ch);
+    if (c.live()) c.check(geotr_maxpool(s_feats, nb, m, ns, h, in_ch, pooled, c.stream));
+    sc = pooled;
+  }
+  if (b.has_shortcut) {
+    float* t = linear(c, b.shortcut, sc, b.shortcut.in, m, 0);
+    sc = norm(c, b.shortcut_norm, t, m, b.shortcut.out, nullptr, 0);
+  }
+  float* z = linear(c, b.unary2, y, b.unary2.in, m, 0);
+  return norm(c, b.unary2_norm, z, m, b.unary2.out, sc, 2);  // leaky_relu(unary2(x) + shortcut)
+}
+
+struct BackboneOut {
+  const float* feats_c;
+  int64_t c_dim;
+};
+
+static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geotr_pyramid& p, const float* feats, float* feats_f_out) {
+  const int S = net.num_stages;
+  const float* enc[GEOTR_MAX_STAGES];
+  int64_t enc_ch[GEOTR_MAX_STAGES];
+  const float* x = block(c, net.blocks[0], feats, p.n[0], p.points[0], p.n[0], p.points[0], p.neighbors[0], p.neighbors_w[0]);
+  x = block(c, net.blocks[1], x, p.n[0], p.points[0], p.n[0], p.points[0], p.neighbors[0], p.neighbors_w[0]);
+  enc[0] = x;
+  enc_ch[0] = net.blocks[1].unary2.out;
+  int bi = 2;
+  for (int s = 1; s < S; ++s) {
+    x = block(c, net.blocks[bi++], x, p.n[s - 1], p.points[s], p.n[s], p.points[s - 1], p.subsampling[s - 1], p.subsampling_w[s - 1]);
+    x = block(c, net.blocks[bi++], x, p.n[s], p.points[s], p.n[s], p.points[s], p.neighbors[s], p.neighbors_w[s]);
+    x = block(c, net.blocks[bi++], x, p.n[s], p.points[s], p.n[s], p.points[s], p.neighbors[s], p.neighbors_w[s]);
+    enc[s] = x;
+    enc_ch[s] = net.blocks[bi - 1].unary2.out;
+  }
+  const float* latent = enc[S - 1];
+  int64_t lat_ch = enc_ch[S - 1];
+  int d = 0;
+  for (int i = S - 2; i >= net.fine_stage; --i, ++d) {
+    const int64_t tot = lat_ch + enc_ch[i];
+    float* cat = c.alloc<float>((size_t)p.n[i] * tot);
+    if (c.live())
+      c.check(geotr_upsample_concat(latent, p.n[i + 1], lat_ch, p.upsampling[i], p.upsampling_w[i], enc[i], enc_ch[i], p.n[i], cat, c.stream));
+    const geotr_linear& l = net.decoder[d];
+    if (i == net.fine_stage) {  // LastUnaryBlock: straight into the caller's buffer
+      if (c.live())
+        c.check(geotr_gemm(cat, tot, l.w, l.in, 0, feats_f_out, l.out, p.n[i], l.out, l.in, 1, 0, 0, 0, l.b, nullptr, nullptr, 0, 1.0f, 0,
+                           c.stream));
+      latent = feats_f_out;
+    } else {
+      float* t = linear(c, l, cat, tot, p.n[i], 0);
+      latent = norm(c, net.decoder_norm[d], t, p.n[i], l.out, nullptr, 2);
+    }
+    lat_ch = l.out;
+  }
+  return {enc[S - 1], enc_ch[S - 1]};
+}
+
+// multi-head attention core on already projected q (n rows, ld ldq), k/v (m rows); returns hidden (n, C)
+static float* attention(Ctx& c, int H, int64_t C, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                        int64_t n, int64_t m, const float* emb, const geotr_linear* proj_p) {
+  const int64_t ch = C / H, mp = (m + 3) / 4 * 4;
+  float* hidden = c.alloc<float>((size_t)n * C);
+  const size_t mk = c.mark();
+  float* scores = c.alloc<float>((size_t)H * n * mp);
+  float* qt = emb ? c.alloc<float>((size_t)n * H * C) : nullptr;
+  float* qb = emb ? c.alloc<float>((size_t)n * H) : nullptr;
+  if (c.live()) {
+    c.check(geotr_gemm(q, ldq, k, ldk, 0, scores, mp, n, m, ch, H, ch, ch, n * mp, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+    if (emb) {
+      c.check(geotr_gemm(q, ldq, proj_p->w, C, 1, qt, H * C, n, C, ch, H, ch, ch * C, C, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+      c.check(geotr_gemm(q, ldq, proj_p->b, 1, 1, qb, H, n, 1, ch, H, ch, ch, 1, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+    }
+    c.check(geotr_attn_softmax(scores, mp, emb, qt, qb, n, m, C, H, 1.0f / sqrtf((float)ch), c.stream));
+    c.check(geotr_gemm(scores, mp, v, ldv, 1, hidden, C, n, ch, m, H, n * mp, ch, ch, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+  }
+  c.release(mk);
+  return hidden;
+}
+
+static float* attn_tail(Ctx& c, const geotr_attn_layer& L, const float* hidden, const float* x, int64_t n, int64_t C) {
+  float* h2 = linear(c, L.out, hidden, C, n, 0);
+  float* y = norm(c, L.norm, h2, n, C, x, 0);                       // LN(linear(attn) + x)
+  float* e = linear(c, L.expand, y, C, n, 1);                       // ReLU fused
+  float* s = linear(c, L.squeeze, e, L.expand.out, n, 0);
+  return norm(c, L.out_norm, s, n, C, y, 0);                        // LN(y + W2 relu(W1 y))
+}
+
+static float* self_layer(Ctx& c, const geotr_attn_layer& L, int H, const float* x, int64_t n, const float* emb) {
+  const int64_t C = L.q.in;
+  const float *q, *k, *v;
+  int64_t ld;
+  if (L.qkv_w) {
+    float* qkv = c.alloc<float>((size_t)n * 3 * C);
+    if (c.live())
+      c.check(geotr_gemm(x, C, L.qkv_w, C, 0, qkv, 3 * C, n, 3 * C, C, 1, 0, 0, 0, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+    q = qkv;
+    k = qkv + C;
+    v = qkv + 2 * C;
+    ld = 3 * C;
+  } else {
+    q = linear(c, L.q, x, C, n, 0);
+    k = linear(c, L.k, x, C, n, 0);
+    v = linear(c, L.v, x, C, n, 0);
+    ld = C;
+  }
+  float* hidden = attention(c, H, C, q, ld, k, ld, v, ld, n, n, emb, &L.p);
+  return attn_tail(c, L, hidden, x, n, C);
+}
+
+static float* cross_layer(Ctx& c, const geotr_attn_layer& L, int H, const float* x, int64_t n, const float* mem, int64_t m) {
+  const int64_t C = L.q.in;
+  const float* q = linear(c, L.q, x, C, n, 0);
+  const float *k, *v;
+  int64_t ld;
+  if (L.kv_w) {
+    float* kv = c.alloc<float>((size_t)m * 2 * C);
+    if (c.live())
+      c.check(geotr_gemm(mem, C, L.kv_w, C, 0, kv, 2 * C, m, 2 * C, C, 1, 0, 0, 0, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+    k = kv;
+    v = kv + C;
+    ld = 2 * C;
+  } else {
+    k = linear(c, L.k, mem, C, m, 0);
+    v = linear(c, L.v, mem, C, m, 0);
+    ld = C;
+  }
+  float* hidden = attention(c, H, C, q, C, k, ld, v, ld, n, m, nullptr, nullptr);
+  return attn_tail(c, L, hidden, x, n, C);
+}
+
+static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t n) {
+  const int64_t D = t.proj_d.out;
+  float* emb = c.alloc<float>((size_t)n * n * D);
+  int32_t* knn = c.alloc<int32_t>((size_t)n * t.angle_k);
+  if (c.live()) {
+    c.check(geotr_gse_knn(pts, n, t.angle_k, knn, c.stream));
+    c.check(geotr_gse_embed(pts, knn, n, t.angle_k, D, t.div_term, t.proj_d.w, t.proj_d.b, t.proj_a.w, t.proj_a.b, t.sigma_d, t.sigma_a,
+                            emb, c.stream));
+  }
+  return emb;
+}
+
+static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const float* features, const geotr_outputs& o) {
+  const int S = net.backbone.num_stages, fine = net.backbone.fine_stage;
+  const int64_t n_c = p.n[S - 1], nr_c = p.ref_n[S - 1], ns_c = n_c - nr_c;
+  const int64_t n_f = p.n[fine], nr_f = p.ref_n[fine], ns_f = n_f - nr_f;
+  const float* pts_c = p.points[S - 1];
+  const float* pts_f = p.points[fine];
+  const int64_t K = net.num_points_in_patch, P = net.num_correspondences;
+
+  // 1. superpoint patches (model.py:98-108)
+  int64_t* p2n = c.alloc<int64_t>((size_t)n_f);
+  uint8_t* node_masks = c.alloc<uint8_t>((size_t)n_c);
+  int64_t* node_knn_idx = c.alloc<int64_t>((size_t)n_c * K);
+  uint8_t* node_knn_mask = c.alloc<uint8_t>((size_t)n_c * K);
+  int32_t* scratch_flag = c.alloc<int32_t>(4);
+  if (c.live()) {
+    if (hipMemsetAsync(scratch_flag, 0, 16, c.stream) != hipSuccess) c.check(fail(GEOTR_E_LAUNCH, "model_forward: memset failed"));
+    c.check(geotr_point_to_node(pts_f, nr_f, pts_c, nr_c, K, p2n, node_masks, node_knn_idx, node_knn_mask, scratch_flag, c.stream));
+    c.check(geotr_point_to_node(pts_f + 3 * nr_f, ns_f, pts_c + 3 * nr_c, ns_c, K, p2n + nr_f, node_masks + nr_c, node_knn_idx + nr_c * K,
+                                node_knn_mask + nr_c * K, scratch_flag, c.stream));
+  }
+
+  // 2. KPConv-FPN (model.py:127-130)
+  const size_t mk_bb = c.mark();
+  BackboneOut bb = backbone_forward(c, net.backbone, p, features, o.feats_f);
+  const int64_t c_f = net.backbone.decoder[net.backbone.num_decoders - 1].out;
+
+  // 3. geometric transformer (model.py:133-145)
+  const geotr_transformer& t = net.transformer;
+  const int64_t C = t.in_proj.out;
+  const float* emb_r = gse(c, t, pts_c, nr_c);
+  const float* emb_s = gse(c, t, pts_c + 3 * nr_c, ns_c);
+  const float* f0 = linear(c, t.in_proj, bb.feats_c, bb.c_dim, nr_c, 0);
+  const float* f1 = linear(c, t.in_proj, bb.feats_c + nr_c * bb.c_dim, bb.c_dim, ns_c, 0);
+  for (int l = 0; l < t.num_layers; ++l) {
+    const geotr_attn_layer& L = t.layers[l];
+    if (L.is_self) {
+      f0 = self_layer(c, L, t.num_heads, f0, nr_c, emb_r);
+      f1 = self_layer(c, L, t.num_heads, f1, ns_c, emb_s);
+    } else {  // sequential: the source attends to the already-updated reference (conditional_transformer.py:110-111)
+      f0 = cross_layer(c, L, t.num_heads, f0, nr_c, f1, ns_c);
+      f1 = cross_layer(c, L, t.num_heads, f1, ns_c, f0, nr_c);
+    }
+  }
+  const int64_t D = t.out_proj.out;
+  float* g0 = linear(c, t.out_proj, f0, C, nr_c, 0);
+  float* g1 = linear(c, t.out_proj, f1, C, ns_c, 0);
+  if (c.live()) {
+    c.check(geotr_l2_normalize(g0, nr_c, D, o.feats_c, c.stream));
+    c.check(geotr_l2_normalize(g1, ns_c, D, o.feats_c + nr_c * D, c.stream));
+  }
+  c.release(mk_bb);  // backbone / transformer intermediates are dead from here on
+
+  // 4. coarse matching (model.py:153-160)
+  float* sim = c.alloc<float>((size_t)nr_c * ns_c);
+  float* rowsum = c.alloc<float>((size_t)nr_c);
+  float* colsum = c.alloc<float>((size_t)ns_c);
+  if (c.live()) {
+    if (hipMemsetAsync(o.ref_node_corr_indices, 0, sizeof(int64_t) * P, c.stream) != hipSuccess ||
+        hipMemsetAsync(o.src_node_corr_indices, 0, sizeof(int64_t) * P, c.stream) != hipSuccess ||
+        hipMemsetAsync(o.node_corr_scores, 0, sizeof(float) * P, c.stream) != hipSuccess)
+      c.check(fail(GEOTR_E_LAUNCH, "model_forward: memset failed"));
+    c.check(geotr_gemm(o.feats_c, D, o.feats_c + nr_c * D, D, 0, sim, ns_c, nr_c, ns_c, D, 1, 0, 0, 0, nullptr, nullptr, nullptr, 0, 1.0f, 0,
+                       c.stream));
+    c.check(geotr_superpoint_match(sim, nr_c, ns_c, node_masks, node_masks + nr_c, net.dual_normalization, P, rowsum, colsum,
+                                   o.ref_node_corr_indices, o.src_node_corr_indices, o.node_corr_scores, o.num_node_corr, c.stream));
+    // 5. patches of the selected pairs (model.py:169-179); rows >= *num_node_corr are neutral (pad index, mask False)
+    c.check(geotr_patch_gather(node_knn_idx, node_knn_mask, pts_f, nr_f, o.ref_node_corr_indices, node_knn_idx + nr_c * K,
+                               node_knn_mask + nr_c * K, pts_f + 3 * nr_f, ns_f, o.src_node_corr_indices, P, K, o.num_node_corr,
+                               o.ref_knn_indices, o.ref_knn_masks, o.ref_knn_points, o.src_knn_indices, o.src_knn_masks,
+                               o.src_knn_points, c.stream));
+    // 6. patch scores + optimal transport (model.py:187-191)
+    c.check(geotr_patch_sinkhorn(o.feats_f, nr_f, o.feats_f + nr_f * c_f, ns_f, c_f, o.ref_knn_indices, o.src_knn_indices, o.ref_knn_masks,
+                                 o.src_knn_masks, P, K, net.alpha, net.num_sinkhorn_iterations, nullptr, o.num_node_corr,
+                                 o.matching_scores, c.stream));
+  }
+  // 7. local-to-global registration on the dustbin-free block (model.py:195-210)
+  const size_t lgr_bytes = geotr_lgr_workspace_bytes(P, K, net.topk);
+  char* lgr_ws = c.alloc<char>(lgr_bytes);
+  if (c.live())
+    c.check(geotr_lgr(o.ref_knn_points, o.src_knn_points, o.ref_knn_masks, o.src_knn_masks, o.matching_scores, (K + 1) * (K + 1), K + 1, P,
+                      K, net.topk, net.confidence_threshold, net.mutual, net.acceptance_radius, net.correspondence_threshold,
+                      net.num_refinement_steps, o.num_node_corr, o.ref_corr_points, o.src_corr_points, o.corr_scores, o.num_corr,
+                      o.estimated_transform, lgr_ws, lgr_bytes, c.stream));
+  return c.rc;
+}
+
+}  // namespace geotr
+
+using namespace geotr;
+
+static int validate(const geotr_model* net, const geotr_pyramid* pyr) {
+  GEOTR_CHECK_ARG(net && pyr, "model_forward: null descriptor");
+  const int S = net->backbone.num_stages;
+  GEOTR_CHECK_ARG(S >= 3 && S <= GEOTR_MAX_STAGES && pyr->num_stages == S, "model_forward: %d stages (pyramid has %d)", S, pyr->num_stages);
+  GEOTR_CHECK_ARG(net->backbone.num_blocks == 2 + 3 * (S - 1), "model_forward: backbone block count does not match the depth");
+  GEOTR_CHECK_ARG(net->transformer.num_layers >= 1 && net->transformer.num_layers <= 8, "model_forward: 1..8 transformer layers");
+  for (int s = 0; s < S; ++s)
+    GEOTR_CHECK_ARG(pyr->n[s] > 0 && pyr->ref_n[s] > 0 && pyr->ref_n[s] < pyr->n[s], "model_forward: empty cloud at stage %d", s);
+  return GEOTR_OK;
+}
+
+extern "C" {
+
+size_t geotr_model_workspace_bytes(const geotr_model* net, const geotr_pyramid* pyr) {
+  if (validate(net, pyr) != GEOTR_OK) return 0;
+  Ctx c;
+  c.base = nullptr;
+  c.cap = 0;
+  c.stream = nullptr;
+  c.dry = true;
+  geotr_outputs none;
+  std::memset(&none, 0, sizeof(none));
+  run(c, *net, *pyr, nullptr, none);
+  return c.peak + 4096;
+}
+
+int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const float* features, const geotr_outputs* out, void* ws,
+                        size_t ws_bytes, void* stream) {
+  const int v = validate(net, pyr);
+  if (v != GEOTR_OK) return v;
+  GEOTR_CHECK_ARG(features && out && ws, "model_forward: null pointer");
+  GEOTR_CHECK_ARG((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "model_forward: workspace must be 256-byte aligned");
+  Ctx c;
+  c.base = reinterpret_cast<char*>(ws);
+  c.cap = ws_bytes;
+  c.stream = (hipStream_t)stream;
+  c.dry = false;
+  return run(c, *net, *pyr, features, *out);
+}
+
+}  // extern "C"

@@ -357,11 +357,35 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
   }
 }
 
+// F.normalize(x, p=2, dim=1) (experiments/.../model.py:141-142): x / max(|x|_2, 1e-12), one wave per row
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, int64_t N, int C, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = x[row * C + c];
+    s = fmaf(v, v, s);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+  for (int c = lane; c < C; c += 64) out[row * C + c] = x[row * C + c] * inv;
+}
+
 }  // namespace geotr
 
 using namespace geotr;
 
 extern "C" {
+
+int geotr_l2_normalize(const float* x, int64_t n, int64_t c, float* out, void* stream) {
+  GEOTR_CHECK_ARG(n >= 0 && c >= 1, "l2_normalize: bad sizes");
+  if (n == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(x && out, "l2_normalize: null pointer");
+  l2_normalize_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(x, n, (int)c, out);
+  GEOTR_CHECK_LAUNCH("l2_normalize");
+  return GEOTR_OK;
+}
 
 int geotr_row_positive(const float* x, int64_t n, int64_t c, uint8_t* flag, void* stream) {
   GEOTR_CHECK_ARG(n >= 0 && c >= 1, "row_positive: bad sizes");

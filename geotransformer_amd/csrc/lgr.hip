@@ -155,8 +155,8 @@ __device__ __forceinline__ float residual(const float* T, const float* s, const 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lgr_corr_kernel(const float* __restrict__ score, int64_t ld_patch, int ld_row, int K, int topk,
                                                        float thr, int mutual, const unsigned char* __restrict__ rmask,
-                                                       const unsigned char* __restrict__ smask, int cap, int* __restrict__ cnt,
-                                                       int* __restrict__ stage_ij, float* __restrict__ stage_score) {
+                                                       const unsigned char* __restrict__ smask, int cap, const int* __restrict__ p_count,
+                                                       int* __restrict__ cnt, int* __restrict__ stage_ij, float* __restrict__ stage_score) {
   extern __shared__ float lds[];
   float* E = lds;                 // [K][K+1]
   float* trow = E + K * (K + 1);  // [K]
@@ -164,6 +164,10 @@ __global__ __launch_bounds__(256) void lgr_corr_kernel(const float* __restrict__
   __shared__ int sm[8];
   __shared__ int base_s;
   const int p = blockIdx.x, tid = threadIdx.x;
+  if (p_count && p >= *p_count) {  // patch pair beyond the device-resident count: contributes nothing
+    if (tid == 0) cnt[p] = 0;
+    return;
+  }
   const float* sp = score + (int64_t)p * ld_patch;
   for (int e = tid; e < K * K; e += 256) {
     const int i = e / K, j = e % K;
@@ -364,8 +368,8 @@ size_t geotr_lgr_workspace_bytes(int64_t p, int64_t k, int64_t topk) {
 int geotr_lgr(const float* ref_knn_points, const float* src_knn_points, const uint8_t* ref_knn_masks,
               const uint8_t* src_knn_masks, const float* score_mat, int64_t ld_patch, int64_t ld_row, int64_t p, int64_t k,
               int64_t topk, float confidence_threshold, int mutual, float acceptance_radius, int64_t correspondence_threshold,
-              int64_t num_refinement_steps, float* ref_corr_points, float* src_corr_points, float* corr_scores,
-              int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream_) {
+              int64_t num_refinement_steps, const int32_t* p_count, float* ref_corr_points, float* src_corr_points,
+              float* corr_scores, int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream_) {
   GEOTR_CHECK_ARG(p >= 1 && k >= 1 && k <= 256 && topk >= 1 && topk <= 4, "lgr: bad sizes (k <= 256, topk <= 4)");
   GEOTR_CHECK_ARG(num_refinement_steps >= 1, "lgr: num_refinement_steps must be >= 1");
   GEOTR_CHECK_ARG(ref_knn_points && src_knn_points && ref_knn_masks && src_knn_masks && score_mat && ref_corr_points &&
@@ -386,8 +390,8 @@ int geotr_lgr(const float* ref_knn_points, const float* src_knn_points, const ui
       hipFuncSetAttribute(reinterpret_cast<const void*>(&lgr_corr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(GEOTR_E_LAUNCH, "lgr: cannot reserve LDS");
   lgr_corr_kernel<<<dim3((unsigned)p), dim3(256), lds, stream>>>(score_mat, ld_patch, (int)ld_row, (int)k, (int)topk,
-                                                                 confidence_threshold, mutual, ref_knn_masks, src_knn_masks, cap, cnt,
-                                                                 stage_ij, stage_score);
+                                                                 confidence_threshold, mutual, ref_knn_masks, src_knn_masks, cap, p_count,
+                                                                 cnt, stage_ij, stage_score);
   lgr_gather_kernel<<<dim3((unsigned)p), dim3(256), 0, stream>>>(ref_knn_points, src_knn_points, (int)k, (int)p, cap, cnt, stage_ij,
                                                                  stage_score, ref_corr_points, src_corr_points, corr_scores, offsets,
                                                                  num_corr);

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
                                                              const unsigned char* __restrict__ src_mask,
                                                              const float* __restrict__ alpha_p, int iters,
                                                              const float* __restrict__ scores_in,
-                                                             float* __restrict__ out) {
+                                                             const int* __restrict__ p_count, float* __restrict__ out) {
+  if (p_count && (int)blockIdx.x >= *p_count) return;  // device-resident number of valid patch pairs
   constexpr int K1 = K + 1;
   constexpr int LD = K1;               // odd leading dimension: bank = (row + col) mod 32
   constexpr int TILES = K / 32;        // 32x32 MFMA tiles per side
@@ -356,11 +357,60 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
   }
 }
 
+// patches of the selected superpoint pairs (experiments/.../model.py:169-174): row p of the outputs = row corr_idx[p] of
+// the per-node tables; grid (P, 2): blockIdx.y = 0 reference side, 1 source side
+__global__ __launch_bounds__(128) void patch_gather_kernel(const int64_t* __restrict__ node_knn_idx0, const unsigned char* __restrict__ node_knn_mask0,
+                                                           const float* __restrict__ pts0, int64_t n0, const int64_t* __restrict__ corr0,
+                                                           const int64_t* __restrict__ node_knn_idx1, const unsigned char* __restrict__ node_knn_mask1,
+                                                           const float* __restrict__ pts1, int64_t n1, const int64_t* __restrict__ corr1, int K,
+                                                           const int* __restrict__ p_count, int64_t* __restrict__ idx_out0,
+                                                           unsigned char* __restrict__ mask_out0, float* __restrict__ pts_out0,
+                                                           int64_t* __restrict__ idx_out1, unsigned char* __restrict__ mask_out1,
+                                                           float* __restrict__ pts_out1) {
+  const int p = blockIdx.x, side = blockIdx.y;
+  const bool live = !p_count || p < *p_count;
+  const int64_t* tab = side ? node_knn_idx1 : node_knn_idx0;
+  const unsigned char* mtab = side ? node_knn_mask1 : node_knn_mask0;
+  const float* pts = side ? pts1 : pts0;
+  const int64_t n = side ? n1 : n0;
+  int64_t* io = (side ? idx_out1 : idx_out0) + (int64_t)p * K;
+  unsigned char* mo = (side ? mask_out1 : mask_out0) + (int64_t)p * K;
+  float* po = (side ? pts_out1 : pts_out0) + (int64_t)p * K * 3;
+  const int64_t node = live ? (side ? corr1 : corr0)[p] : 0;
+  for (int j = threadIdx.x; j < K; j += blockDim.x) {
+    const int64_t id = live ? tab[node * K + j] : n;
+    io[j] = id;
+    mo[j] = live ? mtab[node * K + j] : 0;
+    const bool real = id < n;  // the pad index selects the zero row appended by model.py:114-115
+    po[3 * j] = real ? pts[3 * id] : 0.f;
+    po[3 * j + 1] = real ? pts[3 * id + 1] : 0.f;
+    po[3 * j + 2] = real ? pts[3 * id + 2] : 0.f;
+  }
+}
+
 }  // namespace geotr
 
 using namespace geotr;
 
 extern "C" {
+
+int geotr_patch_gather(const int64_t* ref_node_knn_indices, const uint8_t* ref_node_knn_masks, const float* ref_points, int64_t nr,
+                       const int64_t* ref_corr_indices, const int64_t* src_node_knn_indices, const uint8_t* src_node_knn_masks,
+                       const float* src_points, int64_t ns, const int64_t* src_corr_indices, int64_t p, int64_t k,
+                       const int32_t* p_count, int64_t* ref_knn_indices, uint8_t* ref_knn_masks, float* ref_knn_points,
+                       int64_t* src_knn_indices, uint8_t* src_knn_masks, float* src_knn_points, void* stream) {
+  GEOTR_CHECK_ARG(p >= 0 && k >= 1, "patch_gather: bad sizes");
+  if (p == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(ref_node_knn_indices && ref_node_knn_masks && ref_points && ref_corr_indices && src_node_knn_indices &&
+                      src_node_knn_masks && src_points && src_corr_indices && ref_knn_indices && ref_knn_masks && ref_knn_points &&
+                      src_knn_indices && src_knn_masks && src_knn_points, "patch_gather: null pointer");
+  patch_gather_kernel<<<dim3((unsigned)p, 2), dim3(128), 0, (hipStream_t)stream>>>(
+      ref_node_knn_indices, ref_node_knn_masks, ref_points, nr, ref_corr_indices, src_node_knn_indices, src_node_knn_masks, src_points,
+      ns, src_corr_indices, (int)k, p_count, ref_knn_indices, ref_knn_masks, ref_knn_points, src_knn_indices, src_knn_masks,
+      src_knn_points);
+  GEOTR_CHECK_LAUNCH("patch_gather");
+  return GEOTR_OK;
+}
 
 int geotr_point_to_node(const float* points, int64_t n, const float* nodes, int64_t m, int64_t k, int64_t* point_to_node,
                         uint8_t* node_masks, int64_t* knn_indices, uint8_t* knn_masks, int32_t* overflow, void* stream_) {
@@ -399,7 +449,7 @@ int geotr_superpoint_match(float* scores, int64_t n, int64_t m, const uint8_t* r
 int geotr_patch_sinkhorn(const float* ref_feats, int64_t nr, const float* src_feats, int64_t ns, int64_t c,
                          const int64_t* ref_knn_indices, const int64_t* src_knn_indices, const uint8_t* ref_knn_masks,
                          const uint8_t* src_knn_masks, int64_t p, int64_t k, const float* alpha, int64_t num_iterations,
-                         const float* scores_in, float* matching_scores, void* stream_) {
+                         const float* scores_in, const int32_t* p_count, float* matching_scores, void* stream_) {
   GEOTR_CHECK_ARG(p >= 0 && c >= 4 && c % 4 == 0, "patch_sinkhorn: bad sizes (channels must be a multiple of 4)");
   GEOTR_CHECK_ARG(k == 32 || k == 64 || k == 128, "patch_sinkhorn: points per patch must be 32, 64 or 128 (got %lld)", (long long)k);
   if (p == 0) return GEOTR_OK;
@@ -416,7 +466,7 @@ int geotr_patch_sinkhorn(const float* ref_feats, int64_t nr, const float* src_fe
       return fail(GEOTR_E_LAUNCH, "patch_sinkhorn: cannot reserve %zu B of LDS", lds);                                           \
     patch_sinkhorn_kernel<KK><<<dim3((unsigned)p), dim3(512), lds, stream>>>(ref_feats, nr, src_feats, ns, (int)c, ref_knn_indices, \
                                                                             src_knn_indices, ref_knn_masks, src_knn_masks, alpha, \
-                                                                            (int)num_iterations, scores_in, matching_scores);    \
+                                                                            (int)num_iterations, scores_in, p_count, matching_scores); \
   } while (0)
   if (k == 32) LAUNCH(32);
   else if (k == 64) LAUNCH(64);

@@ -239,7 +239,7 @@ def patch_sinkhorn(alpha, num_iterations, ref_knn_masks, src_knn_masks, scores=N
         args = (ref_feats, ref_feats.shape[0], src_feats, src_feats.shape[0], ref_feats.shape[1], ri, si)
     _lib.check(lib.geotr_patch_sinkhorn(_lib.ptr(args[0]), args[1], _lib.ptr(args[2]), args[3], args[4], _lib.ptr(args[5]),
                                         _lib.ptr(args[6]), _lib.ptr(rm), _lib.ptr(sm), P, K, _lib.ptr(alpha),
-                                        int(num_iterations), _lib.ptr(scores), _lib.ptr(out), _lib.stream_ptr()),
+                                        int(num_iterations), _lib.ptr(scores), None, _lib.ptr(out), _lib.stream_ptr()),
                'geotr_patch_sinkhorn')
     return out
 
@@ -276,7 +276,16 @@ def lgr(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat,
     _lib.check(lib.geotr_lgr(_lib.ptr(ref_knn_points), _lib.ptr(src_knn_points), _lib.ptr(ref_knn_masks.contiguous()),
                              _lib.ptr(src_knn_masks.contiguous()), _lib.ptr(score_mat), score_mat.stride(0), score_mat.stride(1),
                              P, K, int(topk), float(confidence_threshold), int(bool(mutual)), float(acceptance_radius),
-                             int(correspondence_threshold), int(num_refinement_steps), _lib.ptr(ref_corr), _lib.ptr(src_corr),
+                             int(correspondence_threshold), int(num_refinement_steps), None, _lib.ptr(ref_corr), _lib.ptr(src_corr),
                              _lib.ptr(scores), _lib.ptr(num), _lib.ptr(T), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
                'geotr_lgr')
     return ref_corr, src_corr, scores, num, T
+
+
+def l2_normalize(x):
+    """Row-wise x / max(|x|_2, 1e-12) (F.normalize(p=2, dim=1))."""
+    lib = _lib.load()
+    x = _f32c(x)
+    out = torch.empty_like(x)
+    _lib.check(lib.geotr_l2_normalize(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(out), _lib.stream_ptr()), 'geotr_l2_normalize')
+    return out

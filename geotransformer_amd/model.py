@@ -42,11 +42,20 @@ class GeoTransformer(nn.Module):
             correspondence_limit=cfg.fine_matching.correspondence_limit,
             num_refinement_steps=cfg.fine_matching.num_refinement_steps)
         self.optimal_transport = LearnableLogOptimalTransport(cfg.model.num_sinkhorn_iterations)
+        # True: the whole forward runs in the native executor (one C-ABI call, csrc/executor.hip); False: the same kernels
+        # driven module by module from Python (the drop-in module API; used by the parity tests of the individual modules)
+        self.use_native = True
+        self._native = None
 
     @torch.no_grad()
     def forward(self, data_dict):
         if self.training:
             raise NotImplementedError('inference only: call model.eval() (training is outside the hot-path scope)')
+        if self.use_native:
+            from .native import NativeModel
+            if self._native is None:
+                self._native = NativeModel(self)
+            return NativeModel.finalize(self._native.forward(data_dict))
         out = {}
         fine = self.backbone.fine_stage
         feats = data_dict['features']
@@ -74,8 +83,8 @@ class GeoTransformer(nn.Module):
         # 3. geometric transformer on the superpoints (model.py:133-145)
         ref_feats_c, src_feats_c = self.transformer(ref_points_c.unsqueeze(0), src_points_c.unsqueeze(0),
                                                     feats_c[:ref_length_c].unsqueeze(0), feats_c[ref_length_c:].unsqueeze(0))
-        ref_feats_c_norm = torch.nn.functional.normalize(ref_feats_c.squeeze(0), p=2, dim=1)
-        src_feats_c_norm = torch.nn.functional.normalize(src_feats_c.squeeze(0), p=2, dim=1)
+        ref_feats_c_norm = kernels.l2_normalize(ref_feats_c.squeeze(0))
+        src_feats_c_norm = kernels.l2_normalize(src_feats_c.squeeze(0))
         out['ref_feats_c'], out['src_feats_c'] = ref_feats_c_norm, src_feats_c_norm
         ref_feats_f, src_feats_f = feats_f[:ref_length_f], feats_f[ref_length_f:]
         out['ref_feats_f'], out['src_feats_f'] = ref_feats_f, src_feats_f

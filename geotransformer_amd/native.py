@@ -1,0 +1,302 @@
+"""Binding of the native executor (geotr_model_forward, include/geotr.h): descriptor structs + one-call forward.
+
+The ctypes Structures below mirror the C structs field for field.  `NativeModel` walks a `GeoTransformer` module once,
+records the device pointers of its parameters (re-built automatically if a parameter is re-allocated or modified), and
+`forward(data_dict)` allocates the output tensors, sizes the workspace and makes ONE asynchronous C-ABI call per pair.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+MAX_STAGES = 5
+P_F32 = ctypes.c_void_p
+I64 = ctypes.c_int64
+I32 = ctypes.c_int32
+F32 = ctypes.c_float
+
+
+class Linear(ctypes.Structure):
+    _fields_ = [('w', P_F32), ('b', P_F32), ('in_', I64), ('out', I64)]
+
+
+class Norm(ctypes.Structure):
+    _fields_ = [('gamma', P_F32), ('beta', P_F32), ('groups', I64), ('eps', F32), ('pad_', I32)]
+
+
+class KPConvDesc(ctypes.Structure):
+    _fields_ = [('weights', P_F32), ('bias', P_F32), ('kernel_points', P_F32), ('in_', I64), ('out', I64),
+                ('num_kernel_points', I64), ('sigma', F32), ('pad_', I32)]
+
+
+class Block(ctypes.Structure):
+    _fields_ = [('is_conv_block', I32), ('has_unary1', I32), ('has_shortcut', I32), ('strided', I32),
+                ('unary1', Linear), ('unary1_norm', Norm), ('conv', KPConvDesc), ('conv_norm', Norm),
+                ('unary2', Linear), ('unary2_norm', Norm), ('shortcut', Linear), ('shortcut_norm', Norm)]
+
+
+class Backbone(ctypes.Structure):
+    _fields_ = [('num_stages', I32), ('fine_stage', I32), ('num_blocks', I32), ('num_decoders', I32),
+                ('blocks', Block * (2 + 3 * (MAX_STAGES - 1))), ('decoder', Linear * MAX_STAGES),
+                ('decoder_norm', Norm * MAX_STAGES)]
+
+
+class Pyramid(ctypes.Structure):
+    _fields_ = [('num_stages', I32), ('pad_', I32),
+                ('points', P_F32 * MAX_STAGES), ('n', I64 * MAX_STAGES),
+                ('neighbors', P_F32 * MAX_STAGES), ('neighbors_w', I64 * MAX_STAGES),
+                ('subsampling', P_F32 * MAX_STAGES), ('subsampling_w', I64 * MAX_STAGES),
+                ('upsampling', P_F32 * MAX_STAGES), ('upsampling_w', I64 * MAX_STAGES),
+                ('ref_n', I64 * MAX_STAGES)]
+
+
+class AttnLayer(ctypes.Structure):
+    _fields_ = [('is_self', I32), ('pad_', I32), ('q', Linear), ('k', Linear), ('v', Linear), ('p', Linear), ('out', Linear),
+                ('expand', Linear), ('squeeze', Linear), ('norm', Norm), ('out_norm', Norm),
+                ('qkv_w', P_F32), ('qkv_b', P_F32), ('kv_w', P_F32), ('kv_b', P_F32)]
+
+
+class Transformer(ctypes.Structure):
+    _fields_ = [('num_layers', I32), ('num_heads', I32), ('angle_k', I32), ('pad_', I32), ('sigma_d', F32), ('sigma_a', F32),
+                ('div_term', P_F32), ('proj_d', Linear), ('proj_a', Linear), ('in_proj', Linear), ('out_proj', Linear),
+                ('layers', AttnLayer * 8)]
+
+
+class Model(ctypes.Structure):
+    _fields_ = [('backbone', Backbone), ('transformer', Transformer), ('alpha', P_F32),
+                ('num_points_in_patch', I64), ('num_correspondences', I64), ('num_sinkhorn_iterations', I64),
+                ('dual_normalization', I32), ('topk', I32), ('mutual', I32), ('correspondence_threshold', I32),
+                ('num_refinement_steps', I32), ('pad_', I32), ('confidence_threshold', F32), ('acceptance_radius', F32)]
+
+
+class Outputs(ctypes.Structure):
+    _fields_ = [(name, P_F32) for name in (
+        'feats_c', 'feats_f', 'ref_node_corr_indices', 'src_node_corr_indices', 'node_corr_scores', 'num_node_corr',
+        'ref_knn_indices', 'src_knn_indices', 'ref_knn_masks', 'src_knn_masks', 'ref_knn_points', 'src_knn_points',
+        'matching_scores', 'ref_corr_points', 'src_corr_points', 'corr_scores', 'num_corr', 'estimated_transform')]
+
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    lib = _lib.load()
+    if not _bound:
+        lib.geotr_model_workspace_bytes.restype = ctypes.c_size_t
+        lib.geotr_model_workspace_bytes.argtypes = [ctypes.POINTER(Model), ctypes.POINTER(Pyramid)]
+        lib.geotr_model_forward.restype = ctypes.c_int
+        lib.geotr_model_forward.argtypes = [ctypes.POINTER(Model), ctypes.POINTER(Pyramid), ctypes.c_void_p,
+                                            ctypes.POINTER(Outputs), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        _bound = True
+    return lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _linear(mod):
+    return Linear(_ptr(mod.weight), _ptr(mod.bias), mod.weight.shape[1], mod.weight.shape[0])
+
+
+def _norm(mod):
+    """GroupNorm wrapper (modules.kpconv.GroupNorm), nn.LayerNorm, or None."""
+    if mod is None:
+        return Norm(None, None, 0, 0.0, 0)
+    if hasattr(mod, 'norm'):  # kpconv.GroupNorm holds an nn.GroupNorm
+        g = mod.norm
+        return Norm(_ptr(g.weight), _ptr(g.bias), g.num_groups, g.eps, 0)
+    return Norm(_ptr(mod.weight), _ptr(mod.bias), 0, mod.eps, 0)
+
+
+def _kpconv(mod):
+    return KPConvDesc(_ptr(mod.weights), _ptr(mod.bias), _ptr(mod.kernel_points), mod.in_channels, mod.out_channels,
+                      mod.kernel_size, float(mod.sigma), 0)
+
+
+def _block(mod):
+    from .modules.kpconv.modules import ConvBlock, UnaryBlock
+    b = Block()
+    if isinstance(mod, ConvBlock):
+        b.is_conv_block = 1
+        b.conv, b.conv_norm = _kpconv(mod.KPConv), _norm(mod.norm)
+        return b
+    b.strided = int(mod.strided)
+    if isinstance(mod.unary1, UnaryBlock):
+        b.has_unary1 = 1
+        b.unary1, b.unary1_norm = _linear(mod.unary1.mlp), _norm(mod.unary1.norm)
+    b.conv, b.conv_norm = _kpconv(mod.KPConv), _norm(mod.norm_conv)
+    b.unary2, b.unary2_norm = _linear(mod.unary2.mlp), _norm(mod.unary2.norm)
+    if isinstance(mod.unary_shortcut, UnaryBlock):
+        b.has_shortcut = 1
+        b.shortcut, b.shortcut_norm = _linear(mod.unary_shortcut.mlp), _norm(mod.unary_shortcut.norm)
+    return b
+
+
+class NativeModel:
+    """Descriptor of a GeoTransformer module for the native executor (pointers are re-read when parameters change)."""
+
+    def __init__(self, model):
+        self.model = model
+        self._key = None
+        self._keep = []
+        self.desc = None
+
+    def _version_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def _build(self):
+        m = self.model
+        self._keep = []
+        d = Model()
+        bb, net = d.backbone, m.backbone
+        S = net.num_stages
+        bb.num_stages, bb.fine_stage = S, net.fine_stage
+        blocks = [net.encoder1_1, net.encoder1_2]
+        for s in range(2, S + 1):
+            blocks += [getattr(net, f'encoder{s}_{i}') for i in (1, 2, 3)]
+        bb.num_blocks = len(blocks)
+        for i, blk in enumerate(blocks):
+            bb.blocks[i] = _block(blk)
+        n_dec = 0
+        for i in range(S - 2, net.fine_stage - 1, -1):
+            dec = getattr(net, f'decoder{i + 1}')
+            bb.decoder[n_dec] = _linear(dec.mlp)
+            bb.decoder_norm[n_dec] = _norm(getattr(dec, 'norm', None))
+            n_dec += 1
+        bb.num_decoders = n_dec
+        t, tr = d.transformer, m.transformer
+        layers = tr.transformer.layers
+        t.num_layers, t.num_heads = len(layers), layers[0].attention.attention.num_heads
+        t.angle_k, t.sigma_d, t.sigma_a = tr.embedding.angle_k, float(tr.embedding.sigma_d), float(tr.embedding.sigma_a)
+        t.div_term = _ptr(tr.embedding.embedding.div_term)
+        t.proj_d, t.proj_a = _linear(tr.embedding.proj_d), _linear(tr.embedding.proj_a)
+        t.in_proj, t.out_proj = _linear(tr.in_proj), _linear(tr.out_proj)
+        for i, (kind, layer) in enumerate(zip(tr.transformer.blocks, layers)):
+            a = AttnLayer()
+            att = layer.attention.attention
+            a.is_self = int(kind == 'self')
+            a.q, a.k, a.v = _linear(att.proj_q), _linear(att.proj_k), _linear(att.proj_v)
+            if a.is_self:
+                a.p = _linear(att.proj_p)
+                w = torch.cat([att.proj_q.weight, att.proj_k.weight, att.proj_v.weight], 0).detach().contiguous()
+                b = torch.cat([att.proj_q.bias, att.proj_k.bias, att.proj_v.bias], 0).detach().contiguous()
+                a.qkv_w, a.qkv_b = _ptr(w), _ptr(b)
+            else:
+                w = torch.cat([att.proj_k.weight, att.proj_v.weight], 0).detach().contiguous()
+                b = torch.cat([att.proj_k.bias, att.proj_v.bias], 0).detach().contiguous()
+                a.kv_w, a.kv_b = _ptr(w), _ptr(b)
+            self._keep += [w, b]
+            a.out, a.norm = _linear(layer.attention.linear), _norm(layer.attention.norm)
+            a.expand, a.squeeze, a.out_norm = _linear(layer.output.expand), _linear(layer.output.squeeze), _norm(layer.output.norm)
+            t.layers[i] = a
+        d.alpha = _ptr(m.optimal_transport.alpha)
+        d.num_points_in_patch = m.num_points_in_patch
+        d.num_correspondences = m.coarse_matching.num_correspondences
+        d.num_sinkhorn_iterations = m.optimal_transport.num_iterations
+        d.dual_normalization = int(m.coarse_matching.dual_normalization)
+        f = m.fine_matching
+        d.topk, d.mutual, d.correspondence_threshold = f.k, int(f.mutual), f.correspondence_threshold
+        d.num_refinement_steps = f.num_refinement_steps
+        d.confidence_threshold, d.acceptance_radius = float(f.confidence_threshold), float(f.acceptance_radius)
+        self.desc = d
+
+    def descriptor(self):
+        key = self._version_key()
+        if key != self._key:
+            self._build()
+            self._key = key
+        return self.desc
+
+    @staticmethod
+    def pyramid(data_dict, lengths_host):
+        p = Pyramid()
+        S = len(data_dict['points'])
+        p.num_stages = S
+        for i in range(S):
+            pts, nb = data_dict['points'][i], data_dict['neighbors'][i]
+            assert pts.is_contiguous() and nb.is_contiguous()
+            p.points[i], p.n[i] = pts.data_ptr(), pts.shape[0]
+            p.neighbors[i], p.neighbors_w[i] = nb.data_ptr(), nb.shape[1]
+            p.ref_n[i] = int(lengths_host[i][0])
+            if i < S - 1:
+                sub, up = data_dict['subsampling'][i], data_dict['upsampling'][i]
+                assert sub.is_contiguous() and up.is_contiguous()
+                p.subsampling[i], p.subsampling_w[i] = sub.data_ptr(), sub.shape[1]
+                p.upsampling[i], p.upsampling_w[i] = up.data_ptr(), up.shape[1]
+        return p
+
+    @torch.no_grad()
+    def forward(self, data_dict):
+        """Whole forward in one native call.  Returns the output dict (same keys as GeoTransformer.forward)."""
+        lib = _bind()
+        m = self.model
+        desc = self.descriptor()
+        lengths = data_dict.get('lengths_host')
+        if lengths is None:
+            lengths = [l.tolist() for l in data_dict['lengths']]
+        pyr = self.pyramid(data_dict, lengths)
+        S, fine = m.backbone.num_stages, m.backbone.fine_stage
+        feats = data_dict['features']
+        dev = feats.device
+        n_c, n_f = int(pyr.n[S - 1]), int(pyr.n[fine])
+        nr_c, nr_f, nr = int(pyr.ref_n[S - 1]), int(pyr.ref_n[fine]), int(pyr.ref_n[0])
+        P, K, topk = int(desc.num_correspondences), int(desc.num_points_in_patch), int(desc.topk)
+        D = int(desc.transformer.out_proj.out)
+        c_f = int(desc.backbone.decoder[desc.backbone.num_decoders - 1].out)
+        cap = P * K * topk
+        f32, i64 = torch.float32, torch.int64
+        o = {
+            'feats_c': torch.empty((n_c, D), dtype=f32, device=dev), 'feats_f': torch.empty((n_f, c_f), dtype=f32, device=dev),
+            'ref_node_corr_indices': torch.empty(P, dtype=i64, device=dev), 'src_node_corr_indices': torch.empty(P, dtype=i64, device=dev),
+            'node_corr_scores': torch.empty(P, dtype=f32, device=dev), 'num_node_corr': torch.empty(1, dtype=torch.int32, device=dev),
+            'ref_knn_indices': torch.empty((P, K), dtype=i64, device=dev), 'src_knn_indices': torch.empty((P, K), dtype=i64, device=dev),
+            'ref_knn_masks': torch.empty((P, K), dtype=torch.bool, device=dev), 'src_knn_masks': torch.empty((P, K), dtype=torch.bool, device=dev),
+            'ref_knn_points': torch.empty((P, K, 3), dtype=f32, device=dev), 'src_knn_points': torch.empty((P, K, 3), dtype=f32, device=dev),
+            'matching_scores': torch.empty((P, K + 1, K + 1), dtype=f32, device=dev),
+            'ref_corr_points': torch.empty((cap, 3), dtype=f32, device=dev), 'src_corr_points': torch.empty((cap, 3), dtype=f32, device=dev),
+            'corr_scores': torch.empty(cap, dtype=f32, device=dev), 'num_corr': torch.empty(1, dtype=torch.int32, device=dev),
+            'estimated_transform': torch.empty((4, 4), dtype=f32, device=dev),
+        }
+        outs = Outputs(*[o[name].data_ptr() for name, _ in Outputs._fields_])
+        nbytes = lib.geotr_model_workspace_bytes(ctypes.byref(desc), ctypes.byref(pyr))
+        if nbytes == 0:
+            raise RuntimeError('geotr_model_workspace_bytes failed: ' + lib.geotr_last_error().decode('utf-8', 'replace'))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = lib.geotr_model_forward(ctypes.byref(desc), ctypes.byref(pyr), feats.data_ptr(), ctypes.byref(outs), ws.data_ptr(), nbytes,
+                                     torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'geotr_model_forward')
+        ws.record_stream(torch.cuda.current_stream())
+        points_c, points_f, points = data_dict['points'][-1], data_dict['points'][fine], data_dict['points'][0]
+        out = {
+            'ref_points_c': points_c[:nr_c], 'src_points_c': points_c[nr_c:], 'ref_points_f': points_f[:nr_f],
+            'src_points_f': points_f[nr_f:], 'ref_points': points[:nr], 'src_points': points[nr:],
+            'ref_feats_c': o['feats_c'][:nr_c], 'src_feats_c': o['feats_c'][nr_c:],
+            'ref_feats_f': o['feats_f'][:nr_f], 'src_feats_f': o['feats_f'][nr_f:],
+            'matching_scores': o['matching_scores'], 'estimated_transform': o['estimated_transform'],
+            'ref_node_corr_knn_points': o['ref_knn_points'], 'src_node_corr_knn_points': o['src_knn_points'],
+            'ref_node_corr_knn_masks': o['ref_knn_masks'], 'src_node_corr_knn_masks': o['src_knn_masks'],
+            # data-dependent lengths stay on the device; `finalize` trims them with one host read
+            '_ref_node_corr_indices': o['ref_node_corr_indices'], '_src_node_corr_indices': o['src_node_corr_indices'],
+            '_ref_corr_points': o['ref_corr_points'], '_src_corr_points': o['src_corr_points'], '_corr_scores': o['corr_scores'],
+            '_counts': (o['num_node_corr'], o['num_corr']),
+        }
+        return out
+
+    @staticmethod
+    def finalize(out):
+        """Trim the variable-length outputs to their true sizes (the one host<-device read of a pair)."""
+        num_node, num_corr = out.pop('_counts')
+        counts = torch.cat([num_node, num_corr]).tolist()
+        p, c = int(counts[0]), int(counts[1])
+        out['ref_node_corr_indices'] = out.pop('_ref_node_corr_indices')[:p]
+        out['src_node_corr_indices'] = out.pop('_src_node_corr_indices')[:p]
+        for k in ('ref_node_corr_knn_points', 'src_node_corr_knn_points', 'ref_node_corr_knn_masks', 'src_node_corr_knn_masks',
+                  'matching_scores'):
+            out[k] = out[k][:p]
+        out['ref_corr_points'] = out.pop('_ref_corr_points')[:c]
+        out['src_corr_points'] = out.pop('_src_corr_points')[:c]
+        out['corr_scores'] = out.pop('_corr_scores')[:c]
+        return out

@@ -4,6 +4,9 @@ This is the unit bench.py times ("a pair"): 3-4 grid subsa
 (geotransformer/utils/data.py:13-77) followed by GeoTransformer.forward (experiments/*/model.py:69-212), all on
 device-resident inputs.
 """
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
 import torch
 
 from .model import create_model
@@ -38,3 +41,45 @@ class RegistrationPipeline:
     def __call__(self, ref_points, src_points, ref_feats=None, src_feats=None):
         """ref/src points: (N,3) fp32 device tensors.  Returns the model's output dict (incl. 'estimated_transform')."""
         return self.model(self.collate(ref_points, src_points, ref_feats, src_feats))
+
+
+class ConcurrentRegistration:
+    """Keeps several independent pairs in flight on one GPU: one host thread + one HIP stream per lane.
+
+    A single pair's timeline contains many few-workgroup kernels (global top-k, hash-order replay, LGR refinement,
+    300-row GEMMs ...) that leave most of the 256 CUs idle; pairs are independent, so kernels of
+    different pairs are overlapped on separate streams instead of being serialised.  All lanes share the same weights.
+    """
+
+    def __init__(self, pipeline, lanes=2):
+        self.pipeline = pipeline
+        self.lanes = max(1, int(lanes))
+        self.device = pipeline.device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
+        self.pool = ThreadPoolExecutor(max_workers=self.lanes) if self.lanes > 1 else None
+        self._local = threading.local()
+
+    def _run_lane(self, lane, pairs, indices, sink):
+        torch.cuda.set_device(self.device)
+        stream = self.streams[lane]
+        with torch.cuda.stream(stream):
+            for i in indices:
+                ref, src = pairs[i]
+                out = self.pipeline(ref, src)
+                sink(i, out)
+        return stream
+
+    def run_batch(self, pairs, sink):
+        """Register every (ref, src) of `pairs`; `sink(i, output_dict)` is called (on the lane's stream) per pair.
+        Returns after all work is ENQUEUED and the current stream has been made to wait for every lane."""
+        current = torch.cuda.current_stream(self.device)
+        if self.lanes == 1:
+            for i, (ref, src) in enumerate(pairs):
+                sink(i, self.pipeline(ref, src))
+            return
+        for st in self.streams:
+            st.wait_stream(current)  # inputs produced on the caller's stream are visible to the lanes
+        shards = [list(range(lane, len(pairs), self.lanes)) for lane in range(self.lanes)]
+        futures = [self.pool.submit(self._run_lane, lane, pairs, shards[lane], sink) for lane in range(self.lanes)]
+        for f in futures:
+            current.wait_stream(f.result())

@@ -111,6 +111,8 @@ int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, int b_i
  *                                                                               kpconv/modules.py:33-50,142-147,204-224
  *   geotr_layer_norm     : out = LayerNorm(x + residual)       transformer/rpe_transformer.py:102, output_layer.py:20
  * ---------------------------------------------------------------------------------------------- */
+/* out = x / max(|x|_2, 1e-12) row-wise (F.normalize, experiments/.../model.py:141-142) */
+int geotr_l2_normalize(const float* x, int64_t n, int64_t c, float* out, void* stream);
 int geotr_row_positive(const float* x, int64_t n, int64_t c, uint8_t* flag, void* stream);
 int geotr_kpconv_gather(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
                         const float* kernel_points, const uint8_t* pos_flag, int64_t m, int64_t ns, int64_t h,
@@ -156,7 +158,8 @@ int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float*
  *                                                    geotransformer/modules/geotransformer/superpoint_matching.py:13-50
  *   geotr_patch_sinkhorn  : per patch pair: scores = F_r F_s^T / sqrt(c) (gathered rows, pad index -> zero row) or
  *                           `scores_in` (p,k,k); dustbin alpha; masks -> -1e12; num_iterations log-Sinkhorn sweeps;
- *                           out (p,k+1,k+1).  k in {32,64,128}.
+ *                           out (p,k+1,k+1).  k in {32,64,128}.  p_count (device int32, optional): only patch pairs
+ *                           p < *p_count are processed (lets the caller skip the host read of the coarse-match count).
  *                                experiments/.../model.py:169-189, geotransformer/modules/sinkhorn/learnable_sinkhorn.py:13-66
  * ---------------------------------------------------------------------------------------------- */
 int geotr_point_to_node(const float* points, int64_t n, const float* nodes, int64_t m, int64_t k, int64_t* point_to_node,
@@ -167,7 +170,14 @@ int geotr_superpoint_match(float* scores, int64_t n, int64_t m, const uint8_t* r
 int geotr_patch_sinkhorn(const float* ref_feats, int64_t nr, const float* src_feats, int64_t ns, int64_t c,
                          const int64_t* ref_knn_indices, const int64_t* src_knn_indices, const uint8_t* ref_knn_masks,
                          const uint8_t* src_knn_masks, int64_t p, int64_t k, const float* alpha, int64_t num_iterations,
-                         const float* scores_in, float* matching_scores, void* stream);
+                         const float* scores_in, const int32_t* p_count, float* matching_scores, void* stream);
+/* rows p < *p_count (device int32, NULL = all p) of the per-node tables selected by the coarse matches:
+ * knn indices (pad = n), masks and points (pad -> zeros)                      experiments/.../model.py:169-174 */
+int geotr_patch_gather(const int64_t* ref_node_knn_indices, const uint8_t* ref_node_knn_masks, const float* ref_points, int64_t nr,
+                       const int64_t* ref_corr_indices, const int64_t* src_node_knn_indices, const uint8_t* src_node_knn_masks,
+                       const float* src_points, int64_t ns, const int64_t* src_corr_indices, int64_t p, int64_t k,
+                       const int32_t* p_count, int64_t* ref_knn_indices, uint8_t* ref_knn_masks, float* ref_knn_points,
+                       int64_t* src_knn_indices, uint8_t* src_knn_masks, float* src_knn_points, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * L1/L2  local-to-global registration, entirely on the device (the reference does its SVDs on the host)
@@ -186,8 +196,85 @@ size_t geotr_lgr_workspace_bytes(int64_t p, int64_t k, int64_t topk);
 int geotr_lgr(const float* ref_knn_points, const float* src_knn_points, const uint8_t* ref_knn_masks,
               const uint8_t* src_knn_masks, const float* score_mat, int64_t ld_patch, int64_t ld_row, int64_t p, int64_t k,
               int64_t topk, float confidence_threshold, int mutual, float acceptance_radius, int64_t correspondence_threshold,
-              int64_t num_refinement_steps, float* ref_corr_points, float* src_corr_points, float* corr_scores,
-              int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream);
+              int64_t num_refinement_steps, const int32_t* p_count, float* ref_corr_points, float* src_corr_points,
+              float* corr_scores, int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Native executor: the whole inference forward of experiments/<exp>/model.py:69-212 (minus the ground-truth
+ * correspondences, which need the gt transform and only feed loss/eval) as ONE host call.  The launch sequence,
+ * workspace (bump allocator over `ws`) and every intermediate live on the C++ side; nothing is read back to the
+ * host (coarse-match and correspondence counts stay on the device), so the call is fully asynchronous on `stream`.
+ * The descriptor structs hold plain device pointers to the module parameters (state_dict tensors).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct geotr_linear { const float* w; const float* b; int64_t in, out; } geotr_linear;             /* nn.Linear: w (out,in) */
+typedef struct geotr_norm { const float* gamma; const float* beta; int64_t groups; float eps; int32_t pad_; } geotr_norm; /* groups>0: GroupNorm; 0: LayerNorm */
+typedef struct geotr_kpconv {                                        /* geotransformer/modules/kpconv/kpconv.py:10-121 */
+  const float* weights;        /* (num_kernel_points, in, out) */
+  const float* bias;           /* (out) or NULL */
+  const float* kernel_points;  /* (num_kernel_points, 3) */
+  int64_t in, out, num_kernel_points;
+  float sigma; int32_t pad_;
+} geotr_kpconv;
+typedef struct geotr_block {                                         /* ConvBlock / ResidualBlock, kpconv/modules.py:105-225 */
+  int32_t is_conv_block, has_unary1, has_shortcut, strided;
+  geotr_linear unary1; geotr_norm unary1_norm;
+  geotr_kpconv conv;   geotr_norm conv_norm;
+  geotr_linear unary2; geotr_norm unary2_norm;
+  geotr_linear shortcut; geotr_norm shortcut_norm;
+} geotr_block;
+#define GEOTR_MAX_STAGES 5
+typedef struct geotr_backbone {                                      /* KPConvFPN, experiments/<exp>/backbone.py */
+  int32_t num_stages, fine_stage, num_blocks, num_decoders;
+  geotr_block blocks[2 + 3 * (GEOTR_MAX_STAGES - 1)];               /* encoder1_1, encoder1_2, then (_1,_2,_3) per stage */
+  geotr_linear decoder[GEOTR_MAX_STAGES];                            /* coarsest first; the last one is the LastUnaryBlock */
+  geotr_norm decoder_norm[GEOTR_MAX_STAGES];
+} geotr_backbone;
+typedef struct geotr_pyramid {                                       /* output of precompute_data_stack_mode, utils/data.py:13-77 */
+  int32_t num_stages, pad_;
+  const float* points[GEOTR_MAX_STAGES];       int64_t n[GEOTR_MAX_STAGES];
+  const int64_t* neighbors[GEOTR_MAX_STAGES];  int64_t neighbors_w[GEOTR_MAX_STAGES];
+  const int64_t* subsampling[GEOTR_MAX_STAGES]; int64_t subsampling_w[GEOTR_MAX_STAGES];
+  const int64_t* upsampling[GEOTR_MAX_STAGES];  int64_t upsampling_w[GEOTR_MAX_STAGES];
+  int64_t ref_n[GEOTR_MAX_STAGES];             /* points of the reference cloud per stage (lengths[i][0]) */
+} geotr_pyramid;
+typedef struct geotr_attn_layer {                                    /* RPETransformerLayer / TransformerLayer */
+  int32_t is_self, pad_;
+  geotr_linear q, k, v, p, out, expand, squeeze;                     /* p unused for cross layers */
+  geotr_norm norm, out_norm;
+  const float* qkv_w; const float* qkv_b;                            /* optional fused (3C, C) / (3C) projection (self) */
+  const float* kv_w;  const float* kv_b;                             /* optional fused (2C, C) / (2C) projection (cross) */
+} geotr_attn_layer;
+typedef struct geotr_transformer {                                   /* GeometricTransformer, modules/geotransformer/geotransformer.py:75-155 */
+  int32_t num_layers, num_heads, angle_k, pad_;
+  float sigma_d, sigma_a;
+  const float* div_term;                                             /* (hidden/2) */
+  geotr_linear proj_d, proj_a, in_proj, out_proj;
+  geotr_attn_layer layers[8];
+} geotr_transformer;
+typedef struct geotr_model {
+  geotr_backbone backbone;
+  geotr_transformer transformer;
+  const float* alpha;                                                /* optimal_transport.alpha (device scalar) */
+  int64_t num_points_in_patch, num_correspondences, num_sinkhorn_iterations;
+  int32_t dual_normalization, topk, mutual, correspondence_threshold, num_refinement_steps, pad_;
+  float confidence_threshold, acceptance_radius;
+} geotr_model;
+typedef struct geotr_outputs {                                       /* caller-allocated device buffers (reference output dict keys) */
+  float* feats_c;            /* (n_c, D_out)  L2-normalised superpoint features, ref rows first   -> ref/src_feats_c */
+  float* feats_f;            /* (n_f, C_f)    fine features, ref rows first                       -> ref/src_feats_f */
+  int64_t* ref_node_corr_indices; int64_t* src_node_corr_indices; float* node_corr_scores;   /* (P) each */
+  int32_t* num_node_corr;    /* (1) */
+  int64_t* ref_knn_indices;  int64_t* src_knn_indices;   /* (P, K) */
+  uint8_t* ref_knn_masks;    uint8_t* src_knn_masks;     /* (P, K)    -> *_node_corr_knn_masks */
+  float* ref_knn_points;     float* src_knn_points;      /* (P, K, 3) -> *_node_corr_knn_points */
+  float* matching_scores;    /* (P, K+1, K+1) */
+  float* ref_corr_points;    float* src_corr_points;  float* corr_scores;   /* capacity P*K*topk rows */
+  int32_t* num_corr;         /* (1) */
+  float* estimated_transform;/* (4, 4) */
+} geotr_outputs;
+size_t geotr_model_workspace_bytes(const geotr_model* net, const geotr_pyramid* pyr);
+int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const float* features /* (n[0], in_dim) */,
+                        const geotr_outputs* out, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -141,7 +141,13 @@ def test_model_end_to_end_matches_reference_golden(name):
     missing = model.load_state_dict(sd, strict=True)
     model = model.cuda().eval()
     dev = {k: ([t.cuda() for t in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in data.items()}
-    got = model(dev)
+    model.use_native = False
+    by_modules = model(dev)          # kernels driven module by module from Python
+    model.use_native = True
+    got = model(dev)                 # the native executor: one C-ABI call
+    for k in ('ref_feats_c', 'src_feats_f', 'matching_scores', 'corr_scores', 'estimated_transform', 'ref_node_corr_indices',
+              'ref_corr_points', 'src_node_corr_knn_points', 'ref_node_corr_knn_masks'):
+        assert by_modules[k].shape == got[k].shape and torch.equal(by_modules[k], got[k]), f'executor != module path at {k}'
     for k in ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f'):
         mse = float(((got[k].cpu() - out[k]) ** 2).mean())
         assert mse <= 1e-6, (k, mse)  # north_star bound: 1e-4
