@@ -142,19 +142,20 @@ def main():
     torch.cuda.synchronize()
     info['superpoints'] = [int(out['ref_points_c'].shape[0]), int(out['src_points_c'].shape[0])]
 
-    kernels.PROFILE['gse_embed'] = []  # HIP-event pairs around the dominant kernel, on the launch stream
+    from geotransformer_amd.native import GseProfiler
+    prof = GseProfiler(2 * args.steps * args.batch + 8)  # HIP events around the dominant kernel, recorded on the launch stream
     gd.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, record=i)
-    gathered = gd.gather_results(results)  # (world, steps, 4, 4) -- the only collective on the data path
-    gd.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    with prof:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, record=i)
+        gathered = gd.gather_results(results)  # (world, steps, batch, 4, 4) -- the only collective on the data path
+        gd.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     elapsed = gd.max_over_ranks(elapsed, device)
-    events = kernels.PROFILE.pop('gse_embed')
-    kernels.PROFILE.clear()
+    events = prof.results()
 
     if rank == 0:
         assert torch.isfinite(gathered).all()
@@ -162,8 +163,8 @@ def main():
         value = total_pairs / elapsed
         # roofline of the dominant kernel: 2 * n^2 * (1 + k) * D^2 FLOPs per launch (proj_d + k x proj_a)
         D, k = cfg.geotransformer.hidden_dim, cfg.geotransformer.angle_k
-        durs = [s.elapsed_time(e) * 1e-3 for s, e, _ in events]
-        flops = [2.0 * n * n * (1 + k) * D * D for _, _, n in events]
+        durs = [sec for sec, _ in events]
+        flops = [2.0 * n * n * (1 + k) * D * D for _, n in events]
         achieved = (sum(flops) / sum(durs)) / 1e12 if durs else None
         line = {
             'metric': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)', 'value': round(value, 3), 'unit': 'pairs/s',

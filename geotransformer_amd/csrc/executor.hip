@@ -6,11 +6,20 @@
 // issued from Python they cost ~5 ms of interpreter time per pair, more than the kernels themselves need.  Here the launch
 // sequence, the intermediates (bump allocator over the caller's workspace) and the data-dependent counts (kept on the
 // device) all stay on the native side: one asynchronous host call per pair, no host<-device read inside.
+#include <atomic>
 #include <cstring>
 
 #include "common.h"
 
 namespace geotr {
+
+// Optional timing of the dominant kernel: bench.py arms a pool of HIP events (geotr_profile_gse); every gse_embed launch
+// made by the executor is then bracketed by hipEventRecord on the launch stream.  Disarmed (cap = 0) it costs nothing.
+static void** g_prof_start = nullptr;
+static void** g_prof_stop = nullptr;
+static int64_t* g_prof_size = nullptr;
+static int g_prof_cap = 0;
+static std::atomic<int> g_prof_used{0};
 
 struct Ctx {
   char* base;
@@ -231,8 +240,18 @@ static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t 
   int32_t* knn = c.alloc<int32_t>((size_t)n * t.angle_k);
   if (c.live()) {
     c.check(geotr_gse_knn(pts, n, t.angle_k, knn, c.stream));
+    int slot = -1;
+    if (g_prof_cap > 0) {
+      slot = g_prof_used.fetch_add(1);
+      if (slot >= g_prof_cap) slot = -1;
+    }
+    if (slot >= 0) (void)hipEventRecord((hipEvent_t)g_prof_start[slot], c.stream);
     c.check(geotr_gse_embed(pts, knn, n, t.angle_k, D, t.div_term, t.proj_d.w, t.proj_d.b, t.proj_a.w, t.proj_a.b, t.sigma_d, t.sigma_a,
                             emb, c.stream));
+    if (slot >= 0) {
+      (void)hipEventRecord((hipEvent_t)g_prof_stop[slot], c.stream);
+      g_prof_size[slot] = n;
+    }
   }
   return emb;
 }
@@ -339,6 +358,22 @@ static int validate(const geotr_model* net, const geotr_pyramid* pyr) {
 }
 
 extern "C" {
+
+int geotr_profile_gse(void** start_events, void** stop_events, int64_t* sizes, int64_t capacity) {
+  GEOTR_CHECK_ARG(capacity >= 0 && (capacity == 0 || (start_events && stop_events && sizes)), "profile_gse: bad arguments");
+  g_prof_cap = 0;
+  g_prof_start = start_events;
+  g_prof_stop = stop_events;
+  g_prof_size = sizes;
+  g_prof_used.store(0);
+  g_prof_cap = (int)capacity;
+  return GEOTR_OK;
+}
+
+int64_t geotr_profile_gse_count(void) {
+  const int used = g_prof_used.load();
+  return used < g_prof_cap ? used : g_prof_cap;
+}
 
 size_t geotr_model_workspace_bytes(const geotr_model* net, const geotr_pyramid* pyr) {
   if (validate(net, pyr) != GEOTR_OK) return 0;

@@ -238,33 +238,45 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     out[i] = t;
   }
 }
-// pass 2: one wave per (sum | sumsq, channel): fp64 sum over the blocks
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nb, int C, double* __restrict__ stats) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= 2 * C) return;
-  double t = 0.0;
-  for (int b = lane; b < nb; b += 64) t += (double)partial[(int64_t)b * 2 * C + i];
-  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-  if (lane == 0) stats[i] = t;
-}
-// pass 3: per-channel scale / shift so the apply pass is one fma per element:  y = x * a[c] + b[c]
-__global__ void gn_affine_kernel(const double* __restrict__ stats, int64_t N, int C, int groups, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float eps, float* __restrict__ ab) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const int cpg = C / groups, g0 = (c / cpg) * cpg;
+// pass 2: one block per group: fp64 reduction of the group's partials -> mean / rstd -> per-channel scale and shift,
+// so the apply pass is one fma per element:  y = x * a[c] + b[c]
+__global__ __launch_bounds__(256) void gn_group_kernel(const float* __restrict__ partial, int nb, int64_t N, int C, int groups,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                       float* __restrict__ ab) {
+  __shared__ double red[2][4];
+  __shared__ float stat[2];
+  const int g = blockIdx.x, cpg = C / groups, g0 = g * cpg;
   double s = 0.0, ss = 0.0;
-  for (int j = 0; j < cpg; ++j) {
-    s += stats[g0 + j];
-    ss += stats[C + g0 + j];
+  for (int idx = threadIdx.x; idx < nb * cpg; idx += 256) {
+    const int b = idx / cpg, c = g0 + idx % cpg;
+    s += (double)partial[(int64_t)b * 2 * C + c];
+    ss += (double)partial[(int64_t)b * 2 * C + C + c];
   }
-  const double cnt = (double)N * cpg;
-  const double mean = s / cnt;
-  double var = ss / cnt - mean * mean;
-  var = var > 0.0 ? var : 0.0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  ab[c] = rstd * gamma[c];
-  ab[C + c] = beta[c] - (float)mean * rstd * gamma[c];
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    ss += __shfl_xor(ss, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s;
+    red[1][threadIdx.x >> 6] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double S = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), SS = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double cnt = (double)N * cpg;
+    const double mean = S / cnt;
+    double var = SS / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    stat[0] = (float)mean;
+    stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < cpg; j += 256) {
+    const int c = g0 + j;
+    const float a = stat[1] * gamma[c];
+    ab[c] = a;
+    ab[C + c] = beta[c] - stat[0] * a;
+  }
 }
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gn_apply2_kernel(const float* __restrict__ x, int64_t total, int C, const float* __restrict__ ab,
@@ -475,9 +487,8 @@ int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const
   float* partial = reinterpret_cast<float*>(stats_ws + 2 * c);
   const int per = c < 256 ? (int)(256 / c) : 0;
   gn_partial_kernel<<<dim3(nb), dim3(256), sizeof(float) * 2 * (size_t)c * per, stream>>>(x, n, (int)c, partial);
-  gn_finalize_kernel<<<dim3((unsigned)((2 * c + 3) / 4)), dim3(256), 0, stream>>>(partial, (int)nb, (int)c, stats_ws);
   float* ab = partial + (size_t)nb * 2 * c;
-  gn_affine_kernel<<<dim3((unsigned)((c + 255) / 256)), dim3(256), 0, stream>>>(stats_ws, n, (int)c, (int)groups, gamma, beta, eps, ab);
+  gn_group_kernel<<<dim3((unsigned)groups), dim3(256), 0, stream>>>(partial, (int)nb, n, (int)c, (int)groups, gamma, beta, eps, ab);
   const int64_t total = n * c;
   if (c % 4 == 0)
     gn_apply2_kernel<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, residual, act, out);

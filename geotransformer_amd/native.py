@@ -300,3 +300,33 @@ class NativeModel:
         out['src_corr_points'] = out.pop('_src_corr_points')[:c]
         out['corr_scores'] = out.pop('_corr_scores')[:c]
         return out
+
+
+class GseProfiler:
+    """HIP-event timing of the dominant kernel (fused GSE embedding) for launches made by the native executor.
+
+    Events are created here, handed to the library as raw handles and recorded by the executor on the launch stream."""
+
+    def __init__(self, capacity):
+        _bind()
+        self.capacity = capacity
+        self.start = [torch.cuda.Event(enable_timing=True) for _ in range(capacity)]
+        self.stop = [torch.cuda.Event(enable_timing=True) for _ in range(capacity)]
+        for e in self.start + self.stop:
+            e.record()  # forces creation of the underlying hipEvent_t
+        torch.cuda.synchronize()
+        self._start = (ctypes.c_void_p * capacity)(*[e.cuda_event for e in self.start])
+        self._stop = (ctypes.c_void_p * capacity)(*[e.cuda_event for e in self.stop])
+        self._sizes = (ctypes.c_int64 * capacity)()
+
+    def __enter__(self):
+        _lib.check(_lib.load().geotr_profile_gse(self._start, self._stop, self._sizes, self.capacity), 'geotr_profile_gse')
+        return self
+
+    def __exit__(self, *exc):
+        self.used = int(_lib.load().geotr_profile_gse_count())
+        _lib.load().geotr_profile_gse(None, None, None, 0)
+
+    def results(self):
+        """[(seconds, n_superpoints)] for every recorded launch; call after torch.cuda.synchronize()."""
+        return [(self.start[i].elapsed_time(self.stop[i]) * 1e-3, int(self._sizes[i])) for i in range(self.used)]

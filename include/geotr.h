@@ -273,6 +273,11 @@ typedef struct geotr_outputs {                                       /* caller-a
   float* estimated_transform;/* (4, 4) */
 } geotr_outputs;
 size_t geotr_model_workspace_bytes(const geotr_model* net, const geotr_pyramid* pyr);
+/* Measurement hook: arm (capacity > 0) / disarm (capacity = 0) a pool of caller-created hipEvent_t handles; every GSE
+ * embedding launch issued by geotr_model_forward is then bracketed by hipEventRecord(start[i]) / (stop[i]) on the launch
+ * stream and sizes[i] = number of superpoints.  geotr_profile_gse_count() = slots used so far. */
+int geotr_profile_gse(void** start_events, void** stop_events, int64_t* sizes, int64_t capacity);
+int64_t geotr_profile_gse_count(void);
 int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const float* features /* (n[0], in_dim) */,
                         const geotr_outputs* out, void* ws, size_t ws_bytes, void* stream);
 
