@@ -39,8 +39,9 @@ SIGNATURES = {
     'geotr_group_norm': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
     'geotr_layer_norm': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_ptr]),
     'geotr_gse_knn': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
-    'geotr_gse_embed': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_ptr,
-                                c_ptr]),
+    'geotr_gse_embed_workspace_bytes': (c_size, [c_i64, c_int]),
+    'geotr_gse_embed': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_ptr,
+                                c_size, c_ptr, c_ptr]),
     'geotr_attn_softmax': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr]),
     'geotr_point_to_node': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'geotr_superpoint_match': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,

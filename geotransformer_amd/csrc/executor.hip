@@ -238,6 +238,8 @@ static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t 
   const int64_t D = t.proj_d.out;
   float* emb = c.alloc<float>((size_t)n * n * D);
   int32_t* knn = c.alloc<int32_t>((size_t)n * t.angle_k);
+  const size_t gws_bytes = geotr_gse_embed_workspace_bytes(D, t.gse_precision);
+  char* gws = c.alloc<char>(gws_bytes + 16);
   if (c.live()) {
     c.check(geotr_gse_knn(pts, n, t.angle_k, knn, c.stream));
     int slot = -1;
@@ -247,7 +249,7 @@ static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t 
     }
     if (slot >= 0) (void)hipEventRecord((hipEvent_t)g_prof_start[slot], c.stream);
     c.check(geotr_gse_embed(pts, knn, n, t.angle_k, D, t.div_term, t.proj_d.w, t.proj_d.b, t.proj_a.w, t.proj_a.b, t.sigma_d, t.sigma_a,
-                            emb, c.stream));
+                            t.gse_precision, gws, gws_bytes, emb, c.stream));
     if (slot >= 0) {
       (void)hipEventRecord((hipEvent_t)g_prof_stop[slot], c.stream);
       g_prof_size[slot] = n;

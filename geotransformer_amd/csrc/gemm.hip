@@ -202,21 +202,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // own 32x32 A and B chunks through a private LDS slab with all its loads in flight at once, and the four partial
 // accumulators are reduced through LDS before the fused epilogue.  Serial depth per wave = K/4, blocks = (M/32)(N/32).
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kSK = 64;             // K-chunk of the skinny kernel
+constexpr int kSStride = kSK + 1;   // padded LDS row
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
-  __shared__ float slab[4][2 * 32 * kLdsStride];  // per wave: A chunk [32][33], B chunk [32][33]; reused for the reduction
+  __shared__ float slab[4][2 * 32 * kSStride];  // per wave: A chunk [32][33], B chunk [32][33]; reused for the reduction
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   const float* A = g.A + (int64_t)blockIdx.z * g.strideA;
   const float* B = g.B + (int64_t)blockIdx.z * g.strideB;
   float* C = g.C + (int64_t)blockIdx.z * g.strideC;
   float* As = slab[wave];
-  float* Bs = As + 32 * kLdsStride;
-  float4 ra[4], rb[4];
+  float* Bs = As + 32 * kSStride;
+  float4 ra[8], rb[8];
   auto load_chunk = [&](int k0) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int f = lane + 64 * s, row = f >> 3, kq = (f & 7) * 4;
+    for (int s = 0; s < 8; ++s) {
+      const int f = lane + 64 * s, row = f >> 4, kq = (f & 15) * 4;  // 32 rows x 16 float4 (64 k)
       const int gm = m0 + row, gk = k0 + kq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gm < g.M) {
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
           }
         }
       } else {
-        const int kk = f >> 3, nq = (f & 7) * 4;  // 32 k-rows x 8 float4 along n
+        const int kk = f >> 3, nq = (f & 7) * 4;  // 64 k-rows x 8 float4 along n
         const int gk2 = k0 + kk, gn = n0 + nq;
         if (gk2 < g.K) {
           const float* p = B + (int64_t)gk2 * g.ldb + gn;
@@ -265,39 +268,39 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int f = lane + 64 * s, row = f >> 3, kq = (f & 7) * 4;
-      float* d = As + row * kLdsStride + kq;
+    for (int s = 0; s < 8; ++s) {
+      const int f = lane + 64 * s, row = f >> 4, kq = (f & 15) * 4;
+      float* d = As + row * kSStride + kq;
       d[0] = ra[s].x; d[1] = ra[s].y; d[2] = ra[s].z; d[3] = ra[s].w;
       if (!g.b_is_kn) {
-        float* e = Bs + row * kLdsStride + kq;
+        float* e = Bs + row * kSStride + kq;
         e[0] = rb[s].x; e[1] = rb[s].y; e[2] = rb[s].z; e[3] = rb[s].w;
       } else {
         const int kk = f >> 3, nq = (f & 7) * 4;
-        Bs[(nq + 0) * kLdsStride + kk] = rb[s].x;
-        Bs[(nq + 1) * kLdsStride + kk] = rb[s].y;
-        Bs[(nq + 2) * kLdsStride + kk] = rb[s].z;
-        Bs[(nq + 3) * kLdsStride + kk] = rb[s].w;
+        Bs[(nq + 0) * kSStride + kk] = rb[s].x;
+        Bs[(nq + 1) * kSStride + kk] = rb[s].y;
+        Bs[(nq + 2) * kSStride + kk] = rb[s].z;
+        Bs[(nq + 3) * kSStride + kk] = rb[s].w;
       }
     }
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nchunks = (g.K + kBK - 1) / kBK;
+  const int nchunks = (g.K + kSK - 1) / kSK;
   const int fr = lane & 31, fk = lane >> 5;
   int c = wave;
-  if (c < nchunks) load_chunk(c * kBK);
+  if (c < nchunks) load_chunk(c * kSK);
   for (; c < nchunks; c += 4) {
     store_chunk();  // wave-private slab: only wave-level ordering is needed
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (c + 4 < nchunks) load_chunk((c + 4) * kBK);  // next chunk's loads fly under this chunk's MFMAs
+    if (c + 4 < nchunks) load_chunk((c + 4) * kSK);  // next chunk's loads fly under this chunk's MFMAs
 #pragma unroll
-    for (int ks = 0; ks < kBK / 2; ++ks) {
-      const float a = As[fr * kLdsStride + 2 * ks + fk];
-      const float b = Bs[fr * kLdsStride + 2 * ks + fk];
+    for (int ks = 0; ks < kSK / 2; ++ks) {
+      const float a = As[fr * kSStride + 2 * ks + fk];
+      const float b = Bs[fr * kSStride + 2 * ks + fk];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -307,13 +310,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   // reduce the 4 partial tiles: slab[w] holds wave w's 32x32 partial, element (row, col) at row * 33 + col
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) As[((r & 3) + 8 * (r >> 2) + 4 * fk) * kLdsStride + fr] = acc[r];
+  for (int r = 0; r < 16; ++r) As[((r & 3) + 8 * (r >> 2) + 4 * fk) * kSStride + fr] = acc[r];
   __syncthreads();
   for (int e = tid; e < 32 * 32; e += 256) {
     const int row = e >> 5, col = e & 31;
     const int gm = m0 + row, gn = n0 + col;
     if (gm >= g.M || gn >= g.N) continue;
-    const int o = row * kLdsStride + col;
+    const int o = row * kSStride + col;
     float v = ((slab[0][o] + slab[1][o]) + (slab[2][o] + slab[3][o])) * g.alpha;
     if (g.row_div) v = v / (float)max(g.row_div[gm], 1);
     if (g.bias) v += g.bias[gn];
@@ -349,7 +352,7 @@ extern "C" int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t l
   const bool vec = aligned(A, lda, strideA) && aligned(B, ldb, strideB);
   // tall operands with enough 128x128 tiles to fill the chip -> tiled kernel; everything else -> split-K skinny kernel
   const int64_t big_blocks = ((N + 127) / 128) * ((M + 127) / 128) * batch;
-  const bool big = N >= 96 && big_blocks >= 192 && K <= 1024;
+  const bool big = N >= 96 && M >= 1024 && big_blocks >= 40 && K <= 1024;
   if (big) {
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)batch);
     if (vec) gemm_kernel<128, 128, 2, 2, true><<<grid, dim3(256), 0, stream>>>(g);

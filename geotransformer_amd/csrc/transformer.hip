@@ -199,9 +199,144 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------
+// fused GSE on the bf16 matrix pipe with fp32-class accuracy ("bf16x3"):  x = hi + lo with hi = bf16(x), lo = bf16(x - hi),
+// a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  (relative error ~2^-17 per product; the dropped lo*lo term is ~2^-18).
+// v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate, so three of them per 16-deep step cost 3/16 of the
+// fp32 path's matrix time.  Same tiling as gse_embed_kernel (64 pairs x D channels per block, 8 waves x 32 channels);
+// LDS rows are 32 bf16 padded to 40 (80 B): the 16-lane groups of ds_read_b128 then hit 16 distinct 16-B slots.
+// ---------------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr int kGseRS = 40;  // LDS row stride in bf16 elements
+
+__device__ __forceinline__ unsigned f32_to_bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+
+// W (rows, cols) fp32 -> hi / lo bf16 planes
+__global__ void split_bf16_kernel(const float* __restrict__ w, int64_t n, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = w[i];
+  const unsigned h = f32_to_bf16_rne(x);
+  hi[i] = (unsigned short)h;
+  lo[i] = (unsigned short)f32_to_bf16_rne(x - bf16_to_f32(h));
+}
+
+template <int D, int S>
+__global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const float* __restrict__ pts, const int* __restrict__ knn, int n,
+                                                                         const float* __restrict__ div_term,
+                                                                         const unsigned short* __restrict__ wsplit,  // [4][D][D]: d_hi, d_lo, a_hi, a_lo
+                                                                         const float* __restrict__ bd, const float* __restrict__ ba,
+                                                                         float inv_sigma_d, float factor_a, float* __restrict__ out) {
+  constexpr int T = 64 * (D / 32);
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  unsigned short* A_hi = smem16;                         // [S*64][40]
+  unsigned short* A_lo = A_hi + S * kGsePairs * kGseRS;  // [S*64][40]
+  unsigned short* W_s = A_lo + S * kGsePairs * kGseRS;   // [4*D][40]
+  float* idx_s = reinterpret_cast<float*>(W_s + 4 * D * kGseRS);  // [S][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t total = (int64_t)n * n;
+  const int64_t p0 = (int64_t)blockIdx.x * kGsePairs;
+
+  for (int e = tid; e < kGsePairs; e += T) {  // embedding indices, identical to gse_embed_kernel
+    const int64_t p = p0 + e;
+    float vals[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) vals[s] = 0.f;
+    if (p < total) {
+      const int i = (int)(p / n), j = (int)(p - (int64_t)i * n);
+      const float pi[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+      const float pj[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+      vals[0] = sqrtf(expanded_sqdist(pi, pj)) * inv_sigma_d;
+      const float ax = pj[0] - pi[0], ay = pj[1] - pi[1], az = pj[2] - pi[2];
+#pragma unroll
+      for (int x = 0; x < S - 1; ++x) {
+        const int q = knn[i * (S - 1) + x];
+        const float rx = pts[3 * q] - pi[0], ry = pts[3 * q + 1] - pi[1], rz = pts[3 * q + 2] - pi[2];
+        const float cx = ry * az - rz * ay, cy = rz * ax - rx * az, cz = rx * ay - ry * ax;
+        const float sinv = sqrtf((cx * cx + cy * cy) + cz * cz);
+        const float cosv = ((rx * ax + ry * ay) + rz * az) + 0.0f;  // see gse_embed_kernel: keep atan2(+0, +0) = 0
+        vals[1 + x] = atan2f(sinv, cosv) * factor_a;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) idx_s[s * kGsePairs + e] = vals[s];
+  }
+
+  f32x16 acc[2][S];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[r][s][q] = 0.f;
+
+  const int fr = lane & 31, fk = lane >> 5;
+  unsigned* A_hi32 = reinterpret_cast<unsigned*>(A_hi);
+  unsigned* A_lo32 = reinterpret_cast<unsigned*>(A_lo);
+  for (int k0 = 0; k0 < D; k0 += kGseBK) {
+    __syncthreads();
+    // sinusoid tile, split into hi / lo bf16: word t of a row holds (sin, cos) = elements (2t, 2t+1)
+    for (int e = tid; e < S * kGsePairs * (kGseBK / 2); e += T) {
+      const int t = e % (kGseBK / 2);
+      const int row = e / (kGseBK / 2);
+      const float omega = idx_s[row] * div_term[(k0 >> 1) + t];
+      float sv, cv;
+      sincosf(omega, &sv, &cv);
+      const unsigned sh = f32_to_bf16_rne(sv), ch = f32_to_bf16_rne(cv);
+      const unsigned sl = f32_to_bf16_rne(sv - bf16_to_f32(sh)), cl = f32_to_bf16_rne(cv - bf16_to_f32(ch));
+      A_hi32[(row * kGseRS) / 2 + t] = sh | (ch << 16);
+      A_lo32[(row * kGseRS) / 2 + t] = sl | (cl << 16);
+    }
+    // weight rows: 4 planes x D rows x 32 bf16 (= four 16-B vectors per row)
+    for (int e = tid; e < 4 * D * 4; e += T) {
+      const int vec = e & 3, row = e >> 2;  // row = plane * D + col
+      const uint4 v = *reinterpret_cast<const uint4*>(wsplit + (int64_t)row * D + k0 + vec * 8);
+      *reinterpret_cast<uint4*>(W_s + row * kGseRS + vec * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < kGseBK / 16; ++ks) {
+      const int kb = ks * 16 + 8 * fk;
+      bf16x8 b[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) b[v] = *reinterpret_cast<const bf16x8*>(W_s + (v * D + 32 * wave + fr) * kGseRS + kb);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const int row = s * kGsePairs + 32 * r + fr;
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A_hi + row * kGseRS + kb);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(A_lo + row * kGseRS + kb);
+          const bf16x8 bh = s == 0 ? b[0] : b[2], bl = s == 0 ? b[1] : b[3];
+          acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r][s], 0, 0, 0);
+          acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r][s], 0, 0, 0);
+          acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r][s], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int col = 32 * wave + fr;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int64_t p = p0 + 32 * r + (q & 3) + 8 * (q >> 2) + 4 * fk;
+      if (p >= total) continue;
+      float m = acc[r][1][q];
+#pragma unroll
+      for (int s = 2; s < S; ++s) m = fmaxf(m, acc[r][s][q]);
+      out[p * D + col] = (acc[r][0][q] + bd[col]) + (m + ba[col]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // attention scores: positional term + scale + softmax, one block per query row
 // ---------------------------------------------------------------------------------------------------
-constexpr int kAttTile = 64;  // keys per tile
+constexpr int kAttTile = 32;  // keys per tile (small tiles: several blocks per CU keep the embedding stream in flight)
 
 // positional term: one block per (query i, tile of 64 keys):  scores[h,i,j] += e[i,j,:] . qt[i,h,:] + qb[i,h]
 __global__ __launch_bounds__(256) void attn_pos_kernel(float* __restrict__ scores, const float* __restrict__ emb,
@@ -209,8 +344,8 @@ __global__ __launch_bounds__(256) void attn_pos_kernel(float* __restrict__ score
                                                        int ld, int C, int H) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qt_s = smem;                      // [C][H]
-  float* part_s = qt_s + C * H;            // [4][H][64]
-  float* e_s = part_s + 4 * H * kAttTile;  // [64][C + 1]
+  float* part_s = qt_s + C * H;            // [8][H][32]
+  float* e_s = part_s + 8 * H * kAttTile;  // [32][C + 1]
   const int i = blockIdx.x, j0 = blockIdx.y * kAttTile, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int es = C + 1;
   const int rows = min(kAttTile, m - j0);
@@ -229,14 +364,15 @@ __global__ __launch_bounds__(256) void attn_pos_kernel(float* __restrict__ score
     d[3] = v.w;
   }
   __syncthreads();
-  // wave w reduces channels [w*C/4, (w+1)*C/4) for key j0 + lane, all heads
+  // 8 channel slices: (wave w, half-wave) reduces channels [s*C/8, (s+1)*C/8), s = 2w + (lane>>5), for key j0 + (lane & 31)
   float accv[8];
 #pragma unroll
   for (int h = 0; h < 8; ++h) accv[h] = 0.f;
-  if (lane < rows) {
-    const int c0 = wave * (C / 4), c1 = c0 + C / 4;
+  const int key = lane & 31, slice = 2 * wave + (lane >> 5);
+  if (key < rows) {
+    const int c0 = slice * (C / 8), c1 = c0 + C / 8;
     for (int c = c0; c < c1; ++c) {
-      const float ev = e_s[lane * es + c];
+      const float ev = e_s[key * es + c];
 #pragma unroll
       for (int h = 0; h < 8; ++h)
         if (h < H) accv[h] = fmaf(ev, qt_s[c * H + h], accv[h]);
@@ -244,12 +380,12 @@ __global__ __launch_bounds__(256) void attn_pos_kernel(float* __restrict__ score
   }
 #pragma unroll
   for (int h = 0; h < 8; ++h)
-    if (h < H) part_s[(wave * H + h) * kAttTile + lane] = accv[h];
+    if (h < H) part_s[(slice * H + h) * kAttTile + key] = accv[h];
   __syncthreads();
   for (int e = tid; e < H * rows; e += 256) {
     const int h = e / rows, j = e % rows;
     float p = 0.f;
-    for (int w = 0; w < 4; ++w) p += part_s[(w * H + h) * kAttTile + j];
+    for (int w = 0; w < 8; ++w) p += part_s[(w * H + h) * kAttTile + j];
     scores[((int64_t)h * n + i) * ld + j0 + j] += p + qb[i * H + h];
   }
 }
@@ -296,6 +432,28 @@ int geotr_gse_knn(const float* points, int64_t n, int64_t k, int32_t* knn, void*
 }  // extern "C"
 
 template <int D>
+static int launch_gse_bf16x3(int k, const float* pts, const int* knn, int n, const float* div_term, const unsigned short* wsplit,
+                             const float* bd, const float* ba, float inv_sigma_d, float factor_a, float* out, hipStream_t stream) {
+  const int64_t total = (int64_t)n * n;
+  const unsigned nb = (unsigned)((total + kGsePairs - 1) / kGsePairs);
+  const int S = 1 + k;
+  const size_t lds = 2 * ((size_t)2 * S * kGsePairs * kGseRS + (size_t)4 * D * kGseRS) + sizeof(float) * (size_t)S * kGsePairs;
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(GEOTR_E_LAUNCH, "gse_embed: cannot reserve %zu B of LDS", lds);
+    kern<<<dim3(nb), dim3(64 * (D / 32)), lds, stream>>>(pts, knn, n, div_term, wsplit, bd, ba, inv_sigma_d, factor_a, out);
+    return GEOTR_OK;
+  };
+  switch (S) {
+    case 2: return go(gse_embed_bf16x3_kernel<D, 2>);
+    case 3: return go(gse_embed_bf16x3_kernel<D, 3>);
+    case 4: return go(gse_embed_bf16x3_kernel<D, 4>);
+    default: return go(gse_embed_bf16x3_kernel<D, 5>);
+  }
+}
+
+template <int D>
 static int launch_gse(int k, const float* pts, const int* knn, int n, const float* div_term, const float* Wd,
                       const float* bd, const float* Wa, const float* ba, float inv_sigma_d, float factor_a, float* out,
                       hipStream_t stream) {
@@ -320,9 +478,11 @@ static int launch_gse(int k, const float* pts, const int* knn, int n, const floa
 
 extern "C" {
 
+size_t geotr_gse_embed_workspace_bytes(int64_t d, int precision) { return precision == 1 ? (size_t)(8 * d * d) : 0; }
+
 int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t k, int64_t d, const float* div_term,
                     const float* w_d, const float* b_d, const float* w_a, const float* b_a, float sigma_d, float sigma_a,
-                    float* out, void* stream_) {
+                    int precision, void* ws, size_t ws_bytes, float* out, void* stream_) {
   GEOTR_CHECK_ARG(n >= 0 && k >= 1 && k <= kMaxK, "gse_embed: angle_k must be in [1, %d]", kMaxK);
   GEOTR_CHECK_ARG(d == 32 || d == 64 || d == 128 || d == 256, "gse_embed: hidden_dim must be 32, 64, 128 or 256 (got %lld)",
                   (long long)d);
@@ -331,6 +491,26 @@ int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t 
   hipStream_t stream = (hipStream_t)stream_;
   const float inv_sigma_d = 1.0f / sigma_d;
   const float factor_a = (float)(180.0 / ((double)sigma_a * 3.14159265358979323846));  // geotransformer.py:14
+  GEOTR_CHECK_ARG(precision == 0 || precision == 1, "gse_embed: precision must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)");
+  if (precision == 1) {
+    GEOTR_CHECK_ARG(ws && ws_bytes >= (size_t)(8 * d * d) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+                    "gse_embed: split-bf16 path needs a 16-byte aligned workspace of 8*d*d bytes");
+    unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
+    const int64_t dd = d * d;
+    const unsigned nbs = (unsigned)((dd + 255) / 256);
+    split_bf16_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_d, dd, wsplit, wsplit + dd);
+    split_bf16_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_a, dd, wsplit + 2 * dd, wsplit + 3 * dd);
+    int rc2;
+    switch (d) {
+      case 32: rc2 = launch_gse_bf16x3<32>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream); break;
+      case 64: rc2 = launch_gse_bf16x3<64>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream); break;
+      case 128: rc2 = launch_gse_bf16x3<128>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream); break;
+      default: rc2 = launch_gse_bf16x3<256>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream); break;
+    }
+    if (rc2 != GEOTR_OK) return rc2;
+    GEOTR_CHECK_LAUNCH("gse_embed(bf16x3)");
+    return GEOTR_OK;
+  }
   int rc;
   switch (d) {
     case 32: rc = launch_gse<32>((int)k, points, knn, (int)n, div_term, w_d, b_d, w_a, b_a, inv_sigma_d, factor_a, out, stream); break;
@@ -351,7 +531,7 @@ int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float*
   GEOTR_CHECK_ARG(!emb || (c % 16 == 0 && c <= 512), "attn_softmax: channels must be a multiple of 16, <= 512");
   hipStream_t stream = (hipStream_t)stream_;
   if (emb) {
-    const size_t lds = sizeof(float) * (size_t)(c * heads + 4 * heads * kAttTile + kAttTile * (c + 1));
+    const size_t lds = sizeof(float) * (size_t)(c * heads + 8 * heads * kAttTile + kAttTile * (c + 1));
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_pos_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)

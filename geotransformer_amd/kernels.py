@@ -149,7 +149,10 @@ def gse_knn(points, k):
     return knn
 
 
-def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a):
+GSE_PRECISION = 1  # 0: fp32 MFMA (exact fp32 products); 1: split-bf16 "bf16x3" MFMA (~2^-17 relative error per product)
+
+
+def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, precision=None):
     """(n, n, D) geometric structure embedding of one cloud (n, 3)."""
     lib = _lib.load()
     points = _f32c(points)
@@ -159,9 +162,12 @@ def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a):
     if prof is not None:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
+    precision = GSE_PRECISION if precision is None else int(precision)
+    ws = _lib.workspace(lib.geotr_gse_embed_workspace_bytes(d, precision), points.device)
     _lib.check(lib.geotr_gse_embed(_lib.ptr(points), _lib.ptr(knn), n, knn.shape[1], d, _lib.ptr(_f32c(div_term)),
                                    _lib.ptr(_f32c(w_d)), _lib.ptr(b_d), _lib.ptr(_f32c(w_a)), _lib.ptr(b_a), float(sigma_d),
-                                   float(sigma_a), _lib.ptr(out), _lib.stream_ptr()), 'geotr_gse_embed')
+                                   float(sigma_a), precision, _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
+               'geotr_gse_embed')
     if prof is not None:
         end.record()
         prof.append((start, end, n))

@@ -59,7 +59,7 @@ class AttnLayer(ctypes.Structure):
 
 class Transformer(ctypes.Structure):
     _fields_ = [('num_layers', I32), ('num_heads', I32), ('angle_k', I32), ('pad_', I32), ('sigma_d', F32), ('sigma_a', F32),
-                ('div_term', P_F32), ('proj_d', Linear), ('proj_a', Linear), ('in_proj', Linear), ('out_proj', Linear),
+                ('gse_precision', I32), ('pad2_', I32), ('div_term', P_F32), ('proj_d', Linear), ('proj_a', Linear), ('in_proj', Linear), ('out_proj', Linear),
                 ('layers', AttnLayer * 8)]
 
 
@@ -171,6 +171,8 @@ class NativeModel:
         layers = tr.transformer.layers
         t.num_layers, t.num_heads = len(layers), layers[0].attention.attention.num_heads
         t.angle_k, t.sigma_d, t.sigma_a = tr.embedding.angle_k, float(tr.embedding.sigma_d), float(tr.embedding.sigma_a)
+        from . import kernels
+        t.gse_precision = int(kernels.GSE_PRECISION)
         t.div_term = _ptr(tr.embedding.embedding.div_term)
         t.proj_d, t.proj_a = _linear(tr.embedding.proj_d), _linear(tr.embedding.proj_a)
         t.in_proj, t.out_proj = _linear(tr.in_proj), _linear(tr.out_proj)

@@ -142,9 +142,13 @@ int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c
  *                                              transformer/rpe_transformer.py:51-66, vanilla_transformer.py:55-63
  * ---------------------------------------------------------------------------------------------- */
 int geotr_gse_knn(const float* points, int64_t n, int64_t k, int32_t* knn, void* stream);
+/* precision 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products);  precision 1: split-bf16 ("bf16x3") MFMA --
+ * every operand x = hi + lo in bf16, a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, relative error ~2^-17 per product, 3/16 of the
+ * fp32 matrix time; needs ws of geotr_gse_embed_workspace_bytes(d, 1) bytes (16-byte aligned). */
+size_t geotr_gse_embed_workspace_bytes(int64_t d, int precision);
 int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t k, int64_t d, const float* div_term,
                     const float* w_d, const float* b_d, const float* w_a, const float* b_a, float sigma_d, float sigma_a,
-                    float* out, void* stream);
+                    int precision, void* ws, size_t ws_bytes, float* out, void* stream);
 int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m,
                        int64_t c, int64_t heads, float scale, void* stream);
 
@@ -247,6 +251,7 @@ typedef struct geotr_attn_layer {                                    /* RPETrans
 typedef struct geotr_transformer {                                   /* GeometricTransformer, modules/geotransformer/geotransformer.py:75-155 */
   int32_t num_layers, num_heads, angle_k, pad_;
   float sigma_d, sigma_a;
+  int32_t gse_precision, pad2_;                                      /* 0: fp32 MFMA, 1: split-bf16 MFMA (geotr_gse_embed) */
   const float* div_term;                                             /* (hidden/2) */
   geotr_linear proj_d, proj_a, in_proj, out_proj;
   geotr_attn_layer layers[8];

@@ -21,8 +21,9 @@ def _gse_weights(D, seed):
             'e.proj_a.weight': torch.randn(D, D, generator=g) * s, 'e.proj_a.bias': torch.randn(D, generator=g) * 0.1}
 
 
+@pytest.mark.parametrize('precision', [0, 1], ids=['fp32mfma', 'bf16x3'])
 @pytest.mark.parametrize('n,D', [(5, 32), (70, 64), (150, 128), (130, 256), (272, 256)])
-def test_gse_matches_oracle(n, D):
+def test_gse_matches_oracle(n, D, precision):
     from geotransformer_amd import kernels
     from oracle import model_oracle as mo
     pts = _random_superpoints(n, n + D)
@@ -34,7 +35,7 @@ def test_gse_matches_oracle(n, D):
     assert torch.equal(knn.cpu().long(), knn_want[0])
     div_term = torch.exp(torch.arange(0, D, 2).float() * (-np.log(10000.0) / D))
     got = kernels.gse_embed(pts.cuda(), knn, div_term.cuda(), sd['e.proj_d.weight'].cuda(), sd['e.proj_d.bias'].cuda(),
-                            sd['e.proj_a.weight'].cuda(), sd['e.proj_a.bias'].cuda(), 0.2, 15).cpu()
+                            sd['e.proj_a.weight'].cuda(), sd['e.proj_a.bias'].cuda(), 0.2, 15, precision=precision).cpu()
     assert got.shape == want.shape
     # Off-diagonal entries: fp32 summation-order tolerance.  Diagonal entries e[i,i,:]: the reference's self-distance
     # sqrt(clamp(|x|^2 - 2 x.x + |x|^2, 0)) is pure BLAS rounding noise (~1e-3) where this kernel
