@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // own 32x32 A and B chunks through a private LDS slab with all its loads in flight at once, and the four partial
 // accumulators are reduced through LDS before the fused epilogue.  Serial depth per wave = K/4, blocks = (M/32)(N/32).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kSK = 64;             // K-chunk of the skinny kernel
+constexpr int kSK = 32;             // K-chunk of the skinny kernel (64 was slower: 66 KB of LDS per block halves occupancy)
 constexpr int kSStride = kSK + 1;   // padded LDS row
 
 template <bool VEC>
@@ -215,11 +215,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   float* C = g.C + (int64_t)blockIdx.z * g.strideC;
   float* As = slab[wave];
   float* Bs = As + 32 * kSStride;
-  float4 ra[8], rb[8];
+  constexpr int NV = kSK / 8;  // float4 per lane and operand: 32 rows x kSK floats / 64 lanes
+  float4 ra[NV], rb[NV];
   auto load_chunk = [&](int k0) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int f = lane + 64 * s, row = f >> 4, kq = (f & 15) * 4;  // 32 rows x 16 float4 (64 k)
+    for (int s = 0; s < NV; ++s) {
+      const int f = lane + 64 * s, row = f / (kSK / 4), kq = (f % (kSK / 4)) * 4;  // 32 rows x kSK/4 float4
       const int gm = m0 + row, gk = k0 + kq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gm < g.M) {
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
           }
         }
       } else {
-        const int kk = f >> 3, nq = (f & 7) * 4;  // 64 k-rows x 8 float4 along n
+        const int kk = f >> 3, nq = (f & 7) * 4;  // kSK k-rows x 8 float4 along n
         const int gk2 = k0 + kk, gn = n0 + nq;
         if (gk2 < g.K) {
           const float* p = B + (int64_t)gk2 * g.ldb + gn;
@@ -268,8 +269,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int f = lane + 64 * s, row = f >> 4, kq = (f & 15) * 4;
+    for (int s = 0; s < NV; ++s) {
+      const int f = lane + 64 * s, row = f / (kSK / 4), kq = (f % (kSK / 4)) * 4;
       float* d = As + row * kSStride + kq;
       d[0] = ra[s].x; d[1] = ra[s].y; d[2] = ra[s].z; d[3] = ra[s].w;
       if (!g.b_is_kn) {
@@ -351,12 +352,13 @@ extern "C" int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t l
   };
   const bool vec = aligned(A, lda, strideA) && aligned(B, ldb, strideB);
   // tall operands with enough 128x128 tiles to fill the chip -> tiled kernel; everything else -> split-K skinny kernel
-  const int64_t big_blocks = ((N + 127) / 128) * ((M + 127) / 128) * batch;
-  const bool big = N >= 96 && M >= 1024 && big_blocks >= 40 && K <= 1024;
-  if (big) {
-    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)batch);
-    if (vec) gemm_kernel<128, 128, 2, 2, true><<<grid, dim3(256), 0, stream>>>(g);
-    else gemm_kernel<128, 128, 2, 2, false><<<grid, dim3(256), 0, stream>>>(g);
+  // tall operands (many rows, moderate K) -> 64x128 LDS-tiled kernel (>= 2x the blocks of a 128x128 tiling: these
+  // launches have only 2-8 K tiles to pipeline, so occupancy hides the latency); everything else -> split-K skinny kernel
+  const bool tall = N >= 96 && M >= 1024 && K <= 1024;
+  if (tall) {
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 63) / 64), (unsigned)batch);
+    if (vec) gemm_kernel<64, 128, 1, 2, true><<<grid, dim3(256), 0, stream>>>(g);
+    else gemm_kernel<64, 128, 1, 2, false><<<grid, dim3(256), 0, stream>>>(g);
   } else {
     dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32), (unsigned)batch);
     GEOTR_CHECK_ARG(grid.y <= 65535, "gemm: M too large for the skinny kernel");
