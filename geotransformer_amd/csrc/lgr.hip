@@ -17,7 +17,15 @@ namespace geotr {
 // ---------------------------------------------------------------------------------------------
 __device__ void kabsch_rotation(const double Hm[9], double R[9]) {
   double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  for (int i = 0; i < 9; ++i) A[i] = Hm[i];
+  double hmax = 0.0;
+  for (int i = 0; i < 9; ++i) {
+    A[i] = Hm[i];
+    hmax = fmax(hmax, fabs(Hm[i]));
+  }
+  if (!(hmax > 0.0)) {  // H == 0 (no weight at all): LAPACK's SVD gives U = V = I, i.e. the reference returns R = I
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return;
+  }
   for (int sweep = 0; sweep < 40; ++sweep) {
     double off = 0.0;
     for (int p = 0; p < 2; ++p)

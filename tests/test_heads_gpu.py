@@ -107,6 +107,7 @@ def test_weighted_procrustes_matches_oracle():
     src[5, :, 2] = 0.0  # planar source (rank-2 covariance)
     ref[5] = src[5] @ A[5].t() + 0.3
     w[6, 3:] = 0.0      # three effective points
+    w[4] = 0.0          # no weight at all: H = 0, the reference's SVD gives U = V = I -> identity rotation, zero translation
     want = mo.weighted_procrustes(src, ref, w)
     got = weighted_procrustes(src.cuda(), ref.cuda(), w.cuda(), return_transform=True).cpu()
     assert torch.allclose(got, want, atol=2e-4), float((got - want).abs().max())
