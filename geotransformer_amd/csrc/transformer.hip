@@ -206,7 +206,8 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_kernel(const float* _
 // LDS rows are 32 bf16 padded to 40 (80 B): the 16-lane groups of ds_read_b128 then hit 16 distinct 16-B slots.
 // ---------------------------------------------------------------------------------------------------
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-constexpr int kGseRS = 40;  // LDS row stride in bf16 elements
+constexpr int kGseBK2 = 32;  // K-chunk of the split-bf16 kernel (16 was measured slower: 286 vs 259 us per launch)
+constexpr int kGseRS = kGseBK2 + 8;  // LDS row stride in bf16 elements (80 B: conflict-free 16-lane groups, 16-B aligned)
 
 __device__ __forceinline__ unsigned f32_to_bf16_rne(float x) {
   unsigned u = __float_as_uint(x);
@@ -277,29 +278,31 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
   const int fr = lane & 31, fk = lane >> 5;
   unsigned* A_hi32 = reinterpret_cast<unsigned*>(A_hi);
   unsigned* A_lo32 = reinterpret_cast<unsigned*>(A_lo);
-  for (int k0 = 0; k0 < D; k0 += kGseBK) {
+  for (int k0 = 0; k0 < D; k0 += kGseBK2) {
     __syncthreads();
     // sinusoid tile, split into hi / lo bf16: word t of a row holds (sin, cos) = elements (2t, 2t+1)
-    for (int e = tid; e < S * kGsePairs * (kGseBK / 2); e += T) {
-      const int t = e % (kGseBK / 2);
-      const int row = e / (kGseBK / 2);
+    for (int e = tid; e < S * kGsePairs * (kGseBK2 / 2); e += T) {
+      const int t = e % (kGseBK2 / 2);
+      const int row = e / (kGseBK2 / 2);
       const float omega = idx_s[row] * div_term[(k0 >> 1) + t];
-      float sv, cv;
-      sincosf(omega, &sv, &cv);
+      // hardware sin/cos (v_sin_f32 / v_cos_f32 take revolutions, |x| <= 256): ~1e-6 absolute error, well inside what the
+      // split-bf16 products resolve; the fp32-MFMA kernel above keeps the libm sincosf
+      const float rev = omega * 0.15915494309189535f;
+      const float sv = __builtin_amdgcn_sinf(rev), cv = __builtin_amdgcn_cosf(rev);
       const unsigned sh = f32_to_bf16_rne(sv), ch = f32_to_bf16_rne(cv);
       const unsigned sl = f32_to_bf16_rne(sv - bf16_to_f32(sh)), cl = f32_to_bf16_rne(cv - bf16_to_f32(ch));
       A_hi32[(row * kGseRS) / 2 + t] = sh | (ch << 16);
       A_lo32[(row * kGseRS) / 2 + t] = sl | (cl << 16);
     }
-    // weight rows: 4 planes x D rows x 32 bf16 (= four 16-B vectors per row)
-    for (int e = tid; e < 4 * D * 4; e += T) {
-      const int vec = e & 3, row = e >> 2;  // row = plane * D + col
+    // weight rows: 4 planes x D rows x kGseBK2 bf16 (= kGseBK2/8 16-B vectors per row)
+    for (int e = tid; e < 4 * D * (kGseBK2 / 8); e += T) {
+      const int vec = e % (kGseBK2 / 8), row = e / (kGseBK2 / 8);  // row = plane * D + col
       const uint4 v = *reinterpret_cast<const uint4*>(wsplit + (int64_t)row * D + k0 + vec * 8);
       *reinterpret_cast<uint4*>(W_s + row * kGseRS + vec * 8) = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < kGseBK / 16; ++ks) {
+    for (int ks = 0; ks < kGseBK2 / 16; ++ks) {
       const int kb = ks * 16 + 8 * fk;
       bf16x8 b[4];
 #pragma unroll
