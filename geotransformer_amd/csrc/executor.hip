@@ -404,4 +404,69 @@ int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const 
   return run(c, *net, *pyr, features, *out);
 }
 
+size_t geotr_pyramid_workspace_bytes(int64_t n0, int64_t batch, int64_t num_stages) {
+  return align_up(geotr_grid_subsample_workspace_bytes(n0, batch)) +
+         (size_t)num_stages * align_up(geotr_radius_grid_workspace_bytes(n0, batch)) + 4096;
+}
+
+int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t batch, int64_t n0, int64_t num_stages, float voxel_size,
+                        float radius, const int64_t* limits_host, const geotr_pyramid_buffers* buf, int64_t* lengths_host,
+                        int32_t* overflow, void* ws, size_t ws_bytes, void* stream_) {
+  GEOTR_CHECK_ARG(points && lengths && limits_host && buf && lengths_host && ws, "pyramid_build: null pointer");
+  GEOTR_CHECK_ARG(num_stages >= 1 && num_stages <= GEOTR_MAX_STAGES && batch >= 1 && n0 >= 1, "pyramid_build: bad sizes");
+  if (ws_bytes < geotr_pyramid_workspace_bytes(n0, batch, num_stages)) return fail(GEOTR_E_WORKSPACE, "pyramid_build: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int S = (int)num_stages;
+  char* base = reinterpret_cast<char*>(ws);
+  const size_t gs_bytes = align_up(geotr_grid_subsample_workspace_bytes(n0, batch));
+  const size_t grid_bytes = align_up(geotr_radius_grid_workspace_bytes(n0, batch));
+  void* gs_ws = base;
+  const float* pts[GEOTR_MAX_STAGES];
+  const int64_t* len[GEOTR_MAX_STAGES];
+  int64_t n[GEOTR_MAX_STAGES];
+  pts[0] = points;
+  len[0] = lengths;
+  n[0] = n0;
+  if (hipMemcpyAsync(lengths_host, lengths, sizeof(int64_t) * batch, hipMemcpyDeviceToHost, stream) != hipSuccess)
+    return fail(GEOTR_E_LAUNCH, "pyramid_build: memcpy failed");
+  float v = voxel_size;
+  for (int i = 1; i < S; ++i) {  // data.py:23-28: stage i is the grid subsample of stage i-1 at voxel * 2^i
+    v *= 2.0f;
+    int rc = geotr_grid_subsample(pts[i - 1], len[i - 1], batch, n[i - 1], v, buf->points[i], buf->lengths[i], gs_ws, gs_bytes, stream);
+    if (rc != GEOTR_OK) return rc;
+    if (hipMemcpyAsync(lengths_host + (size_t)i * batch, buf->lengths[i], sizeof(int64_t) * batch, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+      return fail(GEOTR_E_LAUNCH, "pyramid_build: reading the stage sizes failed");
+    int64_t tot = 0;
+    for (int64_t b = 0; b < batch; ++b) tot += lengths_host[(size_t)i * batch + b];
+    GEOTR_CHECK_ARG(tot >= 1, "pyramid_build: stage %d is empty", i);
+    pts[i] = buf->points[i];
+    len[i] = buf->lengths[i];
+    n[i] = tot;
+  }
+  // one uniform grid per stage serves the three searches against that stage (data.py:31-69)
+  float r = radius;
+  void* grids[GEOTR_MAX_STAGES];
+  for (int i = 0; i < S; ++i) {
+    grids[i] = base + gs_bytes + (size_t)i * grid_bytes;
+    int rc = geotr_radius_grid_build(pts[i], len[i], batch, n[i], r, grids[i], grid_bytes, stream);
+    if (rc != GEOTR_OK) return rc;
+    r *= 2.0f;
+  }
+  r = radius;
+  for (int i = 0; i < S; ++i) {
+    int rc = geotr_radius_query(grids[i], n[i], pts[i], len[i], batch, n[i], r, limits_host[i], 0, buf->neighbors[i], overflow, stream);
+    if (rc != GEOTR_OK) return rc;
+    if (i < S - 1) {
+      rc = geotr_radius_query(grids[i], n[i], pts[i + 1], len[i + 1], batch, n[i + 1], r, limits_host[i], 0, buf->subsampling[i], overflow, stream);
+      if (rc != GEOTR_OK) return rc;
+      rc = geotr_radius_query(grids[i + 1], n[i + 1], pts[i], len[i], batch, n[i], 2.0f * r, limits_host[i + 1], 0, buf->upsampling[i], overflow,
+                              stream);
+      if (rc != GEOTR_OK) return rc;
+    }
+    r *= 2.0f;
+  }
+  return GEOTR_OK;
+}
+
 }  // extern "C"

@@ -51,6 +51,11 @@ class Pyramid(ctypes.Structure):
                 ('ref_n', I64 * MAX_STAGES)]
 
 
+class PyramidBuffers(ctypes.Structure):
+    _fields_ = [('points', P_F32 * MAX_STAGES), ('lengths', P_F32 * MAX_STAGES), ('neighbors', P_F32 * MAX_STAGES),
+                ('subsampling', P_F32 * MAX_STAGES), ('upsampling', P_F32 * MAX_STAGES)]
+
+
 class AttnLayer(ctypes.Structure):
     _fields_ = [('is_self', I32), ('pad_', I32), ('q', Linear), ('k', Linear), ('v', Linear), ('p', Linear), ('out', Linear),
                 ('expand', Linear), ('squeeze', Linear), ('norm', Norm), ('out_norm', Norm),
@@ -332,3 +337,44 @@ class GseProfiler:
     def results(self):
         """[(seconds, n_superpoints)] for every recorded launch; call after torch.cuda.synchronize()."""
         return [(self.start[i].elapsed_time(self.stop[i]) * 1e-3, int(self._sizes[i])) for i in range(self.used)]
+
+
+@torch.no_grad()
+def build_pyramid(points, lengths, num_stages, voxel_size, radius, neighbor_limits):
+    """precompute_data_stack_mode in one native call (fixed-width neighbour tables).  Device tensors in; returns the
+    reference's dict (lists of device tensors) plus 'lengths_host' (python ints)."""
+    lib = _lib.load()
+    assert points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()
+    dev = points.device
+    n0, B, S = points.shape[0], lengths.shape[0], int(num_stages)
+    limits = (ctypes.c_int64 * S)(*[int(x) for x in neighbor_limits])
+    pts = [points] + [torch.empty((n0, 3), dtype=torch.float32, device=dev) for _ in range(S - 1)]
+    lens = [lengths] + [torch.empty(B, dtype=torch.int64, device=dev) for _ in range(S - 1)]
+    nb = [torch.empty((n0, neighbor_limits[i]), dtype=torch.int64, device=dev) for i in range(S)]
+    sub = [torch.empty((n0, neighbor_limits[i]), dtype=torch.int64, device=dev) for i in range(S - 1)]
+    up = [torch.empty((n0, neighbor_limits[i + 1]), dtype=torch.int64, device=dev) for i in range(S - 1)]
+    buf = PyramidBuffers()
+    for i in range(S):
+        buf.points[i], buf.lengths[i], buf.neighbors[i] = pts[i].data_ptr(), lens[i].data_ptr(), nb[i].data_ptr()
+        if i < S - 1:
+            buf.subsampling[i], buf.upsampling[i] = sub[i].data_ptr(), up[i].data_ptr()
+    host = (ctypes.c_int64 * (S * B))()
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    nbytes = lib.geotr_pyramid_workspace_bytes(n0, B, S)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rc = lib.geotr_pyramid_build(points.data_ptr(), lengths.data_ptr(), B, n0, S, float(voxel_size), float(radius), limits,
+                                 ctypes.byref(buf), host, overflow.data_ptr(), ws.data_ptr(), nbytes,
+                                 torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, 'geotr_pyramid_build')
+    ws.record_stream(torch.cuda.current_stream())
+    lengths_host = [[int(host[i * B + b]) for b in range(B)] for i in range(S)]
+    n = [sum(l) for l in lengths_host]
+    return {
+        'points': [pts[i][: n[i]] for i in range(S)],
+        'lengths': lens,
+        'neighbors': [nb[i][: n[i]] for i in range(S)],
+        'subsampling': [sub[i][: n[i + 1]] for i in range(S - 1)],
+        'upsampling': [up[i][: n[i]] for i in range(S - 1)],
+        'lengths_host': lengths_host,
+        '_overflow': overflow,
+    }

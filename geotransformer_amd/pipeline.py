@@ -31,8 +31,12 @@ class RegistrationPipeline:
             feats = torch.ones((points.shape[0], 1), dtype=torch.float32, device=points.device)
         else:
             feats = torch.cat([ref_feats, src_feats], dim=0)
-        data = precompute_data_stack_mode(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius,
-                                          self.neighbor_limits, exact_width=self.exact_width)
+        if self.exact_width:
+            data = precompute_data_stack_mode(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius,
+                                              self.neighbor_limits, exact_width=True)
+        else:  # whole pyramid in one native call (fixed-width tables; overflow is checked together with the outputs)
+            from .native import build_pyramid
+            data = build_pyramid(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.neighbor_limits)
         data['features'] = feats
         data['batch_size'] = 1
         return data
@@ -40,7 +44,20 @@ class RegistrationPipeline:
     @torch.no_grad()
     def __call__(self, ref_points, src_points, ref_feats=None, src_feats=None):
         """ref/src points: (N,3) fp32 device tensors.  Returns the model's output dict (incl. 'estimated_transform')."""
-        return self.model(self.collate(ref_points, src_points, ref_feats, src_feats))
+        data = self.collate(ref_points, src_points, ref_feats, src_feats)
+        out = self.model(data)
+        overflow = data.get('_overflow')
+        if overflow is not None:
+            out['_neighbor_overflow'] = overflow  # device int32: > 0 means a ball held more than 256 points (see check_overflow)
+        return out
+
+    @staticmethod
+    def check_overflow(out):
+        """Raise if the fixed-capacity radius search overflowed for this pair (one host read; call when convenient)."""
+        flag = out.get('_neighbor_overflow')
+        if flag is not None and int(flag.item()) > 0:
+            raise RuntimeError(f'radius search row capacity exceeded ({int(flag.item())} neighbours in one ball); '
+                               f'rebuild the pipeline with exact_width=True for such dense clouds')
 
 
 class ConcurrentRegistration:

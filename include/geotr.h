@@ -286,6 +286,26 @@ int64_t geotr_profile_gse_count(void);
 int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const float* features /* (n[0], in_dim) */,
                         const geotr_outputs* out, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Native pyramid: precompute_data_stack_mode (geotransformer/utils/data.py:13-77) as one host call: (S-1) grid
+ * subsamples, one radius grid per stage, 3S-2 radius searches with fixed widths `limits[i]` (pad = support count).
+ * Stage buffers have capacity n0 rows (a stage never has more points than the input); the true row counts are returned
+ * in lengths_host (num_stages x batch).  The call synchronises `stream` once per subsampled stage to read those counts.
+ * *overflow (device int32, zeroed by the caller) receives the largest neighbour count if a ball exceeds the row capacity
+ * (256): the tables are then incomplete and the caller must fall back to geotr_radius_count + geotr_radius_query.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct geotr_pyramid_buffers {
+  float* points[GEOTR_MAX_STAGES];          /* stage 0 may alias the input */
+  int64_t* lengths[GEOTR_MAX_STAGES];       /* (batch) device */
+  int64_t* neighbors[GEOTR_MAX_STAGES];     /* (n0, limits[i]) */
+  int64_t* subsampling[GEOTR_MAX_STAGES];   /* (n0, limits[i]),   i < S-1: queries stage i+1, supports stage i */
+  int64_t* upsampling[GEOTR_MAX_STAGES];    /* (n0, limits[i+1]), i < S-1: queries stage i,   supports stage i+1 */
+} geotr_pyramid_buffers;
+size_t geotr_pyramid_workspace_bytes(int64_t n0, int64_t batch, int64_t num_stages);
+int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t batch, int64_t n0, int64_t num_stages, float voxel_size,
+                        float radius, const int64_t* limits_host, const geotr_pyramid_buffers* buf, int64_t* lengths_host,
+                        int32_t* overflow, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,3 +110,27 @@ def test_full_size_3dmatch_pair_properties(oracle_lib):
         assert (np.diff(d) >= 0).all() and (d < r2).all()
         same_cloud = (v < lens[0]) == (i < lens[0])
         assert same_cloud.all()  # never crosses clouds
+
+
+def test_native_pyramid_matches_oracle(oracle_lib):
+    """geotr_pyramid_build (one native call, fixed-width tables) == oracle pyramid, full 20k+20k size."""
+    from geotransformer_amd.native import build_pyramid
+    from geotransformer_amd.synthetic import CONFIGS, make_pair
+    from oracle import neighbors as on
+    cfg = CONFIGS['3dmatch']
+    item = make_pair(1, '3dmatch')
+    pts = np.concatenate([item['ref_points'], item['src_points']])
+    lens = np.array([len(item['ref_points']), len(item['src_points'])], dtype=np.int64)
+    out = build_pyramid(_dev(pts), _dev(lens), cfg['num_stages'], cfg['voxel'], cfg['radius'], cfg['limits'])
+    assert int(out['_overflow'].item()) == 0
+    want = on.precompute_pyramid(oracle_lib, pts, lens, cfg['num_stages'], cfg['voxel'], cfg['radius'], cfg['limits'])
+    for k in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling'):
+        for i, w in enumerate(want[k]):
+            got = out[k][i].cpu().numpy()
+            if k in ('points', 'lengths'):
+                assert got.shape == w.shape and got.tobytes() == w.tobytes(), (k, i)
+            else:  # fixed width = limit: the oracle trims to min(limit, max_count); extra columns must be pad
+                assert got.shape[0] == w.shape[0] and np.array_equal(got[:, : w.shape[1]], w), (k, i)
+                pad = want['points'][i + 1 if k == 'upsampling' else i].shape[0]
+                assert (got[:, w.shape[1]:] == pad).all()
+    assert out['lengths_host'] == [l.tolist() for l in want['lengths']]
