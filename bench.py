@@ -30,7 +30,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the 5 PF marketing figure is 2:1 sparse)
 
 
 def pmc_traffic_bytes(kernel_substr):
@@ -165,7 +166,12 @@ def main():
         D, k = cfg.geotransformer.hidden_dim, cfg.geotransformer.angle_k
         durs = [sec for sec, _ in events]
         flops = [2.0 * n * n * (1 + k) * D * D for _, n in events]
-        achieved = (sum(flops) / sum(durs)) / 1e12 if durs else None
+        algorithmic = (sum(flops) / sum(durs)) / 1e12 if durs else None
+        from geotransformer_amd import kernels as _k
+        split = _k.GSE_PRECISION == 1
+        # split-bf16 path: every product is 3 bf16 MFMA products (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi) -> executed flops = 3x
+        executed = (3.0 * algorithmic if split else algorithmic) if algorithmic else None
+        peak = BF16_MATRIX_PEAK_TFLOPS if split else FP32_MATRIX_PEAK_TFLOPS
         line = {
             'metric': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)', 'value': round(value, 3), 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
@@ -178,10 +184,17 @@ def main():
                        'pairs_per_step_per_gpu': args.batch, 'pairs_in_flight_per_gpu': args.lanes,
                        'parallelism': f'pairs sharded over {world} GPU(s), no data-path collective',
                        'weights': 'random init, seed 7351'},
-            'roofline': {'bound': 'mfma', 'kernel': 'gse_embed_kernel<256,4> (fused GSE: sinusoid -> fp32 MFMA -> max_k)',
-                         'achieved': round(achieved, 2) if achieved else None, 'peak': FP32_MATRIX_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4) if achieved else None,
-                         'traffic': pmc_traffic_bytes('gse_embed_kernel'), 'traffic_unit': 'HBM bytes/launch (rocprofv3 PMC '
+            'roofline': {'bound': 'mfma',
+                         'kernel': ('gse_embed_bf16x3_kernel<256,4> (fused GSE: sinusoid -> split-bf16 MFMA -> max_k)' if split else
+                                    'gse_embed_kernel<256,4> (fused GSE: sinusoid -> fp32 MFMA -> max_k)'),
+                         'achieved': round(executed, 2) if executed else None, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(executed / peak, 4) if executed else None,
+                         'algorithmic_tflops': round(algorithmic, 2) if algorithmic else None,
+                         'note': ('algorithmic work = 2*n^2*(1+k)*D^2 flop per launch (fp32-equivalent); achieved counts the 3 bf16 MFMA '
+                                  'products executed per algorithmic product; durations are HIP events on the launch stream with '
+                                  f'{args.lanes} pair(s) in flight, so co-running kernels of the other lane are included') if split else
+                                 'algorithmic = executed (fp32 MFMA)',
+                         'traffic': pmc_traffic_bytes('gse_embed'), 'traffic_unit': 'HBM bytes/launch (rocprofv3 PMC '
                          'FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/r01_pmc_hbm_traffic.md)', 'launches': len(durs),
                          'avg_launch_us': round(1e6 * sum(durs) / len(durs), 1) if durs else None},
         }
