@@ -116,3 +116,42 @@ def registration_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, searc
         collated['lengths'] = lengths
     collated['batch_size'] = batch_size
     return collated
+
+
+def calibrate_neighbors_stack_mode(dataset, collate_fn, num_stages, voxel_size, search_radius, keep_ratio=0.8,
+                                   sample_threshold=2000):
+    """Neighbour-limit calibration (mirror of geotransformer/utils/data.py:192-217) on the GPU.
+
+    Same result as the reference: per stage, the histogram of self-search neighbour counts (clipped to the theoretical
+    bound hist_n = ceil(4/3 pi (r/v + 1)^3)) is accumulated over dataset items until every stage has more than
+    `sample_threshold` samples, and the limit is the number of histogram bins below `keep_ratio` of the mass.
+    The reference materialises (N, hist_n) neighbour tables to count them; here `geotr_radius_count` counts directly.
+    `collate_fn` is accepted for signature compatibility; items may be registration dicts (ref_points / src_points) or
+    single-cloud dicts (points).
+    """
+    del collate_fn
+    _lib.require_gpu()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    hist_n = int(np.ceil(4 / 3 * np.pi * (search_radius / voxel_size + 1) ** 3))
+    neighbor_hists = np.zeros((num_stages, hist_n), dtype=np.int64)
+    for i in range(len(dataset)):
+        item = dataset[i]
+        clouds = [item['ref_points'], item['src_points']] if 'ref_points' in item else [item['points']]
+        clouds = [torch.from_numpy(c) if isinstance(c, np.ndarray) else c for c in clouds]
+        points = torch.cat([c.float() for c in clouds], dim=0).to(dev).contiguous()
+        lengths = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64, device=dev)
+        v, r = voxel_size, search_radius
+        for s in range(num_stages):
+            if s > 0:
+                buf, lengths = ext.grid_subsample_device(points, lengths, v)
+                points = buf[: int(lengths.sum().item())]
+            v *= 2
+            counts, _ = ext.RadiusGrid(points, lengths, r).count(points, lengths)
+            r *= 2
+            c = torch.clamp(counts.long(), max=hist_n)  # a (N, hist_n) table holds at most hist_n valid entries per row
+            neighbor_hists[s] += torch.bincount(c, minlength=hist_n + 1)[:hist_n].cpu().numpy()
+        if np.min(np.sum(neighbor_hists, axis=1)) > sample_threshold:
+            break
+    cum_sum = np.cumsum(neighbor_hists.T, axis=0)
+    neighbor_limits = np.sum(cum_sum < (keep_ratio * cum_sum[hist_n - 1, :]), axis=0)
+    return neighbor_limits

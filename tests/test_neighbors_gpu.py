@@ -134,3 +134,28 @@ def test_native_pyramid_matches_oracle(oracle_lib):
                 pad = want['points'][i + 1 if k == 'upsampling' else i].shape[0]
                 assert (got[:, w.shape[1]:] == pad).all()
     assert out['lengths_host'] == [l.tolist() for l in want['lengths']]
+
+
+def test_calibrate_neighbors_matches_reference_recipe(oracle_lib):
+    """calibrate_neighbors_stack_mode (utils/data.py:192-217 of the reference) vs the same recipe on the CPU oracle."""
+    from geotransformer_amd.synthetic import CONFIGS, make_pair
+    from geotransformer_amd.utils.data import calibrate_neighbors_stack_mode
+    cfg = CONFIGS['3dmatch']
+    dataset = [make_pair(s, '3dmatch', n_points=4000) for s in (30, 31, 32)]
+    got = calibrate_neighbors_stack_mode(dataset, None, cfg['num_stages'], cfg['voxel'], cfg['radius'], sample_threshold=2000)
+    # reference recipe on the oracle library
+    S, v0, r0 = cfg['num_stages'], cfg['voxel'], cfg['radius']
+    hist_n = int(np.ceil(4 / 3 * np.pi * (r0 / v0 + 1) ** 3))
+    hists = np.zeros((S, hist_n), dtype=np.int64)
+    for item in dataset:
+        pts = np.concatenate([item['ref_points'], item['src_points']])
+        lens = np.array([len(item['ref_points']), len(item['src_points'])], dtype=np.int64)
+        pyr = __import__('oracle.neighbors', fromlist=['x']).precompute_pyramid(oracle_lib, pts, lens, S, v0, r0, [hist_n] * S)
+        counts = [np.sum(nb < nb.shape[0], axis=1) for nb in pyr['neighbors']]
+        hists += np.vstack([np.bincount(c, minlength=hist_n)[:hist_n] for c in counts])
+        if np.min(hists.sum(1)) > 2000:
+            break
+    cum = np.cumsum(hists.T, axis=0)
+    want = np.sum(cum < (0.8 * cum[hist_n - 1, :]), axis=0)
+    assert np.array_equal(got, want), (got, want)
+    assert all(20 <= x <= 60 for x in got)  # the 3DMatch demo limits are [38, 36, 36, 38]
