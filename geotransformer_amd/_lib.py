@@ -50,6 +50,9 @@ SIGNATURES = {
                                      c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'geotr_patch_gather': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr,
                                    c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'geotr_node_correspondences_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
+    'geotr_node_correspondences': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64,
+                                           c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_l2_normalize': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_weighted_procrustes': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_lgr_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),

@@ -406,6 +406,138 @@ __global__ __launch_bounds__(128) void patch_gather_kernel(const int64_t* __rest
 
 using namespace geotr;
 
+// ------------------------------------------------------------------------------------------------
+// Ground-truth superpoint correspondences: get_node_correspondences (geotransformer/modules/registration/matching.py:226-318)
+// ------------------------------------------------------------------------------------------------
+// One wave per superpoint (ref nodes first): transform the src side (apply_transform, ops/transformation.py:36-41),
+// enclosing-sphere radius = max masked |p - node| (matching.py:270-275), number of valid patch points.
+__global__ __launch_bounds__(64) void nc_prepare_kernel(const float* __restrict__ ref_nodes, const float* __restrict__ src_nodes,
+                                                        const float* __restrict__ ref_knn, const float* __restrict__ src_knn,
+                                                        const float* __restrict__ T, const unsigned char* __restrict__ ref_knn_masks,
+                                                        const unsigned char* __restrict__ src_knn_masks, int m, int n, int k,
+                                                        float* __restrict__ src_nodes_t, float* __restrict__ src_knn_t,
+                                                        float* __restrict__ rmax, int* __restrict__ valid) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const bool is_src = b >= m;
+  const int node = is_src ? b - m : b;
+  const float* c = is_src ? src_nodes + 3 * (size_t)node : ref_nodes + 3 * (size_t)node;
+  const float* pts = is_src ? src_knn + 3 * (size_t)node * k : ref_knn + 3 * (size_t)node * k;
+  const unsigned char* msk = is_src ? src_knn_masks + (size_t)node * k : ref_knn_masks + (size_t)node * k;
+  float cx = c[0], cy = c[1], cz = c[2];
+  if (is_src) {
+    float tx = fmaf(cz, T[2], fmaf(cy, T[1], cx * T[0])) + T[3];
+    float ty = fmaf(cz, T[6], fmaf(cy, T[5], cx * T[4])) + T[7];
+    float tz = fmaf(cz, T[10], fmaf(cy, T[9], cx * T[8])) + T[11];
+    cx = tx, cy = ty, cz = tz;
+    if (lane == 0) src_nodes_t[3 * node] = cx, src_nodes_t[3 * node + 1] = cy, src_nodes_t[3 * node + 2] = cz;
+  }
+  float best = 0.f;
+  int cnt = 0;
+  for (int e = lane; e < k; e += 64) {
+    float x = pts[3 * e], y = pts[3 * e + 1], z = pts[3 * e + 2];
+    if (is_src) {
+      float tx = fmaf(z, T[2], fmaf(y, T[1], x * T[0])) + T[3];
+      float ty = fmaf(z, T[6], fmaf(y, T[5], x * T[4])) + T[7];
+      float tz = fmaf(z, T[10], fmaf(y, T[9], x * T[8])) + T[11];
+      x = tx, y = ty, z = tz;
+      float* o = src_knn_t + 3 * ((size_t)node * k + e);
+      o[0] = x, o[1] = y, o[2] = z;
+    }
+    if (msk[e]) {
+      const float dx = x - cx, dy = y - cy, dz = z - cz;
+      best = fmaxf(best, sqrtf(dx * dx + dy * dy + dz * dz));
+      ++cnt;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    best = fmaxf(best, __shfl_xor(best, o, 64));
+    cnt += __shfl_xor(cnt, o, 64);
+  }
+  if (lane == 0) rmax[b] = best, valid[b] = cnt;
+}
+
+// One block per ref superpoint i; loops over the src superpoints, sphere test first (matching.py:277-281), then the (K, K)
+// point test of the surviving pairs (matching.py:293-310).  overlap[i][j] = 0 for pairs that are not correspondences.
+__global__ __launch_bounds__(256) void nc_overlap_kernel(const float* __restrict__ ref_nodes, const float* __restrict__ src_nodes_t,
+                                                         const float* __restrict__ ref_knn, const float* __restrict__ src_knn_t,
+                                                         const unsigned char* __restrict__ ref_masks, const unsigned char* __restrict__ src_masks,
+                                                         const unsigned char* __restrict__ ref_knn_masks,
+                                                         const unsigned char* __restrict__ src_knn_masks, const float* __restrict__ rmax,
+                                                         const int* __restrict__ valid, int m, int n, int k, float pos_radius,
+                                                         float pos_radius_sq, float* __restrict__ overlap) {
+  extern __shared__ float nc_smem[];
+  float* rp = nc_smem;           // k x 4: x, y, z, |p|^2 (|p|^2 < 0 marks a masked point)
+  float* sp = rp + 4 * k;        // k x 4
+  int* rflag = (int*)(sp + 4 * k);
+  int* sflag = rflag + k;
+  const int i = blockIdx.x, t = threadIdx.x;
+  for (int e = t; e < k; e += 256) {
+    const float* p = ref_knn + 3 * ((size_t)i * k + e);
+    const float x = p[0], y = p[1], z = p[2];
+    rp[4 * e] = x, rp[4 * e + 1] = y, rp[4 * e + 2] = z;
+    rp[4 * e + 3] = ref_knn_masks[(size_t)i * k + e] ? (x * x + y * y) + z * z : -1.f;
+  }
+  const float ax = ref_nodes[3 * i], ay = ref_nodes[3 * i + 1], az = ref_nodes[3 * i + 2];
+  const float a2 = (ax * ax + ay * ay) + az * az;
+  const float ar = rmax[i];
+  const bool amask = ref_masks == nullptr || ref_masks[i];
+  const float rv = (float)valid[i];
+  for (int j = 0; j < n; ++j) {
+    const float bx = src_nodes_t[3 * j], by = src_nodes_t[3 * j + 1], bz = src_nodes_t[3 * j + 2];
+    const float b2 = (bx * bx + by * by) + bz * bz;
+    const float xy = fmaf(az, bz, fmaf(ay, by, ax * bx));
+    const float d = sqrtf(fmaxf((a2 - 2.f * xy) + b2, 0.f));
+    const bool hit = amask && (src_masks == nullptr || src_masks[j]) && (((ar + rmax[m + j]) + pos_radius) - d) > 0.f;
+    if (!hit) {
+      if (t == 0) overlap[(size_t)i * n + j] = 0.f;
+      continue;
+    }
+    __syncthreads();
+    for (int e = t; e < k; e += 256) {
+      const float* p = src_knn_t + 3 * ((size_t)j * k + e);
+      const float x = p[0], y = p[1], z = p[2];
+      sp[4 * e] = x, sp[4 * e + 1] = y, sp[4 * e + 2] = z;
+      sp[4 * e + 3] = src_knn_masks[(size_t)j * k + e] ? (x * x + y * y) + z * z : -1.f;
+      rflag[e] = 0, sflag[e] = 0;
+    }
+    __syncthreads();
+    for (int e = t; e < k * k; e += 256) {
+      const int a = e / k, b = e - a * k;
+      const float x2 = rp[4 * a + 3], y2 = sp[4 * b + 3];
+      if (x2 < 0.f || y2 < 0.f) continue;
+      const float dot = fmaf(rp[4 * a + 2], sp[4 * b + 2], fmaf(rp[4 * a + 1], sp[4 * b + 1], rp[4 * a] * sp[4 * b]));
+      if (fmaxf((x2 - 2.f * dot) + y2, 0.f) < pos_radius_sq) rflag[a] = 1, sflag[b] = 1;
+    }
+    __syncthreads();
+    int rc = 0, sc = 0;
+    for (int e = t; e < k; e += 256) rc += rflag[e], sc += sflag[e];
+    rc = __syncthreads_count(rc);  // k <= 256: one flag per thread
+    sc = __syncthreads_count(sc);
+    if (t == 0) overlap[(size_t)i * n + j] = (__fdiv_rn((float)rc, rv) + __fdiv_rn((float)sc, (float)valid[m + j])) / 2.f;
+  }
+}
+
+// Row-major compaction of overlap > 0 (the order torch.nonzero gives, matching.py:283 / 313-316).
+__global__ __launch_bounds__(1024) void nc_compact_kernel(const float* __restrict__ overlap, int m, int n, int64_t* __restrict__ corr_indices,
+                                                          float* __restrict__ corr_overlaps, int32_t* __restrict__ num_corr) {
+  __shared__ int sm[1024 / 64 + 1];
+  const int total = m * n, chunk = (total + 1023) / 1024;
+  const int lo = min(total, (int)threadIdx.x * chunk), hi = min(total, lo + chunk);
+  int cnt = 0;
+  for (int e = lo; e < hi; ++e) cnt += overlap[e] > 0.f;
+  int sum;
+  int pos = block_exclusive_scan<1024>(cnt, sm, sum);
+  for (int e = lo; e < hi; ++e) {
+    const float v = overlap[e];
+    if (v > 0.f) {
+      corr_indices[2 * (size_t)pos] = e / n, corr_indices[2 * (size_t)pos + 1] = e % n;
+      corr_overlaps[pos++] = v;
+    }
+  }
+  if (threadIdx.x == 0) *num_corr = sum;
+}
+
 extern "C" {
 
 int geotr_patch_gather(const int64_t* ref_node_knn_indices, const uint8_t* ref_node_knn_masks, const float* ref_points, int64_t nr,
@@ -487,6 +619,36 @@ int geotr_patch_sinkhorn(const float* ref_feats, int64_t nr, const float* src_fe
   else LAUNCH(128);
 #undef LAUNCH
   GEOTR_CHECK_LAUNCH("patch_sinkhorn");
+  return GEOTR_OK;
+}
+
+size_t geotr_node_correspondences_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  return align_up(12 * n) + align_up(12 * n * k) + 2 * align_up(4 * (m + n)) + align_up(4 * m * n);
+}
+
+int geotr_node_correspondences(const float* ref_nodes, const float* src_nodes, const float* ref_knn_points, const float* src_knn_points,
+                               const float* transform, float pos_radius, const uint8_t* ref_masks, const uint8_t* src_masks,
+                               const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int64_t m, int64_t n, int64_t k,
+                               int64_t* corr_indices, float* corr_overlaps, int32_t* num_corr, void* ws, size_t ws_bytes, void* stream) {
+  GEOTR_CHECK_ARG(m > 0 && n > 0 && k > 0, "geotr_node_correspondences: empty input");
+  GEOTR_CHECK_ARG(k <= 256, "geotr_node_correspondences: at most 256 points per patch");
+  GEOTR_CHECK_ARG(m * n <= ((int64_t)1 << 30), "geotr_node_correspondences: too many superpoint pairs");
+  GEOTR_CHECK_ARG(ws_bytes >= geotr_node_correspondences_workspace_bytes(m, n, k), "geotr_node_correspondences: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  Carver cv(ws);
+  float* src_nodes_t = cv.take<float>(3 * n);
+  float* src_knn_t = cv.take<float>(3 * n * k);
+  float* rmax = cv.take<float>(m + n);
+  int* valid = cv.take<int>(m + n);
+  float* overlap = cv.take<float>(m * n);
+  nc_prepare_kernel<<<(unsigned)(m + n), 64, 0, st>>>(ref_nodes, src_nodes, ref_knn_points, src_knn_points, transform, ref_knn_masks,
+                                                      src_knn_masks, (int)m, (int)n, (int)k, src_nodes_t, src_knn_t, rmax, valid);
+  const size_t lds = (size_t)k * (8 * sizeof(float) + 2 * sizeof(int));
+  const float r2 = (float)((double)pos_radius * (double)pos_radius);
+  nc_overlap_kernel<<<(unsigned)m, 256, lds, st>>>(ref_nodes, src_nodes_t, ref_knn_points, src_knn_t, ref_masks, src_masks, ref_knn_masks,
+                                                   src_knn_masks, rmax, valid, (int)m, (int)n, (int)k, pos_radius, r2, overlap);
+  nc_compact_kernel<<<1, 1024, 0, st>>>(overlap, (int)m, (int)n, corr_indices, corr_overlaps, num_corr);
+  GEOTR_CHECK_LAUNCH("geotr_node_correspondences");
   return GEOTR_OK;
 }
 

@@ -295,3 +295,35 @@ def l2_normalize(x):
     out = torch.empty_like(x)
     _lib.check(lib.geotr_l2_normalize(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(out), _lib.stream_ptr()), 'geotr_l2_normalize')
     return out
+
+
+def node_correspondences(ref_nodes, src_nodes, ref_knn_points, src_knn_points, transform, pos_radius, ref_masks=None,
+                         src_masks=None, ref_knn_masks=None, src_knn_masks=None):
+    """Ground-truth superpoint correspondences (geotr_node_correspondences).  Returns the full-capacity buffers
+    (indices (M*N, 2) int64, overlaps (M*N,) fp32) and the device count (1,) int32; rows past the count are unspecified."""
+    lib = _lib.load()
+    ref_nodes, src_nodes = _f32c(ref_nodes), _f32c(src_nodes)
+    ref_knn_points, src_knn_points = _f32c(ref_knn_points), _f32c(src_knn_points)
+    dev = ref_nodes.device
+    transform = _f32c(transform.to(dev))
+    m, n, k = ref_nodes.shape[0], src_nodes.shape[0], ref_knn_points.shape[1]
+    assert ref_knn_points.shape == (m, k, 3) and src_knn_points.shape == (n, k, 3) and transform.shape == (4, 4)
+
+    def mask(t, shape):
+        if t is None:
+            return torch.ones(shape, dtype=torch.bool, device=dev)
+        assert t.dtype == torch.bool and tuple(t.shape) == tuple(shape)
+        return t.contiguous()
+
+    ref_knn_masks, src_knn_masks = mask(ref_knn_masks, (m, k)), mask(src_knn_masks, (n, k))
+    ref_masks = None if ref_masks is None else mask(ref_masks, (m,))
+    src_masks = None if src_masks is None else mask(src_masks, (n,))
+    idx = torch.empty((m * n, 2), dtype=torch.int64, device=dev)
+    ov = torch.empty(m * n, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(lib.geotr_node_correspondences_workspace_bytes(m, n, k), dev)
+    _lib.check(lib.geotr_node_correspondences(
+        _lib.ptr(ref_nodes), _lib.ptr(src_nodes), _lib.ptr(ref_knn_points), _lib.ptr(src_knn_points), _lib.ptr(transform),
+        float(pos_radius), _lib.ptr(ref_masks), _lib.ptr(src_masks), _lib.ptr(ref_knn_masks), _lib.ptr(src_knn_masks), m, n, k,
+        _lib.ptr(idx), _lib.ptr(ov), _lib.ptr(count), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'geotr_node_correspondences')
+    return idx, ov, count

@@ -4,8 +4,8 @@
 `make_cfg()`), builds sub-modules in the reference's order (same state_dict keys; identical random init under the same
 seeds) and `forward(data_dict)` consumes the reference's collated dict and returns the reference's output dict keys.
 
-Not built here (out of the hot-path scope): the ground-truth node correspondences
-(`gt_node_corr_*`, needs the gt transform and only feeds loss / evaluation) and the training-time target sampling.
+`gt_node_corr_indices / gt_node_corr_overlaps` are produced when the batch carries `transform` (SURVEY.md section 8f "next").
+Not built here (out of the hot-path scope): the training-time target sampling and the losses.
 """
 import torch
 import torch.nn as nn
@@ -47,6 +47,21 @@ class GeoTransformer(nn.Module):
         self.use_native = True
         self._native = None
 
+    def _ground_truth_node_correspondences(self, data_dict, out, ref_part=None, src_part=None):
+        """gt_node_corr_indices / gt_node_corr_overlaps (model.py:105-124): evaluation / loss inputs, produced whenever the
+        batch carries the ground-truth transform.  The native executor keeps its partition internal, so it is redone here."""
+        from .modules.registration import get_node_correspondences
+        K = self.num_points_in_patch
+        ref_c, src_c, ref_f, src_f = out['ref_points_c'], out['src_points_c'], out['ref_points_f'], out['src_points_f']
+        if ref_part is None:
+            ref_part = point_to_node_partition(ref_f, ref_c, K)[1:]
+            src_part = point_to_node_partition(src_f, src_c, K)[1:]
+        ref_knn_points = torch.cat([ref_f, torch.zeros_like(ref_f[:1])], dim=0)[ref_part[1]]
+        src_knn_points = torch.cat([src_f, torch.zeros_like(src_f[:1])], dim=0)[src_part[1]]
+        out['gt_node_corr_indices'], out['gt_node_corr_overlaps'] = get_node_correspondences(
+            ref_c, src_c, ref_knn_points, src_knn_points, data_dict['transform'], self.matching_radius, ref_masks=ref_part[0],
+            src_masks=src_part[0], ref_knn_masks=ref_part[2], src_knn_masks=src_part[2])
+
     @torch.no_grad()
     def forward(self, data_dict):
         if self.training:
@@ -55,7 +70,10 @@ class GeoTransformer(nn.Module):
             from .native import NativeModel
             if self._native is None:
                 self._native = NativeModel(self)
-            return NativeModel.finalize(self._native.forward(data_dict))
+            out = NativeModel.finalize(self._native.forward(data_dict))
+            if 'transform' in data_dict:
+                self._ground_truth_node_correspondences(data_dict, out)
+            return out
         out = {}
         fine = self.backbone.fine_stage
         feats = data_dict['features']
@@ -75,6 +93,10 @@ class GeoTransformer(nn.Module):
         K = self.num_points_in_patch
         _, ref_node_masks, ref_node_knn_indices, ref_node_knn_masks = point_to_node_partition(ref_points_f, ref_points_c, K)
         _, src_node_masks, src_node_knn_indices, src_node_knn_masks = point_to_node_partition(src_points_f, src_points_c, K)
+
+        if 'transform' in data_dict:
+            self._ground_truth_node_correspondences(data_dict, out, (ref_node_masks, ref_node_knn_indices, ref_node_knn_masks),
+                                                    (src_node_masks, src_node_knn_indices, src_node_knn_masks))
 
         # 2. KPConv-FPN (model.py:127-130)
         feats_list = self.backbone(feats, data_dict)

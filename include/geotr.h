@@ -183,6 +183,18 @@ int geotr_patch_gather(const int64_t* ref_node_knn_indices, const uint8_t* ref_n
                        const int32_t* p_count, int64_t* ref_knn_indices, uint8_t* ref_knn_masks, float* ref_knn_points,
                        int64_t* src_knn_indices, uint8_t* src_knn_masks, float* src_knn_points, void* stream);
 
+/* Ground-truth superpoint correspondences: get_node_correspondences (geotransformer/modules/registration/matching.py:226-318).
+ * transform (4,4 row-major, device) is applied to the src side; a superpoint pair survives the enclosing-sphere test
+ * (r_ref + r_src + pos_radius - |c_ref - c_src| > 0, both node masks set) and then needs at least one point pair closer than
+ * pos_radius.  overlap = (|ref points with a partner| / |valid ref points| + same for src) / 2.  Output in row-major (ref, src)
+ * order like torch.nonzero: corr_indices (capacity m*n, 2) int64, corr_overlaps (capacity m*n), *num_corr int32 (device).
+ * ref_masks / src_masks may be NULL (all superpoints valid). k <= 256. */
+size_t geotr_node_correspondences_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int geotr_node_correspondences(const float* ref_nodes, const float* src_nodes, const float* ref_knn_points, const float* src_knn_points,
+                               const float* transform, float pos_radius, const uint8_t* ref_masks, const uint8_t* src_masks,
+                               const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int64_t m, int64_t n, int64_t k,
+                               int64_t* corr_indices, float* corr_overlaps, int32_t* num_corr, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * L1/L2  local-to-global registration, entirely on the device (the reference does its SVDs on the host)
  *   geotr_weighted_procrustes: transforms[b] (4x4 row-major) aligning src[b] (n,3) to ref[b] (n,3) with weights[b] (n) or

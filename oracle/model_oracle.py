@@ -425,6 +425,7 @@ def config_from_reference(cfg):
                             sigma_a=cfg.geotransformer.sigma_a, angle_k=cfg.geotransformer.angle_k,
                             reduction_a=cfg.geotransformer.reduction_a),
         'num_points_in_patch': cfg.model.num_points_in_patch,
+        'matching_radius': cfg.model.ground_truth_matching_radius,
         'num_sinkhorn_iterations': cfg.model.num_sinkhorn_iterations,
         'num_correspondences': cfg.coarse_matching.num_correspondences,
         'dual_normalization': cfg.coarse_matching.dual_normalization,
@@ -436,6 +437,40 @@ def config_from_reference(cfg):
 
 
 @torch.no_grad()
+
+def get_node_correspondences(ref_nodes, src_nodes, ref_knn_points, src_knn_points, transform, pos_radius,
+                             ref_masks=None, src_masks=None, ref_knn_masks=None, src_knn_masks=None):
+    """registration/matching.py:226-318: ground-truth superpoint correspondences and their overlap ratios."""
+    src_nodes = apply_transform(src_nodes, transform)
+    src_knn_points = apply_transform(src_knn_points, transform)
+    if ref_masks is None:
+        ref_masks = torch.ones(ref_nodes.shape[0], dtype=torch.bool)
+    if src_masks is None:
+        src_masks = torch.ones(src_nodes.shape[0], dtype=torch.bool)
+    if ref_knn_masks is None:
+        ref_knn_masks = torch.ones(ref_knn_points.shape[:2], dtype=torch.bool)
+    if src_knn_masks is None:
+        src_knn_masks = torch.ones(src_knn_points.shape[:2], dtype=torch.bool)
+    node_mask = ref_masks[:, None] & src_masks[None, :]
+    # enclosing spheres (matching.py:268-281)
+    ref_r = torch.linalg.norm(ref_knn_points - ref_nodes[:, None], dim=-1).masked_fill(~ref_knn_masks, 0.).max(1)[0]
+    src_r = torch.linalg.norm(src_knn_points - src_nodes[:, None], dim=-1).masked_fill(~src_knn_masks, 0.).max(1)[0]
+    dist = torch.sqrt(pairwise_distance(ref_nodes, src_nodes))
+    hit = ((ref_r[:, None] + src_r[None, :] + pos_radius - dist) > 0) & node_mask
+    sel_ref, sel_src = torch.nonzero(hit, as_tuple=True)
+    # point-level test on the surviving pairs (matching.py:285-310)
+    rk_masks, sk_masks = ref_knn_masks[sel_ref], src_knn_masks[sel_src]
+    rk, sk = ref_knn_points[sel_ref], src_knn_points[sel_src]
+    pair_mask = rk_masks[:, :, None] & sk_masks[:, None, :]
+    d = pairwise_distance(rk, sk).masked_fill(~pair_mask, 1e12)
+    ov = d < pos_radius ** 2
+    ref_cnt = torch.count_nonzero(ov.sum(-1), dim=-1).float()
+    src_cnt = torch.count_nonzero(ov.sum(-2), dim=-1).float()
+    overlaps = (ref_cnt / rk_masks.sum(-1).float() + src_cnt / sk_masks.sum(-1).float()) / 2
+    keep = overlaps > 0
+    return torch.stack([sel_ref[keep], sel_src[keep]], dim=1), overlaps[keep]
+
+
 def forward(sd, cfg, data):
     """GeoTransformer.forward, eval mode.  `data` = collated dict of CPU tensors; returns the output dict
     (plus a few intermediates used by the stage-wise parity tests)."""
@@ -450,6 +485,10 @@ def forward(sd, cfg, data):
     _, src_node_masks, src_knn_idx, src_knn_masks = point_to_node_partition(src_f, src_c, K)
     ref_knn_points = index_select(torch.cat([ref_f, torch.zeros_like(ref_f[:1])], 0), ref_knn_idx, 0)
     src_knn_points = index_select(torch.cat([src_f, torch.zeros_like(src_f[:1])], 0), src_knn_idx, 0)
+    if 'transform' in data:  # model.py:110-124
+        out['gt_node_corr_indices'], out['gt_node_corr_overlaps'] = get_node_correspondences(
+            ref_c, src_c, ref_knn_points, src_knn_points, data['transform'], cfg['matching_radius'], ref_node_masks,
+            src_node_masks, ref_knn_masks, src_knn_masks)
 
     feats_list = backbone(sd, cfg['backbone'], data['features'], data)
     feats_c, feats_f = feats_list[-1], feats_list[0]

@@ -158,3 +158,49 @@ def test_model_end_to_end_matches_reference_golden(name):
     assert got['corr_scores'].shape == out['corr_scores'].shape
     T, Tw = got['estimated_transform'].cpu(), out['estimated_transform']
     assert _rot_err_deg(T, Tw) < 0.05 and float((T[:3, 3] - Tw[:3, 3]).norm()) < 1e-3
+    # ground-truth superpoint correspondences: same pairs in the same (row-major) order, same overlap ratios
+    for res in (got, by_modules):
+        assert torch.equal(res['gt_node_corr_indices'].cpu(), out['gt_node_corr_indices'])
+        assert torch.allclose(res['gt_node_corr_overlaps'].cpu(), out['gt_node_corr_overlaps'], atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize('m,n,k,r', [(37, 53, 32, 0.15), (150, 120, 64, 0.08), (5, 300, 128, 0.3)])
+def test_node_correspondences_matches_oracle(m, n, k, r):
+    """geotr_node_correspondences vs the restatement of registration/matching.py:226-318 on random patches with masks."""
+    from geotransformer_amd.modules.registration import get_node_correspondences
+    from oracle import model_oracle as mo
+    g = torch.Generator().manual_seed(m * 1000 + n)
+    ref_nodes = torch.rand(m, 3, generator=g) * 2
+    src_nodes = torch.rand(n, 3, generator=g) * 2
+    ref_knn = ref_nodes[:, None] + (torch.rand(m, k, 3, generator=g) - 0.5) * 0.4
+    src_knn = src_nodes[:, None] + (torch.rand(n, k, 3, generator=g) - 0.5) * 0.4
+    ref_knn_masks = torch.rand(m, k, generator=g) < 0.8
+    src_knn_masks = torch.rand(n, k, generator=g) < 0.8
+    ref_knn_masks[:, 0] = True
+    src_knn_masks[:, 0] = True
+    ref_masks = torch.rand(m, generator=g) < 0.9
+    src_masks = torch.rand(n, generator=g) < 0.9
+    ang = 0.3
+    T = torch.eye(4)
+    T[:3, :3] = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.]])
+    T[:3, 3] = torch.tensor([0.1, -0.2, 0.05])
+    want_idx, want_ov = mo.get_node_correspondences(ref_nodes, src_nodes, ref_knn, src_knn, T, r, ref_masks, src_masks,
+                                                    ref_knn_masks, src_knn_masks)
+    got_idx, got_ov = get_node_correspondences(ref_nodes.cuda(), src_nodes.cuda(), ref_knn.cuda(), src_knn.cuda(), T.cuda(), r,
+                                               ref_masks.cuda(), src_masks.cuda(), ref_knn_masks.cuda(), src_knn_masks.cuda())
+    got_idx, got_ov = got_idx.cpu(), got_ov.cpu()
+    assert want_idx.shape[0] > 0
+    # a point pair within one rounding of pos_radius^2 may fall on the other side (the reference evaluates the distances
+    # with a BLAS matmul); allow a handful of such pairs, everything else must agree exactly and in order
+    wk = {(int(a), int(b)): float(o) for (a, b), o in zip(want_idx.tolist(), want_ov.tolist())}
+    gk = {(int(a), int(b)): float(o) for (a, b), o in zip(got_idx.tolist(), got_ov.tolist())}
+    both = set(wk) & set(gk)
+    assert len(set(wk) ^ set(gk)) <= max(1, len(wk) // 200), (len(wk), len(gk))
+    bad = [p for p in both if abs(wk[p] - gk[p]) > 1e-6]
+    assert len(bad) <= max(1, len(both) // 100), len(bad)
+    keys = got_idx[:, 0] * n + got_idx[:, 1]
+    assert bool((keys[1:] > keys[:-1]).all()), 'row-major order'
+    # defaults (all masks None) are accepted
+    a, b = get_node_correspondences(ref_nodes.cuda(), src_nodes.cuda(), ref_knn.cuda(), src_knn.cuda(), T.cuda(), r)
+    wa, wb = mo.get_node_correspondences(ref_nodes, src_nodes, ref_knn, src_knn, T, r)
+    assert abs(a.shape[0] - wa.shape[0]) <= max(1, wa.shape[0] // 200)

@@ -32,6 +32,9 @@ def test_forward_matches_reference_golden(name):
     assert torch.allclose(got['ref_corr_points'], out['ref_corr_points'])
     assert torch.allclose(got['corr_scores'], out['corr_scores'], atol=1e-4)
     assert torch.allclose(got['estimated_transform'], out['estimated_transform'], atol=1e-4)
+    # ground-truth superpoint correspondences (registration/matching.py:226-318)
+    assert torch.equal(got['gt_node_corr_indices'], out['gt_node_corr_indices'])
+    assert torch.equal(got['gt_node_corr_overlaps'], out['gt_node_corr_overlaps'])
 
 
 def test_state_dict_layout_is_the_references():
