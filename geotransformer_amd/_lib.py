@@ -53,6 +53,8 @@ SIGNATURES = {
     'geotr_node_correspondences_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
     'geotr_node_correspondences': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64,
                                            c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    'geotr_registration_metrics': (c_int, [c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_ptr,
+                                           c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     'geotr_l2_normalize': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_weighted_procrustes': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_lgr_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),

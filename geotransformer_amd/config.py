@@ -44,6 +44,8 @@ _EXPERIMENTS = {
         fine_matching=dict(topk=3, acceptance_radius=0.1, mutual=True, confidence_threshold=0.05, use_dustbin=False,
                            use_global_score=False, correspondence_threshold=3, correspondence_limit=None,
                            num_refinement_steps=5),
+        eval=dict(acceptance_overlap=0.0, acceptance_radius=0.1, inlier_ratio_threshold=0.05, rmse_threshold=0.2,
+                  rre_threshold=15.0, rte_threshold=0.3),
         neighbor_limits=[38, 36, 36, 38],  # experiments/...3dmatch.../demo.py:52
     ),
     'kitti': dict(
@@ -57,6 +59,7 @@ _EXPERIMENTS = {
         fine_matching=dict(topk=2, acceptance_radius=0.6, mutual=True, confidence_threshold=0.05, use_dustbin=False,
                            use_global_score=False, correspondence_threshold=3, correspondence_limit=None,
                            num_refinement_steps=5),
+        eval=dict(acceptance_overlap=0.0, acceptance_radius=1.0, inlier_ratio_threshold=0.05, rre_threshold=5.0, rte_threshold=2.0),
         neighbor_limits=[40, 40, 40, 40, 40],
     ),
     'modelnet': dict(
@@ -70,6 +73,7 @@ _EXPERIMENTS = {
         fine_matching=dict(topk=3, acceptance_radius=0.1, mutual=True, confidence_threshold=0.05, use_dustbin=False,
                            use_global_score=False, correspondence_threshold=3, correspondence_limit=None,
                            num_refinement_steps=5),
+        eval=dict(acceptance_overlap=0.0, acceptance_radius=0.1, inlier_ratio_threshold=0.05, rre_threshold=1.0, rte_threshold=0.1),
         neighbor_limits=[24, 24, 24],
     ),
 }

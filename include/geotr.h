@@ -195,6 +195,19 @@ int geotr_node_correspondences(const float* ref_nodes, const float* src_nodes, c
                                const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int64_t m, int64_t n, int64_t k,
                                int64_t* corr_indices, float* corr_overlaps, int32_t* num_corr, void* ws, size_t ws_bytes, void* stream);
 
+/* Registration metrics (Evaluator.forward, experiments/<exp>/loss.py:95-159; metrics.py:50-111): one launch, results stay on
+ * the device.  out[5] = { PIR, IR, RRE [deg], RTE, RMSE }.
+ *   PIR  = mean over the num_node_corr predicted superpoint pairs of [pair is a gt pair with overlap > acceptance_overlap]
+ *   IR   = mean over the num_corr point correspondences of [|ref - T_gt src| < acceptance_radius]
+ *   RRE  = acos((trace(R_est^T R_gt) - 1) / 2) * 180 / pi,  RTE = |t_gt - t_est|
+ *   RMSE = mean |T_gt^-1 T_est p - p| over src_points (rmse_mode 0, 3DMatch) or mean |T_est p - T_gt p| (rmse_mode 1, ModelNet)
+ * Empty sets give NaN like torch's mean of an empty tensor.  The recall thresholds are applied by the caller. */
+int geotr_registration_metrics(const int64_t* gt_node_corr_indices, const float* gt_node_corr_overlaps, int64_t num_gt,
+                               float acceptance_overlap, const int64_t* ref_node_corr_indices, const int64_t* src_node_corr_indices,
+                               int64_t num_node_corr, const float* ref_corr_points, const float* src_corr_points, int64_t num_corr,
+                               float acceptance_radius, const float* gt_transform, const float* est_transform, const float* src_points,
+                               int64_t n_src, int rmse_mode, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * L1/L2  local-to-global registration, entirely on the device (the reference does its SVDs on the host)
  *   geotr_weighted_procrustes: transforms[b] (4x4 row-major) aligning src[b] (n,3) to ref[b] (n,3) with weights[b] (n) or

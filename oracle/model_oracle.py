@@ -525,3 +525,39 @@ def forward(sd, cfg, data):
     out['ref_node_knn_indices'], out['src_node_knn_indices'] = ref_knn_idx, src_knn_idx
     out['ref_node_masks'], out['src_node_masks'] = ref_node_masks, src_node_masks
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Evaluator (experiments/*/loss.py `class Evaluator`; modules/registration/metrics.py:50-111)
+# ------------------------------------------------------------------------------------------------
+def isotropic_transform_error(gt_transform, transform):
+    """metrics.py:50-111 for a single (4,4) pair."""
+    mat = transform[:3, :3].t() @ gt_transform[:3, :3]
+    x = (0.5 * (mat[0, 0] + mat[1, 1] + mat[2, 2] - 1.0)).clamp(min=-1.0, max=1.0)
+    rre = 180.0 * torch.arccos(x) / np.pi
+    rte = torch.linalg.norm(gt_transform[:3, 3] - transform[:3, 3], dim=-1)
+    return rre, rte
+
+
+def evaluate(out, data, ev, variant):
+    """Evaluator.forward of the 3dmatch (loss.py:95-159), kitti and modelnet experiments; `ev` = cfg.eval as a dict."""
+    n_ref_c, n_src_c = out['ref_points_c'].shape[0], out['src_points_c'].shape[0]
+    keep = out['gt_node_corr_overlaps'] > ev['acceptance_overlap']
+    gt = out['gt_node_corr_indices'][keep]
+    gt_map = torch.zeros(n_ref_c, n_src_c)
+    gt_map[gt[:, 0], gt[:, 1]] = 1.0
+    res = {'PIR': gt_map[out['ref_node_corr_indices'], out['src_node_corr_indices']].mean()}
+    T, Te = data['transform'], out['estimated_transform']
+    d = torch.linalg.norm(out['ref_corr_points'] - apply_transform(out['src_corr_points'], T), dim=1)
+    res['IR'] = (d < ev['acceptance_radius']).float().mean()
+    res['RRE'], res['RTE'] = isotropic_transform_error(T, Te)
+    src = out['src_points']
+    if variant == '3dmatch':
+        realigned = apply_transform(src, torch.matmul(torch.inverse(T), Te))
+        res['RMSE'] = torch.linalg.norm(realigned - src, dim=1).mean()
+        res['RR'] = (res['RMSE'] < ev['rmse_threshold']).float()
+    else:
+        if variant == 'modelnet':
+            res['RMSE'] = torch.linalg.norm(apply_transform(src, Te) - apply_transform(src, T), dim=1).mean()
+        res['RR'] = torch.logical_and(res['RRE'] < ev['rre_threshold'], res['RTE'] < ev['rte_threshold']).float()
+    return res

@@ -152,3 +152,17 @@ def collate(item, cfg, neighbor_limits):
     data = registration_collate_fn_stack_mode([item], cfg.backbone.num_stages, cfg.backbone.init_voxel_size,
                                               cfg.backbone.init_radius, neighbor_limits)
     return to_cuda(data)  # with the .cuda shim this only makes the sliced neighbour tensors contiguous
+
+
+def load_evaluator(name):
+    """The experiment's own `Evaluator` class (experiments/<exp>/loss.py) and its config, CPU-runnable."""
+    setup()
+    import importlib.util
+    exp_dir = os.path.join(REF_ROOT, 'experiments', EXPERIMENTS[name])
+    out = {}
+    for short in ('config', 'loss'):
+        spec = importlib.util.spec_from_file_location(f'_ref_{name}_{short}', os.path.join(exp_dir, short + '.py'))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        out[short] = m
+    return out['config'].make_cfg(), out['loss'].Evaluator
