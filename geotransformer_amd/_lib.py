@@ -44,8 +44,8 @@ SIGNATURES = {
                                 c_size, c_ptr, c_ptr]),
     'geotr_attn_softmax': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr]),
     'geotr_point_to_node': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
-    'geotr_superpoint_match': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
-                                       c_ptr, c_ptr]),
+    'geotr_superpoint_match_workspace_bytes': (c_size, [c_i64, c_i64]),
+    'geotr_superpoint_match': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_size, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'geotr_patch_sinkhorn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr,
                                      c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'geotr_patch_gather': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr,

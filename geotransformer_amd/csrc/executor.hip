@@ -312,16 +312,12 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
 
   // 4. coarse matching (model.py:153-160)
   float* sim = c.alloc<float>((size_t)nr_c * ns_c);
-  float* rowsum = c.alloc<float>((size_t)nr_c);
-  float* colsum = c.alloc<float>((size_t)ns_c);
+  const size_t spm_bytes = geotr_superpoint_match_workspace_bytes(nr_c, ns_c);
+  char* spm_ws = c.alloc<char>(spm_bytes);
   if (c.live()) {
-    if (hipMemsetAsync(o.ref_node_corr_indices, 0, sizeof(int64_t) * P, c.stream) != hipSuccess ||
-        hipMemsetAsync(o.src_node_corr_indices, 0, sizeof(int64_t) * P, c.stream) != hipSuccess ||
-        hipMemsetAsync(o.node_corr_scores, 0, sizeof(float) * P, c.stream) != hipSuccess)
-      c.check(fail(GEOTR_E_LAUNCH, "model_forward: memset failed"));
     c.check(geotr_gemm(o.feats_c, D, o.feats_c + nr_c * D, D, 0, sim, ns_c, nr_c, ns_c, D, 1, 0, 0, 0, nullptr, nullptr, nullptr, 0, 1.0f, 0,
                        c.stream));
-    c.check(geotr_superpoint_match(sim, nr_c, ns_c, node_masks, node_masks + nr_c, net.dual_normalization, P, rowsum, colsum,
+    c.check(geotr_superpoint_match(sim, nr_c, ns_c, node_masks, node_masks + nr_c, net.dual_normalization, P, spm_ws, spm_bytes,
                                    o.ref_node_corr_indices, o.src_node_corr_indices, o.node_corr_scores, o.num_node_corr, c.stream));
     // 5. patches of the selected pairs (model.py:169-179); rows >= *num_node_corr are neutral (pad index, mask False)
     c.check(geotr_patch_gather(node_knn_idx, node_knn_mask, pts_f, nr_f, o.ref_node_corr_indices, node_knn_idx + nr_c * K,

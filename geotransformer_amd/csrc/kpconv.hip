@@ -29,20 +29,19 @@ __global__ __launch_bounds__(256) void row_positive_kernel(const float* __restri
   if (lane == 0) flag[row] = s > 0.f;
 }
 
-// C_in == 1 (first layer): one thread per query point.
+// C_in == 1 (first layer): 16 lanes per query point, lane k < 15 accumulates kernel point k over the neighbours in order
+// (same per-element arithmetic and order as a serial loop), lane 15 counts the neighbours with a positive feature.
 __global__ __launch_bounds__(256) void kpconv_gather_c1_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
                                                                const float* __restrict__ sp, const int64_t* __restrict__ nb,
                                                                const float* __restrict__ kp, int64_t M, int64_t Ns, int H,
                                                                float sigma, float* __restrict__ out, int* __restrict__ nnum) {
-  __shared__ float kps[kKP * 3];
-  if (threadIdx.x < kKP * 3) kps[threadIdx.x] = kp[threadIdx.x];
-  __syncthreads();
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = threadIdx.x & 15;
+  const int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   if (m >= M) return;
+  const bool is_kp = k < kKP;
+  const float kx = is_kp ? kp[3 * k] : 0.f, ky = is_kp ? kp[3 * k + 1] : 0.f, kz = is_kp ? kp[3 * k + 2] : 0.f;
   const float qx = qp[3 * m], qy = qp[3 * m + 1], qz = qp[3 * m + 2];
-  float acc[kKP];
-#pragma unroll
-  for (int k = 0; k < kKP; ++k) acc[k] = 0.f;
+  float acc = 0.f;
   int cnt = 0;
   for (int h = 0; h < H; ++h) {
     const int64_t idx = nb[m * H + h];
@@ -50,16 +49,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_c1_kernel(const float* __re
     const float f = feats[idx];
     cnt += f > 0.f;
     const float rx = sp[3 * idx] - qx, ry = sp[3 * idx + 1] - qy, rz = sp[3 * idx + 2] - qz;
-#pragma unroll
-    for (int k = 0; k < kKP; ++k) {
-      const float dx = rx - kps[3 * k], dy = ry - kps[3 * k + 1], dz = rz - kps[3 * k + 2];
-      const float w = fmaxf(1.f - sqrtf((dx * dx + dy * dy) + dz * dz) / sigma, 0.f);
-      acc[k] = fmaf(w, f, acc[k]);
-    }
+    const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
+    const float w = fmaxf(1.f - sqrtf((dx * dx + dy * dy) + dz * dz) / sigma, 0.f);
+    acc = fmaf(w, f, acc);
   }
-#pragma unroll
-  for (int k = 0; k < kKP; ++k) out[m * kKP + k] = acc[k];
-  nnum[m] = cnt;
+  if (is_kp) out[m * kKP + k] = acc;
+  else nnum[m] = cnt;
 }
 
 // General case.  A wave processes PPW points at a time; LPP = min(C, 64) lanes per point, CPL = C / LPP channels
@@ -421,7 +416,7 @@ int geotr_kpconv_gather(const float* s_feats, const float* q_points, const float
   GEOTR_CHECK_ARG(h <= kSlotCap, "kpconv_gather: neighbour limit %lld > %d", (long long)h, kSlotCap);
   hipStream_t stream = (hipStream_t)stream_;
   if (c == 1) {
-    kpconv_gather_c1_kernel<<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream>>>(
+    kpconv_gather_c1_kernel<<<dim3((unsigned)((m + 15) / 16)), dim3(256), 0, stream>>>(
         s_feats, q_points, s_points, neighbors, kernel_points, m, ns, (int)h, sigma, weighted, nnum);
   } else {
     GEOTR_CHECK_ARG((c & (c - 1)) == 0 && c <= 512, "kpconv_gather: channels must be a power of two <= 512 (got %lld)",

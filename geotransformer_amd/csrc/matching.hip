@@ -104,95 +104,162 @@ __global__ __launch_bounds__(256) void spm_exp_kernel(float* __restrict__ s, int
   __syncthreads();
   if (threadIdx.x == 0) rowsum[i] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ __launch_bounds__(256) void spm_colsum_kernel(const float* __restrict__ s, int n, int m, float* __restrict__ colsum) {
+// column sums in two levels: kSpmParts row-chunks per column block (fixed order => deterministic), folded by the dual kernel
+constexpr int kSpmParts = 8;
+__global__ __launch_bounds__(256) void spm_colsum_kernel(const float* __restrict__ s, int n, int m, float* __restrict__ colpart) {
   __shared__ float red[4][64];
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int rows = (n + kSpmParts - 1) / kSpmParts, i0 = blockIdx.y * rows, i1 = min(n, i0 + rows);
   float acc = 0.f;
   if (j < m)
-    for (int i = part; i < n; i += 4) acc += s[(int64_t)i * m + j];
+    for (int i = i0 + part; i < i1; i += 4) acc += s[(int64_t)i * m + j];
   red[part][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (part == 0 && j < m) colsum[j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-__global__ void spm_dual_kernel(float* __restrict__ s, int n, int m, const float* __restrict__ rowsum, const float* __restrict__ colsum,
-                                const unsigned char* __restrict__ rmask, const unsigned char* __restrict__ cmask, int dual) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (int64_t)n * m) return;
-  const int i = (int)(e / m), j = (int)(e % m);
-  if (!(rmask[i] && cmask[j])) {
-    s[e] = -1.f;  // excluded from the top-k (valid scores are >= 0)
-    return;
-  }
-  if (dual) s[e] = (s[e] / rowsum[i]) * (s[e] / colsum[j]);
+  if (part == 0 && j < m)
+    colpart[(int64_t)blockIdx.y * m + j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// top-k (largest) of a non-negative score matrix by three radix-histogram passes over the float bits, one block.
-constexpr int kTopkCap = 8192;
-__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ s, int64_t total, int k, int m, int64_t* __restrict__ rows,
-                                                    int64_t* __restrict__ cols, float* __restrict__ vals, int* __restrict__ count_out) {
-  __shared__ unsigned hist[2048];
-  __shared__ unsigned long long cand[kTopkCap];
-  __shared__ unsigned sel_prefix, sel_remaining;
-  __shared__ int ncand, nvalid;
+// ---- global top-k (largest) of the non-negative score matrix: three radix-histogram passes over the float bits
+// (11 + 11 + 10), all multi-block.  No intra-kernel hand-off (an agent-scope release/acquire costs an L2 write-back on this
+// 8-XCD part): histograms are accumulated with device atomics, and every block of the NEXT kernel redundantly picks the bin
+// holding the k-th largest from the finished histogram (8 KB read + one block scan).
+constexpr int kTopkCap = 8192;    // candidate list capacity (k plus exact duplicates of the k-th value)
+constexpr int kTopkChunk = 2048;  // elements per block per sweep
+struct TopkState {                // device, zeroed by the host before the first kernel
+  unsigned hist[3][2048];
+  unsigned long long cand[kTopkCap];
+  unsigned prefix[3], remaining[3];  // after pass p (written by block 0 of the kernel that consumed hist[p])
+  int nvalid, ncand;
+};
+// block-cooperative (256 threads): walk the 2^width bins of `hist` from the top until `rem` elements are covered;
+// returns the bin that holds the rem-th largest and the rank inside it.  Result valid in every thread.
+__device__ void topk_select_bin(const unsigned* __restrict__ hist, int width, unsigned rem, unsigned* sh /* >= 2048 + 8 */,
+                                unsigned& bin, unsigned& rem_out) {
+  const int nb = 1 << width, per = nb / 256;  // 8 or 4 bins per thread
   const int tid = threadIdx.x;
-  if (tid == 0) {
-    sel_prefix = 0;
-    ncand = 0;
-    nvalid = 0;
+  for (int b = tid; b < nb; b += 256) sh[b] = hist[b];
+  __syncthreads();
+  // thread t owns bins [nb - per*(t+1), nb - per*t), i.e. descending order over t
+  unsigned mine = 0;
+  for (int q = 0; q < per; ++q) mine += sh[nb - 1 - (tid * per + q)];
+  int total;
+  const int before = block_exclusive_scan<256>((int)mine, (int*)(sh + 2048), total);  // elements in higher bins
+  if ((unsigned)before < rem && rem <= (unsigned)before + mine) {
+    unsigned r = rem - (unsigned)before;
+    int b = nb - 1 - tid * per;
+    for (;; --b) {
+      if (sh[b] >= r) break;
+      r -= sh[b];
+    }
+    sh[2048 + 6] = (unsigned)b;
+    sh[2048 + 7] = r;
   }
   __syncthreads();
-  // number of valid entries (score >= 0) bounds k (superpoint_matching.py:42)
-  int local = 0;
-  for (int64_t e = tid; e < total; e += 1024) local += s[e] >= 0.f;
-  atomicAdd(&nvalid, local);
+  bin = sh[2048 + 6];
+  rem_out = sh[2048 + 7];
   __syncthreads();
-  const int keff = min(k, nvalid);
-  if (tid == 0) {
-    *count_out = keff;
-    sel_remaining = (unsigned)keff;
+}
+
+// dual normalisation (superpoint_matching.py:36-40) fused with radix pass 0 and the count of valid entries
+__global__ __launch_bounds__(256) void spm_dual_kernel(float* __restrict__ s, int n, int m, const float* __restrict__ rowsum,
+                                                       const float* __restrict__ colpart, const unsigned char* __restrict__ rmask,
+                                                       const unsigned char* __restrict__ cmask, int dual, TopkState* __restrict__ st) {
+  __shared__ unsigned hist[2048];
+  const int tid = threadIdx.x;
+  const int64_t total = (int64_t)n * m;
+  for (int b = tid; b < 2048; b += 256) hist[b] = 0;
+  __syncthreads();
+  int valid = 0;
+  for (int64_t base = (int64_t)blockIdx.x * kTopkChunk; base < total; base += (int64_t)gridDim.x * kTopkChunk) {
+    for (int q = 0; q < kTopkChunk / 256; ++q) {
+      const int64_t e = base + q * 256 + tid;
+      if (e >= total) break;
+      const int i = (int)(e / m), j = (int)(e % m);
+      float v = -1.f;  // excluded from the top-k (valid scores are >= 0)
+      if (rmask[i] && cmask[j]) {
+        v = s[e];
+        if (dual) {
+          float cs = 0.f;
+#pragma unroll
+          for (int pt = 0; pt < kSpmParts; ++pt) cs += colpart[(int64_t)pt * m + j];
+          v = (v / rowsum[i]) * (v / cs);
+        }
+        ++valid;
+        atomicAdd(&hist[__float_as_uint(v) >> 21], 1u);
+      }
+      s[e] = v;
+    }
   }
+  for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o, 64);
+  if ((tid & 63) == 0 && valid) atomicAdd(&st->nvalid, valid);
   __syncthreads();
+  for (int b = tid; b < 2048; b += 256)
+    if (hist[b]) atomicAdd(&st->hist[0][b], hist[b]);
+}
+
+// radix passes 1 (bits 20..10) and 2 (bits 9..0) among the elements whose higher bits equal the running prefix
+__global__ __launch_bounds__(256) void topk_pass_kernel(const float* __restrict__ s, int64_t total, int k, int pass, TopkState* __restrict__ st) {
+  __shared__ unsigned hist[2048 + 8];
+  const int tid = threadIdx.x;
+  const int keff = min(k, st->nvalid);  // number of valid entries bounds k (superpoint_matching.py:42)
   if (keff == 0) return;
-  // pass p looks at bits [shift, shift+width) among the elements whose higher bits equal sel_prefix
-  const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
-  unsigned maskhi = 0;
-  for (int p = 0; p < 3; ++p) {
-    for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
-    __syncthreads();
-    const unsigned prefix = sel_prefix;
-    for (int64_t e = tid; e < total; e += 1024) {
+  // finish the previous pass: which bin of hist[pass-1] holds the k-th largest
+  unsigned bin, rem;
+  topk_select_bin(st->hist[pass - 1], 11, pass == 1 ? (unsigned)keff : st->remaining[0], hist, bin, rem);
+  const unsigned prefix = pass == 1 ? bin << 21 : (st->prefix[0] | (bin << 10));
+  if (blockIdx.x == 0 && tid == 0) st->prefix[pass - 1] = prefix, st->remaining[pass - 1] = rem;
+  const int shift = pass == 1 ? 10 : 0, width = pass == 1 ? 11 : 10;
+  const unsigned maskhi = pass == 1 ? 0x7ffu << 21 : 0x3fffffu << 10, lowmask = (1u << width) - 1u;
+  for (int b = tid; b < 2048; b += 256) hist[b] = 0;
+  __syncthreads();
+  for (int64_t base = (int64_t)blockIdx.x * kTopkChunk; base < total; base += (int64_t)gridDim.x * kTopkChunk) {
+    for (int q = 0; q < kTopkChunk / 256; ++q) {
+      const int64_t e = base + q * 256 + tid;
+      if (e >= total) break;
       const float v = s[e];
       if (v < 0.f) continue;
       const unsigned u = __float_as_uint(v);
-      if ((u & maskhi) == prefix) atomicAdd(&hist[(u >> shifts[p]) & ((1u << widths[p]) - 1u)], 1u);
-    }
-    __syncthreads();
-    if (tid == 0) {  // walk bins from the top until the k-th largest falls inside one
-      unsigned rem = sel_remaining;
-      int b = (1 << widths[p]) - 1;
-      for (; b > 0; --b) {
-        if (hist[b] >= rem) break;
-        rem -= hist[b];
-      }
-      sel_remaining = rem;
-      sel_prefix = prefix | ((unsigned)b << shifts[p]);
-    }
-    maskhi |= ((1u << widths[p]) - 1u) << shifts[p];
-    __syncthreads();
-  }
-  const unsigned thr = sel_prefix;  // bit pattern of the k-th largest value
-  for (int64_t e = tid; e < total; e += 1024) {
-    const float v = s[e];
-    if (v < 0.f) continue;
-    const unsigned u = __float_as_uint(v);
-    if (u >= thr) {
-      const int pos = atomicAdd(&ncand, 1);
-      // order: larger score first, then smaller flat index
-      if (pos < kTopkCap) cand[pos] = ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)e);
+      if ((u & maskhi) == prefix) atomicAdd(&hist[(u >> shift) & lowmask], 1u);
     }
   }
   __syncthreads();
-  const int c = min(ncand, kTopkCap);
+  for (int b = tid; b < (1 << width); b += 256)
+    if (hist[b]) atomicAdd(&st->hist[pass][b], hist[b]);
+}
+
+// collect everything >= the k-th largest bit pattern into the candidate list
+__global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restrict__ s, int64_t total, int k, TopkState* __restrict__ st) {
+  __shared__ unsigned hist[2048 + 8];
+  const int tid = threadIdx.x;
+  const int keff = min(k, st->nvalid);
+  if (keff == 0) return;
+  unsigned bin, rem;
+  topk_select_bin(st->hist[2], 10, st->remaining[1], hist, bin, rem);
+  const unsigned thr = st->prefix[1] | bin;  // bit pattern of the k-th largest value
+  for (int64_t base = (int64_t)blockIdx.x * kTopkChunk; base < total; base += (int64_t)gridDim.x * kTopkChunk) {
+    for (int q = 0; q < kTopkChunk / 256; ++q) {
+      const int64_t e = base + q * 256 + tid;
+      if (e >= total) break;
+      const float v = s[e];
+      if (v < 0.f) continue;
+      const unsigned u = __float_as_uint(v);
+      if (u >= thr) {
+        const int pos = atomicAdd(&st->ncand, 1);
+        if (pos < kTopkCap) st->cand[pos] = ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)e);
+      }
+    }
+  }
+}
+
+// rank the candidates (larger score first, then smaller flat index) and write the k outputs (zeros past the count)
+__global__ __launch_bounds__(1024) void topk_rank_kernel(const TopkState* __restrict__ st, int k, int m, int64_t* __restrict__ rows,
+                                                         int64_t* __restrict__ cols, float* __restrict__ vals, int* __restrict__ count_out) {
+  __shared__ unsigned long long cand[kTopkCap];
+  const int tid = threadIdx.x;
+  const int keff = min(k, st->nvalid);
+  const int c = keff > 0 ? min(st->ncand, kTopkCap) : 0;
+  for (int e = tid; e < c; e += 1024) cand[e] = st->cand[e];
+  __syncthreads();
   for (int e = tid; e < c; e += 1024) {
     const unsigned long long mine = cand[e];
     int rank = 0;
@@ -204,6 +271,8 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ s,
       vals[rank] = __uint_as_float((unsigned)(mine >> 32));
     }
   }
+  for (int e = keff + tid; e < k; e += 1024) rows[e] = 0, cols[e] = 0, vals[e] = 0.f;
+  if (tid == 0) *count_out = keff;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -575,19 +644,33 @@ int geotr_point_to_node(const float* points, int64_t n, const float* nodes, int6
   return GEOTR_OK;
 }
 
+size_t geotr_superpoint_match_workspace_bytes(int64_t n, int64_t m) {
+  return align_up(sizeof(TopkState)) + align_up(sizeof(float) * (size_t)n) + align_up(sizeof(float) * (size_t)m * kSpmParts);
+}
+
 int geotr_superpoint_match(float* scores, int64_t n, int64_t m, const uint8_t* ref_masks, const uint8_t* src_masks,
-                           int dual_normalization, int64_t k, float* rowsum_ws, float* colsum_ws, int64_t* ref_idx,
-                           int64_t* src_idx, float* corr_scores, int32_t* count, void* stream_) {
+                           int dual_normalization, int64_t k, void* ws, size_t ws_bytes, int64_t* ref_idx, int64_t* src_idx,
+                           float* corr_scores, int32_t* count, void* stream_) {
   GEOTR_CHECK_ARG(n >= 1 && m >= 1 && k >= 1 && k <= kTopkCap / 2, "superpoint_match: bad sizes");
   GEOTR_CHECK_ARG(n * m < (1ll << 31), "superpoint_match: score matrix too large");
-  GEOTR_CHECK_ARG(scores && ref_masks && src_masks && rowsum_ws && colsum_ws && ref_idx && src_idx && corr_scores && count,
-                  "superpoint_match: null pointer");
+  GEOTR_CHECK_ARG(scores && ref_masks && src_masks && ws && ref_idx && src_idx && corr_scores && count, "superpoint_match: null pointer");
+  GEOTR_CHECK_ARG(ws_bytes >= geotr_superpoint_match_workspace_bytes(n, m), "superpoint_match: workspace too small");
   hipStream_t stream = (hipStream_t)stream_;
-  spm_exp_kernel<<<dim3((unsigned)n), dim3(256), 0, stream>>>(scores, (int)n, (int)m, ref_masks, src_masks, rowsum_ws);
-  spm_colsum_kernel<<<dim3((unsigned)((m + 63) / 64)), dim3(256), 0, stream>>>(scores, (int)n, (int)m, colsum_ws);
-  spm_dual_kernel<<<dim3((unsigned)((n * m + 255) / 256)), dim3(256), 0, stream>>>(scores, (int)n, (int)m, rowsum_ws, colsum_ws,
-                                                                                 ref_masks, src_masks, dual_normalization);
-  topk_kernel<<<dim3(1), dim3(1024), 0, stream>>>(scores, n * m, (int)k, (int)m, ref_idx, src_idx, corr_scores, count);
+  Carver cv(ws);
+  TopkState* st = cv.take<TopkState>(1);
+  float* rowsum = cv.take<float>((size_t)n);
+  float* colpart = cv.take<float>((size_t)m * kSpmParts);
+  // hist / counters / tickets (everything before the candidate list ... simplest: the whole state) start at zero
+  if (hipMemsetAsync(st, 0, sizeof(TopkState), stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "superpoint_match: memset failed");
+  const int64_t total = n * m;
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + kTopkChunk - 1) / kTopkChunk, 256);
+  spm_exp_kernel<<<dim3((unsigned)n), dim3(256), 0, stream>>>(scores, (int)n, (int)m, ref_masks, src_masks, rowsum);
+  spm_colsum_kernel<<<dim3((unsigned)((m + 63) / 64), kSpmParts), dim3(256), 0, stream>>>(scores, (int)n, (int)m, colpart);
+  spm_dual_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, (int)n, (int)m, rowsum, colpart, ref_masks, src_masks, dual_normalization, st);
+  topk_pass_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, 1, st);
+  topk_pass_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, 2, st);
+  topk_collect_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, st);
+  topk_rank_kernel<<<dim3(1), dim3(1024), 0, stream>>>(st, (int)k, (int)m, ref_idx, src_idx, corr_scores, count);
   GEOTR_CHECK_LAUNCH("superpoint_match");
   return GEOTR_OK;
 }

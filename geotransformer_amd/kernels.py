@@ -214,14 +214,13 @@ def superpoint_match(ref_feats, src_feats, ref_masks, src_masks, num_corresponde
     n, m, k = ref_feats.shape[0], src_feats.shape[0], int(num_correspondences)
     dev = ref_feats.device
     scores = gemm(ref_feats, src_feats)  # (n, m) = <f_r, f_s>
-    rowsum = torch.empty(n, dtype=torch.float32, device=dev)
-    colsum = torch.empty(m, dtype=torch.float32, device=dev)
-    ref_idx = torch.zeros(k, dtype=torch.int64, device=dev)
-    src_idx = torch.zeros(k, dtype=torch.int64, device=dev)
-    vals = torch.zeros(k, dtype=torch.float32, device=dev)
-    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(lib.geotr_superpoint_match_workspace_bytes(n, m), dev)
+    ref_idx = torch.empty(k, dtype=torch.int64, device=dev)
+    src_idx = torch.empty(k, dtype=torch.int64, device=dev)
+    vals = torch.empty(k, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
     _lib.check(lib.geotr_superpoint_match(_lib.ptr(scores), n, m, _lib.ptr(ref_masks), _lib.ptr(src_masks),
-                                          int(bool(dual_normalization)), k, _lib.ptr(rowsum), _lib.ptr(colsum),
+                                          int(bool(dual_normalization)), k, _lib.ptr(ws), ws.numel(),
                                           _lib.ptr(ref_idx), _lib.ptr(src_idx), _lib.ptr(vals), _lib.ptr(count),
                                           _lib.stream_ptr()), 'geotr_superpoint_match')
     return ref_idx, src_idx, vals, count

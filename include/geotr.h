@@ -159,6 +159,7 @@ int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float*
  *                                                    geotransformer/modules/ops/pointcloud_partition.py:61-107
  *   geotr_superpoint_match: in: scores (n,m) = ref_feats . src_feats^T of L2-normalised features (overwritten);
  *                           exp(-(2-2xy)), dual normalisation over valid nodes, global top-k -> indices, scores, count
+ *                           (multi-block radix select; ties: larger score, then smaller flat index; entries past *count are 0)
  *                                                    geotransformer/modules/geotransformer/superpoint_matching.py:13-50
  *   geotr_patch_sinkhorn  : per patch pair: scores = F_r F_s^T / sqrt(c) (gathered rows, pad index -> zero row) or
  *                           `scores_in` (p,k,k); dustbin alpha; masks -> -1e12; num_iterations log-Sinkhorn sweeps;
@@ -168,9 +169,10 @@ int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float*
  * ---------------------------------------------------------------------------------------------- */
 int geotr_point_to_node(const float* points, int64_t n, const float* nodes, int64_t m, int64_t k, int64_t* point_to_node,
                         uint8_t* node_masks, int64_t* knn_indices, uint8_t* knn_masks, int32_t* overflow, void* stream);
+size_t geotr_superpoint_match_workspace_bytes(int64_t n, int64_t m);
 int geotr_superpoint_match(float* scores, int64_t n, int64_t m, const uint8_t* ref_masks, const uint8_t* src_masks,
-                           int dual_normalization, int64_t k, float* rowsum_ws, float* colsum_ws, int64_t* ref_idx,
-                           int64_t* src_idx, float* corr_scores, int32_t* count, void* stream);
+                           int dual_normalization, int64_t k, void* ws, size_t ws_bytes, int64_t* ref_idx, int64_t* src_idx,
+                           float* corr_scores, int32_t* count, void* stream);
 int geotr_patch_sinkhorn(const float* ref_feats, int64_t nr, const float* src_feats, int64_t ns, int64_t c,
                          const int64_t* ref_knn_indices, const int64_t* src_knn_indices, const uint8_t* ref_knn_masks,
                          const uint8_t* src_knn_masks, int64_t p, int64_t k, const float* alpha, int64_t num_iterations,
