@@ -216,28 +216,41 @@ __device__ __forceinline__ unsigned f32_to_bf16_rne(float x) {
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_float(h << 16); }
 
-// W (rows, cols) fp32 -> hi / lo bf16 planes
-__global__ void split_bf16_kernel(const float* __restrict__ w, int64_t n, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float x = w[i];
-  const unsigned h = f32_to_bf16_rne(x);
-  hi[i] = (unsigned short)h;
-  lo[i] = (unsigned short)f32_to_bf16_rne(x - bf16_to_f32(h));
+// W (D out-columns, D k) fp32 -> hi / lo bf16 planes in MFMA B-fragment order:
+//   plane[col_tile = col / 32][kk = k / 16][lane = (col % 32) + 32 * ((k % 16) / 8)][k % 8]
+// so that the B operand of one 32x32x16 step is a single coalesced 1 KB read per wave (no LDS staging of the weights).
+__global__ void split_bf16_swz_kernel(const float* __restrict__ w, int D, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-element vector per thread
+  const int KS = D / 16;
+  if (v >= (int64_t)(D / 32) * KS * 64) return;
+  const int lane = (int)(v & 63), kk = (int)((v >> 6) % KS), ct = (int)((v >> 6) / KS);
+  const float* src = w + (int64_t)(32 * ct + (lane & 31)) * D + 16 * kk + 8 * (lane >> 5);
+  unsigned h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = src[j];
+    h[j] = f32_to_bf16_rne(x);
+    l[j] = f32_to_bf16_rne(x - bf16_to_f32(h[j]));
+  }
+  *reinterpret_cast<uint4*>(hi + v * 8) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+  *reinterpret_cast<uint4*>(lo + v * 8) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+// Schedule: the sinusoid tile of chunk c+1 is generated (VALU + transcendental pipe) into the other LDS buffer while the
+// matrix pipe works on chunk c; the two waves that share a SIMD (w and w+4 when D = 256) run the two phases in opposite order,
+// so one of them feeds the matrix pipe while the other generates.  B operands come straight from L2 in fragment order, one
+// 16-deep step ahead.  One barrier per 32-deep chunk.
 template <int D, int S>
 __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const float* __restrict__ pts, const int* __restrict__ knn, int n,
                                                                          const float* __restrict__ div_term,
-                                                                         const unsigned short* __restrict__ wsplit,  // [4][D][D]: d_hi, d_lo, a_hi, a_lo
+                                                                         const unsigned short* __restrict__ wswz,  // [4][D*D]: d_hi, d_lo, a_hi, a_lo (fragment order)
                                                                          const float* __restrict__ bd, const float* __restrict__ ba,
                                                                          float inv_sigma_d, float factor_a, float* __restrict__ out) {
-  constexpr int T = 64 * (D / 32);
+  constexpr int T = 64 * (D / 32), NW = D / 32, KS = D / 16, CH = D / kGseBK2;
+  constexpr int PLANE = S * kGsePairs * kGseRS;  // bf16 elements of one A plane
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-  unsigned short* A_hi = smem16;                         // [S*64][40]
-  unsigned short* A_lo = A_hi + S * kGsePairs * kGseRS;  // [S*64][40]
-  unsigned short* W_s = A_lo + S * kGsePairs * kGseRS;   // [4*D][40]
-  float* idx_s = reinterpret_cast<float*>(W_s + 4 * D * kGseRS);  // [S][64]
+  // [buf 2][hi, lo][S*64 rows][40]
+  float* idx_s = reinterpret_cast<float*>(smem16 + 4 * PLANE);  // [S][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t total = (int64_t)n * n;
   const int64_t p0 = (int64_t)blockIdx.x * kGsePairs;
@@ -266,21 +279,14 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
 #pragma unroll
     for (int s = 0; s < S; ++s) idx_s[s * kGsePairs + e] = vals[s];
   }
+  __syncthreads();
 
-  f32x16 acc[2][S];
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[r][s][q] = 0.f;
-
-  const int fr = lane & 31, fk = lane >> 5;
-  unsigned* A_hi32 = reinterpret_cast<unsigned*>(A_hi);
-  unsigned* A_lo32 = reinterpret_cast<unsigned*>(A_lo);
-  for (int k0 = 0; k0 < D; k0 += kGseBK2) {
-    __syncthreads();
-    // sinusoid tile, split into hi / lo bf16: word t of a row holds (sin, cos) = elements (2t, 2t+1)
+  // sinusoid tile of chunk c, split into hi / lo bf16: word t of a row holds (sin, cos) = elements (2t, 2t+1)
+  auto generate = [&](int c, int buf) {
+    unsigned* A_hi32 = reinterpret_cast<unsigned*>(smem16 + (2 * buf) * PLANE);
+    unsigned* A_lo32 = reinterpret_cast<unsigned*>(smem16 + (2 * buf + 1) * PLANE);
+    const int k0 = c * kGseBK2;
+#pragma unroll 4
     for (int e = tid; e < S * kGsePairs * (kGseBK2 / 2); e += T) {
       const int t = e % (kGseBK2 / 2);
       const int row = e / (kGseBK2 / 2);
@@ -294,19 +300,37 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
       A_hi32[(row * kGseRS) / 2 + t] = sh | (ch << 16);
       A_lo32[(row * kGseRS) / 2 + t] = sl | (cl << 16);
     }
-    // weight rows: 4 planes x D rows x kGseBK2 bf16 (= kGseBK2/8 16-B vectors per row)
-    for (int e = tid; e < 4 * D * (kGseBK2 / 8); e += T) {
-      const int vec = e % (kGseBK2 / 8), row = e / (kGseBK2 / 8);  // row = plane * D + col
-      const uint4 v = *reinterpret_cast<const uint4*>(wsplit + (int64_t)row * D + k0 + vec * 8);
-      *reinterpret_cast<uint4*>(W_s + row * kGseRS + vec * 8) = v;
-    }
-    __syncthreads();
+  };
+  const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wswz);
+  auto load_b = [&](int kk, bf16x8(&b)[4]) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) b[v] = wfrag[(((int64_t)v * NW + wave) * KS + kk) * 64 + lane];
+  };
+
+  f32x16 acc[2][S];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[r][s][q] = 0.f;
+
+  const int fr = lane & 31, fk = lane >> 5;
+  const bool late_gen = NW == 8 && wave >= 4;  // see the schedule note above
+  bf16x8 bcur[4], bnext[4];
+  load_b(0, bcur);
+  generate(0, 0);
+  __syncthreads();
+  for (int c = 0; c < CH; ++c) {
+    const int buf = c & 1;
+    if (!late_gen && c + 1 < CH) generate(c + 1, buf ^ 1);
+    const unsigned short* A_hi = smem16 + (2 * buf) * PLANE;
+    const unsigned short* A_lo = A_hi + PLANE;
 #pragma unroll
     for (int ks = 0; ks < kGseBK2 / 16; ++ks) {
+      const int kk = c * (kGseBK2 / 16) + ks;
+      if (kk + 1 < KS) load_b(kk + 1, bnext);
       const int kb = ks * 16 + 8 * fk;
-      bf16x8 b[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) b[v] = *reinterpret_cast<const bf16x8*>(W_s + (v * D + 32 * wave + fr) * kGseRS + kb);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
 #pragma unroll
@@ -314,13 +338,17 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
           const int row = s * kGsePairs + 32 * r + fr;
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A_hi + row * kGseRS + kb);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(A_lo + row * kGseRS + kb);
-          const bf16x8 bh = s == 0 ? b[0] : b[2], bl = s == 0 ? b[1] : b[3];
+          const bf16x8 bh = s == 0 ? bcur[0] : bcur[2], bl = s == 0 ? bcur[1] : bcur[3];
           acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r][s], 0, 0, 0);
           acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r][s], 0, 0, 0);
           acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r][s], 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) bcur[v] = bnext[v];
     }
+    if (late_gen && c + 1 < CH) generate(c + 1, buf ^ 1);
+    __syncthreads();
   }
   const int col = 32 * wave + fr;
 #pragma unroll
@@ -440,7 +468,7 @@ static int launch_gse_bf16x3(int k, const float* pts, const int* knn, int n, con
   const int64_t total = (int64_t)n * n;
   const unsigned nb = (unsigned)((total + kGsePairs - 1) / kGsePairs);
   const int S = 1 + k;
-  const size_t lds = 2 * ((size_t)2 * S * kGsePairs * kGseRS + (size_t)4 * D * kGseRS) + sizeof(float) * (size_t)S * kGsePairs;
+  const size_t lds = 2 * ((size_t)4 * S * kGsePairs * kGseRS) + sizeof(float) * (size_t)S * kGsePairs;
   auto go = [&](auto kern) -> int {
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -500,9 +528,9 @@ int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t 
                     "gse_embed: split-bf16 path needs a 16-byte aligned workspace of 8*d*d bytes");
     unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
     const int64_t dd = d * d;
-    const unsigned nbs = (unsigned)((dd + 255) / 256);
-    split_bf16_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_d, dd, wsplit, wsplit + dd);
-    split_bf16_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_a, dd, wsplit + 2 * dd, wsplit + 3 * dd);
+    const unsigned nbs = (unsigned)((dd / 8 + 255) / 256);
+    split_bf16_swz_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_d, (int)d, wsplit, wsplit + dd);
+    split_bf16_swz_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_a, (int)d, wsplit + 2 * dd, wsplit + 3 * dd);
     int rc2;
     switch (d) {
       case 32: rc2 = launch_gse_bf16x3<32>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream); break;
