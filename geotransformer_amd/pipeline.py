@@ -4,8 +4,8 @@ This is the unit bench.py times ("a pair"): 3-4 grid subsa
 (geotransformer/utils/data.py:13-77) followed by GeoTransformer.forward (experiments/*/model.py:69-212), all on
 device-resident inputs.
 """
+import queue
 import threading
-from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
@@ -61,11 +61,13 @@ class RegistrationPipeline:
 
 
 class ConcurrentRegistration:
-    """Keeps several independent pairs in flight on one GPU: one host thread + one HIP stream per lane.
+    """Keeps several independent pairs in flight on one GPU: one persistent host thread + one HIP stream per lane.
 
-    A single pair's timeline contains many few-workgroup kernels (global top-k, hash-order replay, LGR refinement,
-    300-row GEMMs ...) that leave most of the 256 CUs idle; pairs are independent, so kernels of
-    different pairs are overlapped on separate streams instead of being serialised.  All lanes share the same weights.
+    A single pair's timeline contains many few-workgroup kernels (hash-order replay, LGR refinement, 300-row GEMMs ...)
+    that leave most of the 256 CUs idle, and the pyramid reads the stage sizes back on the host; pairs are independent
+    (SURVEY.md section 8e), so the lanes pull pairs from one queue and overlap them on separate streams.  All lanes
+    share the same weights.  `submit` never blocks on the GPU; `drain` waits until every queued pair has been enqueued
+    and makes the caller's stream wait for the lanes.
     """
 
     def __init__(self, pipeline, lanes=2):
@@ -73,30 +75,73 @@ class ConcurrentRegistration:
         self.lanes = max(1, int(lanes))
         self.device = pipeline.device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
-        self.pool = ThreadPoolExecutor(max_workers=self.lanes) if self.lanes > 1 else None
-        self._local = threading.local()
+        self._queue = queue.SimpleQueue()
+        self._pending = 0
+        self._cv = threading.Condition()
+        self._error = None
+        self._threads = []
+        if self.lanes > 1:
+            for lane in range(self.lanes):
+                t = threading.Thread(target=self._lane_main, args=(lane,), daemon=True, name=f'geotr-lane-{lane}')
+                t.start()
+                self._threads.append(t)
 
-    def _run_lane(self, lane, pairs, indices, sink):
+    def _lane_main(self, lane):
         torch.cuda.set_device(self.device)
         stream = self.streams[lane]
         with torch.cuda.stream(stream):
-            for i in indices:
-                ref, src = pairs[i]
-                out = self.pipeline(ref, src)
-                sink(i, out)
-        return stream
+            while True:
+                job = self._queue.get()
+                if job is None:
+                    return
+                index, ref, src, sink, ready = job
+                try:
+                    stream.wait_event(ready)  # inputs produced on the submitter's stream
+                    sink(index, self.pipeline(ref, src))
+                except BaseException as exc:  # surfaced by drain()
+                    with self._cv:
+                        self._error = self._error or exc
+                finally:
+                    with self._cv:
+                        self._pending -= 1
+                        if self._pending == 0:
+                            self._cv.notify_all()
 
-    def run_batch(self, pairs, sink):
-        """Register every (ref, src) of `pairs`; `sink(i, output_dict)` is called (on the lane's stream) per pair.
-        Returns after all work is ENQUEUED and the current stream has been made to wait for every lane."""
-        current = torch.cuda.current_stream(self.device)
+    def submit(self, pairs, sink):
+        """Queue every (ref, src) of `pairs`; `sink(i, output_dict)` is called on the lane's stream per pair."""
         if self.lanes == 1:
             for i, (ref, src) in enumerate(pairs):
                 sink(i, self.pipeline(ref, src))
             return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with self._cv:
+            self._pending += len(pairs)
+        for i, (ref, src) in enumerate(pairs):
+            self._queue.put((i, ref, src, sink, ready))
+
+    def drain(self):
+        """Wait until all submitted pairs are enqueued on their lanes; the current stream then waits for the lanes."""
+        if self.lanes == 1:
+            return
+        with self._cv:
+            while self._pending:
+                self._cv.wait()
+            err, self._error = self._error, None
+        current = torch.cuda.current_stream(self.device)
         for st in self.streams:
-            st.wait_stream(current)  # inputs produced on the caller's stream are visible to the lanes
-        shards = [list(range(lane, len(pairs), self.lanes)) for lane in range(self.lanes)]
-        futures = [self.pool.submit(self._run_lane, lane, pairs, shards[lane], sink) for lane in range(self.lanes)]
-        for f in futures:
-            current.wait_stream(f.result())
+            current.wait_stream(st)
+        if err is not None:
+            raise err
+
+    def run_batch(self, pairs, sink):
+        """submit + drain: returns after all work is ENQUEUED and the current stream waits for every lane."""
+        self.submit(pairs, sink)
+        self.drain()
+
+    def close(self):
+        for _ in self._threads:
+            self._queue.put(None)
+        for t in self._threads:
+            t.join()
+        self._threads = []
