@@ -94,6 +94,7 @@ def main():
     ap.add_argument('--pairs', type=int, default=8, help='distinct synthetic pairs cycled through per rank')
     ap.add_argument('--batch', type=int, default=8, help='pairs per step per GPU (independent pairs of one batch)')
     ap.add_argument('--lanes', type=int, default=8, help='pairs kept in flight concurrently (host thread + HIP stream each)')
+    ap.add_argument('--stack', type=int, default=1, help='pairs stacked into one launch sequence per lane (<= 16; divides --batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -123,7 +124,7 @@ def main():
 
     results = torch.zeros((args.steps, args.batch, 4, 4), dtype=torch.float32, device=device)
     info = {}
-    runner = ConcurrentRegistration(pipe, lanes=args.lanes)
+    runner = ConcurrentRegistration(pipe, lanes=args.lanes, stack=args.stack)
 
     last = {}
 
@@ -162,6 +163,24 @@ def main():
     elapsed = gd.max_over_ranks(elapsed, device)
     events = prof.results()
 
+    # the same kernel with nothing else in flight (after the timed region): separates kernel quality from lane contention
+    isolated = None
+    if rank == 0:
+        emb_mod = pipe.model.transformer.embedding
+        pts_c = out['ref_points_c'].contiguous()
+        knn = kernels.gse_knn(pts_c, emb_mod.angle_k)
+        reps, evs = 10, []
+        for r in range(reps + 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            kernels.gse_embed(pts_c, knn, emb_mod.embedding.div_term, emb_mod.proj_d.weight, emb_mod.proj_d.bias,
+                              emb_mod.proj_a.weight, emb_mod.proj_a.bias, emb_mod.sigma_d, emb_mod.sigma_a)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        iso_s = sum(a.elapsed_time(b) for a, b in evs[2:]) / reps / 1e3  # includes the two weight-split launches (~3 us)
+        isolated = (iso_s, int(pts_c.shape[0]))
+
     if rank == 0:
         assert torch.isfinite(gathered).all()
         total_pairs = args.steps * args.batch * world
@@ -185,7 +204,7 @@ def main():
                                    f'{info["superpoints"][0]}+{info["superpoints"][1]} superpoints, '
                                    f'P={cfg.coarse_matching.num_correspondences}, K={cfg.model.num_points_in_patch}, '
                                    f'pyramid + full forward per pair',
-                       'pairs_per_step_per_gpu': args.batch, 'pairs_in_flight_per_gpu': args.lanes,
+                       'pairs_per_step_per_gpu': args.batch, 'lanes_per_gpu': args.lanes, 'pairs_stacked_per_launch_sequence': args.stack,
                        'parallelism': f'pairs sharded over {world} GPU(s), no data-path collective',
                        'weights': 'random init, seed 7351'},
             'roofline': {'bound': 'mfma',
@@ -200,8 +219,17 @@ def main():
                                  'algorithmic = executed (fp32 MFMA)',
                          'traffic': pmc_traffic_bytes('gse_embed'), 'traffic_unit': 'HBM bytes/launch (rocprofv3 PMC '
                          'FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/r01_pmc_hbm_traffic.md)', 'launches': len(durs),
-                         'avg_launch_us': round(1e6 * sum(durs) / len(durs), 1) if durs else None},
+                         'avg_launch_us': round(1e6 * sum(durs) / len(durs), 1) if durs else None,
+                         'isolated': None},
         }
+        if isolated is not None:
+            iso_s, iso_n = isolated
+            iso_alg = 2.0 * iso_n * iso_n * (1 + k) * D * D / iso_s / 1e12
+            iso_exec = 3.0 * iso_alg if split else iso_alg
+            line['roofline']['isolated'] = {
+                'achieved': round(iso_exec, 2), 'frac': round(iso_exec / peak, 4), 'algorithmic_tflops': round(iso_alg, 2),
+                'avg_launch_us': round(1e6 * iso_s, 1), 'n': iso_n,
+                'note': 'same kernel + its weight-split launches, GPU otherwise idle, HIP events after the timed region'}
         if world == 1 and not args.no_cpu_baseline:
             base, _ = cpu_baseline(cfg, items[0], pipe.model)
             line['cpu_baseline'] = base

@@ -43,6 +43,15 @@ struct Carver {
 };
 
 #ifdef __HIPCC__
+// split-bf16 helpers: x = hi + lo with hi = bf16(x), lo = bf16(x - hi)  (round to nearest even)
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+__device__ __forceinline__ unsigned f32_to_bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ int wave_inclusive_scan(int v) {

@@ -27,6 +27,8 @@ struct Ctx {
   hipStream_t stream;
   bool dry;  // size-query pass: account for allocations, launch nothing
   int rc = GEOTR_OK;
+  int nseg = 1;                                             // stacked pairs: GroupNorm statistics stay inside a pair
+  int64_t seg_rows[GEOTR_MAX_STAGES][GEOTR_MAX_PAIRS] = {};  // rows of pair b at stage s (ref + src)
 
   template <typename T>
   T* alloc(size_t count) {
@@ -48,18 +50,25 @@ struct Ctx {
 static float* linear(Ctx& c, const geotr_linear& l, const float* x, int64_t lda, int64_t m, int act, const float* residual = nullptr,
                      int64_t ldr = 0) {
   float* y = c.alloc<float>((size_t)m * l.out);
-  if (c.live())
-    c.check(geotr_gemm(x, lda, l.w, l.in, 0, y, l.out, m, l.out, l.in, 1, 0, 0, 0, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
+  if (c.live()) {
+    if (l.packed && m >= GEOTR_PACKED_MIN_ROWS)
+      c.check(geotr_gemm_packed(x, lda, l.packed, y, l.out, m, l.out, l.in, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
+    else
+      c.check(geotr_gemm(x, lda, l.w, l.in, 0, y, l.out, m, l.out, l.in, 1, 0, 0, 0, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
+  }
   return y;
 }
 
 // GroupNorm (groups > 0) or LayerNorm (groups == 0) with optional residual / activation; returns a new (n, ch) buffer
-static float* norm(Ctx& c, const geotr_norm& nm, const float* x, int64_t n, int64_t ch, const float* residual, int act) {
+// `stage` selects the pair segments of the row set (GroupNorm only)
+static float* norm(Ctx& c, const geotr_norm& nm, const float* x, int64_t n, int64_t ch, const float* residual, int act, int stage = 0) {
   float* y = c.alloc<float>((size_t)n * ch);
   if (nm.groups > 0) {
     const size_t m = c.mark();
     double* ws = reinterpret_cast<double*>(c.alloc<char>(geotr_group_norm_workspace_bytes(n, ch)));
-    if (c.live()) c.check(geotr_group_norm(x, n, ch, nm.groups, nm.gamma, nm.beta, nm.eps, residual, act, y, ws, c.stream));
+    if (c.live())
+      c.check(geotr_group_norm_segmented(x, n, ch, nm.groups, nm.gamma, nm.beta, nm.eps, residual, act, y, c.seg_rows[stage], c.nseg, ws,
+                                         c.stream));
     c.release(m);
   } else {
     if (c.live()) c.check(geotr_layer_norm(x, residual, n, ch, nm.gamma, nm.beta, nm.eps, y, c.stream));
@@ -79,29 +88,31 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     c.check(geotr_kpconv_gather(s_feats, q_pts, s_pts, nb, kp.kernel_points, flag, m, ns, h, kp.in, kp.num_kernel_points, kp.sigma,
                                 weighted, nnum, c.stream));
     const int64_t kdim = kp.num_kernel_points * kp.in;
-    c.check(geotr_gemm(weighted, kdim, kp.weights, kp.out, 1, out, kp.out, m, kp.out, kdim, 1, 0, 0, 0, kp.bias, nnum, nullptr, 0,
-                       1.0f, 0, c.stream));
+    if (kp.packed && m >= GEOTR_PACKED_MIN_ROWS)
+      c.check(geotr_gemm_packed(weighted, kdim, kp.packed, out, kp.out, m, kp.out, kdim, kp.bias, nnum, nullptr, 0, 1.0f, 0, c.stream));
+    else
+      c.check(geotr_gemm(weighted, kdim, kp.weights, kp.out, 1, out, kp.out, m, kp.out, kdim, 1, 0, 0, 0, kp.bias, nnum, nullptr, 0,
+                         1.0f, 0, c.stream));
   }
   c.release(mk);
   return out;
 }
 
 // ConvBlock / ResidualBlock (modules/kpconv/modules.py:105-225); returns (m, out) features
+// s_stage / q_stage: pyramid stages of the support rows (ns) and the query rows (m)
 static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t ns, const float* q_pts, int64_t m, const float* s_pts,
-                    const int64_t* nb, int64_t h) {
+                    const int64_t* nb, int64_t h, int s_stage, int q_stage) {
   if (b.is_conv_block) {
-    const size_t mk0 = c.mark();
-    (void)mk0;
     float* x = kpconv(c, b.conv, s_feats, ns, q_pts, m, s_pts, nb, h);
-    return norm(c, b.conv_norm, x, m, b.conv.out, nullptr, 2);
+    return norm(c, b.conv_norm, x, m, b.conv.out, nullptr, 2, q_stage);
   }
   const float* x = s_feats;
   if (b.has_unary1) {
     float* t = linear(c, b.unary1, s_feats, b.unary1.in, ns, 0);
-    x = norm(c, b.unary1_norm, t, ns, b.unary1.out, nullptr, 2);
+    x = norm(c, b.unary1_norm, t, ns, b.unary1.out, nullptr, 2, s_stage);
   }
   float* y = kpconv(c, b.conv, x, ns, q_pts, m, s_pts, nb, h);
-  y = norm(c, b.conv_norm, y, m, b.conv.out, nullptr, 2);
+  y = norm(c, b.conv_norm, y, m, b.conv.out, nullptr, 2, q_stage);
   const float* sc = s_feats;  // shortcut branch
   const int64_t in_ch = b.has_unary1 ? b.unary1.in : b.conv.in;
   if (b.strided) {
@@ -111,10 +122,10 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
   }
   if (b.has_shortcut) {
     float* t = linear(c, b.shortcut, sc, b.shortcut.in, m, 0);
-    sc = norm(c, b.shortcut_norm, t, m, b.shortcut.out, nullptr, 0);
+    sc = norm(c, b.shortcut_norm, t, m, b.shortcut.out, nullptr, 0, q_stage);
   }
   float* z = linear(c, b.unary2, y, b.unary2.in, m, 0);
-  return norm(c, b.unary2_norm, z, m, b.unary2.out, sc, 2);  // leaky_relu(unary2(x) + shortcut)
+  return norm(c, b.unary2_norm, z, m, b.unary2.out, sc, 2, q_stage);  // leaky_relu(unary2(x) + shortcut)
 }
 
 struct BackboneOut {
@@ -126,15 +137,15 @@ static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geo
   const int S = net.num_stages;
   const float* enc[GEOTR_MAX_STAGES];
   int64_t enc_ch[GEOTR_MAX_STAGES];
-  const float* x = block(c, net.blocks[0], feats, p.n[0], p.points[0], p.n[0], p.points[0], p.neighbors[0], p.neighbors_w[0]);
-  x = block(c, net.blocks[1], x, p.n[0], p.points[0], p.n[0], p.points[0], p.neighbors[0], p.neighbors_w[0]);
+  const float* x = block(c, net.blocks[0], feats, p.n[0], p.points[0], p.n[0], p.points[0], p.neighbors[0], p.neighbors_w[0], 0, 0);
+  x = block(c, net.blocks[1], x, p.n[0], p.points[0], p.n[0], p.points[0], p.neighbors[0], p.neighbors_w[0], 0, 0);
   enc[0] = x;
   enc_ch[0] = net.blocks[1].unary2.out;
   int bi = 2;
   for (int s = 1; s < S; ++s) {
-    x = block(c, net.blocks[bi++], x, p.n[s - 1], p.points[s], p.n[s], p.points[s - 1], p.subsampling[s - 1], p.subsampling_w[s - 1]);
-    x = block(c, net.blocks[bi++], x, p.n[s], p.points[s], p.n[s], p.points[s], p.neighbors[s], p.neighbors_w[s]);
-    x = block(c, net.blocks[bi++], x, p.n[s], p.points[s], p.n[s], p.points[s], p.neighbors[s], p.neighbors_w[s]);
+    x = block(c, net.blocks[bi++], x, p.n[s - 1], p.points[s], p.n[s], p.points[s - 1], p.subsampling[s - 1], p.subsampling_w[s - 1], s - 1, s);
+    x = block(c, net.blocks[bi++], x, p.n[s], p.points[s], p.n[s], p.points[s], p.neighbors[s], p.neighbors_w[s], s, s);
+    x = block(c, net.blocks[bi++], x, p.n[s], p.points[s], p.n[s], p.points[s], p.neighbors[s], p.neighbors_w[s], s, s);
     enc[s] = x;
     enc_ch[s] = net.blocks[bi - 1].unary2.out;
   }
@@ -148,13 +159,17 @@ static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geo
       c.check(geotr_upsample_concat(latent, p.n[i + 1], lat_ch, p.upsampling[i], p.upsampling_w[i], enc[i], enc_ch[i], p.n[i], cat, c.stream));
     const geotr_linear& l = net.decoder[d];
     if (i == net.fine_stage) {  // LastUnaryBlock: straight into the caller's buffer
-      if (c.live())
-        c.check(geotr_gemm(cat, tot, l.w, l.in, 0, feats_f_out, l.out, p.n[i], l.out, l.in, 1, 0, 0, 0, l.b, nullptr, nullptr, 0, 1.0f, 0,
-                           c.stream));
+      if (c.live()) {
+        if (l.packed && p.n[i] >= GEOTR_PACKED_MIN_ROWS)
+          c.check(geotr_gemm_packed(cat, tot, l.packed, feats_f_out, l.out, p.n[i], l.out, l.in, l.b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+        else
+          c.check(geotr_gemm(cat, tot, l.w, l.in, 0, feats_f_out, l.out, p.n[i], l.out, l.in, 1, 0, 0, 0, l.b, nullptr, nullptr, 0, 1.0f, 0,
+                             c.stream));
+      }
       latent = feats_f_out;
     } else {
       float* t = linear(c, l, cat, tot, p.n[i], 0);
-      latent = norm(c, net.decoder_norm[d], t, p.n[i], l.out, nullptr, 2);
+      latent = norm(c, net.decoder_norm[d], t, p.n[i], l.out, nullptr, 2, i);
     }
     lat_ch = l.out;
   }
@@ -258,13 +273,13 @@ static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t 
   return emb;
 }
 
-static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const float* features, const geotr_outputs& o) {
-  const int S = net.backbone.num_stages, fine = net.backbone.fine_stage;
-  const int64_t n_c = p.n[S - 1], nr_c = p.ref_n[S - 1], ns_c = n_c - nr_c;
-  const int64_t n_f = p.n[fine], nr_f = p.ref_n[fine], ns_f = n_f - nr_f;
-  const float* pts_c = p.points[S - 1];
-  const float* pts_f = p.points[fine];
+// heads of one pair: superpoint patches, geometric transformer, coarse matching, patch OT, LGR.  All pointers are the pair's
+// own slices of the stacked arrays (reference cloud first).
+static void run_pair(Ctx& c, const geotr_model& net, const float* pts_c, int64_t nr_c, int64_t ns_c, const float* pts_f, int64_t nr_f,
+                     int64_t ns_f, const float* feats_c_bb, int64_t c_dim, const float* feats_f, int64_t c_f, const geotr_outputs& o) {
+  const int64_t n_c = nr_c + ns_c, n_f = nr_f + ns_f;
   const int64_t K = net.num_points_in_patch, P = net.num_correspondences;
+  struct { const float* feats_c; int64_t c_dim; } bb = {feats_c_bb, c_dim};
 
   // 1. superpoint patches (model.py:98-108)
   int64_t* p2n = c.alloc<int64_t>((size_t)n_f);
@@ -278,11 +293,7 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
     c.check(geotr_point_to_node(pts_f + 3 * nr_f, ns_f, pts_c + 3 * nr_c, ns_c, K, p2n + nr_f, node_masks + nr_c, node_knn_idx + nr_c * K,
                                 node_knn_mask + nr_c * K, scratch_flag, c.stream));
   }
-
-  // 2. KPConv-FPN (model.py:127-130)
   const size_t mk_bb = c.mark();
-  BackboneOut bb = backbone_forward(c, net.backbone, p, features, o.feats_f);
-  const int64_t c_f = net.backbone.decoder[net.backbone.num_decoders - 1].out;
 
   // 3. geometric transformer (model.py:133-145)
   const geotr_transformer& t = net.transformer;
@@ -325,7 +336,7 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
                                o.ref_knn_indices, o.ref_knn_masks, o.ref_knn_points, o.src_knn_indices, o.src_knn_masks,
                                o.src_knn_points, c.stream));
     // 6. patch scores + optimal transport (model.py:187-191)
-    c.check(geotr_patch_sinkhorn(o.feats_f, nr_f, o.feats_f + nr_f * c_f, ns_f, c_f, o.ref_knn_indices, o.src_knn_indices, o.ref_knn_masks,
+    c.check(geotr_patch_sinkhorn(feats_f, nr_f, feats_f + nr_f * c_f, ns_f, c_f, o.ref_knn_indices, o.src_knn_indices, o.ref_knn_masks,
                                  o.src_knn_masks, P, K, net.alpha, net.num_sinkhorn_iterations, nullptr, o.num_node_corr,
                                  o.matching_scores, c.stream));
   }
@@ -337,6 +348,44 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
                       K, net.topk, net.confidence_threshold, net.mutual, net.acceptance_radius, net.correspondence_threshold,
                       net.num_refinement_steps, o.num_node_corr, o.ref_corr_points, o.src_corr_points, o.corr_scores, o.num_corr,
                       o.estimated_transform, lgr_ws, lgr_bytes, c.stream));
+}
+
+// One forward over `p.num_pairs` stacked pairs (clouds ordered ref_0, src_0, ref_1, src_1, ...): the KPConv-FPN runs once over
+// the whole stack (row-wise kernels; GroupNorm statistics per pair), the per-pair heads run pair after pair on slices.
+static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const float* features, const geotr_outputs* outs) {
+  const int S = net.backbone.num_stages, fine = net.backbone.fine_stage, B = p.num_pairs;
+  c.nseg = B;
+  for (int s = 0; s < S; ++s)
+    for (int b = 0; b < B; ++b) c.seg_rows[s][b] = p.cloud_n[s][2 * b] + p.cloud_n[s][2 * b + 1];
+  const int64_t n_c = p.n[S - 1];
+  const int64_t c_dim = net.backbone.blocks[net.backbone.num_blocks - 1].unary2.out;
+  const int64_t c_f = net.backbone.decoder[net.backbone.num_decoders - 1].out;
+  float* feats_f = c.dry ? nullptr : outs[0].feats_f;  // stacked (n_f, c_f): pair b's rows follow pair b-1's
+
+  // KPConv-FPN (model.py:127-130); only the coarse features outlive the backbone's intermediates
+  float* feats_c = c.alloc<float>((size_t)n_c * c_dim);
+  const size_t mk = c.mark();
+  BackboneOut bb = backbone_forward(c, net.backbone, p, features, feats_f);
+  if (c.live() && hipMemcpyAsync(feats_c, bb.feats_c, sizeof(float) * (size_t)n_c * c_dim, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
+    c.check(fail(GEOTR_E_LAUNCH, "model_forward: copy failed"));
+  c.release(mk);
+
+  int64_t off_c = 0, off_f = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t nr_c = p.cloud_n[S - 1][2 * b], ns_c = p.cloud_n[S - 1][2 * b + 1];
+    const int64_t nr_f = p.cloud_n[fine][2 * b], ns_f = p.cloud_n[fine][2 * b + 1];
+    geotr_outputs o;
+    if (c.dry) std::memset(&o, 0, sizeof(o));
+    else o = outs[b];
+    if (!c.dry && o.feats_f != feats_f + off_f * c_f && c.rc == GEOTR_OK)
+      c.rc = fail(GEOTR_E_INVALID, "model_forward: outputs[%d].feats_f must be row %lld of the stacked fine features", b, (long long)off_f);
+    const size_t mp = c.mark();
+    run_pair(c, net, p.points[S - 1] + 3 * off_c, nr_c, ns_c, p.points[fine] + 3 * off_f, nr_f, ns_f, feats_c + off_c * c_dim, c_dim,
+             feats_f + off_f * c_f, c_f, o);
+    c.release(mp);
+    off_c += nr_c + ns_c;
+    off_f += nr_f + ns_f;
+  }
   return c.rc;
 }
 
@@ -350,8 +399,15 @@ static int validate(const geotr_model* net, const geotr_pyramid* pyr) {
   GEOTR_CHECK_ARG(S >= 3 && S <= GEOTR_MAX_STAGES && pyr->num_stages == S, "model_forward: %d stages (pyramid has %d)", S, pyr->num_stages);
   GEOTR_CHECK_ARG(net->backbone.num_blocks == 2 + 3 * (S - 1), "model_forward: backbone block count does not match the depth");
   GEOTR_CHECK_ARG(net->transformer.num_layers >= 1 && net->transformer.num_layers <= 8, "model_forward: 1..8 transformer layers");
-  for (int s = 0; s < S; ++s)
-    GEOTR_CHECK_ARG(pyr->n[s] > 0 && pyr->ref_n[s] > 0 && pyr->ref_n[s] < pyr->n[s], "model_forward: empty cloud at stage %d", s);
+  GEOTR_CHECK_ARG(pyr->num_pairs >= 1 && pyr->num_pairs <= GEOTR_MAX_PAIRS, "model_forward: 1..%d stacked pairs", GEOTR_MAX_PAIRS);
+  for (int s = 0; s < S; ++s) {
+    int64_t tot = 0;
+    for (int q = 0; q < 2 * pyr->num_pairs; ++q) {
+      GEOTR_CHECK_ARG(pyr->cloud_n[s][q] > 0, "model_forward: empty cloud %d at stage %d", q, s);
+      tot += pyr->cloud_n[s][q];
+    }
+    GEOTR_CHECK_ARG(tot == pyr->n[s], "model_forward: stage %d has %lld rows but its clouds sum to %lld", s, (long long)pyr->n[s], (long long)tot);
+  }
   return GEOTR_OK;
 }
 
@@ -380,9 +436,7 @@ size_t geotr_model_workspace_bytes(const geotr_model* net, const geotr_pyramid* 
   c.cap = 0;
   c.stream = nullptr;
   c.dry = true;
-  geotr_outputs none;
-  std::memset(&none, 0, sizeof(none));
-  run(c, *net, *pyr, nullptr, none);
+  run(c, *net, *pyr, nullptr, nullptr);
   return c.peak + 4096;
 }
 
@@ -397,7 +451,7 @@ int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const 
   c.cap = ws_bytes;
   c.stream = (hipStream_t)stream;
   c.dry = false;
-  return run(c, *net, *pyr, features, *out);
+  return run(c, *net, *pyr, features, out);
 }
 
 size_t geotr_pyramid_workspace_bytes(int64_t n0, int64_t batch, int64_t num_stages) {

@@ -328,6 +328,178 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") variant for the tall backbone contractions with static weights:
+//   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi   (x = hi + lo, hi = bf16(x), lo = bf16(x - hi); relative error ~2^-17 per
+//   product, fp32 accumulation) on v_mfma_f32_32x32x16_bf16, which runs at 16x the fp32 MFMA rate.
+// The weight is packed ONCE (geotr_gemm_pack) into hi / lo planes in MFMA B-fragment order, so the B operand of a 16-deep
+// step is one coalesced 1 KB read per wave straight from L2 -- no LDS staging, no per-launch split.  The activation tile
+// (128 rows x 32 k, fp32) is split on the fly while it is written to LDS (rows of 32 bf16 padded to 40 = 80 B:
+// conflict-free ds_read_b128), double-buffered: one barrier per 32-deep step, next tile's global loads in flight
+// under the MFMAs.  Block = 4 waves; wave tile = (32*WM) x (32*WN); BM = 128.
+// packed layout: plane[ct = n / 32][kk = k / 16][lane = n % 32 + 32 * ((k % 16) / 8)][k % 8], K padded to 32, N to 32.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kPRS = 40;  // LDS row stride of the packed kernel in bf16 elements
+
+struct PackedArgs {
+  const float* A;
+  const unsigned short* Bhi;
+  const unsigned short* Blo;
+  float* C;
+  const float* bias;
+  const int32_t* row_div;
+  const float* residual;
+  int64_t lda, ldc, ldr;
+  int M, N, K, KS, NT;  // KS = padded K / 16, NT = padded N / 32
+  float alpha;
+  int act;
+};
+
+__global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b_is_kn, int N, int K, int KS, int64_t nvec,
+                                 unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-element vector per thread
+  if (v >= nvec) return;
+  const int lane = (int)(v & 63), kk = (int)((v >> 6) % KS), ct = (int)((v >> 6) / KS);
+  const int n = 32 * ct + (lane & 31), k0 = 16 * kk + 8 * (lane >> 5);
+  unsigned h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k0 + j;
+    float x = 0.f;
+    if (n < N && k < K) x = b_is_kn ? B[(int64_t)k * ldb + n] : B[(int64_t)n * ldb + k];
+    h[j] = f32_to_bf16_rne(x);
+    l[j] = f32_to_bf16_rne(x - bf16_to_f32(h[j]));
+  }
+  *reinterpret_cast<uint4*>(hi + v * 8) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+  *reinterpret_cast<uint4*>(lo + v * 8) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+template <int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
+  constexpr int BM = 128;
+  constexpr int WAVES_M = BM / (32 * WM), WAVES_N = 4 / WAVES_M, BN = 32 * WN * WAVES_N;
+  constexpr int PLANE = BM * kPRS;
+  __shared__ __attribute__((aligned(16))) unsigned short sm[2 * 2 * PLANE];  // [buf][hi, lo][128][40]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int wrow = (wave / WAVES_N) * 32 * WM, wct = n0 / 32 + (wave % WAVES_N) * WN;  // wave's first row / column tile
+  const int fr = lane & 31, fk = lane >> 5;
+
+  float4 ra[4];  // 128 rows x 8 float4 per row / 256 threads
+  auto load_a = [&](int k0) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int f = tid + 256 * s, row = f >> 3, kq = (f & 7) * 4;
+      const int gm = m0 + row, gk = k0 + kq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gm < g.M) {
+        const float* p = g.A + (int64_t)gm * g.lda + gk;
+        if (VEC && gk + 3 < g.K) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gk < g.K) v.x = p[0];
+          if (gk + 1 < g.K) v.y = p[1];
+          if (gk + 2 < g.K) v.z = p[2];
+          if (gk + 3 < g.K) v.w = p[3];
+        }
+      }
+      ra[s] = v;
+    }
+  };
+  auto store_a = [&](int buf) {
+    unsigned short* hi = sm + (2 * buf) * PLANE;
+    unsigned short* lo = hi + PLANE;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int f = tid + 256 * s, row = f >> 3, kq = (f & 7) * 4;
+      const float x[4] = {ra[s].x, ra[s].y, ra[s].z, ra[s].w};
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = f32_to_bf16_rne(x[j]);
+        l[j] = f32_to_bf16_rne(x[j] - bf16_to_f32(h[j]));
+      }
+      *reinterpret_cast<uint2*>(hi + row * kPRS + kq) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+      *reinterpret_cast<uint2*>(lo + row * kPRS + kq) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    }
+  };
+  const bf16x8* bhi = reinterpret_cast<const bf16x8*>(g.Bhi);
+  const bf16x8* blo = reinterpret_cast<const bf16x8*>(g.Blo);
+  bf16x8 bh[WN], bl[WN], nh[WN], nl[WN];
+  auto load_b = [&](int kk, bf16x8(&h)[WN], bf16x8(&l)[WN]) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int64_t o = ((int64_t)min(wct + j, g.NT - 1) * g.KS + kk) * 64 + lane;  // column tiles past N: clamped, never stored
+      h[j] = bhi[o];
+      l[j] = blo[o];
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt = g.KS / 2;  // 32-deep steps (K is padded to 32 in the packed weight)
+  load_a(0);
+  load_b(0, bh, bl);
+  store_a(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_a((kt + 1) * 32);
+    const unsigned short* A_hi = sm + (2 * buf) * PLANE;
+    const unsigned short* A_lo = A_hi + PLANE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kk = 2 * kt + ks;
+      if (kk + 1 < g.KS) load_b(kk + 1, nh, nl);
+      const int kb = 16 * ks + 8 * fk;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A_hi + (wrow + 32 * i + fr) * kPRS + kb);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(A_lo + (wrow + 32 * i + fr) * kPRS + kb);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bh[j] = nh[j], bl[j] = nl[j];
+    }
+    if (kt + 1 < nkt) store_a(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int gn = 32 * (wct + j) + fr;
+      if (gn >= g.N) continue;
+      const float bias = g.bias ? g.bias[gn] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wrow + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (gm >= g.M) continue;
+        float v = acc[i][j][r] * g.alpha;
+        if (g.row_div) v = v / (float)max(g.row_div[gm], 1);
+        v += bias;
+        if (g.residual) v += g.residual[(int64_t)gm * g.ldr + gn];
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+        g.C[(int64_t)gm * g.ldc + gn] = v;
+      }
+    }
+}
+
 }  // namespace geotr
 
 using namespace geotr;
@@ -366,5 +538,52 @@ extern "C" int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t l
     else gemm_skinny_kernel<false><<<grid, dim3(256), 0, stream>>>(g);
   }
   GEOTR_CHECK_LAUNCH("gemm");
+  return GEOTR_OK;
+}
+
+static inline int64_t pack_pad32(int64_t x) { return (x + 31) / 32 * 32; }
+
+extern "C" size_t geotr_gemm_pack_bytes(int64_t n, int64_t k) { return (size_t)(2 * 2 * pack_pad32(n) * pack_pad32(k)); }
+
+extern "C" int geotr_gemm_pack(const float* B, int64_t ldb, int b_is_kn, int64_t n, int64_t k, void* packed, void* stream) {
+  GEOTR_CHECK_ARG(n >= 1 && k >= 1 && n < (1ll << 24) && k < (1ll << 24), "gemm_pack: bad sizes");
+  GEOTR_CHECK_ARG(B && packed && (reinterpret_cast<uintptr_t>(packed) & 15) == 0, "gemm_pack: null or unaligned pointer");
+  const int64_t np = pack_pad32(n), kp = pack_pad32(k), nvec = np * kp / 8;
+  unsigned short* hi = reinterpret_cast<unsigned short*>(packed);
+  gemm_pack_kernel<<<dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(B, ldb, b_is_kn, (int)n, (int)k, (int)(kp / 16),
+                                                                                              nvec, hi, hi + np * kp);
+  GEOTR_CHECK_LAUNCH("gemm_pack");
+  return GEOTR_OK;
+}
+
+extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                 const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
+                                 void* stream_) {
+  GEOTR_CHECK_ARG(M >= 0 && N >= 1 && K >= 1, "gemm_packed: bad sizes");
+  if (M == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(A && packed && C, "gemm_packed: null pointer");
+  GEOTR_CHECK_ARG(M < (1ll << 31) && N < (1ll << 24) && K < (1ll << 24), "gemm_packed: size out of range");
+  GEOTR_CHECK_ARG(act >= 0 && act <= 2, "gemm_packed: unknown activation %d", act);
+  const int64_t np = pack_pad32(N), kp = pack_pad32(K);
+  PackedArgs g;
+  g.A = A; g.Bhi = reinterpret_cast<const unsigned short*>(packed); g.Blo = g.Bhi + np * kp;
+  g.C = C; g.bias = bias; g.row_div = row_div; g.residual = residual;
+  g.lda = lda; g.ldc = ldc; g.ldr = residual ? ldr : 0;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.KS = (int)(kp / 16); g.NT = (int)(np / 32); g.alpha = alpha; g.act = act;
+  const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  const unsigned gy = (unsigned)((M + 127) / 128);
+  GEOTR_CHECK_ARG(gy <= 65535, "gemm_packed: M too large");
+#define GEOTR_PACKED(WM, WN, BN)                                                                              \
+  do {                                                                                                        \
+    dim3 grid((unsigned)((N + BN - 1) / BN), gy);                                                             \
+    if (vec) gemm_packed_kernel<WM, WN, true><<<grid, dim3(256), 0, stream>>>(g);                             \
+    else gemm_packed_kernel<WM, WN, false><<<grid, dim3(256), 0, stream>>>(g);                                \
+  } while (0)
+  if (N > 64) GEOTR_PACKED(2, 2, 128);
+  else if (N > 32) GEOTR_PACKED(1, 2, 64);
+  else GEOTR_PACKED(1, 1, 32);
+#undef GEOTR_PACKED
+  GEOTR_CHECK_LAUNCH("gemm_packed");
   return GEOTR_OK;
 }

@@ -192,10 +192,29 @@ __global__ void upsample_concat_kernel(const float* __restrict__ coarse, int64_t
 constexpr int kGnRows = 32;  // rows per block in the statistics pass (many small blocks: the pass is latency-bound)
 
 // pass 1: per-block, per-channel partial (sum, sum of squares) over kGnRows rows -- no atomics
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int64_t N, int C, float* __restrict__ partial) {
+// Row segments (one per stacked pair: statistics never mix pairs).  Statistics blocks start at segment starts, so a
+// segment's partials are the same whether it is normalised alone or inside a stack.
+struct GnSegs {
+  int nseg;
+  int blk0[GEOTR_MAX_PAIRS + 1];      // first statistics block of each segment
+  int64_t row0[GEOTR_MAX_PAIRS + 1];  // first row of each segment
+};
+__device__ __forceinline__ int gn_seg_of_block(const GnSegs& sg, int b) {
+  int s = 0;
+  while (s + 1 < sg.nseg && b >= sg.blk0[s + 1]) ++s;
+  return s;
+}
+__device__ __forceinline__ int gn_seg_of_row(const GnSegs& sg, int64_t r) {
+  int s = 0;
+  while (s + 1 < sg.nseg && r >= sg.row0[s + 1]) ++s;
+  return s;
+}
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, GnSegs sg, int C, float* __restrict__ partial) {
   extern __shared__ float red[];  // [phases][2][C] when C < 256
-  const int64_t r0 = (int64_t)blockIdx.x * kGnRows;
-  const int64_t r1 = r0 + kGnRows < N ? r0 + kGnRows : N;
+  const int seg = gn_seg_of_block(sg, blockIdx.x);
+  const int64_t r0 = sg.row0[seg] + (int64_t)(blockIdx.x - sg.blk0[seg]) * kGnRows;
+  const int64_t r1 = r0 + kGnRows < sg.row0[seg + 1] ? r0 + kGnRows : sg.row0[seg + 1];
   float* out = partial + (int64_t)blockIdx.x * 2 * C;
   if (C >= 256) {
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -235,9 +254,14 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 }
 // pass 2: one block per group: fp64 reduction of the group's partials -> mean / rstd -> per-channel scale and shift,
 // so the apply pass is one fma per element:  y = x * a[c] + b[c]
-__global__ __launch_bounds__(256) void gn_group_kernel(const float* __restrict__ partial, int nb, int64_t N, int C, int groups,
+__global__ __launch_bounds__(256) void gn_group_kernel(const float* __restrict__ partial_all, GnSegs sg, int C, int groups,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                       float* __restrict__ ab) {
+                                                       float* __restrict__ ab_all) {
+  const int seg = blockIdx.y;
+  const float* partial = partial_all + (int64_t)sg.blk0[seg] * 2 * C;
+  const int nb = sg.blk0[seg + 1] - sg.blk0[seg];
+  const int64_t N = sg.row0[seg + 1] - sg.row0[seg];
+  float* ab = ab_all + (int64_t)seg * 2 * C;
   __shared__ double red[2][4];
   __shared__ float stat[2];
   const int g = blockIdx.x, cpg = C / groups, g0 = g * cpg;
@@ -274,10 +298,11 @@ __global__ __launch_bounds__(256) void gn_group_kernel(const float* __restrict__
   }
 }
 template <bool VEC4>
-__global__ __launch_bounds__(256) void gn_apply2_kernel(const float* __restrict__ x, int64_t total, int C, const float* __restrict__ ab,
-                                                        const float* __restrict__ residual, int act, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void gn_apply2_kernel(const float* __restrict__ x, int64_t total, int C, const float* __restrict__ ab_all,
+                                                        GnSegs sg, const float* __restrict__ residual, int act, float* __restrict__ out) {
   const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (VEC4 ? 4 : 1);
   if (e >= total) return;
+  const float* ab = ab_all + (int64_t)(sg.nseg > 1 ? gn_seg_of_row(sg, e / C) : 0) * 2 * C;
   if (VEC4) {
     const int c = (int)(e % C);
     const float4 v = *reinterpret_cast<const float4*>(x + e);
@@ -467,30 +492,52 @@ int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int
 }
 
 size_t geotr_group_norm_workspace_bytes(int64_t n, int64_t c) {
-  const size_t nb = (size_t)((n + kGnRows - 1) / kGnRows);
-  return sizeof(double) * 2 * (size_t)c + sizeof(float) * 2 * (size_t)c * ((nb > 0 ? nb : 1) + 1);
+  const size_t nb = (size_t)((n + kGnRows - 1) / kGnRows) + GEOTR_MAX_PAIRS;  // every segment may end in a partial block
+  return sizeof(double) * 2 * (size_t)c + sizeof(float) * 2 * (size_t)c * (nb + GEOTR_MAX_PAIRS);
+}
+
+int geotr_group_norm_segmented(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                               const float* residual, int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws,
+                               void* stream_) {
+  GEOTR_CHECK_ARG(n >= 0 && c >= 1 && groups >= 1 && c % groups == 0, "group_norm: %lld channels / %lld groups",
+                  (long long)c, (long long)groups);
+  GEOTR_CHECK_ARG(nseg >= 1 && nseg <= GEOTR_MAX_PAIRS && seg_rows_host, "group_norm: 1..%d row segments", GEOTR_MAX_PAIRS);
+  if (n == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(x && gamma && beta && out && stats_ws, "group_norm: null pointer");
+  GnSegs sg;
+  sg.nseg = (int)nseg;
+  int64_t row = 0;
+  int blk = 0;
+  for (int s = 0; s < (int)nseg; ++s) {
+    GEOTR_CHECK_ARG(seg_rows_host[s] >= 1, "group_norm: empty row segment %d", s);
+    sg.row0[s] = row;
+    sg.blk0[s] = blk;
+    row += seg_rows_host[s];
+    blk += (int)((seg_rows_host[s] + kGnRows - 1) / kGnRows);
+  }
+  sg.row0[nseg] = row;
+  sg.blk0[nseg] = blk;
+  GEOTR_CHECK_ARG(row == n, "group_norm: segments cover %lld rows, expected %lld", (long long)row, (long long)n);
+  hipStream_t stream = (hipStream_t)stream_;
+  const unsigned nb = (unsigned)blk;
+  float* partial = reinterpret_cast<float*>(stats_ws + 2 * c);
+  const int per = c < 256 ? (int)(256 / c) : 0;
+  gn_partial_kernel<<<dim3(nb), dim3(256), sizeof(float) * 2 * (size_t)c * per, stream>>>(x, sg, (int)c, partial);
+  float* ab = partial + (size_t)nb * 2 * c;
+  gn_group_kernel<<<dim3((unsigned)groups, (unsigned)nseg), dim3(256), 0, stream>>>(partial, sg, (int)c, (int)groups, gamma, beta, eps, ab);
+  const int64_t total = n * c;
+  if (c % 4 == 0)
+    gn_apply2_kernel<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, act, out);
+  else
+    gn_apply2_kernel<false><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, act, out);
+  GEOTR_CHECK_LAUNCH("group_norm");
+  return GEOTR_OK;
 }
 
 int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
                      float eps, const float* residual, int act, float* out, double* stats_ws, void* stream_) {
-  GEOTR_CHECK_ARG(n >= 0 && c >= 1 && groups >= 1 && c % groups == 0, "group_norm: %lld channels / %lld groups",
-                  (long long)c, (long long)groups);
   if (n == 0) return GEOTR_OK;
-  GEOTR_CHECK_ARG(x && gamma && beta && out && stats_ws, "group_norm: null pointer");
-  hipStream_t stream = (hipStream_t)stream_;
-  const unsigned nb = (unsigned)((n + kGnRows - 1) / kGnRows);
-  float* partial = reinterpret_cast<float*>(stats_ws + 2 * c);
-  const int per = c < 256 ? (int)(256 / c) : 0;
-  gn_partial_kernel<<<dim3(nb), dim3(256), sizeof(float) * 2 * (size_t)c * per, stream>>>(x, n, (int)c, partial);
-  float* ab = partial + (size_t)nb * 2 * c;
-  gn_group_kernel<<<dim3((unsigned)groups), dim3(256), 0, stream>>>(partial, (int)nb, n, (int)c, (int)groups, gamma, beta, eps, ab);
-  const int64_t total = n * c;
-  if (c % 4 == 0)
-    gn_apply2_kernel<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, residual, act, out);
-  else
-    gn_apply2_kernel<false><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, residual, act, out);
-  GEOTR_CHECK_LAUNCH("group_norm");
-  return GEOTR_OK;
+  return geotr_group_norm_segmented(x, n, c, groups, gamma, beta, eps, residual, act, out, &n, 1, stats_ws, stream_);
 }
 
 int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c, const float* gamma, const float* beta,

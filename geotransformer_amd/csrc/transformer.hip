@@ -205,16 +205,9 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_kernel(const float* _
 // fp32 path's matrix time.  Same tiling as gse_embed_kernel (64 pairs x D channels per block, 8 waves x 32 channels);
 // LDS rows are 32 bf16 padded to 40 (80 B): the 16-lane groups of ds_read_b128 then hit 16 distinct 16-B slots.
 // ---------------------------------------------------------------------------------------------------
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int kGseBK2 = 32;  // K-chunk of the split-bf16 kernel (16 was measured slower: 286 vs 259 us per launch)
 constexpr int kGseRS = kGseBK2 + 8;  // LDS row stride in bf16 elements (80 B: conflict-free 16-lane groups, 16-B aligned)
 
-__device__ __forceinline__ unsigned f32_to_bf16_rne(float x) {
-  unsigned u = __float_as_uint(x);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
-}
-__device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_float(h << 16); }
 
 // W (D out-columns, D k) fp32 -> hi / lo bf16 planes in MFMA B-fragment order:
 //   plane[col_tile = col / 32][kk = k / 16][lane = (col % 32) + 32 * ((k % 16) / 8)][k % 8]

@@ -47,14 +47,59 @@ def gemm(a, b, b_is_kn=False, bias=None, row_div=None, residual=None, alpha=1.0,
     return out
 
 
-def linear(x, weight, bias=None, act=None, residual=None):
-    """F.linear(x, weight, bias) on the matrix cores; x may have leading batch dims."""
+GEMM_PACKED = False     # False: exact fp32 MFMA for every backbone contraction
+PACKED_MIN_ROWS = 1024  # activations with at least this many rows use the packed split-bf16 GEMM when a packed weight is given
+_PACK_CACHE = {}
+
+
+def gemm_pack(weight, b_is_kn=False):
+    """Packed hi/lo bf16 planes of a static 2-D weight ((N,K), or (K,N) with b_is_kn) for gemm_packed; cached per
+    (storage, version), so an updated parameter is re-packed."""
+    assert weight.dim() == 2 and weight.stride(-1) == 1 and weight.dtype == torch.float32
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0), bool(b_is_kn), weight.device.index)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit
+    lib = _lib.load()
+    n, k = (weight.shape[1], weight.shape[0]) if b_is_kn else (weight.shape[0], weight.shape[1])
+    packed = torch.empty(lib.geotr_gemm_pack_bytes(n, k), dtype=torch.uint8, device=weight.device)
+    _lib.check(lib.geotr_gemm_pack(_lib.ptr(weight), weight.stride(0), int(b_is_kn), n, k, _lib.ptr(packed), _lib.stream_ptr()),
+               'geotr_gemm_pack')
+    if len(_PACK_CACHE) > 4096:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = packed
+    return packed
+
+
+def gemm_packed(a, packed, n, bias=None, row_div=None, residual=None, alpha=1.0, act=None, out=None):
+    """out (M, n) = act(alpha * a @ W^T / row_div + bias + residual) with W given by gemm_pack (split-bf16 MFMA)."""
+    lib = _lib.load()
+    assert a.dim() == 2 and a.stride(-1) == 1
+    M, K = a.shape
+    if out is None:
+        out = torch.empty((M, n), dtype=torch.float32, device=a.device)
+    ldr = 0
+    if residual is not None:
+        assert residual.stride(-1) == 1
+        ldr = residual.stride(0)
+    _lib.check(lib.geotr_gemm_packed(_lib.ptr(a), a.stride(0), _lib.ptr(packed), _lib.ptr(out), out.stride(0), M, n, K, _lib.ptr(bias),
+                                     _lib.ptr(row_div), _lib.ptr(residual), ldr, float(alpha), ACT[act], _lib.stream_ptr()),
+               'geotr_gemm_packed')
+    return out
+
+
+def linear(x, weight, bias=None, act=None, residual=None, packed=False):
+    """F.linear(x, weight, bias) on the matrix cores; x may have leading batch dims.  packed=True (static backbone
+    weights): activations with >= PACKED_MIN_ROWS rows go through the packed split-bf16 GEMM, like the native executor."""
     shape = x.shape
     x2 = x.reshape(-1, shape[-1])
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     res2 = residual.reshape(-1, weight.shape[0]) if residual is not None else None
-    y = gemm(x2, weight, bias=bias, act=act, residual=res2)
+    if packed and GEMM_PACKED and x2.shape[0] >= PACKED_MIN_ROWS:
+        y = gemm_packed(x2, gemm_pack(weight), weight.shape[0], bias=bias, act=act, residual=res2)
+    else:
+        y = gemm(x2, weight, bias=bias, act=act, residual=res2)
     return y.view(*shape[:-1], weight.shape[0])
 
 

@@ -42,7 +42,7 @@ class UnaryBlock(nn.Module):
         self.leaky_relu = nn.LeakyReLU(0.1) if has_relu else None
 
     def forward(self, x, residual=None, act_after_residual=None):
-        x = kernels.linear(x, self.mlp.weight, self.mlp.bias)
+        x = kernels.linear(x, self.mlp.weight, self.mlp.bias, packed=True)
         if residual is not None:  # fused tail of ResidualBlock: leaky_relu(norm(x) + shortcut)
             return self.norm(x, residual=residual, act=act_after_residual)
         return self.norm(x, act='leaky' if self.leaky_relu is not None else None)
@@ -56,7 +56,7 @@ class LastUnaryBlock(nn.Module):
         self.mlp = nn.Linear(in_channels, out_channels, bias=bias)
 
     def forward(self, x):
-        return kernels.linear(x, self.mlp.weight, self.mlp.bias)
+        return kernels.linear(x, self.mlp.weight, self.mlp.bias, packed=True)
 
 
 class ConvBlock(nn.Module):

@@ -5,12 +5,14 @@ records the device pointers of its parameters (re-built automatically if a param
 `forward(data_dict)` allocates the output tensors, sizes the workspace and makes ONE asynchronous C-ABI call per pair.
 """
 import ctypes
+import threading
 
 import torch
 
-from . import _lib
+from . import _lib, kernels
 
 MAX_STAGES = 5
+MAX_PAIRS = 16  # GEOTR_MAX_PAIRS
 P_F32 = ctypes.c_void_p
 I64 = ctypes.c_int64
 I32 = ctypes.c_int32
@@ -18,7 +20,7 @@ F32 = ctypes.c_float
 
 
 class Linear(ctypes.Structure):
-    _fields_ = [('w', P_F32), ('b', P_F32), ('in_', I64), ('out', I64)]
+    _fields_ = [('w', P_F32), ('b', P_F32), ('in_', I64), ('out', I64), ('packed', ctypes.c_void_p)]
 
 
 class Norm(ctypes.Structure):
@@ -27,7 +29,7 @@ class Norm(ctypes.Structure):
 
 class KPConvDesc(ctypes.Structure):
     _fields_ = [('weights', P_F32), ('bias', P_F32), ('kernel_points', P_F32), ('in_', I64), ('out', I64),
-                ('num_kernel_points', I64), ('sigma', F32), ('pad_', I32)]
+                ('num_kernel_points', I64), ('sigma', F32), ('pad_', I32), ('packed', ctypes.c_void_p)]
 
 
 class Block(ctypes.Structure):
@@ -43,12 +45,12 @@ class Backbone(ctypes.Structure):
 
 
 class Pyramid(ctypes.Structure):
-    _fields_ = [('num_stages', I32), ('pad_', I32),
+    _fields_ = [('num_stages', I32), ('num_pairs', I32),
                 ('points', P_F32 * MAX_STAGES), ('n', I64 * MAX_STAGES),
                 ('neighbors', P_F32 * MAX_STAGES), ('neighbors_w', I64 * MAX_STAGES),
                 ('subsampling', P_F32 * MAX_STAGES), ('subsampling_w', I64 * MAX_STAGES),
                 ('upsampling', P_F32 * MAX_STAGES), ('upsampling_w', I64 * MAX_STAGES),
-                ('ref_n', I64 * MAX_STAGES)]
+                ('cloud_n', (I64 * (2 * MAX_PAIRS)) * MAX_STAGES)]
 
 
 class PyramidBuffers(ctypes.Structure):
@@ -102,8 +104,13 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _linear(mod):
-    return Linear(_ptr(mod.weight), _ptr(mod.bias), mod.weight.shape[1], mod.weight.shape[0])
+def _linear(mod, keep=None):
+    """`keep` (a list) requests the packed split-bf16 weight for tall activations; it holds the tensor alive."""
+    packed = None
+    if keep is not None and kernels.GEMM_PACKED:
+        keep.append(kernels.gemm_pack(mod.weight))
+        packed = keep[-1].data_ptr()
+    return Linear(_ptr(mod.weight), _ptr(mod.bias), mod.weight.shape[1], mod.weight.shape[0], packed)
 
 
 def _norm(mod):
@@ -116,27 +123,31 @@ def _norm(mod):
     return Norm(_ptr(mod.weight), _ptr(mod.bias), 0, mod.eps, 0)
 
 
-def _kpconv(mod):
+def _kpconv(mod, keep=None):
+    packed = None
+    if keep is not None and kernels.GEMM_PACKED:
+        keep.append(kernels.gemm_pack(mod.weights.view(mod.kernel_size * mod.in_channels, mod.out_channels), b_is_kn=True))
+        packed = keep[-1].data_ptr()
     return KPConvDesc(_ptr(mod.weights), _ptr(mod.bias), _ptr(mod.kernel_points), mod.in_channels, mod.out_channels,
-                      mod.kernel_size, float(mod.sigma), 0)
+                      mod.kernel_size, float(mod.sigma), 0, packed)
 
 
-def _block(mod):
+def _block(mod, keep=None):
     from .modules.kpconv.modules import ConvBlock, UnaryBlock
     b = Block()
     if isinstance(mod, ConvBlock):
         b.is_conv_block = 1
-        b.conv, b.conv_norm = _kpconv(mod.KPConv), _norm(mod.norm)
+        b.conv, b.conv_norm = _kpconv(mod.KPConv, keep), _norm(mod.norm)
         return b
     b.strided = int(mod.strided)
     if isinstance(mod.unary1, UnaryBlock):
         b.has_unary1 = 1
-        b.unary1, b.unary1_norm = _linear(mod.unary1.mlp), _norm(mod.unary1.norm)
-    b.conv, b.conv_norm = _kpconv(mod.KPConv), _norm(mod.norm_conv)
-    b.unary2, b.unary2_norm = _linear(mod.unary2.mlp), _norm(mod.unary2.norm)
+        b.unary1, b.unary1_norm = _linear(mod.unary1.mlp, keep), _norm(mod.unary1.norm)
+    b.conv, b.conv_norm = _kpconv(mod.KPConv, keep), _norm(mod.norm_conv)
+    b.unary2, b.unary2_norm = _linear(mod.unary2.mlp, keep), _norm(mod.unary2.norm)
     if isinstance(mod.unary_shortcut, UnaryBlock):
         b.has_shortcut = 1
-        b.shortcut, b.shortcut_norm = _linear(mod.unary_shortcut.mlp), _norm(mod.unary_shortcut.norm)
+        b.shortcut, b.shortcut_norm = _linear(mod.unary_shortcut.mlp, keep), _norm(mod.unary_shortcut.norm)
     return b
 
 
@@ -148,6 +159,7 @@ class NativeModel:
         self._key = None
         self._keep = []
         self.desc = None
+        self._lock = threading.Lock()
 
     def _version_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
@@ -164,11 +176,11 @@ class NativeModel:
             blocks += [getattr(net, f'encoder{s}_{i}') for i in (1, 2, 3)]
         bb.num_blocks = len(blocks)
         for i, blk in enumerate(blocks):
-            bb.blocks[i] = _block(blk)
+            bb.blocks[i] = _block(blk, self._keep)  # backbone weights also in packed split-bf16 form (tall activations)
         n_dec = 0
         for i in range(S - 2, net.fine_stage - 1, -1):
             dec = getattr(net, f'decoder{i + 1}')
-            bb.decoder[n_dec] = _linear(dec.mlp)
+            bb.decoder[n_dec] = _linear(dec.mlp, self._keep)
             bb.decoder_norm[n_dec] = _norm(getattr(dec, 'norm', None))
             n_dec += 1
         bb.num_decoders = n_dec
@@ -213,8 +225,11 @@ class NativeModel:
     def descriptor(self):
         key = self._version_key()
         if key != self._key:
-            self._build()
-            self._key = key
+            with self._lock:  # lanes share one model: build once, and only publish after the derived weights are complete
+                if key != self._key:
+                    self._build()
+                    torch.cuda.current_stream().synchronize()  # fused / packed weights are produced on this thread's stream
+                    self._key = key
         return self.desc
 
     @staticmethod
@@ -222,12 +237,15 @@ class NativeModel:
         p = Pyramid()
         S = len(data_dict['points'])
         p.num_stages = S
+        p.num_pairs = len(lengths_host[0]) // 2
         for i in range(S):
             pts, nb = data_dict['points'][i], data_dict['neighbors'][i]
             assert pts.is_contiguous() and nb.is_contiguous()
             p.points[i], p.n[i] = pts.data_ptr(), pts.shape[0]
             p.neighbors[i], p.neighbors_w[i] = nb.data_ptr(), nb.shape[1]
-            p.ref_n[i] = int(lengths_host[i][0])
+            assert len(lengths_host[i]) % 2 == 0 and len(lengths_host[i]) <= 2 * MAX_PAIRS, 'clouds come in (ref, src) pairs'
+            for q, l in enumerate(lengths_host[i]):
+                p.cloud_n[i][q] = int(l)
             if i < S - 1:
                 sub, up = data_dict['subsampling'][i], data_dict['upsampling'][i]
                 assert sub.is_contiguous() and up.is_contiguous()
@@ -237,7 +255,13 @@ class NativeModel:
 
     @torch.no_grad()
     def forward(self, data_dict):
-        """Whole forward in one native call.  Returns the output dict (same keys as GeoTransformer.forward)."""
+        """Whole forward of one pair in one native call.  Returns the output dict (same keys as GeoTransformer.forward)."""
+        return self.forward_batch(data_dict)[0]
+
+    @torch.no_grad()
+    def forward_batch(self, data_dict):
+        """One native call for B stacked pairs (clouds ordered ref_0, src_0, ref_1, src_1, ...; B = len(lengths[0]) / 2):
+        the KPConv-FPN runs once over the whole stack, the heads pair by pair.  Returns B output dicts."""
         lib = _bind()
         m = self.model
         desc = self.descriptor()
@@ -245,52 +269,72 @@ class NativeModel:
         if lengths is None:
             lengths = [l.tolist() for l in data_dict['lengths']]
         pyr = self.pyramid(data_dict, lengths)
+        B = int(pyr.num_pairs)
         S, fine = m.backbone.num_stages, m.backbone.fine_stage
         feats = data_dict['features']
         dev = feats.device
         n_c, n_f = int(pyr.n[S - 1]), int(pyr.n[fine])
-        nr_c, nr_f, nr = int(pyr.ref_n[S - 1]), int(pyr.ref_n[fine]), int(pyr.ref_n[0])
         P, K, topk = int(desc.num_correspondences), int(desc.num_points_in_patch), int(desc.topk)
         D = int(desc.transformer.out_proj.out)
         c_f = int(desc.backbone.decoder[desc.backbone.num_decoders - 1].out)
         cap = P * K * topk
         f32, i64 = torch.float32, torch.int64
+        # one allocation per output key for the whole stack; pair b uses slice b
         o = {
             'feats_c': torch.empty((n_c, D), dtype=f32, device=dev), 'feats_f': torch.empty((n_f, c_f), dtype=f32, device=dev),
-            'ref_node_corr_indices': torch.empty(P, dtype=i64, device=dev), 'src_node_corr_indices': torch.empty(P, dtype=i64, device=dev),
-            'node_corr_scores': torch.empty(P, dtype=f32, device=dev), 'num_node_corr': torch.empty(1, dtype=torch.int32, device=dev),
-            'ref_knn_indices': torch.empty((P, K), dtype=i64, device=dev), 'src_knn_indices': torch.empty((P, K), dtype=i64, device=dev),
-            'ref_knn_masks': torch.empty((P, K), dtype=torch.bool, device=dev), 'src_knn_masks': torch.empty((P, K), dtype=torch.bool, device=dev),
-            'ref_knn_points': torch.empty((P, K, 3), dtype=f32, device=dev), 'src_knn_points': torch.empty((P, K, 3), dtype=f32, device=dev),
-            'matching_scores': torch.empty((P, K + 1, K + 1), dtype=f32, device=dev),
-            'ref_corr_points': torch.empty((cap, 3), dtype=f32, device=dev), 'src_corr_points': torch.empty((cap, 3), dtype=f32, device=dev),
-            'corr_scores': torch.empty(cap, dtype=f32, device=dev), 'num_corr': torch.empty(1, dtype=torch.int32, device=dev),
-            'estimated_transform': torch.empty((4, 4), dtype=f32, device=dev),
+            'ref_node_corr_indices': torch.empty((B, P), dtype=i64, device=dev), 'src_node_corr_indices': torch.empty((B, P), dtype=i64, device=dev),
+            'node_corr_scores': torch.empty((B, P), dtype=f32, device=dev), 'num_node_corr': torch.empty((B, 1), dtype=torch.int32, device=dev),
+            'ref_knn_indices': torch.empty((B, P, K), dtype=i64, device=dev), 'src_knn_indices': torch.empty((B, P, K), dtype=i64, device=dev),
+            'ref_knn_masks': torch.empty((B, P, K), dtype=torch.bool, device=dev), 'src_knn_masks': torch.empty((B, P, K), dtype=torch.bool, device=dev),
+            'ref_knn_points': torch.empty((B, P, K, 3), dtype=f32, device=dev), 'src_knn_points': torch.empty((B, P, K, 3), dtype=f32, device=dev),
+            'matching_scores': torch.empty((B, P, K + 1, K + 1), dtype=f32, device=dev),
+            'ref_corr_points': torch.empty((B, cap, 3), dtype=f32, device=dev), 'src_corr_points': torch.empty((B, cap, 3), dtype=f32, device=dev),
+            'corr_scores': torch.empty((B, cap), dtype=f32, device=dev), 'num_corr': torch.empty((B, 1), dtype=torch.int32, device=dev),
+            'estimated_transform': torch.empty((B, 4, 4), dtype=f32, device=dev),
         }
-        outs = Outputs(*[o[name].data_ptr() for name, _ in Outputs._fields_])
+        off = [[0] for _ in range(S)]  # cloud row offsets per stage
+        for i in range(S):
+            for l in lengths[i]:
+                off[i].append(off[i][-1] + int(l))
+        outs = (Outputs * B)()
+        for b in range(B):
+            vals = {}
+            for name, _ in Outputs._fields_:
+                if name == 'feats_c':
+                    vals[name] = o[name][off[S - 1][2 * b]:].data_ptr()
+                elif name == 'feats_f':
+                    vals[name] = o[name][off[fine][2 * b]:].data_ptr()
+                else:
+                    vals[name] = o[name][b].data_ptr()
+            outs[b] = Outputs(*[vals[name] for name, _ in Outputs._fields_])
         nbytes = lib.geotr_model_workspace_bytes(ctypes.byref(desc), ctypes.byref(pyr))
         if nbytes == 0:
             raise RuntimeError('geotr_model_workspace_bytes failed: ' + lib.geotr_last_error().decode('utf-8', 'replace'))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        rc = lib.geotr_model_forward(ctypes.byref(desc), ctypes.byref(pyr), feats.data_ptr(), ctypes.byref(outs), ws.data_ptr(), nbytes,
+        rc = lib.geotr_model_forward(ctypes.byref(desc), ctypes.byref(pyr), feats.data_ptr(), outs, ws.data_ptr(), nbytes,
                                      torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, 'geotr_model_forward')
         ws.record_stream(torch.cuda.current_stream())
         points_c, points_f, points = data_dict['points'][-1], data_dict['points'][fine], data_dict['points'][0]
-        out = {
-            'ref_points_c': points_c[:nr_c], 'src_points_c': points_c[nr_c:], 'ref_points_f': points_f[:nr_f],
-            'src_points_f': points_f[nr_f:], 'ref_points': points[:nr], 'src_points': points[nr:],
-            'ref_feats_c': o['feats_c'][:nr_c], 'src_feats_c': o['feats_c'][nr_c:],
-            'ref_feats_f': o['feats_f'][:nr_f], 'src_feats_f': o['feats_f'][nr_f:],
-            'matching_scores': o['matching_scores'], 'estimated_transform': o['estimated_transform'],
-            'ref_node_corr_knn_points': o['ref_knn_points'], 'src_node_corr_knn_points': o['src_knn_points'],
-            'ref_node_corr_knn_masks': o['ref_knn_masks'], 'src_node_corr_knn_masks': o['src_knn_masks'],
-            # data-dependent lengths stay on the device; `finalize` trims them with one host read
-            '_ref_node_corr_indices': o['ref_node_corr_indices'], '_src_node_corr_indices': o['src_node_corr_indices'],
-            '_ref_corr_points': o['ref_corr_points'], '_src_corr_points': o['src_corr_points'], '_corr_scores': o['corr_scores'],
-            '_counts': (o['num_node_corr'], o['num_corr']),
-        }
-        return out
+        results = []
+        for b in range(B):
+            c0, c1, c2 = off[S - 1][2 * b], off[S - 1][2 * b + 1], off[S - 1][2 * b + 2]
+            f0, f1, f2 = off[fine][2 * b], off[fine][2 * b + 1], off[fine][2 * b + 2]
+            r0, r1, r2 = off[0][2 * b], off[0][2 * b + 1], off[0][2 * b + 2]
+            results.append({
+                'ref_points_c': points_c[c0:c1], 'src_points_c': points_c[c1:c2], 'ref_points_f': points_f[f0:f1],
+                'src_points_f': points_f[f1:f2], 'ref_points': points[r0:r1], 'src_points': points[r1:r2],
+                'ref_feats_c': o['feats_c'][c0:c1], 'src_feats_c': o['feats_c'][c1:c2],
+                'ref_feats_f': o['feats_f'][f0:f1], 'src_feats_f': o['feats_f'][f1:f2],
+                'matching_scores': o['matching_scores'][b], 'estimated_transform': o['estimated_transform'][b],
+                'ref_node_corr_knn_points': o['ref_knn_points'][b], 'src_node_corr_knn_points': o['src_knn_points'][b],
+                'ref_node_corr_knn_masks': o['ref_knn_masks'][b], 'src_node_corr_knn_masks': o['src_knn_masks'][b],
+                # data-dependent lengths stay on the device; `finalize` trims them with one host read
+                '_ref_node_corr_indices': o['ref_node_corr_indices'][b], '_src_node_corr_indices': o['src_node_corr_indices'][b],
+                '_ref_corr_points': o['ref_corr_points'][b], '_src_corr_points': o['src_corr_points'][b], '_corr_scores': o['corr_scores'][b],
+                '_counts': (o['num_node_corr'][b], o['num_corr'][b]),
+            })
+        return results
 
     @staticmethod
     def finalize(out):

@@ -13,6 +13,13 @@ from .model import create_model
 from .utils.data import precompute_data_stack_mode
 
 
+def _check_cloud(points):
+    if not (torch.is_tensor(points) and points.dim() == 2 and points.shape[1] == 3 and points.shape[0] > 0
+            and points.dtype == torch.float32 and points.is_cuda):
+        raise ValueError('a cloud must be a non-empty (N, 3) float32 device tensor, got '
+                         f'{tuple(points.shape) if torch.is_tensor(points) else type(points)}')
+
+
 class RegistrationPipeline:
     def __init__(self, cfg, model=None, device=None, exact_width=False):
         self.cfg = cfg
@@ -25,6 +32,7 @@ class RegistrationPipeline:
     def collate(self, ref_points, src_points, ref_feats=None, src_feats=None):
         """Device-resident equivalent of registration_collate_fn_stack_mode for one pair."""
         b = self.cfg.backbone
+        _check_cloud(ref_points), _check_cloud(src_points)
         points = torch.cat([ref_points, src_points], dim=0)
         lengths = torch.tensor([ref_points.shape[0], src_points.shape[0]], dtype=torch.int64, device=points.device)
         if ref_feats is None:
@@ -51,6 +59,30 @@ class RegistrationPipeline:
             out['_neighbor_overflow'] = overflow  # device int32: > 0 means a ball held more than 256 points (see check_overflow)
         return out
 
+    @torch.no_grad()
+    def register_batch(self, pairs):
+        """Several independent pairs through ONE launch sequence: the clouds are stacked (ref_0, src_0, ref_1, ...), the
+        pyramid and the KPConv-FPN run once over the stack (GroupNorm statistics stay per pair), the heads run pair by
+        pair.  `pairs` = [(ref_points, src_points), ...] (at most 16); returns one output dict per pair.  Per-pair results
+        agree with `__call__` to fp32 rounding (a taller stacked GEMM may use a different tiling than a single pair's)."""
+        from .native import NativeModel, build_pyramid
+        assert 1 <= len(pairs) <= 16 and not self.exact_width and self.model.use_native
+        b = self.cfg.backbone
+        clouds = [c for pair in pairs for c in pair]
+        for c in clouds:
+            _check_cloud(c)
+        points = torch.cat(clouds, dim=0)
+        lengths = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64, device=points.device)
+        data = build_pyramid(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.neighbor_limits)
+        data['features'] = torch.ones((points.shape[0], 1), dtype=torch.float32, device=points.device)
+        data['batch_size'] = len(pairs)
+        if self.model._native is None:
+            self.model._native = NativeModel(self.model)
+        outs = [NativeModel.finalize(o) for o in self.model._native.forward_batch(data)]
+        for o in outs:
+            o['_neighbor_overflow'] = data['_overflow']
+        return outs
+
     @staticmethod
     def check_overflow(out):
         """Raise if the fixed-capacity radius search overflowed for this pair (one host read; call when convenient)."""
@@ -70,9 +102,12 @@ class ConcurrentRegistration:
     and makes the caller's stream wait for the lanes.
     """
 
-    def __init__(self, pipeline, lanes=2):
+    def __init__(self, pipeline, lanes=2, stack=1):
+        """`stack` > 1: a lane takes up to `stack` queued pairs at a time and runs them as one stacked launch sequence
+        (RegistrationPipeline.register_batch)."""
         self.pipeline = pipeline
         self.lanes = max(1, int(lanes))
+        self.stack = max(1, min(16, int(stack)))
         self.device = pipeline.device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
         self._queue = queue.SimpleQueue()
@@ -94,31 +129,42 @@ class ConcurrentRegistration:
                 job = self._queue.get()
                 if job is None:
                     return
-                index, ref, src, sink, ready = job
                 try:
-                    stream.wait_event(ready)  # inputs produced on the submitter's stream
-                    sink(index, self.pipeline(ref, src))
+                    for index, ref, src, sink, ready in job:
+                        stream.wait_event(ready)  # inputs produced on the submitter's stream
+                    if len(job) == 1:
+                        index, ref, src, sink, _ = job[0]
+                        sink(index, self.pipeline(ref, src))
+                    else:
+                        outs = self.pipeline.register_batch([(ref, src) for _, ref, src, _, _ in job])
+                        for (index, _, _, sink, _), out in zip(job, outs):
+                            sink(index, out)
                 except BaseException as exc:  # surfaced by drain()
                     with self._cv:
                         self._error = self._error or exc
                 finally:
                     with self._cv:
-                        self._pending -= 1
+                        self._pending -= len(job)
                         if self._pending == 0:
                             self._cv.notify_all()
 
     def submit(self, pairs, sink):
         """Queue every (ref, src) of `pairs`; `sink(i, output_dict)` is called on the lane's stream per pair."""
         if self.lanes == 1:
-            for i, (ref, src) in enumerate(pairs):
-                sink(i, self.pipeline(ref, src))
+            for g in range(0, len(pairs), self.stack):
+                group = pairs[g:g + self.stack]
+                if len(group) == 1:
+                    sink(g, self.pipeline(*group[0]))
+                else:
+                    for j, out in enumerate(self.pipeline.register_batch(group)):
+                        sink(g + j, out)
             return
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
         with self._cv:
             self._pending += len(pairs)
-        for i, (ref, src) in enumerate(pairs):
-            self._queue.put((i, ref, src, sink, ready))
+        for g in range(0, len(pairs), self.stack):  # a job = up to `stack` pairs for one lane
+            self._queue.put([(g + j, ref, src, sink, ready) for j, (ref, src) in enumerate(pairs[g:g + self.stack])])
 
     def drain(self):
         """Wait until all submitted pairs are enqueued on their lanes; the current stream then waits for the lanes."""

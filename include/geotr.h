@@ -96,6 +96,18 @@ int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, int b_i
                const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                void* stream);
 
+/* Split-bf16 ("bf16x3") GEMM for tall activations against a STATIC weight:  C = act(alpha * A * W^T / row_div + bias + residual)
+ * with every fp32 product evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (hi = bf16(x),
+ * lo = bf16(x - hi); ~2^-17 relative error per product, fp32 accumulation).  geotr_gemm_pack converts the weight once
+ * -- W given as (n, k) row-major [b_is_kn = 0, nn.Linear] or (k, n) row-major [b_is_kn = 1, KPConv's flattened
+ * (15*C_in, C_out)] -- into geotr_gemm_pack_bytes(n, k) bytes of hi / lo planes in MFMA fragment order (16-byte aligned).
+ * geotr_gemm_packed has geotr_gemm's epilogue; intended for M >= 1024 (128-row tiles). */
+size_t geotr_gemm_pack_bytes(int64_t n, int64_t k);
+int geotr_gemm_pack(const float* B, int64_t ldb, int b_is_kn, int64_t n, int64_t k, void* packed, void* stream);
+int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                      const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K1/K2  KPConv backbone pieces
  *   geotr_row_positive   : flag[j] = (sum_c feats[j,c] > 0)                     kpconv/kpconv.py:113-114
@@ -125,6 +137,12 @@ int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int
 size_t geotr_group_norm_workspace_bytes(int64_t n, int64_t c);
 int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
                      float eps, const float* residual, int act, float* out, double* stats_ws, void* stream);
+/* GroupNorm with the statistics confined to row segments (one per stacked pair when several pairs share one launch
+ * sequence): seg_rows_host[nseg] (host) = rows per segment, summing to n; nseg <= GEOTR_MAX_PAIRS.  nseg = 1 is geotr_group_norm.
+ * A segment's result does not depend on what it is stacked with. */
+int geotr_group_norm_segmented(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                               const float* residual, int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws,
+                               void* stream);
 int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c, const float* gamma, const float* beta,
                      float eps, float* out, void* stream);
 
@@ -237,7 +255,11 @@ int geotr_lgr(const float* ref_knn_points, const float* src_knn_points, const ui
  * host (coarse-match and correspondence counts stay on the device), so the call is fully asynchronous on `stream`.
  * The descriptor structs hold plain device pointers to the module parameters (state_dict tensors).
  * ---------------------------------------------------------------------------------------------- */
-typedef struct geotr_linear { const float* w; const float* b; int64_t in, out; } geotr_linear;             /* nn.Linear: w (out,in) */
+typedef struct geotr_linear { const float* w; const float* b; int64_t in, out;
+  const void* packed;          /* optional geotr_gemm_pack(w, in, 0, out, in): used when the activation has >= GEOTR_PACKED_MIN_ROWS rows */
+} geotr_linear;                                                      /* nn.Linear: w (out,in) */
+#define GEOTR_PACKED_MIN_ROWS 1024
+#define GEOTR_MAX_PAIRS 16          /* pairs stacked into one forward (geotr_model_forward) / row segments of a GroupNorm */
 typedef struct geotr_norm { const float* gamma; const float* beta; int64_t groups; float eps; int32_t pad_; } geotr_norm; /* groups>0: GroupNorm; 0: LayerNorm */
 typedef struct geotr_kpconv {                                        /* geotransformer/modules/kpconv/kpconv.py:10-121 */
   const float* weights;        /* (num_kernel_points, in, out) */
@@ -245,6 +267,7 @@ typedef struct geotr_kpconv {                                        /* geotrans
   const float* kernel_points;  /* (num_kernel_points, 3) */
   int64_t in, out, num_kernel_points;
   float sigma; int32_t pad_;
+  const void* packed;          /* optional geotr_gemm_pack(weights, out, 1, out, num_kernel_points*in) */
 } geotr_kpconv;
 typedef struct geotr_block {                                         /* ConvBlock / ResidualBlock, kpconv/modules.py:105-225 */
   int32_t is_conv_block, has_unary1, has_shortcut, strided;
@@ -261,12 +284,12 @@ typedef struct geotr_backbone {                                      /* KPConvFP
   geotr_norm decoder_norm[GEOTR_MAX_STAGES];
 } geotr_backbone;
 typedef struct geotr_pyramid {                                       /* output of precompute_data_stack_mode, utils/data.py:13-77 */
-  int32_t num_stages, pad_;
+  int32_t num_stages, num_pairs;               /* num_pairs >= 1 pairs stacked as ref_0, src_0, ref_1, src_1, ... */
   const float* points[GEOTR_MAX_STAGES];       int64_t n[GEOTR_MAX_STAGES];
   const int64_t* neighbors[GEOTR_MAX_STAGES];  int64_t neighbors_w[GEOTR_MAX_STAGES];
   const int64_t* subsampling[GEOTR_MAX_STAGES]; int64_t subsampling_w[GEOTR_MAX_STAGES];
   const int64_t* upsampling[GEOTR_MAX_STAGES];  int64_t upsampling_w[GEOTR_MAX_STAGES];
-  int64_t ref_n[GEOTR_MAX_STAGES];             /* points of the reference cloud per stage (lengths[i][0]) */
+  int64_t cloud_n[GEOTR_MAX_STAGES][2 * GEOTR_MAX_PAIRS]; /* points per cloud per stage (lengths[i][:]) */
 } geotr_pyramid;
 typedef struct geotr_attn_layer {                                    /* RPETransformerLayer / TransformerLayer */
   int32_t is_self, pad_;
