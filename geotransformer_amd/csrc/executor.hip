@@ -61,8 +61,9 @@ static float* linear(Ctx& c, const geotr_linear& l, const float* x, int64_t lda,
 
 // GroupNorm (groups > 0) or LayerNorm (groups == 0) with optional residual / activation; returns a new (n, ch) buffer
 // `stage` selects the pair segments of the row set (GroupNorm only)
-static float* norm(Ctx& c, const geotr_norm& nm, const float* x, int64_t n, int64_t ch, const float* residual, int act, int stage = 0) {
-  float* y = c.alloc<float>((size_t)n * ch);
+static float* norm(Ctx& c, const geotr_norm& nm, const float* x, int64_t n, int64_t ch, const float* residual, int act, int stage = 0,
+                   float* y = nullptr) {
+  if (!y) y = c.alloc<float>((size_t)n * ch);
   if (nm.groups > 0) {
     const size_t m = c.mark();
     double* ws = reinterpret_cast<double*>(c.alloc<char>(geotr_group_norm_workspace_bytes(n, ch)));
@@ -178,9 +179,9 @@ static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geo
 
 // multi-head attention core on already projected q (n rows, ld ldq), k/v (m rows); returns hidden (n, C)
 static float* attention(Ctx& c, int H, int64_t C, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                        int64_t n, int64_t m, const float* emb, const geotr_linear* proj_p) {
+                        int64_t n, int64_t m, const float* emb, const geotr_linear* proj_p, float* hidden = nullptr) {
   const int64_t ch = C / H, mp = (m + 3) / 4 * 4;
-  float* hidden = c.alloc<float>((size_t)n * C);
+  if (!hidden) hidden = c.alloc<float>((size_t)n * C);
   const size_t mk = c.mark();
   float* scores = c.alloc<float>((size_t)H * n * mp);
   float* qt = emb ? c.alloc<float>((size_t)n * H * C) : nullptr;
@@ -198,63 +199,22 @@ static float* attention(Ctx& c, int H, int64_t C, const float* q, int64_t ldq, c
   return hidden;
 }
 
-static float* attn_tail(Ctx& c, const geotr_attn_layer& L, const float* hidden, const float* x, int64_t n, int64_t C) {
+static float* attn_tail(Ctx& c, const geotr_attn_layer& L, const float* hidden, const float* x, int64_t n, int64_t C, float* out = nullptr) {
   float* h2 = linear(c, L.out, hidden, C, n, 0);
   float* y = norm(c, L.norm, h2, n, C, x, 0);                       // LN(linear(attn) + x)
   float* e = linear(c, L.expand, y, C, n, 1);                       // ReLU fused
   float* s = linear(c, L.squeeze, e, L.expand.out, n, 0);
-  return norm(c, L.out_norm, s, n, C, y, 0);                        // LN(y + W2 relu(W1 y))
+  return norm(c, L.out_norm, s, n, C, y, 0, 0, out);                // LN(y + W2 relu(W1 y))
 }
 
-static float* self_layer(Ctx& c, const geotr_attn_layer& L, int H, const float* x, int64_t n, const float* emb) {
-  const int64_t C = L.q.in;
-  const float *q, *k, *v;
-  int64_t ld;
-  if (L.qkv_w) {
-    float* qkv = c.alloc<float>((size_t)n * 3 * C);
-    if (c.live())
-      c.check(geotr_gemm(x, C, L.qkv_w, C, 0, qkv, 3 * C, n, 3 * C, C, 1, 0, 0, 0, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-    q = qkv;
-    k = qkv + C;
-    v = qkv + 2 * C;
-    ld = 3 * C;
-  } else {
-    q = linear(c, L.q, x, C, n, 0);
-    k = linear(c, L.k, x, C, n, 0);
-    v = linear(c, L.v, x, C, n, 0);
-    ld = C;
-  }
-  float* hidden = attention(c, H, C, q, ld, k, ld, v, ld, n, n, emb, &L.p);
-  return attn_tail(c, L, hidden, x, n, C);
-}
-
-static float* cross_layer(Ctx& c, const geotr_attn_layer& L, int H, const float* x, int64_t n, const float* mem, int64_t m) {
-  const int64_t C = L.q.in;
-  const float* q = linear(c, L.q, x, C, n, 0);
-  const float *k, *v;
-  int64_t ld;
-  if (L.kv_w) {
-    float* kv = c.alloc<float>((size_t)m * 2 * C);
-    if (c.live())
-      c.check(geotr_gemm(mem, C, L.kv_w, C, 0, kv, 2 * C, m, 2 * C, C, 1, 0, 0, 0, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-    k = kv;
-    v = kv + C;
-    ld = 2 * C;
-  } else {
-    k = linear(c, L.k, mem, C, m, 0);
-    v = linear(c, L.v, mem, C, m, 0);
-    ld = C;
-  }
-  float* hidden = attention(c, H, C, q, C, k, ld, v, ld, n, m, nullptr, nullptr);
-  return attn_tail(c, L, hidden, x, n, C);
-}
-
-static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t n) {
+// `shared_ws` (optional): split-weight workspace shared by all clouds of a stack; `first` = this call fills it
+static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t n, char* shared_ws = nullptr, bool first = true) {
   const int64_t D = t.proj_d.out;
   float* emb = c.alloc<float>((size_t)n * n * D);
   int32_t* knn = c.alloc<int32_t>((size_t)n * t.angle_k);
   const size_t gws_bytes = geotr_gse_embed_workspace_bytes(D, t.gse_precision);
-  char* gws = c.alloc<char>(gws_bytes + 16);
+  char* gws = shared_ws ? shared_ws : c.alloc<char>(gws_bytes + 16);
+  const int precision = (t.gse_precision == 1 && shared_ws && !first) ? 2 : t.gse_precision;
   if (c.live()) {
     c.check(geotr_gse_knn(pts, n, t.angle_k, knn, c.stream));
     int slot = -1;
@@ -264,7 +224,7 @@ static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t 
     }
     if (slot >= 0) (void)hipEventRecord((hipEvent_t)g_prof_start[slot], c.stream);
     c.check(geotr_gse_embed(pts, knn, n, t.angle_k, D, t.div_term, t.proj_d.w, t.proj_d.b, t.proj_a.w, t.proj_a.b, t.sigma_d, t.sigma_a,
-                            t.gse_precision, gws, gws_bytes, emb, c.stream));
+                            precision, gws, gws_bytes, emb, c.stream));
     if (slot >= 0) {
       (void)hipEventRecord((hipEvent_t)g_prof_stop[slot], c.stream);
       g_prof_size[slot] = n;
@@ -273,13 +233,124 @@ static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t 
   return emb;
 }
 
+// ---- geometric transformer over a stack of pairs (model.py:133-145, conditional_transformer.py:97-117) --------------------
+// Working layout "refs first": rows [ref_0 .. ref_{B-1} | src_0 .. src_{B-1}], so that every row-wise op (projections, output
+// linear, LayerNorm, FFN) is ONE launch over all clouds (self layers) or over all reference / all source clouds (the two
+// sequential halves of a cross layer); only the attention core runs per cloud.
+struct RowMove {
+  int n;
+  int64_t src0[2 * GEOTR_MAX_PAIRS], dst0[2 * GEOTR_MAX_PAIRS], rows[2 * GEOTR_MAX_PAIRS];
+};
+__global__ __launch_bounds__(256) void move_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int C4, RowMove mv) {
+  const int seg = blockIdx.y;
+  const float4* s = reinterpret_cast<const float4*>(src) + mv.src0[seg] * C4;
+  float4* d = reinterpret_cast<float4*>(dst) + mv.dst0[seg] * C4;
+  const int64_t total = mv.rows[seg] * C4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) d[e] = s[e];
+}
+static void move_rows(Ctx& c, const float* src, float* dst, int64_t C, const RowMove& mv) {
+  if (!c.live()) return;
+  int64_t mx = 0;
+  for (int i = 0; i < mv.n; ++i) mx = std::max(mx, mv.rows[i]);
+  const unsigned gx = (unsigned)std::min<int64_t>((mx * (C / 4) + 255) / 256, 64);
+  move_rows_kernel<<<dim3(gx, (unsigned)mv.n), dim3(256), 0, c.stream>>>(src, dst, (int)(C / 4), mv);
+  if (hipGetLastError() != hipSuccess) c.check(fail(GEOTR_E_LAUNCH, "model_forward: move_rows launch failed"));
+}
+
+// feats_bb: (n_c, c_dim) coarse backbone features in stack order (ref_0, src_0, ref_1, ...); cloud_n[2B] superpoints per cloud;
+// feats_out: (n_c, D) L2-normalised transformer features, stack order (what the matching heads read).
+static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const int64_t* cloud_n, const float* pts_c, const float* feats_bb,
+                              int64_t c_dim, float* feats_out) {
+  const int64_t C = t.in_proj.out, D = t.out_proj.out;
+  const int H = t.num_heads;
+  int64_t stack0[2 * GEOTR_MAX_PAIRS], work0[2 * GEOTR_MAX_PAIRS];  // first row of cloud q in the stack / working layout
+  int64_t NR = 0, NS = 0, N = 0;
+  for (int b = 0; b < B; ++b) NR += cloud_n[2 * b], NS += cloud_n[2 * b + 1];
+  {
+    int64_t r = 0, s = NR;
+    for (int q = 0; q < 2 * B; ++q) {
+      stack0[q] = N;
+      N += cloud_n[q];
+      if (q % 2 == 0) work0[q] = r, r += cloud_n[q];
+      else work0[q] = s, s += cloud_n[q];
+    }
+  }
+  RowMove to_work, to_stack;
+  to_work.n = to_stack.n = 2 * B;
+  for (int q = 0; q < 2 * B; ++q) {
+    to_work.src0[q] = stack0[q], to_work.dst0[q] = work0[q], to_work.rows[q] = cloud_n[q];
+    to_stack.src0[q] = work0[q], to_stack.dst0[q] = stack0[q], to_stack.rows[q] = cloud_n[q];
+  }
+  // geometric structure embeddings, one (n, n, D) tensor per cloud, shared split-weight workspace
+  const float* emb[2 * GEOTR_MAX_PAIRS];
+  char* gws = c.alloc<char>(geotr_gse_embed_workspace_bytes(t.proj_d.out, t.gse_precision) + 16);
+  for (int q = 0; q < 2 * B; ++q) emb[q] = gse(c, t, pts_c + 3 * stack0[q], cloud_n[q], gws, q == 0);
+
+  float* xin = c.alloc<float>((size_t)N * c_dim);
+  move_rows(c, feats_bb, xin, c_dim, to_work);
+  const float* x = linear(c, t.in_proj, xin, c_dim, N, 0);
+  for (int l = 0; l < t.num_layers; ++l) {
+    const geotr_attn_layer& L = t.layers[l];
+    float* y = c.alloc<float>((size_t)N * C);
+    if (L.is_self) {
+      const float *q, *k, *v;
+      int64_t ld;
+      if (L.qkv_w) {
+        float* qkv = c.alloc<float>((size_t)N * 3 * C);
+        if (c.live())
+          c.check(geotr_gemm(x, C, L.qkv_w, C, 0, qkv, 3 * C, N, 3 * C, C, 1, 0, 0, 0, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+        q = qkv, k = qkv + C, v = qkv + 2 * C, ld = 3 * C;
+      } else {
+        q = linear(c, L.q, x, C, N, 0), k = linear(c, L.k, x, C, N, 0), v = linear(c, L.v, x, C, N, 0), ld = C;
+      }
+      float* hidden = c.alloc<float>((size_t)N * C);
+      for (int g = 0; g < 2 * B; ++g) {
+        const int64_t r0 = work0[g], n = cloud_n[g];
+        attention(c, H, C, q + r0 * ld, ld, k + r0 * ld, ld, v + r0 * ld, ld, n, n, emb[g], &L.p, hidden + r0 * C);
+      }
+      attn_tail(c, L, hidden, x, N, C, y);
+    } else {
+      // sequential cross-attention (conditional_transformer.py:110-111): refs attend to the sources, then the sources to the
+      // UPDATED refs; half 0: targets = refs (rows [0, NR)), memory = sources; half 1: the other way round on y's new ref rows
+      for (int half = 0; half < 2; ++half) {
+        const int64_t t0 = half == 0 ? 0 : NR, nt = half == 0 ? NR : NS;
+        const int64_t m0 = half == 0 ? NR : 0, nm = half == 0 ? NS : NR;
+        const float* xt = x + t0 * C;
+        const float* xm = half == 0 ? x + m0 * C : y + m0 * C;
+        const float* q = linear(c, L.q, xt, C, nt, 0);
+        const float *k, *v;
+        int64_t ld;
+        if (L.kv_w) {
+          float* kv = c.alloc<float>((size_t)nm * 2 * C);
+          if (c.live())
+            c.check(geotr_gemm(xm, C, L.kv_w, C, 0, kv, 2 * C, nm, 2 * C, C, 1, 0, 0, 0, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+          k = kv, v = kv + C, ld = 2 * C;
+        } else {
+          k = linear(c, L.k, xm, C, nm, 0), v = linear(c, L.v, xm, C, nm, 0), ld = C;
+        }
+        float* hidden = c.alloc<float>((size_t)nt * C);
+        for (int b = 0; b < B; ++b) {
+          const int gt = 2 * b + half, gm = 2 * b + 1 - half;  // target / memory cloud of pair b
+          const int64_t rt = work0[gt] - t0, rm = work0[gm] - m0;
+          attention(c, H, C, q + rt * C, C, k + rm * ld, ld, v + rm * ld, ld, cloud_n[gt], cloud_n[gm], nullptr, nullptr, hidden + rt * C);
+        }
+        attn_tail(c, L, hidden, xt, nt, C, y + t0 * C);
+      }
+    }
+    x = y;
+  }
+  float* g = linear(c, t.out_proj, x, C, N, 0);
+  float* gn = c.alloc<float>((size_t)N * D);
+  if (c.live()) c.check(geotr_l2_normalize(g, N, D, gn, c.stream));
+  move_rows(c, gn, feats_out, D, to_stack);
+}
+
 // heads of one pair: superpoint patches, geometric transformer, coarse matching, patch OT, LGR.  All pointers are the pair's
 // own slices of the stacked arrays (reference cloud first).
 static void run_pair(Ctx& c, const geotr_model& net, const float* pts_c, int64_t nr_c, int64_t ns_c, const float* pts_f, int64_t nr_f,
-                     int64_t ns_f, const float* feats_c_bb, int64_t c_dim, const float* feats_f, int64_t c_f, const geotr_outputs& o) {
+                     int64_t ns_f, const float* feats_f, int64_t c_f, const geotr_outputs& o) {
   const int64_t n_c = nr_c + ns_c, n_f = nr_f + ns_f;
   const int64_t K = net.num_points_in_patch, P = net.num_correspondences;
-  struct { const float* feats_c; int64_t c_dim; } bb = {feats_c_bb, c_dim};
 
   // 1. superpoint patches (model.py:98-108)
   int64_t* p2n = c.alloc<int64_t>((size_t)n_f);
@@ -293,33 +364,7 @@ static void run_pair(Ctx& c, const geotr_model& net, const float* pts_c, int64_t
     c.check(geotr_point_to_node(pts_f + 3 * nr_f, ns_f, pts_c + 3 * nr_c, ns_c, K, p2n + nr_f, node_masks + nr_c, node_knn_idx + nr_c * K,
                                 node_knn_mask + nr_c * K, scratch_flag, c.stream));
   }
-  const size_t mk_bb = c.mark();
-
-  // 3. geometric transformer (model.py:133-145)
-  const geotr_transformer& t = net.transformer;
-  const int64_t C = t.in_proj.out;
-  const float* emb_r = gse(c, t, pts_c, nr_c);
-  const float* emb_s = gse(c, t, pts_c + 3 * nr_c, ns_c);
-  const float* f0 = linear(c, t.in_proj, bb.feats_c, bb.c_dim, nr_c, 0);
-  const float* f1 = linear(c, t.in_proj, bb.feats_c + nr_c * bb.c_dim, bb.c_dim, ns_c, 0);
-  for (int l = 0; l < t.num_layers; ++l) {
-    const geotr_attn_layer& L = t.layers[l];
-    if (L.is_self) {
-      f0 = self_layer(c, L, t.num_heads, f0, nr_c, emb_r);
-      f1 = self_layer(c, L, t.num_heads, f1, ns_c, emb_s);
-    } else {  // sequential: the source attends to the already-updated reference (conditional_transformer.py:110-111)
-      f0 = cross_layer(c, L, t.num_heads, f0, nr_c, f1, ns_c);
-      f1 = cross_layer(c, L, t.num_heads, f1, ns_c, f0, nr_c);
-    }
-  }
-  const int64_t D = t.out_proj.out;
-  float* g0 = linear(c, t.out_proj, f0, C, nr_c, 0);
-  float* g1 = linear(c, t.out_proj, f1, C, ns_c, 0);
-  if (c.live()) {
-    c.check(geotr_l2_normalize(g0, nr_c, D, o.feats_c, c.stream));
-    c.check(geotr_l2_normalize(g1, ns_c, D, o.feats_c + nr_c * D, c.stream));
-  }
-  c.release(mk_bb);  // backbone / transformer intermediates are dead from here on
+  const int64_t D = net.transformer.out_proj.out;  // o.feats_c already holds the L2-normalised transformer features (transformer_stack)
 
   // 4. coarse matching (model.py:153-160)
   float* sim = c.alloc<float>((size_t)nr_c * ns_c);
@@ -370,6 +415,14 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
     c.check(fail(GEOTR_E_LAUNCH, "model_forward: copy failed"));
   c.release(mk);
 
+  // geometric transformer over the whole stack -> L2-normalised superpoint features in the caller's stack-ordered buffer
+  {
+    const size_t mt = c.mark();
+    float* feats_c_out = c.dry ? nullptr : outs[0].feats_c;
+    transformer_stack(c, net.transformer, B, p.cloud_n[S - 1], p.points[S - 1], feats_c, c_dim, feats_c_out);
+    c.release(mt);
+  }
+
   int64_t off_c = 0, off_f = 0;
   for (int b = 0; b < B; ++b) {
     const int64_t nr_c = p.cloud_n[S - 1][2 * b], ns_c = p.cloud_n[S - 1][2 * b + 1];
@@ -377,11 +430,11 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
     geotr_outputs o;
     if (c.dry) std::memset(&o, 0, sizeof(o));
     else o = outs[b];
-    if (!c.dry && o.feats_f != feats_f + off_f * c_f && c.rc == GEOTR_OK)
-      c.rc = fail(GEOTR_E_INVALID, "model_forward: outputs[%d].feats_f must be row %lld of the stacked fine features", b, (long long)off_f);
+    if (!c.dry && (o.feats_f != feats_f + off_f * c_f || o.feats_c != outs[0].feats_c + off_c * net.transformer.out_proj.out) &&
+        c.rc == GEOTR_OK)
+      c.rc = fail(GEOTR_E_INVALID, "model_forward: outputs[%d].feats_f / feats_c must be the pair's rows of the stacked buffers", b);
     const size_t mp = c.mark();
-    run_pair(c, net, p.points[S - 1] + 3 * off_c, nr_c, ns_c, p.points[fine] + 3 * off_f, nr_f, ns_f, feats_c + off_c * c_dim, c_dim,
-             feats_f + off_f * c_f, c_f, o);
+    run_pair(c, net, p.points[S - 1] + 3 * off_c, nr_c, ns_c, p.points[fine] + 3 * off_f, nr_f, ns_f, feats_f + off_f * c_f, c_f, o);
     c.release(mp);
     off_c += nr_c + ns_c;
     off_f += nr_f + ns_f;

@@ -502,7 +502,7 @@ static int launch_gse(int k, const float* pts, const int* knn, int n, const floa
 
 extern "C" {
 
-size_t geotr_gse_embed_workspace_bytes(int64_t d, int precision) { return precision == 1 ? (size_t)(8 * d * d) : 0; }
+size_t geotr_gse_embed_workspace_bytes(int64_t d, int precision) { return precision >= 1 ? (size_t)(8 * d * d) : 0; }
 
 int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t k, int64_t d, const float* div_term,
                     const float* w_d, const float* b_d, const float* w_a, const float* b_a, float sigma_d, float sigma_a,
@@ -515,15 +515,17 @@ int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t 
   hipStream_t stream = (hipStream_t)stream_;
   const float inv_sigma_d = 1.0f / sigma_d;
   const float factor_a = (float)(180.0 / ((double)sigma_a * 3.14159265358979323846));  // geotransformer.py:14
-  GEOTR_CHECK_ARG(precision == 0 || precision == 1, "gse_embed: precision must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)");
-  if (precision == 1) {
+  GEOTR_CHECK_ARG(precision >= 0 && precision <= 2, "gse_embed: precision must be 0 (fp32 MFMA), 1 (split-bf16 MFMA) or 2 (1, workspace reused)");
+  if (precision >= 1) {
     GEOTR_CHECK_ARG(ws && ws_bytes >= (size_t)(8 * d * d) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
                     "gse_embed: split-bf16 path needs a 16-byte aligned workspace of 8*d*d bytes");
     unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
     const int64_t dd = d * d;
     const unsigned nbs = (unsigned)((dd / 8 + 255) / 256);
-    split_bf16_swz_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_d, (int)d, wsplit, wsplit + dd);
-    split_bf16_swz_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_a, (int)d, wsplit + 2 * dd, wsplit + 3 * dd);
+    if (precision == 1) {  // precision 2: `ws` still holds the split weights of an earlier call with the same w_d / w_a
+      split_bf16_swz_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_d, (int)d, wsplit, wsplit + dd);
+      split_bf16_swz_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_a, (int)d, wsplit + 2 * dd, wsplit + 3 * dd);
+    }
     int rc2;
     switch (d) {
       case 32: rc2 = launch_gse_bf16x3<32>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream); break;

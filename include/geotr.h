@@ -162,7 +162,8 @@ int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c
 int geotr_gse_knn(const float* points, int64_t n, int64_t k, int32_t* knn, void* stream);
 /* precision 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products);  precision 1: split-bf16 ("bf16x3") MFMA --
  * every operand x = hi + lo in bf16, a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, relative error ~2^-17 per product, 3/16 of the
- * fp32 matrix time; needs ws of geotr_gse_embed_workspace_bytes(d, 1) bytes (16-byte aligned). */
+ * fp32 matrix time; needs ws of geotr_gse_embed_workspace_bytes(d, 1) bytes (16-byte aligned);  precision 2: as 1, but `ws` still
+ * holds the split weights written by an earlier precision-1 call with the same w_d / w_a (one split per stack of clouds). */
 size_t geotr_gse_embed_workspace_bytes(int64_t d, int precision);
 int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t k, int64_t d, const float* div_term,
                     const float* w_d, const float* b_d, const float* w_a, const float* b_a, float sigma_d, float sigma_a,
