@@ -414,6 +414,65 @@ __global__ __launch_bounds__(256) void attn_pos_kernel(float* __restrict__ score
   }
 }
 
+// Self-attention with relative positions, one block per query row i, all heads:
+//   scores[h,i,j] <- softmax_j( (scores[h,i,j] + e[i,j,:] . qt[i,h,:] + qb[i,h]) * scale )
+// One lane per key: the lane streams its key's embedding row in 128-byte bursts (8 x float4 = one cache line per burst), the
+// query's qt row sits in LDS and is read as broadcasts.  The (n, n, C) embedding is read exactly once per layer -- this kernel
+// is its only consumer -- so it is bound by that stream.
+template <int H>
+__global__ __launch_bounds__(256) void attn_pos_softmax_kernel(float* __restrict__ scores, const float* __restrict__ emb,
+                                                               const float* __restrict__ qt, const float* __restrict__ qb, int n, int m,
+                                                               int ld, int C, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* qt_s = smem;          // [C][H]
+  float* sc_s = smem + C * H;  // [H][m]
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < C * H; e += 256) {
+    const int c = e / H, h = e % H;
+    qt_s[e] = qt[((int64_t)i * H + h) * C + c];
+  }
+  __syncthreads();
+  float qbv[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) qbv[h] = qb[(int64_t)i * H + h];
+  for (int j = tid; j < m; j += 256) {
+    const float4* row = reinterpret_cast<const float4*>(emb + ((int64_t)i * m + j) * C);
+    float acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[h] = 0.f;
+    for (int cb = 0; cb < C / 32; ++cb) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = row[cb * 8 + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* w = qt_s + (cb * 32 + u * 4) * H;
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+          acc[h] = fmaf(v[u].w, w[3 * H + h], fmaf(v[u].z, w[2 * H + h], fmaf(v[u].y, w[H + h], fmaf(v[u].x, w[h], acc[h]))));
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) sc_s[h * m + j] = (scores[((int64_t)h * n + i) * ld + j] + (acc[h] + qbv[h])) * scale;
+  }
+  __syncthreads();
+  for (int h = wave; h < H; h += 4) {  // wave per head
+    float mx = -3.4e38f;
+    for (int j = lane; j < m; j += 64) mx = fmaxf(mx, sc_s[h * m + j]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = lane; j < m; j += 64) {
+      const float ev = expf(sc_s[h * m + j] - mx);
+      sc_s[h * m + j] = ev;
+      sum += ev;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.f / sum;
+    float* dst = scores + ((int64_t)h * n + i) * ld;
+    for (int j = lane; j < m; j += 64) dst[j] = sc_s[h * m + j] * inv;
+  }
+}
+
 // softmax over the keys of one query row, all heads: scores <- softmax(scores * scale)
 __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ scores, int n, int m, int ld, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) float sc_s[];  // [H][m]
@@ -556,6 +615,27 @@ int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float*
   GEOTR_CHECK_ARG(scores && (!emb || (qt && qb)), "attn_softmax: null pointer");
   GEOTR_CHECK_ARG(!emb || (c % 16 == 0 && c <= 512), "attn_softmax: channels must be a multiple of 16, <= 512");
   hipStream_t stream = (hipStream_t)stream_;
+  if (emb && c % 32 == 0 && (heads == 1 || heads == 2 || heads == 4 || heads == 8)) {  // fused positional term + softmax
+    const size_t lds = sizeof(float) * (size_t)(c * heads + heads * m);
+    if (lds > 160 * 1024) return fail(GEOTR_E_CAPACITY, "attn_softmax: %lld keys need %zu B of LDS", (long long)m, lds);
+    auto go = [&](auto kern) -> int {
+      if (lds > 64 * 1024 &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return fail(GEOTR_E_LAUNCH, "attn_softmax: cannot reserve %zu B of LDS", lds);
+      kern<<<dim3((unsigned)n), dim3(256), lds, stream>>>(scores, emb, qt, qb, (int)n, (int)m, (int)ld, (int)c, scale);
+      return GEOTR_OK;
+    };
+    int rc;
+    switch (heads) {
+      case 1: rc = go(attn_pos_softmax_kernel<1>); break;
+      case 2: rc = go(attn_pos_softmax_kernel<2>); break;
+      case 4: rc = go(attn_pos_softmax_kernel<4>); break;
+      default: rc = go(attn_pos_softmax_kernel<8>); break;
+    }
+    if (rc != GEOTR_OK) return rc;
+    GEOTR_CHECK_LAUNCH("attn_softmax");
+    return GEOTR_OK;
+  }
   if (emb) {
     const size_t lds = sizeof(float) * (size_t)(c * heads + 8 * heads * kAttTile + kAttTile * (c + 1));
     if (lds > 64 * 1024 &&
