@@ -35,13 +35,93 @@ struct GemmArgs {
   int act;  // 0 none, 1 relu, 2 leaky relu (0.1)
 };
 
+
+// Fused epilogue of a wave's (32*WM) x (32*WN) accumulator block:  C = act(alpha * acc / row_div + bias + residual).
+// The MFMA C/D layout (col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) gives each lane one column of 16
+// scattered rows; storing from it directly (two 128-byte pieces per instruction) cost ~6-10 us per launch, so the block is
+// transposed in a wave-private LDS slab ((32*WM) x (32*WN + 4) floats) and written as float4 row segments.
+template <int WM, int WN>
+__device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float* slab, int lane, int row0, int col0, int M, int N,
+                                             float alpha, const float* __restrict__ bias, const int32_t* __restrict__ row_div,
+                                             const float* __restrict__ residual, int64_t ldr, int act, float* __restrict__ C, int64_t ldc) {
+  constexpr int TW = 32 * WN, TS = TW + 4;
+  const int fr = lane & 31, fk = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk) * TS + 32 * j + fr] = acc[i][j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr int V4 = TW / 4, RPI = 64 / V4;  // float4 per row, rows per wave instruction
+  const int cq = (lane % V4) * 4, rl = lane / V4;
+  const int gn = col0 + cq;
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (ldc % 4 == 0) &&
+                      (!residual || ((reinterpret_cast<uintptr_t>(residual) & 15) == 0 && ldr % 4 == 0)) &&
+                      (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+  const bool full = vec_ok && gn + 3 < N;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+    if (full) {
+      const float4 q = *reinterpret_cast<const float4*>(bias + gn);
+      bv[0] = q.x, bv[1] = q.y, bv[2] = q.z, bv[3] = q.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gn + e < N) bv[e] = bias[gn + e];
+    }
+  }
+#pragma unroll 4
+  for (int rr = rl; rr < 32 * WM; rr += RPI) {
+    const int gm = row0 + rr;
+    if (gm >= M || gn >= N) continue;
+    const float4 a = *reinterpret_cast<const float4*>(slab + rr * TS + cq);
+    float x[4] = {a.x * alpha, a.y * alpha, a.z * alpha, a.w * alpha};
+    if (row_div) {
+      const float d = (float)max(row_div[gm], 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = x[e] / d;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] += bv[e];
+    if (residual) {
+      const float* rp = residual + (int64_t)gm * ldr + gn;
+      if (full) {
+        const float4 q = *reinterpret_cast<const float4*>(rp);
+        x[0] += q.x, x[1] += q.y, x[2] += q.z, x[3] += q.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gn + e < N) x[e] += rp[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (act == 1) x[e] = fmaxf(x[e], 0.f);
+      if (act == 2) x[e] = x[e] > 0.f ? x[e] : 0.1f * x[e];
+    }
+    float* cp = C + (int64_t)gm * ldc + gn;
+    if (full) {
+      *reinterpret_cast<float4*>(cp) = make_float4(x[0], x[1], x[2], x[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gn + e < N) cp[e] = x[e];
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int WAVES_N = BN / (32 * WN);
   constexpr int T = 256;
   static_assert((BM / (32 * WM)) * WAVES_N == 4, "4 waves per block");
-  __shared__ float As[BM * kLdsStride];
-  __shared__ float Bs[BN * kLdsStride];
+  constexpr int kTileFloats = (BM + BN) * kLdsStride, kSlabFloats = 4 * 32 * WM * (32 * WN + 4);
+  __shared__ __attribute__((aligned(16))) float smem_t[kTileFloats > kSlabFloats ? kTileFloats : kSlabFloats];
+  float* As = smem_t;
+  float* Bs = smem_t + BM * kLdsStride;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -173,27 +253,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int gn = n0 + wcol + 32 * j + fr;
-      if (gn >= g.N) continue;
-      const float bias = g.bias ? g.bias[gn] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + wrow + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
-        if (gm >= g.M) continue;
-        float v = acc[i][j][r] * g.alpha;
-        if (g.row_div) v = v / (float)max(g.row_div[gm], 1);
-        v += bias;
-        if (g.residual) v += g.residual[(int64_t)blockIdx.z * g.strideC + (int64_t)gm * g.ldr + gn];
-        if (g.act == 1) v = fmaxf(v, 0.f);
-        if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
-        C[(int64_t)gm * g.ldc + gn] = v;
-      }
-    }
+  // (the K loop ended with a barrier: the staging tiles are free and become the per-wave transpose slabs)
+  const float* res = g.residual ? g.residual + (int64_t)blockIdx.z * g.strideC : nullptr;
+  epilogue_lds<WM, WN>(acc, smem_t + wave * (32 * WM * (32 * WN + 4)), lane, m0 + wrow, n0 + wcol, g.M, g.N, g.alpha, g.bias, g.row_div, res,
+                       g.ldr, g.act, C, g.ldc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -340,8 +403,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 // under the MFMAs.  Block = 4 waves; wave tile = (32*WM) x (32*WN); BM = 128.
 // packed layout: plane[ct = n / 32][kk = k / 16][lane = n % 32 + 32 * ((k % 16) / 8)][k % 8], K padded to 32, N to 32.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kPRS = 40;  // LDS row stride of the packed kernel in bf16 elements
-
 struct PackedArgs {
   const float* A;
   const unsigned short* Bhi;
@@ -375,64 +436,70 @@ __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b
   *reinterpret_cast<uint4*>(lo + v * 8) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
-template <int WM, int WN, bool VEC>
+// Pipeline: both operands of a 32-deep step are DMA'd straight into LDS (global_load_lds_dwordx4: no register staging), kPStages
+// steps deep -- the activation tile raw fp32 (128 rows x 128 B, 16-byte chunks XOR-swizzled by row so the fragment reads are
+// at most 2-way conflicted), the weight fragments as packed.  The fp32 -> (hi, lo) bf16 split happens when a wave reads its A
+// fragment (v_cvt_pk_bf16_f32).  One barrier per step; each wave issues 4 + WAVES... loads per step and waits on its own
+// vmcnt, then the barrier publishes the stage to the other waves.
+constexpr int kPStages = 4;
+#define GEOTR_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | (((N) >> 4) << 14) | 0x0F70)
+// LDS reads of DMA-written data go through inline asm: the compiler's own waitcnt insertion would otherwise drain ALL
+// outstanding LDS DMA (vmcnt(0)) before any ds_read it can see.  One asm block = a batch of ds_read_b128 + s_waitcnt lgkmcnt(0),
+// so its outputs are valid when it ends.  Addresses are byte offsets into LDS; OFF* are compile-time immediates.
+template <int O1, int O2, int O3>
+__device__ __forceinline__ void lds_read4(unsigned addr, uint4& r0, uint4& r1, uint4& r2, uint4& r3) {
+  asm volatile(
+      "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(addr), "n"(O1), "n"(O2), "n"(O3)
+      : "memory");
+}
+template <int O1>
+__device__ __forceinline__ void lds_read2(unsigned addr, uint4& r0, uint4& r1) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(r0), "=&v"(r1)
+               : "v"(addr), "n"(O1)
+               : "memory");
+}
+template <int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   constexpr int BM = 128;
-  constexpr int WAVES_M = BM / (32 * WM), WAVES_N = 4 / WAVES_M, BN = 32 * WN * WAVES_N;
-  constexpr int PLANE = BM * kPRS;
-  __shared__ __attribute__((aligned(16))) unsigned short sm[2 * 2 * PLANE];  // [buf][hi, lo][128][40]
+  constexpr int WAVES_M = BM / (32 * WM), WAVES_N = 4 / WAVES_M, NT_BLK = WN * WAVES_N;  // column tiles per block
+  constexpr int A_BYTES = BM * 128, B_BYTES = NT_BLK * 2 * 2 * 1024, STAGE = A_BYTES + B_BYTES;
+  constexpr int B_INSTR = NT_BLK * 4;              // 1 KB weight chunks per stage: (plane, ct, kk)
+  constexpr int B_PER_WAVE = (B_INSTR + 3) / 4;    // issued round-robin by the 4 waves
+  constexpr int LOADS = 4 + B_PER_WAVE;            // DMA instructions per wave and stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int wrow = (wave / WAVES_N) * 32 * WM, wct = n0 / 32 + (wave % WAVES_N) * WN;  // wave's first row / column tile
+  const int m0 = blockIdx.y * BM, ct0 = blockIdx.x * NT_BLK;
+  const int wrow = (wave / WAVES_N) * 32 * WM, wctl = (wave % WAVES_N) * WN;  // wave's first row / local column tile
   const int fr = lane & 31, fk = lane >> 5;
+  const int nkt = g.KS / 2;
+  const int64_t plane_elems = (int64_t)g.NT * g.KS * 512;  // bf16 elements per plane
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)psm;
 
-  float4 ra[4];  // 128 rows x 8 float4 per row / 256 threads
-  auto load_a = [&](int k0) {
+  // per-lane source addresses of the A DMA: instruction t covers rows 8t .. 8t+7, lane -> (row, swizzled 16-byte chunk)
+  const float* a_src[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int f = tid + 256 * s, row = f >> 3, kq = (f & 7) * 4;
-      const int gm = m0 + row, gk = k0 + kq;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gm < g.M) {
-        const float* p = g.A + (int64_t)gm * g.lda + gk;
-        if (VEC && gk + 3 < g.K) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (gk < g.K) v.x = p[0];
-          if (gk + 1 < g.K) v.y = p[1];
-          if (gk + 2 < g.K) v.z = p[2];
-          if (gk + 3 < g.K) v.w = p[3];
-        }
-      }
-      ra[s] = v;
-    }
-  };
-  auto store_a = [&](int buf) {
-    unsigned short* hi = sm + (2 * buf) * PLANE;
-    unsigned short* lo = hi + PLANE;
+  for (int s = 0; s < 4; ++s) {
+    const int r = 8 * (4 * wave + s) + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    const int gm = min(m0 + r, g.M - 1);  // rows past M: any valid row (never stored)
+    a_src[s] = g.A + (int64_t)gm * g.lda + 4 * c;
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = psm + (kt % kPStages) * STAGE;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int f = tid + 256 * s, row = f >> 3, kq = (f & 7) * 4;
-      const float x[4] = {ra[s].x, ra[s].y, ra[s].z, ra[s].w};
-      unsigned h[4], l[4];
+    for (int s = 0; s < 4; ++s)
+      __builtin_amdgcn_global_load_lds(a_src[s] + kt * 32, (__attribute__((address_space(3))) void*)(st + (4 * wave + s) * 1024), 16, 0, 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        h[j] = f32_to_bf16_rne(x[j]);
-        l[j] = f32_to_bf16_rne(x[j] - bf16_to_f32(h[j]));
-      }
-      *reinterpret_cast<uint2*>(hi + row * kPRS + kq) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-      *reinterpret_cast<uint2*>(lo + row * kPRS + kq) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
-    }
-  };
-  const bf16x8* bhi = reinterpret_cast<const bf16x8*>(g.Bhi);
-  const bf16x8* blo = reinterpret_cast<const bf16x8*>(g.Blo);
-  bf16x8 bh[WN], bl[WN], nh[WN], nl[WN];
-  auto load_b = [&](int kk, bf16x8(&h)[WN], bf16x8(&l)[WN]) {
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int64_t o = ((int64_t)min(wct + j, g.NT - 1) * g.KS + kk) * 64 + lane;  // column tiles past N: clamped, never stored
-      h[j] = bhi[o];
-      l[j] = blo[o];
+    for (int s = 0; s < B_PER_WAVE; ++s) {
+      const int idx = min(wave + 4 * s, B_INSTR - 1);  // (tail duplicates keep LOADS uniform across waves)
+      const int pl = idx / (NT_BLK * 2), ctl = (idx / 2) % NT_BLK, kq = idx & 1;
+      const int ct = min(ct0 + ctl, g.NT - 1);
+      const unsigned short* src = g.Bhi + pl * plane_elems + (((int64_t)ct * g.KS + 2 * kt + kq) * 64 + lane) * 8;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + A_BYTES + idx * 1024), 16, 0, 0);
     }
   };
 
@@ -444,60 +511,54 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nkt = g.KS / 2;  // 32-deep steps (K is padded to 32 in the packed weight)
-  load_a(0);
-  load_b(0, bh, bl);
-  store_a(0);
-  __syncthreads();
+  for (int kt = 0; kt < kPStages - 1 && kt < nkt; ++kt) issue(kt);
   for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_a((kt + 1) * 32);
-    const unsigned short* A_hi = sm + (2 * buf) * PLANE;
-    const unsigned short* A_lo = A_hi + PLANE;
+    // stage kt must have landed; stages kt+1 .. min(kt + kPStages - 2, nkt - 1) may still be in flight
+    const int later = min(kt + kPStages - 2, nkt - 1) - kt;
+    if (later >= 2) GEOTR_WAIT_VMCNT(2 * LOADS);
+    else if (later == 1) GEOTR_WAIT_VMCNT(LOADS);
+    else GEOTR_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in LDS, and everyone is done with the slot refilled below
+    if (kt + kPStages - 1 < nkt) issue(kt + kPStages - 1);
+    const unsigned st = lds_base + (kt % kPStages) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int kk = 2 * kt + ks;
-      if (kk + 1 < g.KS) load_b(kk + 1, nh, nl);
-      const int kb = 16 * ks + 8 * fk;
+      // B fragments of this wave's WN column tiles: (plane, tile) at constant offsets from the first one
+      constexpr int PL = NT_BLK * 2 * 1024, CT = 2 * 1024;
+      const unsigned ab = st + A_BYTES + (wctl * 2 + ks) * 1024 + lane * 16;
+      uint4 rb[2][2], ra[2][2];
+      if constexpr (WN == 2) lds_read4<PL, CT, PL + CT>(ab, rb[0][0], rb[1][0], rb[0][1], rb[1][1]);
+      else lds_read2<PL>(ab, rb[0][0], rb[1][0]);
+      // A fragment: two swizzled 16-byte chunks of row r (row tile i = 1 sits 32 rows = 4096 B further, same swizzle)
+      const int r = wrow + fr, c0 = 4 * ks + 2 * fk;
+      const unsigned a0 = st + (r * 8 + (c0 ^ (r & 7))) * 16, a1 = st + (r * 8 + ((c0 + 1) ^ (r & 7))) * 16;
+      lds_read2<4096>(a0, ra[0][0], ra[1][0]);
+      lds_read2<4096>(a1, ra[0][1], ra[1][1]);
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A_hi + (wrow + 32 * i + fr) * kPRS + kb);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(A_lo + (wrow + 32 * i + fr) * kPRS + kb);
+        const float x[8] = {__uint_as_float(ra[i][0].x), __uint_as_float(ra[i][0].y), __uint_as_float(ra[i][0].z), __uint_as_float(ra[i][0].w),
+                            __uint_as_float(ra[i][1].x), __uint_as_float(ra[i][1].y), __uint_as_float(ra[i][1].z), __uint_as_float(ra[i][1].w)};
+        bf16x8 ah, al;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ah[e] = (__bf16)x[e];
+          al[e] = (__bf16)(x[e] - (float)ah[e]);
+        }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, rb[0][j]), bl = __builtin_bit_cast(bf16x8, rb[1][j]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
         }
       }
-#pragma unroll
-      for (int j = 0; j < WN; ++j) bh[j] = nh[j], bl[j] = nl[j];
     }
-    if (kt + 1 < nkt) store_a(buf ^ 1);
-    __syncthreads();
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int gn = 32 * (wct + j) + fr;
-      if (gn >= g.N) continue;
-      const float bias = g.bias ? g.bias[gn] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + wrow + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
-        if (gm >= g.M) continue;
-        float v = acc[i][j][r] * g.alpha;
-        if (g.row_div) v = v / (float)max(g.row_div[gm], 1);
-        v += bias;
-        if (g.residual) v += g.residual[(int64_t)gm * g.ldr + gn];
-        if (g.act == 1) v = fmaxf(v, 0.f);
-        if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
-        g.C[(int64_t)gm * g.ldc + gn] = v;
-      }
-    }
+  // epilogue through LDS (the ring is free once every wave has read the last stage)
+  __builtin_amdgcn_s_barrier();
+  epilogue_lds<WM, WN>(acc, reinterpret_cast<float*>(psm) + wave * (32 * WM * (32 * WN + 4)), lane, m0 + wrow, 32 * (ct0 + wctl), g.M, g.N,
+                       g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act, g.C, g.ldc);
 }
 
 }  // namespace geotr
@@ -570,15 +631,18 @@ extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed
   g.C = C; g.bias = bias; g.row_div = row_div; g.residual = residual;
   g.lda = lda; g.ldc = ldc; g.ldr = residual ? ldr : 0;
   g.M = (int)M; g.N = (int)N; g.K = (int)K; g.KS = (int)(kp / 16); g.NT = (int)(np / 32); g.alpha = alpha; g.act = act;
-  const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
+  GEOTR_CHECK_ARG((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && K % 32 == 0,
+                  "gemm_packed: A must be 16-byte aligned with lda %% 4 == 0 and K %% 32 == 0 (use geotr_gemm otherwise)");
   hipStream_t stream = (hipStream_t)stream_;
   const unsigned gy = (unsigned)((M + 127) / 128);
   GEOTR_CHECK_ARG(gy <= 65535, "gemm_packed: M too large");
-#define GEOTR_PACKED(WM, WN, BN)                                                                              \
-  do {                                                                                                        \
-    dim3 grid((unsigned)((N + BN - 1) / BN), gy);                                                             \
-    if (vec) gemm_packed_kernel<WM, WN, true><<<grid, dim3(256), 0, stream>>>(g);                             \
-    else gemm_packed_kernel<WM, WN, false><<<grid, dim3(256), 0, stream>>>(g);                                \
+#define GEOTR_PACKED(WM, WN, BN)                                                                                        \
+  do {                                                                                                                  \
+    const int lds = kPStages * (128 * 128 + (BN / 32) * 4096);                                                          \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            lds) != hipSuccess)                                                                         \
+      return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);                                      \
+    gemm_packed_kernel<WM, WN><<<dim3((unsigned)((N + BN - 1) / BN), gy), dim3(256), lds, stream>>>(g);                 \
   } while (0)
   if (N > 64) GEOTR_PACKED(2, 2, 128);
   else if (N > 32) GEOTR_PACKED(1, 2, 64);

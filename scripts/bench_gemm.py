@@ -40,7 +40,7 @@ def main():
         out = torch.empty(M, N, device=dev)
         t = timeit(lambda: kernels.gemm(a, w, bias=bias, out=out))
         ref = out.clone()
-        if M >= 1024 and K % 4 == 0:
+        if M >= 1024 and K % 32 == 0:
             pk = kernels.gemm_pack(w)
             tp = timeit(lambda: kernels.gemm_packed(a, pk, N, bias=bias, out=out))
             err = float((out - ref).abs().max() / ref.abs().max())
