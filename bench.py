@@ -92,9 +92,9 @@ def main():
     ap.add_argument('--config', default='3dmatch', choices=['3dmatch', 'modelnet', 'kitti'])
     ap.add_argument('--points', type=int, default=None, help='points per cloud (default: the config\'s)')
     ap.add_argument('--pairs', type=int, default=8, help='distinct synthetic pairs cycled through per rank')
-    ap.add_argument('--batch', type=int, default=8, help='pairs per step per GPU (independent pairs of one batch)')
-    ap.add_argument('--lanes', type=int, default=8, help='pairs kept in flight concurrently (host thread + HIP stream each)')
-    ap.add_argument('--stack', type=int, default=1, help='pairs stacked into one launch sequence per lane (<= 16; divides --batch)')
+    ap.add_argument('--batch', type=int, default=32, help='pairs per step per GPU (independent pairs of one batch)')
+    ap.add_argument('--lanes', type=int, default=4, help='pairs kept in flight concurrently (host thread + HIP stream each)')
+    ap.add_argument('--stack', type=int, default=8, help='pairs stacked into one launch sequence per lane (<= 16; divides --batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

@@ -47,11 +47,16 @@ struct Ctx {
   }
 };
 
+// packed split-bf16 path: tall activations, 16-byte aligned rows, K a multiple of 32 (geotr_gemm_packed's contract)
+static inline bool use_packed(const void* packed, const float* a, int64_t lda, int64_t m, int64_t k) {
+  return packed && m >= GEOTR_PACKED_MIN_ROWS && k % 32 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0;
+}
+
 static float* linear(Ctx& c, const geotr_linear& l, const float* x, int64_t lda, int64_t m, int act, const float* residual = nullptr,
                      int64_t ldr = 0) {
   float* y = c.alloc<float>((size_t)m * l.out);
   if (c.live()) {
-    if (l.packed && m >= GEOTR_PACKED_MIN_ROWS)
+    if (use_packed(l.packed, x, lda, m, l.in))
       c.check(geotr_gemm_packed(x, lda, l.packed, y, l.out, m, l.out, l.in, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
     else
       c.check(geotr_gemm(x, lda, l.w, l.in, 0, y, l.out, m, l.out, l.in, 1, 0, 0, 0, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
@@ -89,7 +94,7 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     c.check(geotr_kpconv_gather(s_feats, q_pts, s_pts, nb, kp.kernel_points, flag, m, ns, h, kp.in, kp.num_kernel_points, kp.sigma,
                                 weighted, nnum, c.stream));
     const int64_t kdim = kp.num_kernel_points * kp.in;
-    if (kp.packed && m >= GEOTR_PACKED_MIN_ROWS)
+    if (use_packed(kp.packed, weighted, kdim, m, kdim))
       c.check(geotr_gemm_packed(weighted, kdim, kp.packed, out, kp.out, m, kp.out, kdim, kp.bias, nnum, nullptr, 0, 1.0f, 0, c.stream));
     else
       c.check(geotr_gemm(weighted, kdim, kp.weights, kp.out, 1, out, kp.out, m, kp.out, kdim, 1, 0, 0, 0, kp.bias, nnum, nullptr, 0,
@@ -161,7 +166,7 @@ static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geo
     const geotr_linear& l = net.decoder[d];
     if (i == net.fine_stage) {  // LastUnaryBlock: straight into the caller's buffer
       if (c.live()) {
-        if (l.packed && p.n[i] >= GEOTR_PACKED_MIN_ROWS)
+        if (use_packed(l.packed, cat, tot, p.n[i], l.in))
           c.check(geotr_gemm_packed(cat, tot, l.packed, feats_f_out, l.out, p.n[i], l.out, l.in, l.b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
         else
           c.check(geotr_gemm(cat, tot, l.w, l.in, 0, feats_f_out, l.out, p.n[i], l.out, l.in, 1, 0, 0, 0, l.b, nullptr, nullptr, 0, 1.0f, 0,

@@ -47,9 +47,15 @@ def gemm(a, b, b_is_kn=False, bias=None, row_div=None, residual=None, alpha=1.0,
     return out
 
 
-GEMM_PACKED = False     # False: exact fp32 MFMA for every backbone contraction
+GEMM_PACKED = True      # False: exact fp32 MFMA for every backbone contraction
 PACKED_MIN_ROWS = 1024  # activations with at least this many rows use the packed split-bf16 GEMM when a packed weight is given
 _PACK_CACHE = {}
+
+
+def use_packed(a):
+    """Same predicate as the native executor: tall, 16-byte aligned rows, K a multiple of 32."""
+    return (GEMM_PACKED and a.shape[0] >= PACKED_MIN_ROWS and a.shape[1] % 32 == 0 and a.stride(0) % 4 == 0
+            and a.data_ptr() % 16 == 0)
 
 
 def gemm_pack(weight, b_is_kn=False):
@@ -96,7 +102,7 @@ def linear(x, weight, bias=None, act=None, residual=None, packed=False):
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     res2 = residual.reshape(-1, weight.shape[0]) if residual is not None else None
-    if packed and GEMM_PACKED and x2.shape[0] >= PACKED_MIN_ROWS:
+    if packed and use_packed(x2):
         y = gemm_packed(x2, gemm_pack(weight), weight.shape[0], bias=bias, act=act, residual=res2)
     else:
         y = gemm(x2, weight, bias=bias, act=act, residual=res2)

@@ -46,7 +46,7 @@ class KPConv(nn.Module):
         """s_feats (N, C_in), q_points (M, 3), s_points (N, 3), neighbor_indices (M, H) int64 -> (M, C_out)."""
         weighted, nnum = kernels.kpconv_gather(s_feats, q_points, s_points, neighbor_indices, self.kernel_points, self.sigma)
         w2d = self.weights.view(self.kernel_size * self.in_channels, self.out_channels)  # (15*C_in, C_out), K-major
-        if kernels.GEMM_PACKED and weighted.shape[0] >= kernels.PACKED_MIN_ROWS:  # same dispatch as the native executor
+        if kernels.use_packed(weighted):  # same dispatch as the native executor
             return kernels.gemm_packed(weighted, kernels.gemm_pack(w2d, b_is_kn=True), self.out_channels, bias=self.bias, row_div=nnum)
         return kernels.gemm(weighted, w2d, b_is_kn=True, bias=self.bias, row_div=nnum)
 
