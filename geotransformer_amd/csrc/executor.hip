@@ -302,8 +302,12 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
       int64_t ld;
       if (L.qkv_w) {
         float* qkv = c.alloc<float>((size_t)N * 3 * C);
-        if (c.live())
-          c.check(geotr_gemm(x, C, L.qkv_w, C, 0, qkv, 3 * C, N, 3 * C, C, 1, 0, 0, 0, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+        if (c.live()) {
+          if (use_packed(L.qkv_packed, x, C, N, C))
+            c.check(geotr_gemm_packed(x, C, L.qkv_packed, qkv, 3 * C, N, 3 * C, C, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+          else
+            c.check(geotr_gemm(x, C, L.qkv_w, C, 0, qkv, 3 * C, N, 3 * C, C, 1, 0, 0, 0, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+        }
         q = qkv, k = qkv + C, v = qkv + 2 * C, ld = 3 * C;
       } else {
         q = linear(c, L.q, x, C, N, 0), k = linear(c, L.k, x, C, N, 0), v = linear(c, L.v, x, C, N, 0), ld = C;
@@ -327,8 +331,12 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
         int64_t ld;
         if (L.kv_w) {
           float* kv = c.alloc<float>((size_t)nm * 2 * C);
-          if (c.live())
-            c.check(geotr_gemm(xm, C, L.kv_w, C, 0, kv, 2 * C, nm, 2 * C, C, 1, 0, 0, 0, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+          if (c.live()) {
+            if (use_packed(L.kv_packed, xm, C, nm, C))
+              c.check(geotr_gemm_packed(xm, C, L.kv_packed, kv, 2 * C, nm, 2 * C, C, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+            else
+              c.check(geotr_gemm(xm, C, L.kv_w, C, 0, kv, 2 * C, nm, 2 * C, C, 1, 0, 0, 0, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+          }
           k = kv, v = kv + C, ld = 2 * C;
         } else {
           k = linear(c, L.k, xm, C, nm, 0), v = linear(c, L.v, xm, C, nm, 0), ld = C;

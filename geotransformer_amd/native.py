@@ -61,7 +61,7 @@ class PyramidBuffers(ctypes.Structure):
 class AttnLayer(ctypes.Structure):
     _fields_ = [('is_self', I32), ('pad_', I32), ('q', Linear), ('k', Linear), ('v', Linear), ('p', Linear), ('out', Linear),
                 ('expand', Linear), ('squeeze', Linear), ('norm', Norm), ('out_norm', Norm),
-                ('qkv_w', P_F32), ('qkv_b', P_F32), ('kv_w', P_F32), ('kv_b', P_F32)]
+                ('qkv_w', P_F32), ('qkv_b', P_F32), ('kv_w', P_F32), ('kv_b', P_F32), ('qkv_packed', ctypes.c_void_p), ('kv_packed', ctypes.c_void_p)]
 
 
 class Transformer(ctypes.Structure):
@@ -192,24 +192,31 @@ class NativeModel:
         t.gse_precision = int(kernels.GSE_PRECISION)
         t.div_term = _ptr(tr.embedding.embedding.div_term)
         t.proj_d, t.proj_a = _linear(tr.embedding.proj_d), _linear(tr.embedding.proj_a)
-        t.in_proj, t.out_proj = _linear(tr.in_proj), _linear(tr.out_proj)
+        t.in_proj, t.out_proj = _linear(tr.in_proj, self._keep), _linear(tr.out_proj, self._keep)  # packed: used when pairs are stacked
         for i, (kind, layer) in enumerate(zip(tr.transformer.blocks, layers)):
             a = AttnLayer()
             att = layer.attention.attention
             a.is_self = int(kind == 'self')
-            a.q, a.k, a.v = _linear(att.proj_q), _linear(att.proj_k), _linear(att.proj_v)
+            a.q, a.k, a.v = _linear(att.proj_q, self._keep), _linear(att.proj_k), _linear(att.proj_v)
             if a.is_self:
                 a.p = _linear(att.proj_p)
                 w = torch.cat([att.proj_q.weight, att.proj_k.weight, att.proj_v.weight], 0).detach().contiguous()
                 b = torch.cat([att.proj_q.bias, att.proj_k.bias, att.proj_v.bias], 0).detach().contiguous()
                 a.qkv_w, a.qkv_b = _ptr(w), _ptr(b)
+                if kernels.GEMM_PACKED:
+                    self._keep.append(kernels.gemm_pack(w))
+                    a.qkv_packed = self._keep[-1].data_ptr()
             else:
                 w = torch.cat([att.proj_k.weight, att.proj_v.weight], 0).detach().contiguous()
                 b = torch.cat([att.proj_k.bias, att.proj_v.bias], 0).detach().contiguous()
                 a.kv_w, a.kv_b = _ptr(w), _ptr(b)
+                if kernels.GEMM_PACKED:
+                    self._keep.append(kernels.gemm_pack(w))
+                    a.kv_packed = self._keep[-1].data_ptr()
             self._keep += [w, b]
-            a.out, a.norm = _linear(layer.attention.linear), _norm(layer.attention.norm)
-            a.expand, a.squeeze, a.out_norm = _linear(layer.output.expand), _linear(layer.output.squeeze), _norm(layer.output.norm)
+            a.out, a.norm = _linear(layer.attention.linear, self._keep), _norm(layer.attention.norm)
+            a.expand, a.squeeze = _linear(layer.output.expand, self._keep), _linear(layer.output.squeeze, self._keep)
+            a.out_norm = _norm(layer.output.norm)
             t.layers[i] = a
         d.alpha = _ptr(m.optimal_transport.alpha)
         d.num_points_in_patch = m.num_points_in_patch

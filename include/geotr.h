@@ -298,6 +298,7 @@ typedef struct geotr_attn_layer {                                    /* RPETrans
   geotr_norm norm, out_norm;
   const float* qkv_w; const float* qkv_b;                            /* optional fused (3C, C) / (3C) projection (self) */
   const float* kv_w;  const float* kv_b;                             /* optional fused (2C, C) / (2C) projection (cross) */
+  const void* qkv_packed; const void* kv_packed;                     /* optional geotr_gemm_pack of the fused weights (stacked pairs) */
 } geotr_attn_layer;
 typedef struct geotr_transformer {                                   /* GeometricTransformer, modules/geotransformer/geotransformer.py:75-155 */
   int32_t num_layers, num_heads, angle_k, pad_;
