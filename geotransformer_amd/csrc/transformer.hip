@@ -10,6 +10,8 @@
 //                        qt = W_p[h]^T q[h] is the algebraic collapse of proj_p over the (N,N,D) embedding
 //                        (transformer/rpe_transformer.py:51-62).  With emb == NULL it is the plain
 //                        scaled softmax of transformer/vanilla_transformer.py:55-63.
+#include <algorithm>
+
 #include "common.h"
 
 namespace geotr {
@@ -343,18 +345,27 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
     if (late_gen && c + 1 < CH) generate(c + 1, buf ^ 1);
     __syncthreads();
   }
+  // epilogue d + max_k(a) + biases: the MFMA C layout gives each lane one channel of 16 scattered pairs, so the 64 x D tile is
+  // transposed through LDS (the A buffers are free after the loop's last barrier) and every wave writes whole 4*D-byte rows.
   const int col = 32 * wave + fr;
+  constexpr int TS = D + 4;
+  float* tile = reinterpret_cast<float*>(smem16);  // [64][D + 4] floats over the (now free) A buffers; the launch reserves max(A, tile)
+  const float bdv = bd[col], bav = ba[col];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int64_t p = p0 + 32 * r + (q & 3) + 8 * (q >> 2) + 4 * fk;
-      if (p >= total) continue;
       float m = acc[r][1][q];
 #pragma unroll
       for (int s = 2; s < S; ++s) m = fmaxf(m, acc[r][s][q]);
-      out[p * D + col] = (acc[r][0][q] + bd[col]) + (m + ba[col]);
+      tile[(32 * r + (q & 3) + 8 * (q >> 2) + 4 * fk) * TS + col] = (acc[r][0][q] + bdv) + (m + bav);
     }
+  __syncthreads();
+  for (int e = tid; e < kGsePairs * (D / 4); e += T) {
+    const int row = e / (D / 4), c4 = e % (D / 4);
+    const int64_t p = p0 + row;
+    if (p < total) *reinterpret_cast<float4*>(out + p * D + 4 * c4) = *reinterpret_cast<const float4*>(tile + row * TS + 4 * c4);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -520,7 +531,8 @@ static int launch_gse_bf16x3(int k, const float* pts, const int* knn, int n, con
   const int64_t total = (int64_t)n * n;
   const unsigned nb = (unsigned)((total + kGsePairs - 1) / kGsePairs);
   const int S = 1 + k;
-  const size_t lds = 2 * ((size_t)4 * S * kGsePairs * kGseRS) + sizeof(float) * (size_t)S * kGsePairs;
+  const size_t lds = std::max<size_t>(2 * ((size_t)4 * S * kGsePairs * kGseRS) + sizeof(float) * (size_t)S * kGsePairs,
+                                      sizeof(float) * kGsePairs * (size_t)(D + 4));  // A ring + indices, or the epilogue tile
   auto go = [&](auto kern) -> int {
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

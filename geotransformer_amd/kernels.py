@@ -49,7 +49,6 @@ def gemm(a, b, b_is_kn=False, bias=None, row_div=None, residual=None, alpha=1.0,
 
 GEMM_PACKED = True      # False: exact fp32 MFMA for every backbone contraction
 PACKED_MIN_ROWS = 1024  # activations with at least this many rows use the packed split-bf16 GEMM when a packed weight is given
-_PACK_CACHE = {}
 
 
 def use_packed(a):
@@ -58,22 +57,25 @@ def use_packed(a):
             and a.data_ptr() % 16 == 0)
 
 
-def gemm_pack(weight, b_is_kn=False):
-    """Packed hi/lo bf16 planes of a static 2-D weight ((N,K), or (K,N) with b_is_kn) for gemm_packed; cached per
-    (storage, version), so an updated parameter is re-packed."""
-    assert weight.dim() == 2 and weight.stride(-1) == 1 and weight.dtype == torch.float32
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0), bool(b_is_kn), weight.device.index)
-    hit = _PACK_CACHE.get(key)
-    if hit is not None:
-        return hit
+def gemm_pack(weight, b_is_kn=False, view=None):
+    """Packed hi/lo bf16 planes of a static weight for gemm_packed.  `weight` is the parameter itself (2-D (N,K), or (K,N) with
+    b_is_kn; `view` = 2-D shape to read it as, e.g. KPConv's (15*C_in, C_out)).  The result is cached ON the tensor object
+    together with its version counter, so an in-place update re-packs and a freed tensor cannot leave a stale entry behind."""
+    w2 = weight.detach() if view is None else weight.detach().view(*view)
+    assert w2.dim() == 2 and w2.stride(-1) == 1 and w2.dtype == torch.float32
+    key = (weight._version, weight.data_ptr(), tuple(w2.shape), w2.stride(0), bool(b_is_kn), weight.device.index)
+    hit = getattr(weight, '_geotr_packed', None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
     lib = _lib.load()
-    n, k = (weight.shape[1], weight.shape[0]) if b_is_kn else (weight.shape[0], weight.shape[1])
+    n, k = (w2.shape[1], w2.shape[0]) if b_is_kn else (w2.shape[0], w2.shape[1])
     packed = torch.empty(lib.geotr_gemm_pack_bytes(n, k), dtype=torch.uint8, device=weight.device)
-    _lib.check(lib.geotr_gemm_pack(_lib.ptr(weight), weight.stride(0), int(b_is_kn), n, k, _lib.ptr(packed), _lib.stream_ptr()),
+    _lib.check(lib.geotr_gemm_pack(_lib.ptr(w2), w2.stride(0), int(b_is_kn), n, k, _lib.ptr(packed), _lib.stream_ptr()),
                'geotr_gemm_pack')
-    if len(_PACK_CACHE) > 4096:
-        _PACK_CACHE.clear()
-    _PACK_CACHE[key] = packed
+    try:
+        weight._geotr_packed = (key, packed)
+    except AttributeError:  # tensors that reject attributes are simply not cached
+        pass
     return packed
 
 

@@ -47,7 +47,8 @@ class KPConv(nn.Module):
         weighted, nnum = kernels.kpconv_gather(s_feats, q_points, s_points, neighbor_indices, self.kernel_points, self.sigma)
         w2d = self.weights.view(self.kernel_size * self.in_channels, self.out_channels)  # (15*C_in, C_out), K-major
         if kernels.use_packed(weighted):  # same dispatch as the native executor
-            return kernels.gemm_packed(weighted, kernels.gemm_pack(w2d, b_is_kn=True), self.out_channels, bias=self.bias, row_div=nnum)
+            packed = kernels.gemm_pack(self.weights, b_is_kn=True, view=(self.kernel_size * self.in_channels, self.out_channels))
+            return kernels.gemm_packed(weighted, packed, self.out_channels, bias=self.bias, row_div=nnum)
         return kernels.gemm(weighted, w2d, b_is_kn=True, bias=self.bias, row_div=nnum)
 
     def __repr__(self):

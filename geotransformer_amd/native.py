@@ -126,7 +126,7 @@ def _norm(mod):
 def _kpconv(mod, keep=None):
     packed = None
     if keep is not None and kernels.GEMM_PACKED:
-        keep.append(kernels.gemm_pack(mod.weights.view(mod.kernel_size * mod.in_channels, mod.out_channels), b_is_kn=True))
+        keep.append(kernels.gemm_pack(mod.weights, b_is_kn=True, view=(mod.kernel_size * mod.in_channels, mod.out_channels)))
         packed = keep[-1].data_ptr()
     return KPConvDesc(_ptr(mod.weights), _ptr(mod.bias), _ptr(mod.kernel_points), mod.in_channels, mod.out_channels,
                       mod.kernel_size, float(mod.sigma), 0, packed)
