@@ -40,7 +40,7 @@ def _run(exp, overrides, n_points, seed, overlap=0.6):
     return cfg, got, want
 
 
-def _check(got, want, min_overlap=0.97):
+def _check(got, want, min_overlap=0.97, min_same_order=0.9):
     """Continuous outputs: feature MSE <= 1e-6 (north_star bound 1e-4).  Discrete coarse selection (global top-k of nearly flat
     scores under random weights): the selected pair SETS must overlap >= min_overlap and the sorted score lists must agree;
     when the selection is identical, everything downstream is compared one to one."""
@@ -60,7 +60,7 @@ def _check(got, want, min_overlap=0.97):
         # compare the patches whose point order is identical, and require that to be nearly all of them
         same_order = (torch.eq(got['ref_node_corr_knn_points'].cpu(), want['ref_node_corr_knn_points']).flatten(1).all(1) &
                       torch.eq(got['src_node_corr_knn_points'].cpu(), want['src_node_corr_knn_points']).flatten(1).all(1))
-        assert float(same_order.float().mean()) >= 0.9, float(same_order.float().mean())
+        assert float(same_order.float().mean()) >= min_same_order, float(same_order.float().mean())
         gm, wm = gm[same_order], wm[same_order]
         live = wm > -1e11  # masked entries are -1e12 + O(ulp(1e12)) noise in any implementation
         assert torch.equal(live, gm > -1e11)
@@ -96,3 +96,39 @@ def test_modelnet_three_stage_full_width():
     cfg, got, want = _run('modelnet', None, 1024, 8)
     assert cfg.backbone.num_stages == 3 and got['matching_scores'].shape[1:] == (129, 129)
     _check(got, want)
+
+
+@pytest.mark.parametrize('exp,over,n_points', [
+    ('3dmatch', None, 6000),   # full widths: packed split-bf16 GEMMs and the stacked transformer engage (>= 1024 stacked rows)
+    ('modelnet', {'backbone.init_dim': 16, 'backbone.group_norm': 4, 'backbone.output_dim': 64, 'geotransformer.input_dim': 128,
+                  'geotransformer.hidden_dim': 64, 'geotransformer.output_dim': 64}, 1024),
+    ('kitti', {'backbone.init_dim': 16, 'backbone.group_norm': 4, 'backbone.output_dim': 64, 'geotransformer.input_dim': 512,
+               'geotransformer.hidden_dim': 128, 'geotransformer.output_dim': 64, 'coarse_matching.num_correspondences': 64}, 12000),
+])
+def test_stacked_pairs_vs_oracle(exp, over, n_points):
+    """Three pairs of different sizes through ONE stacked launch sequence (pyramid, KPConv-FPN with segmented GroupNorm, stacked
+    transformer), each compared with the CPU oracle run on that pair alone."""
+    from geotransformer_amd.config import make_cfg
+    from geotransformer_amd.pipeline import RegistrationPipeline
+    from geotransformer_amd.synthetic import make_pair
+    from oracle import model_oracle as mo
+    from oracle import neighbors as on
+    cfg = make_cfg(exp, over)
+    torch.manual_seed(cfg.seed)
+    np.random.seed(cfg.seed)
+    pipe = RegistrationPipeline(cfg, device='cuda:0')
+    items = [make_pair(90 + i, exp, n_points=int(n_points * (1.0 + 0.15 * i))) for i in range(3)]
+    pairs = [(torch.from_numpy(it['ref_points']).cuda(), torch.from_numpy(it['src_points']).cuda()) for it in items]
+    outs = pipe.register_batch(pairs)
+    sd = {k: v.detach().cpu() for k, v in pipe.model.state_dict().items()}
+    b = cfg.backbone
+    for it, got in zip(items, outs):
+        pts = np.concatenate([it['ref_points'], it['src_points']])
+        lens = np.array([len(it['ref_points']), len(it['src_points'])], dtype=np.int64)
+        pyr = on.precompute_pyramid(on.restated(), pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+        assert got['ref_points_c'].shape[0] + got['src_points_c'].shape[0] == pyr['points'][-1].shape[0]
+        assert np.array_equal(torch.cat([got['ref_points_c'], got['src_points_c']]).cpu().numpy(), pyr['points'][-1])
+        odata = {k: [torch.from_numpy(np.ascontiguousarray(a)) for a in v] for k, v in pyr.items()}
+        odata['features'] = torch.ones((pts.shape[0], 1))
+        want = mo.forward(sd, mo.config_from_reference(cfg), odata)
+        _check(got, want, min_overlap=0.95, min_same_order=0.75)  # small ModelNet-shape clouds have many equidistant points
