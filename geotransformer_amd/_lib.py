@@ -55,6 +55,8 @@ SIGNATURES = {
                                            c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_registration_metrics': (c_int, [c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_ptr,
                                            c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    'geotr_attn_softmax_grouped': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_f32, c_ptr]),
+    'geotr_gemm_grouped': (c_int, [c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_i64, c_f32, c_ptr]),
     'geotr_gemm_pack_bytes': (c_size, [c_i64, c_i64]),
     'geotr_gemm_pack': (c_int, [c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_gemm_packed': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),

@@ -262,6 +262,51 @@ static void move_rows(Ctx& c, const float* src, float* dst, int64_t C, const Row
   if (hipGetLastError() != hipSuccess) c.check(fail(GEOTR_E_LAUNCH, "model_forward: move_rows launch failed"));
 }
 
+// Attention cores of G (target, memory) cloud pairs in three grouped launches (+ two for the positional collapse):
+// q rows of group g start at q + qrow[g] * ldq (n[g] rows), k / v rows at k + krow[g] * ldkv (m[g] rows); hidden (rows, C) gets the
+// result at row qrow[g].  emb != nullptr (self-attention): emb[g] = (n[g], n[g], C) embedding, proj_p collapsed into qt / qb.
+static void attention_groups(Ctx& c, int H, int64_t C, int G, const int64_t* n, const int64_t* m, const float* q, int64_t ldq,
+                             const int64_t* qrow, int64_t q_rows_total, const float* k, const float* v, int64_t ldkv, const int64_t* krow,
+                             const float* const* emb, const geotr_linear* proj_p, float* hidden) {
+  const int64_t ch = C / H;
+  const size_t mk = c.mark();
+  geotr_gemm_groups g1, g2;
+  geotr_attn_groups ga;
+  std::memset(&g1, 0, sizeof(g1)), std::memset(&g2, 0, sizeof(g2)), std::memset(&ga, 0, sizeof(ga));
+  g1.count = g2.count = ga.count = G;
+  int64_t total = 0;
+  for (int g = 0; g < G; ++g) {
+    const int64_t mp = (m[g] + 3) / 4 * 4;
+    // scores_g (H, n, mp) = q_h k_h^T
+    g1.m[g] = n[g], g1.n[g] = m[g], g1.k[g] = ch;
+    g1.lda[g] = ldq, g1.ldb[g] = ldkv, g1.ldc[g] = mp;
+    g1.a_off[g] = qrow[g] * ldq, g1.b_off[g] = krow[g] * ldkv, g1.c_off[g] = total;
+    g1.a_head_stride[g] = ch, g1.b_head_stride[g] = ch, g1.c_head_stride[g] = n[g] * mp;
+    // hidden_g (n, C) = softmax(scores_g) v_h
+    g2.m[g] = n[g], g2.n[g] = ch, g2.k[g] = m[g];
+    g2.lda[g] = mp, g2.ldb[g] = ldkv, g2.ldc[g] = C;
+    g2.a_off[g] = total, g2.b_off[g] = krow[g] * ldkv, g2.c_off[g] = qrow[g] * C;
+    g2.a_head_stride[g] = n[g] * mp, g2.b_head_stride[g] = ch, g2.c_head_stride[g] = ch;
+    ga.n[g] = n[g], ga.m[g] = m[g], ga.ld[g] = mp, ga.scores_off[g] = total, ga.q_row0[g] = qrow[g];
+    ga.emb[g] = emb ? emb[g] : nullptr;
+    total += (int64_t)H * n[g] * mp;
+  }
+  float* scores = c.alloc<float>((size_t)total);
+  float* qt = emb ? c.alloc<float>((size_t)q_rows_total * H * C) : nullptr;
+  float* qb = emb ? c.alloc<float>((size_t)q_rows_total * H) : nullptr;
+  if (c.live()) {
+    c.check(geotr_gemm_grouped(q, k, 0, scores, &g1, H, 1.0f, c.stream));
+    if (emb) {  // qt[:, h, :] = q_h W_p[h], qb[:, h] = q_h . b_p[h] for the rows of ALL groups at once
+      c.check(geotr_gemm(q, ldq, proj_p->w, C, 1, qt, H * C, q_rows_total, C, ch, H, ch, ch * C, C, nullptr, nullptr, nullptr, 0, 1.0f, 0,
+                         c.stream));
+      c.check(geotr_gemm(q, ldq, proj_p->b, 1, 1, qb, H, q_rows_total, 1, ch, H, ch, ch, 1, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+    }
+    c.check(geotr_attn_softmax_grouped(scores, &ga, qt, qb, C, H, 1.0f / sqrtf((float)ch), c.stream));
+    c.check(geotr_gemm_grouped(scores, v, 1, hidden, &g2, H, 1.0f, c.stream));
+  }
+  c.release(mk);
+}
+
 // feats_bb: (n_c, c_dim) coarse backbone features in stack order (ref_0, src_0, ref_1, ...); cloud_n[2B] superpoints per cloud;
 // feats_out: (n_c, D) L2-normalised transformer features, stack order (what the matching heads read).
 static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const int64_t* cloud_n, const float* pts_c, const float* feats_bb,
@@ -313,10 +358,7 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
         q = linear(c, L.q, x, C, N, 0), k = linear(c, L.k, x, C, N, 0), v = linear(c, L.v, x, C, N, 0), ld = C;
       }
       float* hidden = c.alloc<float>((size_t)N * C);
-      for (int g = 0; g < 2 * B; ++g) {
-        const int64_t r0 = work0[g], n = cloud_n[g];
-        attention(c, H, C, q + r0 * ld, ld, k + r0 * ld, ld, v + r0 * ld, ld, n, n, emb[g], &L.p, hidden + r0 * C);
-      }
+      attention_groups(c, H, C, 2 * B, cloud_n, cloud_n, q, ld, work0, N, k, v, ld, work0, emb, &L.p, hidden);
       attn_tail(c, L, hidden, x, N, C, y);
     } else {
       // sequential cross-attention (conditional_transformer.py:110-111): refs attend to the sources, then the sources to the
@@ -342,11 +384,12 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
           k = linear(c, L.k, xm, C, nm, 0), v = linear(c, L.v, xm, C, nm, 0), ld = C;
         }
         float* hidden = c.alloc<float>((size_t)nt * C);
+        int64_t gn[GEOTR_MAX_PAIRS], gmm[GEOTR_MAX_PAIRS], qrow[GEOTR_MAX_PAIRS], krow[GEOTR_MAX_PAIRS];
         for (int b = 0; b < B; ++b) {
           const int gt = 2 * b + half, gm = 2 * b + 1 - half;  // target / memory cloud of pair b
-          const int64_t rt = work0[gt] - t0, rm = work0[gm] - m0;
-          attention(c, H, C, q + rt * C, C, k + rm * ld, ld, v + rm * ld, ld, cloud_n[gt], cloud_n[gm], nullptr, nullptr, hidden + rt * C);
+          gn[b] = cloud_n[gt], gmm[b] = cloud_n[gm], qrow[b] = work0[gt] - t0, krow[b] = work0[gm] - m0;
         }
+        attention_groups(c, H, C, B, gn, gmm, q, C, qrow, nt, k, v, ld, krow, nullptr, nullptr, hidden);
         attn_tail(c, L, hidden, xt, nt, C, y + t0 * C);
       }
     }

@@ -268,14 +268,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 constexpr int kSK = 32;             // K-chunk of the skinny kernel (64 was slower: 66 KB of LDS per block halves occupancy)
 constexpr int kSStride = kSK + 1;   // padded LDS row
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+// Ragged groups for the skinny kernel (attention cores of all clouds of a stack in one launch): blockIdx.z = group * heads + head;
+// every group has its own shape, leading dimensions and base offsets (elements), heads are strided inside a group.
+struct SkinnyGroups {
+  int heads;
+  int m[GEOTR_MAX_GROUPS], n[GEOTR_MAX_GROUPS], k[GEOTR_MAX_GROUPS];
+  int lda[GEOTR_MAX_GROUPS], ldb[GEOTR_MAX_GROUPS], ldc[GEOTR_MAX_GROUPS];
+  int64_t a_off[GEOTR_MAX_GROUPS], b_off[GEOTR_MAX_GROUPS], c_off[GEOTR_MAX_GROUPS];
+  int64_t a_hs[GEOTR_MAX_GROUPS], b_hs[GEOTR_MAX_GROUPS], c_hs[GEOTR_MAX_GROUPS];  // per-head strides
+};
+
+template <bool VEC, bool GROUPED>
+__device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const SkinnyGroups* gr) {
   __shared__ float slab[4][2 * 32 * kSStride];  // per wave: A chunk [32][33], B chunk [32][33]; reused for the reduction
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  int M = g.M, N = g.N, K = g.K;
+  int64_t lda = g.lda, ldb = g.ldb, ldc = g.ldc;
   const float* A = g.A + (int64_t)blockIdx.z * g.strideA;
   const float* B = g.B + (int64_t)blockIdx.z * g.strideB;
   float* C = g.C + (int64_t)blockIdx.z * g.strideC;
+  if (GROUPED) {
+    const int grp = blockIdx.z / gr->heads, head = blockIdx.z % gr->heads;
+    M = gr->m[grp], N = gr->n[grp], K = gr->k[grp];
+    if (m0 >= M || n0 >= N) return;  // the grid covers the largest group
+    lda = gr->lda[grp], ldb = gr->ldb[grp], ldc = gr->ldc[grp];
+    A = g.A + gr->a_off[grp] + head * gr->a_hs[grp];
+    B = g.B + gr->b_off[grp] + head * gr->b_hs[grp];
+    C = g.C + gr->c_off[grp] + head * gr->c_hs[grp];
+  }
   float* As = slab[wave];
   float* Bs = As + 32 * kSStride;
   constexpr int NV = kSK / 8;  // float4 per lane and operand: 32 rows x kSK floats / 64 lanes
@@ -286,44 +307,44 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
       const int f = lane + 64 * s, row = f / (kSK / 4), kq = (f % (kSK / 4)) * 4;  // 32 rows x kSK/4 float4
       const int gm = m0 + row, gk = k0 + kq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gm < g.M) {
-        const float* p = A + (int64_t)gm * g.lda + gk;
-        if (VEC && gk + 3 < g.K) {
+      if (gm < M) {
+        const float* p = A + (int64_t)gm * lda + gk;
+        if (VEC && gk + 3 < K) {
           v = *reinterpret_cast<const float4*>(p);
         } else {
-          if (gk < g.K) v.x = p[0];
-          if (gk + 1 < g.K) v.y = p[1];
-          if (gk + 2 < g.K) v.z = p[2];
-          if (gk + 3 < g.K) v.w = p[3];
+          if (gk < K) v.x = p[0];
+          if (gk + 1 < K) v.y = p[1];
+          if (gk + 2 < K) v.z = p[2];
+          if (gk + 3 < K) v.w = p[3];
         }
       }
       ra[s] = v;
       float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!g.b_is_kn) {
         const int gn = n0 + row;
-        if (gn < g.N) {
-          const float* p = B + (int64_t)gn * g.ldb + gk;
-          if (VEC && gk + 3 < g.K) {
+        if (gn < N) {
+          const float* p = B + (int64_t)gn * ldb + gk;
+          if (VEC && gk + 3 < K) {
             w = *reinterpret_cast<const float4*>(p);
           } else {
-            if (gk < g.K) w.x = p[0];
-            if (gk + 1 < g.K) w.y = p[1];
-            if (gk + 2 < g.K) w.z = p[2];
-            if (gk + 3 < g.K) w.w = p[3];
+            if (gk < K) w.x = p[0];
+            if (gk + 1 < K) w.y = p[1];
+            if (gk + 2 < K) w.z = p[2];
+            if (gk + 3 < K) w.w = p[3];
           }
         }
       } else {
         const int kk = f >> 3, nq = (f & 7) * 4;  // kSK k-rows x 8 float4 along n
         const int gk2 = k0 + kk, gn = n0 + nq;
-        if (gk2 < g.K) {
-          const float* p = B + (int64_t)gk2 * g.ldb + gn;
-          if (VEC && gn + 3 < g.N) {
+        if (gk2 < K) {
+          const float* p = B + (int64_t)gk2 * ldb + gn;
+          if (VEC && gn + 3 < N) {
             w = *reinterpret_cast<const float4*>(p);
           } else {
-            if (gn < g.N) w.x = p[0];
-            if (gn + 1 < g.N) w.y = p[1];
-            if (gn + 2 < g.N) w.z = p[2];
-            if (gn + 3 < g.N) w.w = p[3];
+            if (gn < N) w.x = p[0];
+            if (gn + 1 < N) w.y = p[1];
+            if (gn + 2 < N) w.z = p[2];
+            if (gn + 3 < N) w.w = p[3];
           }
         }
       }
@@ -351,7 +372,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nchunks = (g.K + kSK - 1) / kSK;
+  const int nchunks = (K + kSK - 1) / kSK;
   const int fr = lane & 31, fk = lane >> 5;
   int c = wave;
   if (c < nchunks) load_chunk(c * kSK);
@@ -379,7 +400,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   for (int e = tid; e < 32 * 32; e += 256) {
     const int row = e >> 5, col = e & 31;
     const int gm = m0 + row, gn = n0 + col;
-    if (gm >= g.M || gn >= g.N) continue;
+    if (gm >= M || gn >= N) continue;
     const int o = row * kSStride + col;
     float v = ((slab[0][o] + slab[1][o]) + (slab[2][o] + slab[3][o])) * g.alpha;
     if (g.row_div) v = v / (float)max(g.row_div[gm], 1);
@@ -387,10 +408,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
     if (g.residual) v += g.residual[(int64_t)blockIdx.z * g.strideC + (int64_t)gm * g.ldr + gn];
     if (g.act == 1) v = fmaxf(v, 0.f);
     if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
-    C[(int64_t)gm * g.ldc + gn] = v;
+    C[(int64_t)gm * ldc + gn] = v;
   }
 }
 
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+  gemm_skinny_body<VEC, false>(g, nullptr);
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_skinny_grouped_kernel(GemmArgs g, SkinnyGroups gr) {
+  gemm_skinny_body<VEC, true>(g, &gr);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Split-bf16 ("bf16x3") variant for the tall backbone contractions with static weights:
@@ -649,5 +678,40 @@ extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed
   else GEOTR_PACKED(1, 1, 32);
 #undef GEOTR_PACKED
   GEOTR_CHECK_LAUNCH("gemm_packed");
+  return GEOTR_OK;
+}
+
+extern "C" int geotr_gemm_grouped(const float* A, const float* B, int b_is_kn, float* C, const geotr_gemm_groups* groups, int64_t heads,
+                                  float alpha, void* stream_) {
+  GEOTR_CHECK_ARG(A && B && C && groups, "gemm_grouped: null pointer");
+  GEOTR_CHECK_ARG(groups->count >= 1 && groups->count <= GEOTR_MAX_GROUPS && heads >= 1 && groups->count * heads < 65536,
+                  "gemm_grouped: 1..%d groups", GEOTR_MAX_GROUPS);
+  SkinnyGroups gr;
+  gr.heads = (int)heads;
+  int maxm = 0, maxn = 0;
+  bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+  for (int i = 0; i < groups->count; ++i) {
+    GEOTR_CHECK_ARG(groups->m[i] >= 1 && groups->n[i] >= 1 && groups->k[i] >= 1, "gemm_grouped: empty group %d", i);
+    gr.m[i] = (int)groups->m[i], gr.n[i] = (int)groups->n[i], gr.k[i] = (int)groups->k[i];
+    gr.lda[i] = (int)groups->lda[i], gr.ldb[i] = (int)groups->ldb[i], gr.ldc[i] = (int)groups->ldc[i];
+    gr.a_off[i] = groups->a_off[i], gr.b_off[i] = groups->b_off[i], gr.c_off[i] = groups->c_off[i];
+    gr.a_hs[i] = groups->a_head_stride[i], gr.b_hs[i] = groups->b_head_stride[i], gr.c_hs[i] = groups->c_head_stride[i];
+    maxm = std::max(maxm, gr.m[i]), maxn = std::max(maxn, gr.n[i]);
+    vec = vec && ((gr.lda[i] | gr.ldb[i]) & 3) == 0 && ((gr.a_off[i] | gr.b_off[i] | gr.a_hs[i] | gr.b_hs[i]) & 3) == 0;
+  }
+  for (int i = groups->count; i < GEOTR_MAX_GROUPS; ++i) {
+    gr.m[i] = gr.n[i] = gr.k[i] = gr.lda[i] = gr.ldb[i] = gr.ldc[i] = 0;
+    gr.a_off[i] = gr.b_off[i] = gr.c_off[i] = gr.a_hs[i] = gr.b_hs[i] = gr.c_hs[i] = 0;
+  }
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.row_div = nullptr; g.residual = nullptr;
+  g.lda = g.ldb = g.ldc = g.ldr = 0; g.strideA = g.strideB = g.strideC = 0;
+  g.M = g.N = g.K = 0; g.b_is_kn = b_is_kn; g.alpha = alpha; g.act = 0;
+  dim3 grid((unsigned)((maxn + 31) / 32), (unsigned)((maxm + 31) / 32), (unsigned)(groups->count * heads));
+  GEOTR_CHECK_ARG(grid.y <= 65535, "gemm_grouped: group too tall for the skinny kernel");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (vec) gemm_skinny_grouped_kernel<true><<<grid, dim3(256), 0, stream>>>(g, gr);
+  else gemm_skinny_grouped_kernel<false><<<grid, dim3(256), 0, stream>>>(g, gr);
+  GEOTR_CHECK_LAUNCH("gemm_grouped");
   return GEOTR_OK;
 }

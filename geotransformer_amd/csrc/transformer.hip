@@ -430,11 +430,28 @@ __global__ __launch_bounds__(256) void attn_pos_kernel(float* __restrict__ score
 // One lane per key: the lane streams its key's embedding row in 128-byte bursts (8 x float4 = one cache line per burst), the
 // query's qt row sits in LDS and is read as broadcasts.  The (n, n, C) embedding is read exactly once per layer -- this kernel
 // is its only consumer -- so it is bound by that stream.
-template <int H>
-__global__ __launch_bounds__(256) void attn_pos_softmax_kernel(float* __restrict__ scores, const float* __restrict__ emb,
-                                                               const float* __restrict__ qt, const float* __restrict__ qb, int n, int m,
-                                                               int ld, int C, float scale) {
+// Ragged groups (one per cloud of a stack): blockIdx.y = group, blockIdx.x = query row (rows past the group's n exit).
+struct AttnGroups {
+  int count;
+  int n[GEOTR_MAX_GROUPS], m[GEOTR_MAX_GROUPS], ld[GEOTR_MAX_GROUPS];
+  int64_t sc_off[GEOTR_MAX_GROUPS], q_off[GEOTR_MAX_GROUPS];  // scores offset (elements); first query row in qt / qb
+  const float* emb[GEOTR_MAX_GROUPS];
+};
+
+template <int H, bool GROUPED>
+__device__ __forceinline__ void attn_pos_softmax_body(float* __restrict__ scores, const float* __restrict__ emb,
+                                                      const float* __restrict__ qt, const float* __restrict__ qb, int n, int m, int ld,
+                                                      int C, float scale, const AttnGroups* gr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (GROUPED) {
+    const int g = blockIdx.y;
+    n = gr->n[g], m = gr->m[g], ld = gr->ld[g];
+    if ((int)blockIdx.x >= n) return;
+    scores += gr->sc_off[g];
+    emb = gr->emb[g];
+    qt += gr->q_off[g] * H * C;
+    qb += gr->q_off[g] * H;
+  }
   float* qt_s = smem;          // [C][H]
   float* sc_s = smem + C * H;  // [H][m]
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -484,9 +501,28 @@ __global__ __launch_bounds__(256) void attn_pos_softmax_kernel(float* __restrict
   }
 }
 
+template <int H>
+__global__ __launch_bounds__(256) void attn_pos_softmax_kernel(float* __restrict__ scores, const float* __restrict__ emb,
+                                                               const float* __restrict__ qt, const float* __restrict__ qb, int n, int m,
+                                                               int ld, int C, float scale) {
+  attn_pos_softmax_body<H, false>(scores, emb, qt, qb, n, m, ld, C, scale, nullptr);
+}
+template <int H>
+__global__ __launch_bounds__(256) void attn_pos_softmax_grouped_kernel(float* __restrict__ scores, const float* __restrict__ qt,
+                                                                       const float* __restrict__ qb, int C, float scale, AttnGroups gr) {
+  attn_pos_softmax_body<H, true>(scores, nullptr, qt, qb, 0, 0, 0, C, scale, &gr);
+}
+
 // softmax over the keys of one query row, all heads: scores <- softmax(scores * scale)
-__global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ scores, int n, int m, int ld, int H, float scale) {
+template <bool GROUPED>
+__device__ __forceinline__ void attn_softmax_body(float* __restrict__ scores, int n, int m, int ld, int H, float scale, const AttnGroups* gr) {
   extern __shared__ __attribute__((aligned(16))) float sc_s[];  // [H][m]
+  if (GROUPED) {
+    const int g = blockIdx.y;
+    n = gr->n[g], m = gr->m[g], ld = gr->ld[g];
+    if ((int)blockIdx.x >= n) return;
+    scores += gr->sc_off[g];
+  }
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < H * m; e += 256) sc_s[e] = scores[((int64_t)(e / m) * n + i) * ld + (e % m)];
   __syncthreads();
@@ -505,6 +541,12 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ s
     float* dst = scores + ((int64_t)h * n + i) * ld;
     for (int j = lane; j < m; j += 64) dst[j] = sc_s[h * m + j] * inv;
   }
+}
+__global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ scores, int n, int m, int ld, int H, float scale) {
+  attn_softmax_body<false>(scores, n, m, ld, H, scale, nullptr);
+}
+__global__ __launch_bounds__(256) void attn_softmax_grouped_kernel(float* __restrict__ scores, int H, float scale, AttnGroups gr) {
+  attn_softmax_body<true>(scores, 0, 0, 0, H, scale, &gr);
 }
 
 }  // namespace geotr
@@ -665,6 +707,48 @@ int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float*
     return fail(GEOTR_E_LAUNCH, "attn_softmax: cannot reserve %zu B of LDS", lds2);
   attn_softmax_kernel<<<dim3((unsigned)n), dim3(256), lds2, stream>>>(scores, (int)n, (int)m, (int)ld, (int)heads, scale);
   GEOTR_CHECK_LAUNCH("attn_softmax");
+  return GEOTR_OK;
+}
+
+int geotr_attn_softmax_grouped(float* scores, const geotr_attn_groups* groups, const float* qt, const float* qb, int64_t c, int64_t heads,
+                               float scale, void* stream_) {
+  GEOTR_CHECK_ARG(scores && groups && groups->count >= 1 && groups->count <= GEOTR_MAX_GROUPS, "attn_softmax_grouped: 1..%d groups",
+                  GEOTR_MAX_GROUPS);
+  GEOTR_CHECK_ARG(heads == 1 || heads == 2 || heads == 4 || heads == 8, "attn_softmax_grouped: heads must be 1, 2, 4 or 8");
+  const bool pos = groups->emb[0] != nullptr;
+  GEOTR_CHECK_ARG(!pos || (qt && qb && c % 32 == 0 && c <= 512), "attn_softmax_grouped: positional term needs qt, qb and c %% 32 == 0");
+  AttnGroups gr;
+  gr.count = groups->count;
+  int maxn = 0, maxm = 0;
+  for (int i = 0; i < GEOTR_MAX_GROUPS; ++i) {
+    const bool on = i < groups->count;
+    gr.n[i] = on ? (int)groups->n[i] : 0, gr.m[i] = on ? (int)groups->m[i] : 0, gr.ld[i] = on ? (int)groups->ld[i] : 0;
+    gr.sc_off[i] = on ? groups->scores_off[i] : 0, gr.q_off[i] = on ? groups->q_row0[i] : 0;
+    gr.emb[i] = on ? groups->emb[i] : nullptr;
+    if (on) {
+      GEOTR_CHECK_ARG(gr.n[i] >= 1 && gr.m[i] >= 1 && gr.ld[i] >= gr.m[i] && (pos == (gr.emb[i] != nullptr)), "attn_softmax_grouped: bad group %d", i);
+      maxn = std::max(maxn, gr.n[i]), maxm = std::max(maxm, gr.m[i]);
+    }
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t lds = sizeof(float) * (size_t)((pos ? c * heads : 0) + heads * maxm);
+  if (lds > 160 * 1024) return fail(GEOTR_E_CAPACITY, "attn_softmax_grouped: %d keys need %zu B of LDS", maxm, lds);
+  const dim3 grid((unsigned)maxn, (unsigned)groups->count);
+  auto go = [&](auto kern, auto... args) -> int {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(GEOTR_E_LAUNCH, "attn_softmax_grouped: cannot reserve %zu B of LDS", lds);
+    kern<<<grid, dim3(256), lds, stream>>>(args...);
+    return GEOTR_OK;
+  };
+  int rc;
+  if (!pos) rc = go(attn_softmax_grouped_kernel, scores, (int)heads, scale, gr);
+  else if (heads == 1) rc = go(attn_pos_softmax_grouped_kernel<1>, scores, qt, qb, (int)c, scale, gr);
+  else if (heads == 2) rc = go(attn_pos_softmax_grouped_kernel<2>, scores, qt, qb, (int)c, scale, gr);
+  else if (heads == 4) rc = go(attn_pos_softmax_grouped_kernel<4>, scores, qt, qb, (int)c, scale, gr);
+  else rc = go(attn_pos_softmax_grouped_kernel<8>, scores, qt, qb, (int)c, scale, gr);
+  if (rc != GEOTR_OK) return rc;
+  GEOTR_CHECK_LAUNCH("attn_softmax_grouped");
   return GEOTR_OK;
 }
 

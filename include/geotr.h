@@ -96,6 +96,20 @@ int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, int b_i
                const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                void* stream);
 
+/* Ragged grouped GEMM (attention cores of every cloud of a stack in one launch): for group i and head h
+ *   C_i,h (m_i x n_i) = alpha * A_i,h (m_i x k_i) * op(B_i,h),   X_i,h = X + x_off[i] + h * x_head_stride[i]   (offsets in elements)
+ * with per-group leading dimensions; op as in geotr_gemm (b_is_kn).  Exact fp32 MFMA (the split-K "skinny" kernel). */
+#define GEOTR_MAX_GROUPS 32
+typedef struct geotr_gemm_groups {
+  int32_t count, pad_;
+  int64_t m[GEOTR_MAX_GROUPS], n[GEOTR_MAX_GROUPS], k[GEOTR_MAX_GROUPS];
+  int64_t lda[GEOTR_MAX_GROUPS], ldb[GEOTR_MAX_GROUPS], ldc[GEOTR_MAX_GROUPS];
+  int64_t a_off[GEOTR_MAX_GROUPS], b_off[GEOTR_MAX_GROUPS], c_off[GEOTR_MAX_GROUPS];
+  int64_t a_head_stride[GEOTR_MAX_GROUPS], b_head_stride[GEOTR_MAX_GROUPS], c_head_stride[GEOTR_MAX_GROUPS];
+} geotr_gemm_groups;
+int geotr_gemm_grouped(const float* A, const float* B, int b_is_kn, float* C, const geotr_gemm_groups* groups, int64_t heads, float alpha,
+                       void* stream);
+
 /* Split-bf16 ("bf16x3") GEMM for tall activations against a STATIC weight:  C = act(alpha * A * W^T / row_div + bias + residual)
  * with every fp32 product evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (hi = bf16(x),
  * lo = bf16(x - hi); ~2^-17 relative error per product, fp32 accumulation).  geotr_gemm_pack converts the weight once
@@ -170,6 +184,16 @@ int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t 
                     int precision, void* ws, size_t ws_bytes, float* out, void* stream);
 int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m,
                        int64_t c, int64_t heads, float scale, void* stream);
+/* The same over ragged groups (one per cloud of a stack) in one launch: group i has n[i] query rows, m[i] keys, score rows of leading
+ * dimension ld[i] starting at scores + scores_off[i] (head stride n[i]*ld[i]), embedding emb[i] (all NULL: plain scaled softmax) and
+ * its query rows start at row q_row0[i] of qt (rows, heads, c) / qb (rows, heads).  heads in {1,2,4,8}; c % 32 == 0. */
+typedef struct geotr_attn_groups {
+  int32_t count, pad_;
+  int64_t n[32], m[32], ld[32], scores_off[32], q_row0[32];
+  const float* emb[32];
+} geotr_attn_groups;
+int geotr_attn_softmax_grouped(float* scores, const geotr_attn_groups* groups, const float* qt, const float* qb, int64_t c, int64_t heads,
+                               float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * P1/M1/S1/S2  matching heads

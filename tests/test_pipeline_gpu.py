@@ -69,8 +69,11 @@ def test_stacked_pairs_match_single_pair_runs():
             assert torch.allclose(w['matching_scores'], g['matching_scores'], atol=1e-3, rtol=1e-3)
         T, Tw = g['estimated_transform'].cpu(), w['estimated_transform'].cpu()
         assert torch.isfinite(T).all()
-    same = sum(torch.equal(w['ref_node_corr_indices'], g['ref_node_corr_indices']) for w, g in zip(want, got))
-    assert same >= 3, same
+    # coarse selection: a global top-k over nearly flat scores (random weights) -- compare the selected SETS
+    for w, g in zip(want, got):
+        ws = set(zip(w['ref_node_corr_indices'].tolist(), w['src_node_corr_indices'].tolist()))
+        gs = set(zip(g['ref_node_corr_indices'].tolist(), g['src_node_corr_indices'].tolist()))
+        assert len(ws & gs) >= 0.9 * len(ws), (len(ws & gs), len(ws))
     # a stack of one is exactly the single-pair path
     one = pipe.register_batch(pairs[:1])[0]
     for k in ('ref_feats_c', 'matching_scores', 'estimated_transform', 'ref_node_corr_indices'):
