@@ -42,6 +42,22 @@ struct Carver {
   }
 };
 
+// LGR over several stacked pairs in one launch sequence (lgr.hip): byte distance between the per-pair arrays of consecutive pairs
+struct LgrBatch {
+  int64_t knn_pts, knn_mask, score, pcount, corr_pts, corr_score, total, transform, ws;
+};
+int lgr_launch(const float* ref_knn_points, const float* src_knn_points, const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks,
+               const float* score_mat, int64_t ld_patch, int64_t ld_row, int64_t p, int64_t k, int64_t topk, float confidence_threshold,
+               int mutual, float acceptance_radius, int64_t correspondence_threshold, int64_t num_refinement_steps, const int32_t* p_count,
+               float* ref_corr_points, float* src_corr_points, float* corr_scores, int32_t* num_corr, float* estimated_transform, void* ws,
+               size_t ws_bytes, void* stream, int batch, const LgrBatch& bs);
+
+int sinkhorn_launch(int batch, const float* const* ref_feats, const int64_t* nr, const float* const* src_feats, const int64_t* ns, int64_t c,
+                    const int64_t* ref_knn_indices, const int64_t* src_knn_indices, const uint8_t* ref_knn_masks,
+                    const uint8_t* src_knn_masks, int64_t idx_stride, int64_t mask_stride, int64_t p, int64_t k, const float* alpha,
+                    int64_t num_iterations, const int32_t* p_count, int64_t pcount_stride, float* matching_scores, int64_t out_stride,
+                    void* stream);
+
 #ifdef __HIPCC__
 // split-bf16 helpers: x = hi + lo with hi = bf16(x), lo = bf16(x - hi)  (round to nearest even)
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;

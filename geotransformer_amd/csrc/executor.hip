@@ -404,7 +404,7 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
 // heads of one pair: superpoint patches, geometric transformer, coarse matching, patch OT, LGR.  All pointers are the pair's
 // own slices of the stacked arrays (reference cloud first).
 static void run_pair(Ctx& c, const geotr_model& net, const float* pts_c, int64_t nr_c, int64_t ns_c, const float* pts_f, int64_t nr_f,
-                     int64_t ns_f, const float* feats_f, int64_t c_f, const geotr_outputs& o) {
+                     int64_t ns_f, const float* feats_f, int64_t c_f, const geotr_outputs& o, bool per_pair_tail) {
   const int64_t n_c = nr_c + ns_c, n_f = nr_f + ns_f;
   const int64_t K = net.num_points_in_patch, P = net.num_correspondences;
 
@@ -436,11 +436,12 @@ static void run_pair(Ctx& c, const geotr_model& net, const float* pts_c, int64_t
                                node_knn_mask + nr_c * K, pts_f + 3 * nr_f, ns_f, o.src_node_corr_indices, P, K, o.num_node_corr,
                                o.ref_knn_indices, o.ref_knn_masks, o.ref_knn_points, o.src_knn_indices, o.src_knn_masks,
                                o.src_knn_points, c.stream));
-    // 6. patch scores + optimal transport (model.py:187-191)
-    c.check(geotr_patch_sinkhorn(feats_f, nr_f, feats_f + nr_f * c_f, ns_f, c_f, o.ref_knn_indices, o.src_knn_indices, o.ref_knn_masks,
-                                 o.src_knn_masks, P, K, net.alpha, net.num_sinkhorn_iterations, nullptr, o.num_node_corr,
-                                 o.matching_scores, c.stream));
+    if (per_pair_tail)  // 6. patch scores + optimal transport (model.py:187-191)
+      c.check(geotr_patch_sinkhorn(feats_f, nr_f, feats_f + nr_f * c_f, ns_f, c_f, o.ref_knn_indices, o.src_knn_indices, o.ref_knn_masks,
+                                   o.src_knn_masks, P, K, net.alpha, net.num_sinkhorn_iterations, nullptr, o.num_node_corr,
+                                   o.matching_scores, c.stream));
   }
+  if (!per_pair_tail) return;
   // 7. local-to-global registration on the dustbin-free block (model.py:195-210)
   const size_t lgr_bytes = geotr_lgr_workspace_bytes(P, K, net.topk);
   char* lgr_ws = c.alloc<char>(lgr_bytes);
@@ -449,6 +450,16 @@ static void run_pair(Ctx& c, const geotr_model& net, const float* pts_c, int64_t
                       K, net.topk, net.confidence_threshold, net.mutual, net.acceptance_radius, net.correspondence_threshold,
                       net.num_refinement_steps, o.num_node_corr, o.ref_corr_points, o.src_corr_points, o.corr_scores, o.num_corr,
                       o.estimated_transform, lgr_ws, lgr_bytes, c.stream));
+}
+
+// byte distance outs[1].x - outs[0].x if every pair b has x at outs[0].x + b * that distance, else -1
+template <typename F>
+static int64_t uniform_stride(const geotr_outputs* outs, int B, F field) {
+  if (B < 2) return 0;
+  const int64_t d = reinterpret_cast<const char*>(field(outs[1])) - reinterpret_cast<const char*>(field(outs[0]));
+  for (int b = 2; b < B; ++b)
+    if (reinterpret_cast<const char*>(field(outs[b])) - reinterpret_cast<const char*>(field(outs[0])) != d * b) return -1;
+  return d;
 }
 
 // One forward over `p.num_pairs` stacked pairs (clouds ordered ref_0, src_0, ref_1, src_1, ...): the KPConv-FPN runs once over
@@ -479,7 +490,36 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
     c.release(mt);
   }
 
+  // The patch Sinkhorn and the local-to-global registration have the same shapes for every pair, so they run ONCE for the whole
+  // stack (blockIdx.y = pair) when the caller laid the per-pair outputs out at a constant stride (native.py does); else per pair.
+  const int64_t K = net.num_points_in_patch, P = net.num_correspondences;
+  LgrBatch lb;
+  std::memset(&lb, 0, sizeof(lb));
+  bool batched_tail = !c.dry && B > 1;
+  int64_t idx_stride = 0;
+  if (batched_tail) {
+    lb.knn_pts = uniform_stride(outs, B, [](const geotr_outputs& o) { return o.ref_knn_points; });
+    lb.knn_mask = uniform_stride(outs, B, [](const geotr_outputs& o) { return o.ref_knn_masks; });
+    lb.score = uniform_stride(outs, B, [](const geotr_outputs& o) { return o.matching_scores; });
+    lb.pcount = uniform_stride(outs, B, [](const geotr_outputs& o) { return o.num_node_corr; });
+    lb.corr_pts = uniform_stride(outs, B, [](const geotr_outputs& o) { return o.ref_corr_points; });
+    lb.corr_score = uniform_stride(outs, B, [](const geotr_outputs& o) { return o.corr_scores; });
+    lb.total = uniform_stride(outs, B, [](const geotr_outputs& o) { return o.num_corr; });
+    lb.transform = uniform_stride(outs, B, [](const geotr_outputs& o) { return o.estimated_transform; });
+    idx_stride = uniform_stride(outs, B, [](const geotr_outputs& o) { return o.ref_knn_indices; });
+    batched_tail = lb.knn_pts > 0 && lb.knn_mask > 0 && lb.score > 0 && lb.pcount > 0 && lb.corr_pts > 0 && lb.corr_score > 0 &&
+                   lb.total > 0 && lb.transform > 0 && idx_stride > 0 &&
+                   lb.knn_pts == uniform_stride(outs, B, [](const geotr_outputs& o) { return o.src_knn_points; }) &&
+                   lb.knn_mask == uniform_stride(outs, B, [](const geotr_outputs& o) { return o.src_knn_masks; }) &&
+                   lb.corr_pts == uniform_stride(outs, B, [](const geotr_outputs& o) { return o.src_corr_points; }) &&
+                   idx_stride == uniform_stride(outs, B, [](const geotr_outputs& o) { return o.src_knn_indices; });
+  }
+  if (c.dry) batched_tail = B > 1;  // size query: reserve the batched workspace
+
   int64_t off_c = 0, off_f = 0;
+  const float* tail_ref_feats[GEOTR_MAX_PAIRS];
+  const float* tail_src_feats[GEOTR_MAX_PAIRS];
+  int64_t tail_nr[GEOTR_MAX_PAIRS], tail_ns[GEOTR_MAX_PAIRS];
   for (int b = 0; b < B; ++b) {
     const int64_t nr_c = p.cloud_n[S - 1][2 * b], ns_c = p.cloud_n[S - 1][2 * b + 1];
     const int64_t nr_f = p.cloud_n[fine][2 * b], ns_f = p.cloud_n[fine][2 * b + 1];
@@ -490,10 +530,27 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
         c.rc == GEOTR_OK)
       c.rc = fail(GEOTR_E_INVALID, "model_forward: outputs[%d].feats_f / feats_c must be the pair's rows of the stacked buffers", b);
     const size_t mp = c.mark();
-    run_pair(c, net, p.points[S - 1] + 3 * off_c, nr_c, ns_c, p.points[fine] + 3 * off_f, nr_f, ns_f, feats_f + off_f * c_f, c_f, o);
+    run_pair(c, net, p.points[S - 1] + 3 * off_c, nr_c, ns_c, p.points[fine] + 3 * off_f, nr_f, ns_f, feats_f + off_f * c_f, c_f, o,
+             !batched_tail);
+    tail_ref_feats[b] = feats_f + off_f * c_f, tail_src_feats[b] = feats_f + (off_f + nr_f) * c_f, tail_nr[b] = nr_f, tail_ns[b] = ns_f;
     c.release(mp);
     off_c += nr_c + ns_c;
     off_f += nr_f + ns_f;
+  }
+  if (batched_tail) {
+    const size_t lgr_bytes = align_up(geotr_lgr_workspace_bytes(P, K, net.topk));
+    char* lgr_ws = c.alloc<char>(lgr_bytes * (size_t)B);
+    if (c.live()) {
+      const geotr_outputs& o = outs[0];
+      lb.ws = (int64_t)lgr_bytes;
+      c.check(sinkhorn_launch(B, tail_ref_feats, tail_nr, tail_src_feats, tail_ns, c_f, o.ref_knn_indices, o.src_knn_indices, o.ref_knn_masks,
+                              o.src_knn_masks, idx_stride / 8, lb.knn_mask, P, K, net.alpha,
+                              net.num_sinkhorn_iterations, o.num_node_corr, lb.pcount / 4, o.matching_scores, lb.score / 4, c.stream));
+      c.check(lgr_launch(o.ref_knn_points, o.src_knn_points, o.ref_knn_masks, o.src_knn_masks, o.matching_scores, (K + 1) * (K + 1), K + 1, P, K,
+                         net.topk, net.confidence_threshold, net.mutual, net.acceptance_radius, net.correspondence_threshold,
+                         net.num_refinement_steps, o.num_node_corr, o.ref_corr_points, o.src_corr_points, o.corr_scores, o.num_corr,
+                         o.estimated_transform, lgr_ws, lgr_bytes, c.stream, B, lb));
+    }
   }
   return c.rc;
 }

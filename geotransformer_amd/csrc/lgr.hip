@@ -7,6 +7,8 @@
 // Everything stays on the device: the 3x3 SVDs run in fp64 one-sided Jacobi inside the kernels, correspondence
 // compaction uses block scans, and the number of correspondences is only read back by the caller at the very end.
 #include <algorithm>
+#include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -158,13 +160,28 @@ __device__ __forceinline__ float residual(const float* T, const float* s, const 
   return sqrtf((dx * dx + dy * dy) + dz * dz);
 }
 
+// Several pairs in one launch (stacked forward): blockIdx.y = pair, every per-pair array of pair b sits a fixed number of BYTES
+// after pair 0's (LgrBatch; all zero for a single pair).
+template <typename T>
+__device__ __forceinline__ T* lgr_shift(T* p, int64_t bytes) {
+  return p ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + (int64_t)blockIdx.y * bytes) : p;
+}
+
 // ---------------------------------------------------------------------------------------------
 // (1) per patch pair: exp, mutual top-k, threshold, masks -> row-major compacted list
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lgr_corr_kernel(const float* __restrict__ score, int64_t ld_patch, int ld_row, int K, int topk,
                                                        float thr, int mutual, const unsigned char* __restrict__ rmask,
                                                        const unsigned char* __restrict__ smask, int cap, const int* __restrict__ p_count,
-                                                       int* __restrict__ cnt, int* __restrict__ stage_ij, float* __restrict__ stage_score) {
+                                                       int* __restrict__ cnt, int* __restrict__ stage_ij, float* __restrict__ stage_score, LgrBatch bs) {
+  score = lgr_shift(score, bs.score);
+  rmask = lgr_shift(rmask, bs.knn_mask);
+  smask = lgr_shift(smask, bs.knn_mask);
+  p_count = lgr_shift(p_count, bs.pcount);
+  cnt = lgr_shift(cnt, bs.ws);
+  stage_ij = lgr_shift(stage_ij, bs.ws);
+  stage_score = lgr_shift(stage_score, bs.ws);
+
   extern __shared__ float lds[];
   float* E = lds;                 // [K][K+1]
   float* trow = E + K * (K + 1);  // [K]
@@ -233,7 +250,18 @@ __global__ __launch_bounds__(256) void lgr_gather_kernel(const float* __restrict
                                                          int P, int cap, const int* __restrict__ cnt, const int* __restrict__ stage_ij,
                                                          const float* __restrict__ stage_score, float* __restrict__ ref_corr,
                                                          float* __restrict__ src_corr, float* __restrict__ scores,
-                                                         int* __restrict__ offsets, int* __restrict__ total) {
+                                                         int* __restrict__ offsets, int* __restrict__ total, LgrBatch bs) {
+  ref_pts = lgr_shift(ref_pts, bs.knn_pts);
+  src_pts = lgr_shift(src_pts, bs.knn_pts);
+  cnt = lgr_shift(cnt, bs.ws);
+  stage_ij = lgr_shift(stage_ij, bs.ws);
+  stage_score = lgr_shift(stage_score, bs.ws);
+  ref_corr = lgr_shift(ref_corr, bs.corr_pts);
+  src_corr = lgr_shift(src_corr, bs.corr_pts);
+  scores = lgr_shift(scores, bs.corr_score);
+  offsets = lgr_shift(offsets, bs.ws);
+  total = lgr_shift(total, bs.total);
+
   __shared__ int sm[8];
   const int p = blockIdx.x, tid = threadIdx.x;
   int part = 0;
@@ -262,7 +290,15 @@ __global__ __launch_bounds__(256) void lgr_gather_kernel(const float* __restrict
 __global__ __launch_bounds__(64) void lgr_local_kernel(const float* __restrict__ ref_corr, const float* __restrict__ src_corr,
                                                        const float* __restrict__ scores, const int* __restrict__ cnt,
                                                        const int* __restrict__ offsets, int min_corr, float* __restrict__ T_all,
-                                                       int* __restrict__ valid) {
+                                                       int* __restrict__ valid, LgrBatch bs) {
+  ref_corr = lgr_shift(ref_corr, bs.corr_pts);
+  src_corr = lgr_shift(src_corr, bs.corr_pts);
+  scores = lgr_shift(scores, bs.corr_score);
+  cnt = lgr_shift(cnt, bs.ws);
+  offsets = lgr_shift(offsets, bs.ws);
+  T_all = lgr_shift(T_all, bs.ws);
+  valid = lgr_shift(valid, bs.ws);
+
   __shared__ double red[16];
   __shared__ float T[16];
   const int p = blockIdx.x;
@@ -281,7 +317,14 @@ __global__ __launch_bounds__(64) void lgr_local_kernel(const float* __restrict__
 // (4) inlier count of every hypothesis over ALL correspondences (:172-177)
 __global__ __launch_bounds__(256) void lgr_score_kernel(const float* __restrict__ ref_corr, const float* __restrict__ src_corr,
                                                         const int* __restrict__ total, const float* __restrict__ T_all,
-                                                        const int* __restrict__ valid, float radius, int* __restrict__ inliers) {
+                                                        const int* __restrict__ valid, float radius, int* __restrict__ inliers, LgrBatch bs) {
+  ref_corr = lgr_shift(ref_corr, bs.corr_pts);
+  src_corr = lgr_shift(src_corr, bs.corr_pts);
+  total = lgr_shift(total, bs.total);
+  T_all = lgr_shift(T_all, bs.ws);
+  valid = lgr_shift(valid, bs.ws);
+  inliers = lgr_shift(inliers, bs.ws);
+
   __shared__ int sm[4];
   const int p = blockIdx.x;
   if (!valid[p]) {
@@ -304,7 +347,15 @@ __global__ __launch_bounds__(256) void lgr_score_kernel(const float* __restrict_
 __global__ __launch_bounds__(1024) void lgr_refine_kernel(const float* __restrict__ ref_corr, const float* __restrict__ src_corr,
                                                           const float* __restrict__ scores, const int* __restrict__ total,
                                                           const float* __restrict__ T_all, const int* __restrict__ inliers, int P,
-                                                          float radius, int steps, float* __restrict__ T_final) {
+                                                          float radius, int steps, float* __restrict__ T_final, LgrBatch bs) {
+  ref_corr = lgr_shift(ref_corr, bs.corr_pts);
+  src_corr = lgr_shift(src_corr, bs.corr_pts);
+  scores = lgr_shift(scores, bs.corr_score);
+  total = lgr_shift(total, bs.total);
+  T_all = lgr_shift(T_all, bs.ws);
+  inliers = lgr_shift(inliers, bs.ws);
+  T_final = lgr_shift(T_final, bs.transform);
+
   __shared__ double red[16 * 16];
   __shared__ float T[16];
   __shared__ int best_p;
@@ -356,6 +407,49 @@ __global__ __launch_bounds__(256) void procrustes_kernel(const float* __restrict
 
 using namespace geotr;
 
+namespace geotr {
+int lgr_launch(const float* ref_knn_points, const float* src_knn_points, const uint8_t* ref_knn_masks,
+              const uint8_t* src_knn_masks, const float* score_mat, int64_t ld_patch, int64_t ld_row, int64_t p, int64_t k,
+              int64_t topk, float confidence_threshold, int mutual, float acceptance_radius, int64_t correspondence_threshold,
+              int64_t num_refinement_steps, const int32_t* p_count, float* ref_corr_points, float* src_corr_points,
+              float* corr_scores, int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream_, int batch,
+               const LgrBatch& bs) {
+  GEOTR_CHECK_ARG(p >= 1 && k >= 1 && k <= 256 && topk >= 1 && topk <= 4, "lgr: bad sizes (k <= 256, topk <= 4)");
+  GEOTR_CHECK_ARG(num_refinement_steps >= 1, "lgr: num_refinement_steps must be >= 1");
+  GEOTR_CHECK_ARG(ref_knn_points && src_knn_points && ref_knn_masks && src_knn_masks && score_mat && ref_corr_points &&
+                      src_corr_points && corr_scores && num_corr && estimated_transform && ws, "lgr: null pointer");
+  if (ws_bytes < geotr_lgr_workspace_bytes(p, k, topk)) return fail(GEOTR_E_WORKSPACE, "lgr: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int cap = (int)(k * topk);
+  Carver c(ws);
+  int* stage_ij = c.take<int>((size_t)p * cap);
+  float* stage_score = c.take<float>((size_t)p * cap);
+  int* cnt = c.take<int>((size_t)p);
+  int* offsets = c.take<int>((size_t)p);
+  int* valid = c.take<int>((size_t)p);
+  int* inliers = c.take<int>((size_t)p);
+  float* T_all = c.take<float>((size_t)p * 16);
+  const size_t lds = sizeof(float) * ((size_t)k * (k + 1) + 2 * (size_t)k);
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&lgr_corr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(GEOTR_E_LAUNCH, "lgr: cannot reserve LDS");
+  lgr_corr_kernel<<<dim3((unsigned)p, (unsigned)batch), dim3(256), lds, stream>>>(score_mat, ld_patch, (int)ld_row, (int)k, (int)topk,
+                                                                 confidence_threshold, mutual, ref_knn_masks, src_knn_masks, cap, p_count,
+                                                                 cnt, stage_ij, stage_score, bs);
+  lgr_gather_kernel<<<dim3((unsigned)p, (unsigned)batch), dim3(256), 0, stream>>>(ref_knn_points, src_knn_points, (int)k, (int)p, cap, cnt, stage_ij,
+                                                                 stage_score, ref_corr_points, src_corr_points, corr_scores, offsets,
+                                                                 num_corr, bs);
+  lgr_local_kernel<<<dim3((unsigned)p, (unsigned)batch), dim3(64), 0, stream>>>(ref_corr_points, src_corr_points, corr_scores, cnt, offsets,
+                                                               (int)correspondence_threshold, T_all, valid, bs);
+  lgr_score_kernel<<<dim3((unsigned)p, (unsigned)batch), dim3(256), 0, stream>>>(ref_corr_points, src_corr_points, num_corr, T_all, valid,
+                                                                acceptance_radius, inliers, bs);
+  lgr_refine_kernel<<<dim3(1, (unsigned)batch), dim3(1024), 0, stream>>>(ref_corr_points, src_corr_points, corr_scores, num_corr, T_all, inliers,
+                                                        (int)p, acceptance_radius, (int)num_refinement_steps, estimated_transform, bs);
+  GEOTR_CHECK_LAUNCH("lgr");
+  return GEOTR_OK;
+}
+}  // namespace geotr
+
 extern "C" {
 
 int geotr_weighted_procrustes(const float* src_points, const float* ref_points, const float* weights, int64_t batch, int64_t n,
@@ -378,39 +472,11 @@ int geotr_lgr(const float* ref_knn_points, const float* src_knn_points, const ui
               int64_t topk, float confidence_threshold, int mutual, float acceptance_radius, int64_t correspondence_threshold,
               int64_t num_refinement_steps, const int32_t* p_count, float* ref_corr_points, float* src_corr_points,
               float* corr_scores, int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream_) {
-  GEOTR_CHECK_ARG(p >= 1 && k >= 1 && k <= 256 && topk >= 1 && topk <= 4, "lgr: bad sizes (k <= 256, topk <= 4)");
-  GEOTR_CHECK_ARG(num_refinement_steps >= 1, "lgr: num_refinement_steps must be >= 1");
-  GEOTR_CHECK_ARG(ref_knn_points && src_knn_points && ref_knn_masks && src_knn_masks && score_mat && ref_corr_points &&
-                      src_corr_points && corr_scores && num_corr && estimated_transform && ws, "lgr: null pointer");
-  if (ws_bytes < geotr_lgr_workspace_bytes(p, k, topk)) return fail(GEOTR_E_WORKSPACE, "lgr: workspace too small");
-  hipStream_t stream = (hipStream_t)stream_;
-  const int cap = (int)(k * topk);
-  Carver c(ws);
-  int* stage_ij = c.take<int>((size_t)p * cap);
-  float* stage_score = c.take<float>((size_t)p * cap);
-  int* cnt = c.take<int>((size_t)p);
-  int* offsets = c.take<int>((size_t)p);
-  int* valid = c.take<int>((size_t)p);
-  int* inliers = c.take<int>((size_t)p);
-  float* T_all = c.take<float>((size_t)p * 16);
-  const size_t lds = sizeof(float) * ((size_t)k * (k + 1) + 2 * (size_t)k);
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&lgr_corr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return fail(GEOTR_E_LAUNCH, "lgr: cannot reserve LDS");
-  lgr_corr_kernel<<<dim3((unsigned)p), dim3(256), lds, stream>>>(score_mat, ld_patch, (int)ld_row, (int)k, (int)topk,
-                                                                 confidence_threshold, mutual, ref_knn_masks, src_knn_masks, cap, p_count,
-                                                                 cnt, stage_ij, stage_score);
-  lgr_gather_kernel<<<dim3((unsigned)p), dim3(256), 0, stream>>>(ref_knn_points, src_knn_points, (int)k, (int)p, cap, cnt, stage_ij,
-                                                                 stage_score, ref_corr_points, src_corr_points, corr_scores, offsets,
-                                                                 num_corr);
-  lgr_local_kernel<<<dim3((unsigned)p), dim3(64), 0, stream>>>(ref_corr_points, src_corr_points, corr_scores, cnt, offsets,
-                                                               (int)correspondence_threshold, T_all, valid);
-  lgr_score_kernel<<<dim3((unsigned)p), dim3(256), 0, stream>>>(ref_corr_points, src_corr_points, num_corr, T_all, valid,
-                                                                acceptance_radius, inliers);
-  lgr_refine_kernel<<<dim3(1), dim3(1024), 0, stream>>>(ref_corr_points, src_corr_points, corr_scores, num_corr, T_all, inliers,
-                                                        (int)p, acceptance_radius, (int)num_refinement_steps, estimated_transform);
-  GEOTR_CHECK_LAUNCH("lgr");
-  return GEOTR_OK;
+  LgrBatch bs;
+  std::memset(&bs, 0, sizeof(bs));
+  return lgr_launch(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, ld_patch, ld_row, p, k, topk,
+                    confidence_threshold, mutual, acceptance_radius, correspondence_threshold, num_refinement_steps, p_count,
+                    ref_corr_points, src_corr_points, corr_scores, num_corr, estimated_transform, ws, ws_bytes, stream_, 1, bs);
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 //                           geotransformer/modules/sinkhorn/learnable_sinkhorn.py:13-66 (100 log-domain iterations with
 //                           the (K+1)x(K+1) matrix resident in LDS)
 #include <algorithm>
+#include <cstring>
 
 #include "common.h"
 
@@ -281,6 +282,13 @@ __global__ __launch_bounds__(1024) void topk_rank_kernel(const TopkState* __rest
 // ------------------------------------------------------------------------------------------------
 constexpr float kSinkInf = 1e12f;
 
+struct SinkhornBatch {  // count == 0: single pair (the plain arguments are used as they are); strides in elements
+  int count;
+  const float* ref_feats[GEOTR_MAX_PAIRS];
+  const float* src_feats[GEOTR_MAX_PAIRS];
+  int64_t nr[GEOTR_MAX_PAIRS], ns[GEOTR_MAX_PAIRS];
+  int64_t idx_stride, mask_stride, pcount_stride, out_stride;
+};
 template <int K>  // points per patch: 32, 64 or 128
 __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __restrict__ ref_feats, int64_t nr,
                                                              const float* __restrict__ src_feats, int64_t ns, int C,
@@ -289,7 +297,15 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
                                                              const unsigned char* __restrict__ src_mask,
                                                              const float* __restrict__ alpha_p, int iters,
                                                              const float* __restrict__ scores_in,
-                                                             const int* __restrict__ p_count, float* __restrict__ out) {
+                                                             const int* __restrict__ p_count, float* __restrict__ out, SinkhornBatch sb) {
+  if (sb.count > 0) {  // several stacked pairs in one launch: blockIdx.y = pair (ragged feature slices, uniformly strided patches)
+    const int b = blockIdx.y;
+    ref_feats = sb.ref_feats[b], src_feats = sb.src_feats[b], nr = sb.nr[b], ns = sb.ns[b];
+    ref_idx += b * sb.idx_stride, src_idx += b * sb.idx_stride;
+    ref_mask += b * sb.mask_stride, src_mask += b * sb.mask_stride;
+    if (p_count) p_count += b * sb.pcount_stride;
+    out += b * sb.out_stride;
+  }
   if (p_count && (int)blockIdx.x >= *p_count) return;  // device-resident number of valid patch pairs
   constexpr int K1 = K + 1;
   constexpr int LD = K1;               // odd leading dimension: bank = (row + col) mod 32
@@ -607,6 +623,55 @@ __global__ __launch_bounds__(1024) void nc_compact_kernel(const float* __restric
   if (threadIdx.x == 0) *num_corr = sum;
 }
 
+static int sinkhorn_launch_impl(const float* ref_feats, int64_t nr, const float* src_feats, int64_t ns, int64_t c,
+                         const int64_t* ref_knn_indices, const int64_t* src_knn_indices, const uint8_t* ref_knn_masks,
+                         const uint8_t* src_knn_masks, int64_t p, int64_t k, const float* alpha, int64_t num_iterations,
+                         const float* scores_in, const int32_t* p_count, float* matching_scores, void* stream_, const SinkhornBatch& sb) {
+  GEOTR_CHECK_ARG(p >= 0 && c >= 4 && c % 4 == 0, "patch_sinkhorn: bad sizes (channels must be a multiple of 4)");
+  GEOTR_CHECK_ARG(k == 32 || k == 64 || k == 128, "patch_sinkhorn: points per patch must be 32, 64 or 128 (got %lld)", (long long)k);
+  if (p == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(ref_knn_masks && src_knn_masks && alpha && matching_scores, "patch_sinkhorn: null pointer");
+  GEOTR_CHECK_ARG(scores_in || (ref_feats && src_feats && ref_knn_indices && src_knn_indices),
+                  "patch_sinkhorn: need either scores_in or features + indices");
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t k1 = (size_t)k + 1;
+  const size_t lds = sizeof(float) * (k1 * k1 + 4 * k1 + 2 * (size_t)k * 33);
+#define LAUNCH(KK)                                                                                                              \
+  do {                                                                                                                          \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sinkhorn_kernel<KK>),                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
+      return fail(GEOTR_E_LAUNCH, "patch_sinkhorn: cannot reserve %zu B of LDS", lds);                                           \
+    patch_sinkhorn_kernel<KK><<<dim3((unsigned)p, (unsigned)(sb.count > 0 ? sb.count : 1)), dim3(512), lds, stream>>>(ref_feats, nr, src_feats, ns, (int)c, ref_knn_indices, \
+                                                                            src_knn_indices, ref_knn_masks, src_knn_masks, alpha, \
+                                                                            (int)num_iterations, scores_in, p_count, matching_scores, sb); \
+  } while (0)
+  if (k == 32) LAUNCH(32);
+  else if (k == 64) LAUNCH(64);
+  else LAUNCH(128);
+#undef LAUNCH
+  GEOTR_CHECK_LAUNCH("patch_sinkhorn");
+  return GEOTR_OK;
+}
+
+namespace geotr {
+// patch scores + optimal transport of `batch` stacked pairs in one launch: pair b reads ref_feats[b] (nr[b] rows) / src_feats[b];
+// the patch arrays of pair b are pair 0's shifted by b * (element stride)
+int sinkhorn_launch(int batch, const float* const* ref_feats, const int64_t* nr, const float* const* src_feats, const int64_t* ns, int64_t c,
+                    const int64_t* ref_knn_indices, const int64_t* src_knn_indices, const uint8_t* ref_knn_masks,
+                    const uint8_t* src_knn_masks, int64_t idx_stride, int64_t mask_stride, int64_t p, int64_t k, const float* alpha,
+                    int64_t num_iterations, const int32_t* p_count, int64_t pcount_stride, float* matching_scores, int64_t out_stride,
+                    void* stream) {
+  GEOTR_CHECK_ARG(batch >= 1 && batch <= GEOTR_MAX_PAIRS, "sinkhorn_launch: 1..%d pairs", GEOTR_MAX_PAIRS);
+  SinkhornBatch sb;
+  std::memset(&sb, 0, sizeof(sb));
+  sb.count = batch;
+  for (int b = 0; b < batch; ++b) sb.ref_feats[b] = ref_feats[b], sb.src_feats[b] = src_feats[b], sb.nr[b] = nr[b], sb.ns[b] = ns[b];
+  sb.idx_stride = idx_stride, sb.mask_stride = mask_stride, sb.pcount_stride = pcount_stride, sb.out_stride = out_stride;
+  return sinkhorn_launch_impl(ref_feats[0], nr[0], src_feats[0], ns[0], c, ref_knn_indices, src_knn_indices, ref_knn_masks, src_knn_masks, p, k,
+                              alpha, num_iterations, nullptr, p_count, matching_scores, stream, sb);
+}
+}  // namespace geotr
+
 extern "C" {
 
 int geotr_patch_gather(const int64_t* ref_node_knn_indices, const uint8_t* ref_node_knn_masks, const float* ref_points, int64_t nr,
@@ -679,30 +744,10 @@ int geotr_patch_sinkhorn(const float* ref_feats, int64_t nr, const float* src_fe
                          const int64_t* ref_knn_indices, const int64_t* src_knn_indices, const uint8_t* ref_knn_masks,
                          const uint8_t* src_knn_masks, int64_t p, int64_t k, const float* alpha, int64_t num_iterations,
                          const float* scores_in, const int32_t* p_count, float* matching_scores, void* stream_) {
-  GEOTR_CHECK_ARG(p >= 0 && c >= 4 && c % 4 == 0, "patch_sinkhorn: bad sizes (channels must be a multiple of 4)");
-  GEOTR_CHECK_ARG(k == 32 || k == 64 || k == 128, "patch_sinkhorn: points per patch must be 32, 64 or 128 (got %lld)", (long long)k);
-  if (p == 0) return GEOTR_OK;
-  GEOTR_CHECK_ARG(ref_knn_masks && src_knn_masks && alpha && matching_scores, "patch_sinkhorn: null pointer");
-  GEOTR_CHECK_ARG(scores_in || (ref_feats && src_feats && ref_knn_indices && src_knn_indices),
-                  "patch_sinkhorn: need either scores_in or features + indices");
-  hipStream_t stream = (hipStream_t)stream_;
-  const size_t k1 = (size_t)k + 1;
-  const size_t lds = sizeof(float) * (k1 * k1 + 4 * k1 + 2 * (size_t)k * 33);
-#define LAUNCH(KK)                                                                                                              \
-  do {                                                                                                                          \
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sinkhorn_kernel<KK>),                        \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
-      return fail(GEOTR_E_LAUNCH, "patch_sinkhorn: cannot reserve %zu B of LDS", lds);                                           \
-    patch_sinkhorn_kernel<KK><<<dim3((unsigned)p), dim3(512), lds, stream>>>(ref_feats, nr, src_feats, ns, (int)c, ref_knn_indices, \
-                                                                            src_knn_indices, ref_knn_masks, src_knn_masks, alpha, \
-                                                                            (int)num_iterations, scores_in, p_count, matching_scores); \
-  } while (0)
-  if (k == 32) LAUNCH(32);
-  else if (k == 64) LAUNCH(64);
-  else LAUNCH(128);
-#undef LAUNCH
-  GEOTR_CHECK_LAUNCH("patch_sinkhorn");
-  return GEOTR_OK;
+  SinkhornBatch sb;
+  std::memset(&sb, 0, sizeof(sb));
+  return sinkhorn_launch_impl(ref_feats, nr, src_feats, ns, c, ref_knn_indices, src_knn_indices, ref_knn_masks, src_knn_masks, p, k, alpha,
+                              num_iterations, scores_in, p_count, matching_scores, stream_, sb);
 }
 
 size_t geotr_node_correspondences_workspace_bytes(int64_t m, int64_t n, int64_t k) {
