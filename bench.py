@@ -196,10 +196,13 @@ def main():
         executed = (3.0 * algorithmic if split else algorithmic) if algorithmic else None
         peak = BF16_MATRIX_PEAK_TFLOPS if split else FP32_MATRIX_PEAK_TFLOPS
         line = {
-            'metric': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)', 'value': round(value, 3), 'unit': 'pairs/s',
+            'metric': {'3dmatch': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)',
+                       'kitti': 'registration pairs/sec (120k-pt synthetic KITTI-shape pair)',
+                       'modelnet': 'registration pairs/sec (1k-pt synthetic ModelNet-shape pair)'}[args.config],
+            'value': round(value, 3), 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[1]: synthetic {args.config} pair, {n_points}+{n_points} pts, '
+            'config': {'workload': f'BASELINE configs[{ {"3dmatch": 1, "kitti": 3, "modelnet": 0}[args.config] }]: synthetic {args.config} pair, {n_points}+{n_points} pts, '
                                    f'{cfg.backbone.num_stages}-stage KPConv-FPN, d={D}, '
                                    f'{info["superpoints"][0]}+{info["superpoints"][1]} superpoints, '
                                    f'P={cfg.coarse_matching.num_correspondences}, K={cfg.model.num_points_in_patch}, '
