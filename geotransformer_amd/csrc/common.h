@@ -58,6 +58,14 @@ int sinkhorn_launch(int batch, const float* const* ref_feats, const int64_t* nr,
                     int64_t num_iterations, const int32_t* p_count, int64_t pcount_stride, float* matching_scores, int64_t out_stride,
                     void* stream);
 
+int p2n_launch(const float* points, const float* nodes, int clouds, const int64_t* f0, const int64_t* c0, int64_t k, int64_t* point_to_node,
+               uint8_t* node_masks, int64_t* knn_indices, uint8_t* knn_masks, int32_t* overflow, void* stream);
+
+size_t spm_stack_workspace_bytes(int pairs, const int64_t* n, const int64_t* m);
+int spm_stack_launch(float* scores, int pairs, const int64_t* n, const int64_t* m, const int64_t* s_off, const uint8_t* masks,
+                     const int64_t* mask_off, int dual_normalization, int64_t k, void* ws, size_t ws_bytes, int64_t* ref_idx, int64_t* src_idx,
+                     float* corr_scores, int32_t* count, int64_t out_stride, int64_t count_stride, void* stream);
+
 #ifdef __HIPCC__
 // split-bf16 helpers: x = hi + lo with hi = bf16(x), lo = bf16(x - hi)  (round to nearest even)
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;

@@ -403,34 +403,26 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
 
 // heads of one pair: superpoint patches, geometric transformer, coarse matching, patch OT, LGR.  All pointers are the pair's
 // own slices of the stacked arrays (reference cloud first).
+// node_masks / node_knn_idx / node_knn_mask: the pair's slices of the stack-wide superpoint partition (reference cloud first)
 static void run_pair(Ctx& c, const geotr_model& net, const float* pts_c, int64_t nr_c, int64_t ns_c, const float* pts_f, int64_t nr_f,
-                     int64_t ns_f, const float* feats_f, int64_t c_f, const geotr_outputs& o, bool per_pair_tail) {
-  const int64_t n_c = nr_c + ns_c, n_f = nr_f + ns_f;
+                     int64_t ns_f, const float* feats_f, int64_t c_f, const uint8_t* node_masks, const int64_t* node_knn_idx,
+                     const uint8_t* node_knn_mask, const geotr_outputs& o, bool per_pair_tail, bool coarse_done) {
+  (void)pts_c;
   const int64_t K = net.num_points_in_patch, P = net.num_correspondences;
 
-  // 1. superpoint patches (model.py:98-108)
-  int64_t* p2n = c.alloc<int64_t>((size_t)n_f);
-  uint8_t* node_masks = c.alloc<uint8_t>((size_t)n_c);
-  int64_t* node_knn_idx = c.alloc<int64_t>((size_t)n_c * K);
-  uint8_t* node_knn_mask = c.alloc<uint8_t>((size_t)n_c * K);
-  int32_t* scratch_flag = c.alloc<int32_t>(4);
-  if (c.live()) {
-    if (hipMemsetAsync(scratch_flag, 0, 16, c.stream) != hipSuccess) c.check(fail(GEOTR_E_LAUNCH, "model_forward: memset failed"));
-    c.check(geotr_point_to_node(pts_f, nr_f, pts_c, nr_c, K, p2n, node_masks, node_knn_idx, node_knn_mask, scratch_flag, c.stream));
-    c.check(geotr_point_to_node(pts_f + 3 * nr_f, ns_f, pts_c + 3 * nr_c, ns_c, K, p2n + nr_f, node_masks + nr_c, node_knn_idx + nr_c * K,
-                                node_knn_mask + nr_c * K, scratch_flag, c.stream));
-  }
   const int64_t D = net.transformer.out_proj.out;  // o.feats_c already holds the L2-normalised transformer features (transformer_stack)
 
-  // 4. coarse matching (model.py:153-160)
-  float* sim = c.alloc<float>((size_t)nr_c * ns_c);
-  const size_t spm_bytes = geotr_superpoint_match_workspace_bytes(nr_c, ns_c);
-  char* spm_ws = c.alloc<char>(spm_bytes);
+  // 4. coarse matching (model.py:153-160) -- unless it already ran for the whole stack
+  float* sim = coarse_done ? nullptr : c.alloc<float>((size_t)nr_c * ns_c);
+  const size_t spm_bytes = coarse_done ? 0 : geotr_superpoint_match_workspace_bytes(nr_c, ns_c);
+  char* spm_ws = coarse_done ? nullptr : c.alloc<char>(spm_bytes);
   if (c.live()) {
-    c.check(geotr_gemm(o.feats_c, D, o.feats_c + nr_c * D, D, 0, sim, ns_c, nr_c, ns_c, D, 1, 0, 0, 0, nullptr, nullptr, nullptr, 0, 1.0f, 0,
-                       c.stream));
-    c.check(geotr_superpoint_match(sim, nr_c, ns_c, node_masks, node_masks + nr_c, net.dual_normalization, P, spm_ws, spm_bytes,
-                                   o.ref_node_corr_indices, o.src_node_corr_indices, o.node_corr_scores, o.num_node_corr, c.stream));
+    if (!coarse_done) {
+      c.check(geotr_gemm(o.feats_c, D, o.feats_c + nr_c * D, D, 0, sim, ns_c, nr_c, ns_c, D, 1, 0, 0, 0, nullptr, nullptr, nullptr, 0, 1.0f, 0,
+                         c.stream));
+      c.check(geotr_superpoint_match(sim, nr_c, ns_c, node_masks, node_masks + nr_c, net.dual_normalization, P, spm_ws, spm_bytes,
+                                     o.ref_node_corr_indices, o.src_node_corr_indices, o.node_corr_scores, o.num_node_corr, c.stream));
+    }
     // 5. patches of the selected pairs (model.py:169-179); rows >= *num_node_corr are neutral (pad index, mask False)
     c.check(geotr_patch_gather(node_knn_idx, node_knn_mask, pts_f, nr_f, o.ref_node_corr_indices, node_knn_idx + nr_c * K,
                                node_knn_mask + nr_c * K, pts_f + 3 * nr_f, ns_f, o.src_node_corr_indices, P, K, o.num_node_corr,
@@ -516,6 +508,53 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
   }
   if (c.dry) batched_tail = B > 1;  // size query: reserve the batched workspace
 
+  // superpoint patches (model.py:98-108) of every cloud of the stack in one launch pair
+  const int64_t n_f_all = p.n[fine];
+  int64_t* p2n = c.alloc<int64_t>((size_t)n_f_all);
+  uint8_t* node_masks = c.alloc<uint8_t>((size_t)n_c);
+  int64_t* node_knn_idx = c.alloc<int64_t>((size_t)n_c * K);
+  uint8_t* node_knn_mask = c.alloc<uint8_t>((size_t)n_c * K);
+  int32_t* scratch_flag = c.alloc<int32_t>(4);
+  if (c.live()) {
+    int64_t f0[2 * GEOTR_MAX_PAIRS + 1], c0[2 * GEOTR_MAX_PAIRS + 1];
+    f0[0] = c0[0] = 0;
+    for (int q = 0; q < 2 * B; ++q) f0[q + 1] = f0[q] + p.cloud_n[fine][q], c0[q + 1] = c0[q] + p.cloud_n[S - 1][q];
+    if (hipMemsetAsync(scratch_flag, 0, 16, c.stream) != hipSuccess) c.check(fail(GEOTR_E_LAUNCH, "model_forward: memset failed"));
+    c.check(p2n_launch(p.points[fine], p.points[S - 1], 2 * B, f0, c0, K, p2n, node_masks, node_knn_idx, node_knn_mask, scratch_flag, c.stream));
+  }
+
+  // coarse matching (model.py:153-160) of all pairs in one launch sequence when the per-pair outputs are uniformly strided
+  bool coarse_stack = batched_tail;
+  int64_t corr_stride = 0;
+  if (coarse_stack && !c.dry) {
+    corr_stride = uniform_stride(outs, B, [](const geotr_outputs& o) { return o.ref_node_corr_indices; });
+    coarse_stack = corr_stride > 0 && corr_stride == uniform_stride(outs, B, [](const geotr_outputs& o) { return o.src_node_corr_indices; }) &&
+                   corr_stride / 2 == uniform_stride(outs, B, [](const geotr_outputs& o) { return o.node_corr_scores; });
+  }
+  if (coarse_stack) {
+    const int64_t D = net.transformer.out_proj.out;
+    int64_t pn[GEOTR_MAX_PAIRS], pm[GEOTR_MAX_PAIRS], s_off[GEOTR_MAX_PAIRS], m_off[GEOTR_MAX_PAIRS];
+    geotr_gemm_groups gg;
+    std::memset(&gg, 0, sizeof(gg));
+    gg.count = B;
+    int64_t tot = 0, oc = 0;
+    for (int b = 0; b < B; ++b) {
+      pn[b] = p.cloud_n[S - 1][2 * b], pm[b] = p.cloud_n[S - 1][2 * b + 1], s_off[b] = tot, m_off[b] = oc;
+      gg.m[b] = pn[b], gg.n[b] = pm[b], gg.k[b] = D, gg.lda[b] = D, gg.ldb[b] = D, gg.ldc[b] = pm[b];
+      gg.a_off[b] = oc * D, gg.b_off[b] = (oc + pn[b]) * D, gg.c_off[b] = tot;
+      tot += pn[b] * pm[b], oc += pn[b] + pm[b];
+    }
+    float* sims = c.alloc<float>((size_t)tot);
+    const size_t wsb = spm_stack_workspace_bytes(B, pn, pm);
+    char* ws2 = c.alloc<char>(wsb);
+    if (c.live()) {
+      const geotr_outputs& o = outs[0];
+      c.check(geotr_gemm_grouped(o.feats_c, o.feats_c, 0, sims, &gg, 1, 1.0f, c.stream));
+      c.check(spm_stack_launch(sims, B, pn, pm, s_off, node_masks, m_off, net.dual_normalization, P, ws2, wsb, o.ref_node_corr_indices,
+                               o.src_node_corr_indices, o.node_corr_scores, o.num_node_corr, corr_stride / 8, lb.pcount / 4, c.stream));
+    }
+  }
+
   int64_t off_c = 0, off_f = 0;
   const float* tail_ref_feats[GEOTR_MAX_PAIRS];
   const float* tail_src_feats[GEOTR_MAX_PAIRS];
@@ -530,8 +569,8 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
         c.rc == GEOTR_OK)
       c.rc = fail(GEOTR_E_INVALID, "model_forward: outputs[%d].feats_f / feats_c must be the pair's rows of the stacked buffers", b);
     const size_t mp = c.mark();
-    run_pair(c, net, p.points[S - 1] + 3 * off_c, nr_c, ns_c, p.points[fine] + 3 * off_f, nr_f, ns_f, feats_f + off_f * c_f, c_f, o,
-             !batched_tail);
+    run_pair(c, net, p.points[S - 1] + 3 * off_c, nr_c, ns_c, p.points[fine] + 3 * off_f, nr_f, ns_f, feats_f + off_f * c_f, c_f,
+             node_masks + off_c, node_knn_idx + off_c * K, node_knn_mask + off_c * K, o, !batched_tail, coarse_stack);
     tail_ref_feats[b] = feats_f + off_f * c_f, tail_src_feats[b] = feats_f + (off_f + nr_f) * c_f, tail_nr[b] = nr_f, tail_ns[b] = ns_f;
     c.release(mp);
     off_c += nr_c + ns_c;

@@ -24,10 +24,23 @@ __device__ __forceinline__ float sqdist_expanded(const float* a, const float* b)
 // ------------------------------------------------------------------------------------------------
 // P1: point -> nearest node, then per node the K nearest owned points
 // ------------------------------------------------------------------------------------------------
+// Several clouds in one launch (stacked forward): blockIdx.y = cloud; cloud q owns rows [f0[q], f0[q+1]) of the stacked points /
+// point_to_node and rows [c0[q], c0[q+1]) of the stacked nodes / node arrays.  count == 0: the plain single-cloud arguments.
+struct P2nClouds {
+  int count;
+  int64_t f0[2 * GEOTR_MAX_PAIRS + 1], c0[2 * GEOTR_MAX_PAIRS + 1];
+};
+
 __global__ __launch_bounds__(256) void p2n_assign_kernel(const float* __restrict__ pts, int64_t N, const float* __restrict__ nodes,
                                                          int M, int64_t* __restrict__ point_to_node,
-                                                         unsigned char* __restrict__ node_masks) {
+                                                         unsigned char* __restrict__ node_masks, P2nClouds tb) {
   extern __shared__ float nd[];  // [M][3]
+  if (tb.count > 0) {
+    const int q = blockIdx.y;
+    N = tb.f0[q + 1] - tb.f0[q], M = (int)(tb.c0[q + 1] - tb.c0[q]);
+    pts += 3 * tb.f0[q], nodes += 3 * tb.c0[q], point_to_node += tb.f0[q], node_masks += tb.c0[q];
+    if ((int64_t)blockIdx.x * blockDim.x >= N) return;
+  }
   for (int e = threadIdx.x; e < 3 * M; e += blockDim.x) nd[e] = nodes[e];
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,10 +64,17 @@ constexpr int kP2nCap = 4096;  // owned points per node kept in LDS
 __global__ __launch_bounds__(256) void p2n_knn_kernel(const float* __restrict__ pts, int64_t N, const float* __restrict__ nodes,
                                                       const int64_t* __restrict__ point_to_node, int K,
                                                       int64_t* __restrict__ knn_idx, unsigned char* __restrict__ knn_mask,
-                                                      int* __restrict__ overflow) {
+                                                      int* __restrict__ overflow, P2nClouds tb) {
   __shared__ unsigned long long keys[kP2nCap];
   __shared__ int cnt;
   const int node = blockIdx.x;
+  if (tb.count > 0) {
+    const int q = blockIdx.y;
+    if (node >= (int)(tb.c0[q + 1] - tb.c0[q])) return;
+    N = tb.f0[q + 1] - tb.f0[q];
+    pts += 3 * tb.f0[q], nodes += 3 * tb.c0[q], point_to_node += tb.f0[q];
+    knn_idx += tb.c0[q] * K, knn_mask += tb.c0[q] * K;
+  }
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
   const float nd[3] = {nodes[3 * node], nodes[3 * node + 1], nodes[3 * node + 2]};
@@ -89,8 +109,24 @@ __global__ __launch_bounds__(256) void p2n_knn_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // M1: coarse matching.  xy (n,m) = ref_feats . src_feats^T comes from gemm.hip.
 // ------------------------------------------------------------------------------------------------
+// Coarse matching of several stacked pairs in one launch sequence: blockIdx.y (z for the column sums) = pair; pair b has its own
+// (n, m), score matrix at s + s_off[b], superpoint masks at rmask + mask_off[b] (reference) followed by the source's, sums at
+// row_off / col_off and selection state st[b]; the per-pair outputs sit out_stride / count_stride elements apart.  count == 0: single.
+struct SpmBatch {
+  int count;
+  int n[GEOTR_MAX_PAIRS], m[GEOTR_MAX_PAIRS];
+  int64_t s_off[GEOTR_MAX_PAIRS], mask_off[GEOTR_MAX_PAIRS], row_off[GEOTR_MAX_PAIRS], col_off[GEOTR_MAX_PAIRS];
+  int64_t out_stride, count_stride;
+};
+
 __global__ __launch_bounds__(256) void spm_exp_kernel(float* __restrict__ s, int n, int m, const unsigned char* __restrict__ rmask,
-                                                      const unsigned char* __restrict__ cmask, float* __restrict__ rowsum) {
+                                                      const unsigned char* __restrict__ cmask, float* __restrict__ rowsum, SpmBatch sb) {
+  if (sb.count > 0) {
+    const int b = blockIdx.y;
+    n = sb.n[b], m = sb.m[b];
+    if ((int)blockIdx.x >= n) return;
+    s += sb.s_off[b], rmask += sb.mask_off[b], cmask = rmask + n, rowsum += sb.row_off[b];
+  }
   __shared__ float red[4];
   const int i = blockIdx.x;
   float acc = 0.f;
@@ -107,7 +143,13 @@ __global__ __launch_bounds__(256) void spm_exp_kernel(float* __restrict__ s, int
 }
 // column sums in two levels: kSpmParts row-chunks per column block (fixed order => deterministic), folded by the dual kernel
 constexpr int kSpmParts = 8;
-__global__ __launch_bounds__(256) void spm_colsum_kernel(const float* __restrict__ s, int n, int m, float* __restrict__ colpart) {
+__global__ __launch_bounds__(256) void spm_colsum_kernel(const float* __restrict__ s, int n, int m, float* __restrict__ colpart, SpmBatch sb) {
+  if (sb.count > 0) {
+    const int b = blockIdx.z;
+    n = sb.n[b], m = sb.m[b];
+    if ((int)blockIdx.x * 64 >= m) return;
+    s += sb.s_off[b], colpart += sb.col_off[b];
+  }
   __shared__ float red[4][64];
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   const int rows = (n + kSpmParts - 1) / kSpmParts, i0 = blockIdx.y * rows, i1 = min(n, i0 + rows);
@@ -164,7 +206,12 @@ __device__ void topk_select_bin(const unsigned* __restrict__ hist, int width, un
 // dual normalisation (superpoint_matching.py:36-40) fused with radix pass 0 and the count of valid entries
 __global__ __launch_bounds__(256) void spm_dual_kernel(float* __restrict__ s, int n, int m, const float* __restrict__ rowsum,
                                                        const float* __restrict__ colpart, const unsigned char* __restrict__ rmask,
-                                                       const unsigned char* __restrict__ cmask, int dual, TopkState* __restrict__ st) {
+                                                       const unsigned char* __restrict__ cmask, int dual, TopkState* __restrict__ st, SpmBatch sb) {
+  if (sb.count > 0) {
+    const int b = blockIdx.y;
+    n = sb.n[b], m = sb.m[b];
+    s += sb.s_off[b], rmask += sb.mask_off[b], cmask = rmask + n, rowsum += sb.row_off[b], colpart += sb.col_off[b], st += b;
+  }
   __shared__ unsigned hist[2048];
   const int tid = threadIdx.x;
   const int64_t total = (int64_t)n * m;
@@ -199,7 +246,12 @@ __global__ __launch_bounds__(256) void spm_dual_kernel(float* __restrict__ s, in
 }
 
 // radix passes 1 (bits 20..10) and 2 (bits 9..0) among the elements whose higher bits equal the running prefix
-__global__ __launch_bounds__(256) void topk_pass_kernel(const float* __restrict__ s, int64_t total, int k, int pass, TopkState* __restrict__ st) {
+__global__ __launch_bounds__(256) void topk_pass_kernel(const float* __restrict__ s, int64_t total, int k, int pass, TopkState* __restrict__ st,
+                                                        SpmBatch sb) {
+  if (sb.count > 0) {
+    const int b = blockIdx.y;
+    total = (int64_t)sb.n[b] * sb.m[b], s += sb.s_off[b], st += b;
+  }
   __shared__ unsigned hist[2048 + 8];
   const int tid = threadIdx.x;
   const int keff = min(k, st->nvalid);  // number of valid entries bounds k (superpoint_matching.py:42)
@@ -229,7 +281,12 @@ __global__ __launch_bounds__(256) void topk_pass_kernel(const float* __restrict_
 }
 
 // collect everything >= the k-th largest bit pattern into the candidate list
-__global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restrict__ s, int64_t total, int k, TopkState* __restrict__ st) {
+__global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restrict__ s, int64_t total, int k, TopkState* __restrict__ st,
+                                                           SpmBatch sb) {
+  if (sb.count > 0) {
+    const int b = blockIdx.y;
+    total = (int64_t)sb.n[b] * sb.m[b], s += sb.s_off[b], st += b;
+  }
   __shared__ unsigned hist[2048 + 8];
   const int tid = threadIdx.x;
   const int keff = min(k, st->nvalid);
@@ -254,7 +311,13 @@ __global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restri
 
 // rank the candidates (larger score first, then smaller flat index) and write the k outputs (zeros past the count)
 __global__ __launch_bounds__(1024) void topk_rank_kernel(const TopkState* __restrict__ st, int k, int m, int64_t* __restrict__ rows,
-                                                         int64_t* __restrict__ cols, float* __restrict__ vals, int* __restrict__ count_out) {
+                                                         int64_t* __restrict__ cols, float* __restrict__ vals, int* __restrict__ count_out,
+                                                         SpmBatch sb) {
+  if (sb.count > 0) {
+    const int b = blockIdx.y;
+    m = sb.m[b], st += b;
+    rows += b * sb.out_stride, cols += b * sb.out_stride, vals += b * sb.out_stride, count_out += b * sb.count_stride;
+  }
   __shared__ unsigned long long cand[kTopkCap];
   const int tid = threadIdx.x;
   const int keff = min(k, st->nvalid);
@@ -672,6 +735,80 @@ int sinkhorn_launch(int batch, const float* const* ref_feats, const int64_t* nr,
 }
 }  // namespace geotr
 
+namespace geotr {
+// partition of `clouds` stacked clouds in one launch pair: cloud q = fine rows [f0[q], f0[q+1]), superpoints [c0[q], c0[q+1])
+int p2n_launch(const float* points, const float* nodes, int clouds, const int64_t* f0, const int64_t* c0, int64_t k, int64_t* point_to_node,
+               uint8_t* node_masks, int64_t* knn_indices, uint8_t* knn_masks, int32_t* overflow, void* stream_) {
+  GEOTR_CHECK_ARG(clouds >= 1 && clouds <= 2 * GEOTR_MAX_PAIRS && k >= 1, "point_to_node: 1..%d clouds", 2 * GEOTR_MAX_PAIRS);
+  GEOTR_CHECK_ARG(points && nodes && point_to_node && node_masks && knn_indices && knn_masks, "point_to_node: null pointer");
+  P2nClouds tb;
+  std::memset(&tb, 0, sizeof(tb));
+  tb.count = clouds;
+  int64_t maxn = 0, maxm = 0;
+  for (int q = 0; q <= clouds; ++q) tb.f0[q] = f0[q], tb.c0[q] = c0[q];
+  for (int q = 0; q < clouds; ++q) {
+    GEOTR_CHECK_ARG(f0[q + 1] > f0[q] && c0[q + 1] > c0[q], "point_to_node: empty cloud %d", q);
+    maxn = std::max(maxn, f0[q + 1] - f0[q]), maxm = std::max(maxm, c0[q + 1] - c0[q]);
+  }
+  GEOTR_CHECK_ARG(maxm <= 12000, "point_to_node: at most 12000 nodes (got %lld)", (long long)maxm);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hipMemsetAsync(node_masks, 0, (size_t)c0[clouds], stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "point_to_node: memset failed");
+  const size_t lds = sizeof(float) * 3 * (size_t)maxm;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(GEOTR_E_LAUNCH, "point_to_node: cannot reserve LDS");
+  p2n_assign_kernel<<<dim3((unsigned)((maxn + 255) / 256), (unsigned)clouds), dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node,
+                                                                                                    node_masks, tb);
+  p2n_knn_kernel<<<dim3((unsigned)maxm, (unsigned)clouds), dim3(256), 0, stream>>>(points, 0, nodes, point_to_node, (int)k, knn_indices, knn_masks,
+                                                                                 overflow, tb);
+  GEOTR_CHECK_LAUNCH("point_to_node");
+  return GEOTR_OK;
+}
+}  // namespace geotr
+
+namespace geotr {
+size_t spm_stack_workspace_bytes(int pairs, const int64_t* n, const int64_t* m) {
+  size_t b = align_up(sizeof(TopkState) * (size_t)pairs);
+  int64_t sn = 0, sm = 0;
+  for (int i = 0; i < pairs; ++i) sn += n[i], sm += m[i];
+  return b + align_up(sizeof(float) * (size_t)sn) + align_up(sizeof(float) * (size_t)sm * kSpmParts);
+}
+// coarse matching of `pairs` stacked pairs: scores + s_off[b] = (n[b], m[b]) inner products (overwritten); masks + mask_off[b] = the
+// pair's superpoint masks (reference first); outputs of pair b at ref_idx + b * out_stride etc.
+int spm_stack_launch(float* scores, int pairs, const int64_t* n, const int64_t* m, const int64_t* s_off, const uint8_t* masks,
+                     const int64_t* mask_off, int dual_normalization, int64_t k, void* ws, size_t ws_bytes, int64_t* ref_idx, int64_t* src_idx,
+                     float* corr_scores, int32_t* count, int64_t out_stride, int64_t count_stride, void* stream_) {
+  GEOTR_CHECK_ARG(pairs >= 1 && pairs <= GEOTR_MAX_PAIRS && k >= 1 && k <= kTopkCap / 2, "superpoint_match: bad sizes");
+  GEOTR_CHECK_ARG(ws_bytes >= spm_stack_workspace_bytes(pairs, n, m), "superpoint_match: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  SpmBatch sb;
+  std::memset(&sb, 0, sizeof(sb));
+  sb.count = pairs, sb.out_stride = out_stride, sb.count_stride = count_stride;
+  int64_t ro = 0, co = 0, maxn = 0, maxm = 0, maxtot = 0;
+  for (int b = 0; b < pairs; ++b) {
+    GEOTR_CHECK_ARG(n[b] >= 1 && m[b] >= 1 && n[b] * m[b] < (1ll << 31), "superpoint_match: bad pair %d", b);
+    sb.n[b] = (int)n[b], sb.m[b] = (int)m[b], sb.s_off[b] = s_off[b], sb.mask_off[b] = mask_off[b], sb.row_off[b] = ro, sb.col_off[b] = co;
+    ro += n[b], co += m[b] * kSpmParts;
+    maxn = std::max(maxn, n[b]), maxm = std::max(maxm, m[b]), maxtot = std::max(maxtot, n[b] * m[b]);
+  }
+  Carver cv(ws);
+  TopkState* st = cv.take<TopkState>((size_t)pairs);
+  float* rowsum = cv.take<float>((size_t)ro);
+  float* colpart = cv.take<float>((size_t)co);
+  if (hipMemsetAsync(st, 0, sizeof(TopkState) * (size_t)pairs, stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "superpoint_match: memset failed");
+  const unsigned blocks = (unsigned)std::min<int64_t>((maxtot + kTopkChunk - 1) / kTopkChunk, 256), P = (unsigned)pairs;
+  spm_exp_kernel<<<dim3((unsigned)maxn, P), dim3(256), 0, stream>>>(scores, 0, 0, masks, nullptr, rowsum, sb);
+  spm_colsum_kernel<<<dim3((unsigned)((maxm + 63) / 64), kSpmParts, P), dim3(256), 0, stream>>>(scores, 0, 0, colpart, sb);
+  spm_dual_kernel<<<dim3(blocks, P), dim3(256), 0, stream>>>(scores, 0, 0, rowsum, colpart, masks, nullptr, dual_normalization, st, sb);
+  topk_pass_kernel<<<dim3(blocks, P), dim3(256), 0, stream>>>(scores, 0, (int)k, 1, st, sb);
+  topk_pass_kernel<<<dim3(blocks, P), dim3(256), 0, stream>>>(scores, 0, (int)k, 2, st, sb);
+  topk_collect_kernel<<<dim3(blocks, P), dim3(256), 0, stream>>>(scores, 0, (int)k, st, sb);
+  topk_rank_kernel<<<dim3(1, P), dim3(1024), 0, stream>>>(st, (int)k, 0, ref_idx, src_idx, corr_scores, count, sb);
+  GEOTR_CHECK_LAUNCH("superpoint_match");
+  return GEOTR_OK;
+}
+}  // namespace geotr
+
 extern "C" {
 
 int geotr_patch_gather(const int64_t* ref_node_knn_indices, const uint8_t* ref_node_knn_masks, const float* ref_points, int64_t nr,
@@ -695,18 +832,8 @@ int geotr_patch_gather(const int64_t* ref_node_knn_indices, const uint8_t* ref_n
 int geotr_point_to_node(const float* points, int64_t n, const float* nodes, int64_t m, int64_t k, int64_t* point_to_node,
                         uint8_t* node_masks, int64_t* knn_indices, uint8_t* knn_masks, int32_t* overflow, void* stream_) {
   GEOTR_CHECK_ARG(n >= 1 && m >= 1 && k >= 1, "point_to_node: bad sizes");
-  GEOTR_CHECK_ARG(points && nodes && point_to_node && node_masks && knn_indices && knn_masks, "point_to_node: null pointer");
-  GEOTR_CHECK_ARG(m <= 12000, "point_to_node: at most 12000 nodes (got %lld)", (long long)m);
-  hipStream_t stream = (hipStream_t)stream_;
-  if (hipMemsetAsync(node_masks, 0, (size_t)m, stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "point_to_node: memset failed");
-  const size_t lds = sizeof(float) * 3 * (size_t)m;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return fail(GEOTR_E_LAUNCH, "point_to_node: cannot reserve LDS");
-  p2n_assign_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream>>>(points, n, nodes, (int)m, point_to_node, node_masks);
-  p2n_knn_kernel<<<dim3((unsigned)m), dim3(256), 0, stream>>>(points, n, nodes, point_to_node, (int)k, knn_indices, knn_masks, overflow);
-  GEOTR_CHECK_LAUNCH("point_to_node");
-  return GEOTR_OK;
+  const int64_t f0[2] = {0, n}, c0[2] = {0, m};
+  return p2n_launch(points, nodes, 1, f0, c0, k, point_to_node, node_masks, knn_indices, knn_masks, overflow, stream_);
 }
 
 size_t geotr_superpoint_match_workspace_bytes(int64_t n, int64_t m) {
@@ -729,13 +856,15 @@ int geotr_superpoint_match(float* scores, int64_t n, int64_t m, const uint8_t* r
   if (hipMemsetAsync(st, 0, sizeof(TopkState), stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "superpoint_match: memset failed");
   const int64_t total = n * m;
   const unsigned blocks = (unsigned)std::min<int64_t>((total + kTopkChunk - 1) / kTopkChunk, 256);
-  spm_exp_kernel<<<dim3((unsigned)n), dim3(256), 0, stream>>>(scores, (int)n, (int)m, ref_masks, src_masks, rowsum);
-  spm_colsum_kernel<<<dim3((unsigned)((m + 63) / 64), kSpmParts), dim3(256), 0, stream>>>(scores, (int)n, (int)m, colpart);
-  spm_dual_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, (int)n, (int)m, rowsum, colpart, ref_masks, src_masks, dual_normalization, st);
-  topk_pass_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, 1, st);
-  topk_pass_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, 2, st);
-  topk_collect_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, st);
-  topk_rank_kernel<<<dim3(1), dim3(1024), 0, stream>>>(st, (int)k, (int)m, ref_idx, src_idx, corr_scores, count);
+  SpmBatch sb;
+  std::memset(&sb, 0, sizeof(sb));
+  spm_exp_kernel<<<dim3((unsigned)n), dim3(256), 0, stream>>>(scores, (int)n, (int)m, ref_masks, src_masks, rowsum, sb);
+  spm_colsum_kernel<<<dim3((unsigned)((m + 63) / 64), kSpmParts), dim3(256), 0, stream>>>(scores, (int)n, (int)m, colpart, sb);
+  spm_dual_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, (int)n, (int)m, rowsum, colpart, ref_masks, src_masks, dual_normalization, st, sb);
+  topk_pass_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, 1, st, sb);
+  topk_pass_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, 2, st, sb);
+  topk_collect_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, st, sb);
+  topk_rank_kernel<<<dim3(1), dim3(1024), 0, stream>>>(st, (int)k, (int)m, ref_idx, src_idx, corr_scores, count, sb);
   GEOTR_CHECK_LAUNCH("superpoint_match");
   return GEOTR_OK;
 }
