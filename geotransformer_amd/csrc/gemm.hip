@@ -470,7 +470,7 @@ __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b
 // at most 2-way conflicted), the weight fragments as packed.  The fp32 -> (hi, lo) bf16 split happens when a wave reads its A
 // fragment (v_cvt_pk_bf16_f32).  One barrier per step; each wave issues 4 + WAVES... loads per step and waits on its own
 // vmcnt, then the barrier publishes the stage to the other waves.
-constexpr int kPStages = 4;
+constexpr int kPStages = 2;
 #define GEOTR_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | (((N) >> 4) << 14) | 0x0F70)
 // LDS reads of DMA-written data go through inline asm: the compiler's own waitcnt insertion would otherwise drain ALL
 // outstanding LDS DMA (vmcnt(0)) before any ds_read it can see.  One asm block = a batch of ds_read_b128 + s_waitcnt lgkmcnt(0),
@@ -667,7 +667,7 @@ extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed
   GEOTR_CHECK_ARG(gy <= 65535, "gemm_packed: M too large");
 #define GEOTR_PACKED(WM, WN, BN)                                                                                        \
   do {                                                                                                                  \
-    const int lds = kPStages * (128 * 128 + (BN / 32) * 4096);                                                          \
+    const int lds = std::max(kPStages * (128 * 128 + (BN / 32) * 4096), 4 * 32 * WM * (32 * WN + 4) * 4); /* ring | epilogue slabs */ \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             lds) != hipSuccess)                                                                         \
       return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);                                      \
