@@ -56,6 +56,11 @@ SIGNATURES = {
     'geotr_registration_metrics': (c_int, [c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_ptr,
                                            c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     'geotr_attn_softmax_grouped': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_f32, c_ptr]),
+    'geotr_kdtree_workspace_bytes': (c_size, [c_i64, c_i64]),
+    'geotr_kdtree_build': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
+    'geotr_kdtree_search_scratch_bytes': (c_size, [c_i64, c_i64]),
+    'geotr_kdtree_radius_search': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_f32, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
+                                           c_ptr, c_size, c_ptr]),
     'geotr_gemm_grouped': (c_int, [c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_i64, c_f32, c_ptr]),
     'geotr_gemm_pack_bytes': (c_size, [c_i64, c_i64]),
     'geotr_gemm_pack': (c_int, [c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr, c_ptr]),

@@ -112,11 +112,47 @@ def grid_subsample_device(points, lengths, voxel_size):
     return s_points, s_lengths
 
 
-def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius):
+class KdTreeIndex:
+    """Opt-in reference tie order: nanoflann-shaped kd-tree of the stacked support clouds (geotr_kdtree_build), reusable for every
+    search against them.  `query` returns rows bit-identical to the reference extension, ties included (geotr_kdtree_radius_search)."""
+
+    def __init__(self, s_points, s_lengths):
+        lib = _lib.load()
+        self.s, self.sl = s_points.contiguous(), s_lengths.contiguous()
+        self.ns, self.batch = self.s.shape[0], self.sl.numel()
+        self.ws = _lib.workspace(lib.geotr_kdtree_workspace_bytes(self.ns, self.batch), self.s.device)
+        _lib.check(lib.geotr_kdtree_build(_lib.ptr(self.s), _lib.ptr(self.sl), self.batch, self.ns, _lib.ptr(self.ws), self.ws.numel(),
+                                          _lib.stream_ptr()), 'geotr_kdtree_build')
+
+    def query(self, q_points, q_lengths, radius, limit=None, capacity=512):
+        """-> int64 (nq, min(max_count, limit)) like radius_search(...)[:, :limit]; one host read (the row width)."""
+        lib = _lib.load()
+        q, ql = q_points.contiguous(), q_lengths.contiguous()
+        nq, dev = q.shape[0], q.device
+        ld = capacity if limit is None else min(int(limit), capacity)
+        out = torch.empty((nq, ld), dtype=torch.int64, device=dev)
+        counts = torch.empty(nq, dtype=torch.int32, device=dev)
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)  # [max_count, overflow]
+        scratch = _lib.workspace(lib.geotr_kdtree_search_scratch_bytes(nq, capacity), dev)
+        _lib.check(lib.geotr_kdtree_radius_search(_lib.ptr(self.ws), _lib.ptr(self.s), self.ns, _lib.ptr(q), _lib.ptr(ql), self.batch, nq,
+                                                  float(radius), ld, capacity, _lib.ptr(out), _lib.ptr(counts), _lib.ptr(flags),
+                                                  _lib.ptr(flags[1:]), _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()),
+                   'geotr_kdtree_radius_search')
+        max_count, overflow = [int(v) for v in flags.tolist()]
+        if overflow > 0:
+            if capacity >= 65536:
+                raise RuntimeError(f'radius search (reference tie order): {overflow} neighbours in one ball exceed the supported 65536')
+            return self.query(q_points, q_lengths, radius, limit=limit, capacity=min(65536, max(2 * capacity, overflow)))
+        return out[:, :max_count] if max_count < ld else out
+
+
+def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, tie_order='canonical'):
     """ext.radius_neighbors (pybind.cpp:8-12; radius_neighbors.cpp:5-68).
 
     Returns a new int64 tensor (total_q, max_count) on ``q_points.device``; max_count is the largest
     neighbour count over all queries of all batch elements, pad value = total support count.
+    tie_order: 'canonical' (default, fast grid search: equal-distance neighbours ordered by index) or 'reference'
+    (equal-distance neighbours in exactly the reference's nanoflann + std::sort order; validation mode for quantised scans).
     """
     _check_points(q_points, 'q_points')
     _check_points(s_points, 's_points')
@@ -125,6 +161,10 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius):
     if q_lengths.numel() != s_lengths.numel():
         raise RuntimeError('q_lengths and s_lengths must have the same batch size')
     (q, s, ql, sl), home = _to_device(q_points, s_points, q_lengths, s_lengths)
+    if tie_order == 'reference':
+        return KdTreeIndex(s, sl).query(q, ql, radius).to(home).contiguous()
+    if tie_order != 'canonical':
+        raise ValueError("tie_order must be 'canonical' or 'reference'")
     grid = RadiusGrid(s, sl, radius)
     _, max_count = grid.count(q, ql)
     width = int(max_count.item())  # data-dependent output width: the one host sync of this entry point

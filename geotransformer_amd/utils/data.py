@@ -12,16 +12,20 @@ import torch
 from .. import _lib, ext
 
 
-def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits, exact_width=True):
+def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, neighbor_limits, exact_width=True,
+                               tie_order='canonical'):
     """Pyramid of points + neighbour index tensors (data.py:13-77).
 
     Args mirror the reference.  ``points``/``lengths`` may be CPU or device tensors; outputs live on the
     same device.  ``exact_width=True`` reproduces the reference's column count
     ``min(max_count, neighbor_limit)`` (needs one host read per search); ``exact_width=False`` always
     emits ``neighbor_limit`` columns (extra columns hold the pad index, which every consumer treats as
-    "no neighbour") and never synchronises on the search results.
+    "no neighbour") and never synchronises on the search results.  ``tie_order='reference'`` (with exact_width=True)
+    orders equal-distance neighbours exactly like the reference's nanoflann + std::sort (validation mode for quantised
+    real scans; the default 'canonical' orders ties by index).
     """
     assert num_stages == len(neighbor_limits)
+    assert tie_order in ('canonical', 'reference') and (tie_order == 'canonical' or exact_width)
     _lib.require_gpu()
     home = points.device
     dev = home if home.type == 'cuda' else torch.device('cuda', torch.cuda.current_device())
@@ -44,10 +48,16 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
     grids = []
     r = radius
     for i in range(num_stages):
-        grids.append(ext.RadiusGrid(points_list[i], lengths_list[i], r))
+        if tie_order == 'reference':  # one nanoflann-shaped tree per stage cloud, shared by the searches against it
+            grids.append((ext.KdTreeIndex(points_list[i], lengths_list[i]), r))
+        else:
+            grids.append(ext.RadiusGrid(points_list[i], lengths_list[i], r))
         r *= 2
 
     def search(grid, q_points, q_lengths, limit):
+        if tie_order == 'reference':
+            index, r_stage = grid
+            return index.query(q_points, q_lengths, r_stage, limit=limit if limit > 0 else None)
         if exact_width or limit <= 0:
             _, max_count = grid.count(q_points, q_lengths)
             max_count = int(max_count.item())
@@ -82,7 +92,7 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
 
 
 def registration_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits,
-                                       precompute_data=True, device=None, exact_width=True):
+                                       precompute_data=True, device=None, exact_width=True, tie_order='canonical'):
     """Registration collate in stack mode (data.py:139-189): [ref_1..ref_B, src_1..src_B] stacking.
 
     ``device`` (optional): place the stacked cloud on that device before the pyramid is built, so the
@@ -110,7 +120,7 @@ def registration_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, searc
     collated['features'] = feats
     if precompute_data:
         collated.update(precompute_data_stack_mode(points, lengths, num_stages, voxel_size, search_radius,
-                                                   neighbor_limits, exact_width=exact_width))
+                                                   neighbor_limits, exact_width=exact_width, tie_order=tie_order))
     else:
         collated['points'] = points
         collated['lengths'] = lengths

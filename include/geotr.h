@@ -80,6 +80,21 @@ int geotr_radius_query(const void* grid_ws, int64_t ns, const float* q_points, c
                        int64_t nq, float radius, int64_t width, int64_t row_capacity, int64_t* out, int32_t* overflow,
                        void* stream);
 
+/* Opt-in "reference tie order" radius search: rows bit-identical to the reference's nanoflann kd-tree
+ * (leaf size 10) + std::sort output INCLUDING the order of equal-distance neighbours (geotransformer/extensions/cpu/radius_neighbors/
+ * radius_neighbors_cpu.cpp:3-91, extra/nanoflann/nanoflann.hpp:857-1000,1348-1411, libstdc++ introsort).  geotr_kdtree_build restates
+ * the tree construction per support cloud into `ws` (geotr_kdtree_workspace_bytes, 256-byte aligned); geotr_kdtree_radius_search
+ * walks it per query in the reference's visiting order, replays std::sort and writes the first `ld` entries of every row
+ * (value = local index + cloud start, pad = ns), the true row lengths in counts, their maximum in *max_count (zeroed by the caller).
+ * `capacity` bounds a row (>= the largest ball population, <= 65536); *overflow (zeroed by the caller) > 0 if one was larger.
+ * A validation mode for quantised real data -- the grid search above (canonical (d, index) tie order) is the fast default. */
+size_t geotr_kdtree_workspace_bytes(int64_t ns, int64_t batch);
+int geotr_kdtree_build(const float* s_points, const int64_t* s_lengths, int64_t batch, int64_t ns, void* ws, size_t ws_bytes, void* stream);
+size_t geotr_kdtree_search_scratch_bytes(int64_t nq, int64_t capacity);
+int geotr_kdtree_radius_search(const void* tree_ws, const float* s_points, int64_t ns, const float* q_points, const int64_t* q_lengths,
+                               int64_t batch, int64_t nq, float radius, int64_t ld, int64_t capacity, int64_t* neighbors, int32_t* counts,
+                               int32_t* max_count, int32_t* overflow, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense contraction on the matrix cores (exact fp32: v_mfma_f32_32x32x2_f32).
  *   C[b] = act( alpha * A[b] (M,K) * op(B[b]) / max(row_div,1) + bias + residual ),  b < batch

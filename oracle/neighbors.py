@@ -120,3 +120,29 @@ def precompute_pyramid(lib, points, lengths, num_stages, voxel_size, radius, nei
             up.append(lib.radius_neighbors(pts[i], pts[i + 1], lens[i], lens[i + 1], r * 2, neighbor_limits[i + 1]))
         r *= 2
     return {'points': pts, 'lengths': lens, 'neighbors': neigh, 'subsampling': sub, 'upsampling': up}
+
+
+def kdorder_host():
+    """Host build of geotransformer_amd/csrc/kdorder.h (oracle/kdorder_host.cpp): radius search in the REFERENCE tie order."""
+    if 'k' not in _cache:
+        path = os.path.join(_HERE, 'libkdorder_host.so')
+        if not os.path.exists(path):
+            build()
+        lib = ctypes.CDLL(path)
+        lib.kdorder_radius_neighbors.restype = _i64p
+        lib.kdorder_free.argtypes = [ctypes.c_void_p]
+        _cache['k'] = lib
+    lib = _cache['k']
+
+    def radius_neighbors(q, s, q_len, s_len, radius, limit=0):
+        q, s, q_len, s_len = _f32(q).reshape(-1, 3), _f32(s).reshape(-1, 3), _i64(q_len), _i64(s_len)
+        width = ctypes.c_int64(0)
+        ptr = lib.kdorder_radius_neighbors(q.ctypes.data_as(_f32p), s.ctypes.data_as(_f32p), q_len.ctypes.data_as(_i64p),
+                                           s_len.ctypes.data_as(_i64p), ctypes.c_int64(len(q_len)), ctypes.c_int64(q.shape[0]),
+                                           ctypes.c_int64(s.shape[0]), ctypes.c_float(radius), ctypes.byref(width))
+        w = width.value
+        out = np.ctypeslib.as_array(ptr, shape=(max(q.shape[0] * w, 1),))[: q.shape[0] * w].copy().reshape(q.shape[0], w)
+        lib.kdorder_free(ptr)
+        return out[:, :limit] if limit > 0 else out
+
+    return radius_neighbors

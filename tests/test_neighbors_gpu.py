@@ -159,3 +159,43 @@ def test_calibrate_neighbors_matches_reference_recipe(oracle_lib):
     want = np.sum(cum < (0.8 * cum[hist_n - 1, :]), axis=0)
     assert np.array_equal(got, want), (got, want)
     assert all(20 <= x <= 60 for x in got)  # the 3DMatch demo limits are [38, 36, 36, 38]
+
+
+@pytest.mark.parametrize('path', GOLDENS, ids=[os.path.basename(p)[:-4] for p in GOLDENS])
+def test_reference_tie_order_matches_goldens_exactly(path):
+    """tie_order='reference': the device kd-tree emulation gives the REAL reference's tables entry for entry -- equal-distance
+    neighbours in the reference's own order, no canonicalisation (incl. the tie-heavy quantised golden)."""
+    from geotransformer_amd.utils.data import precompute_data_stack_mode
+    g = np.load(path)
+    S = int(g['num_stages'])
+    limits = [int(x) for x in g['limits']]
+    out = precompute_data_stack_mode(_dev(g['points0']), _dev(g['lengths0']), S, float(g['voxel']), float(g['radius']), limits,
+                                     exact_width=True, tie_order='reference')
+    for key in ('neighbors', 'subsampling', 'upsampling'):
+        for i in range(S if key == 'neighbors' else S - 1):
+            lim = limits[i + 1] if key == 'upsampling' else limits[i]
+            want = g[f'{key}{i}'].astype(np.int64)[:, :lim]
+            got = out[key][i].cpu().numpy()
+            assert got.shape == want.shape and np.array_equal(got, want), f'{key}{i}'
+
+
+def test_reference_tie_order_full_size_vs_live_reference(reference_lib):
+    """3DMatch-size quantised pair (1 mm grid like real scans: most rows contain ties) through the ext boundary, full row width."""
+    from geotransformer_amd import ext
+    rng = np.random.default_rng(11)
+    n1, n2 = 20000, 18500
+    pts = [(np.round(rng.random((n, 3)) * 2.0 / 0.001) * 0.001).astype(np.float32) for n in (n1, n2)]
+    s = np.concatenate(pts)
+    sl = np.array([n1, n2], dtype=np.int64)
+    want = reference_lib.radius_neighbors(s, s, sl, sl, 0.0625)
+    got = ext.radius_neighbors(torch.from_numpy(s), torch.from_numpy(s), torch.from_numpy(sl), torch.from_numpy(sl), 0.0625,
+                               tie_order='reference')
+    assert got.device.type == 'cpu' and tuple(got.shape) == want.shape
+    assert np.array_equal(got.numpy(), want)
+    # cross search (different query set, wider radius -> rows beyond the 16-element insertion-sort threshold)
+    q = np.concatenate([pts[0][::4], pts[1][::4]])
+    ql = np.array([len(pts[0][::4]), len(pts[1][::4])], dtype=np.int64)
+    want = reference_lib.radius_neighbors(q, s, ql, sl, 0.11)
+    got = ext.radius_neighbors(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(ql).cuda(),
+                               torch.from_numpy(sl).cuda(), 0.11, tie_order='reference')
+    assert np.array_equal(got.cpu().numpy(), want)

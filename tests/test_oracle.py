@@ -103,3 +103,43 @@ def test_edge_cases(oracle_lib):
     s2 = np.array([[0, 0, 0], [0.5, 0, 0]], dtype=np.float32)
     nb = oracle_lib.radius_neighbors(s2[:1], s2, np.array([1]), np.array([2]), 0.5)
     assert nb.tolist() == [[0]]
+
+
+# ---- reference tie order: the emulation header the GPU kernel is built from, pinned on the CPU -------------
+def _quantised_pair(seed, n1, n2, step):
+    rng = np.random.default_rng(seed)
+    pts = [(np.round(rng.random((n, 3)) / step) * step).astype(np.float32) for n in (n1, n2)]
+    return np.concatenate(pts), np.array([n1, n2], dtype=np.int64)
+
+
+@pytest.mark.parametrize('path', sorted(__import__('glob').glob(os.path.join(GOLDEN, 'neighbors_*.npz'))),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_tie_order_emulation_matches_reference_goldens(path):
+    """kdorder.h (host build) reproduces the REAL reference's neighbour tables exactly -- equal-distance neighbours in the
+    reference's own order, no canonicalisation -- on the committed goldens (continuous, tie-heavy quantised, 3DMatch-shape)."""
+    from oracle import neighbors as on
+    rn = on.kdorder_host()
+    g = np.load(path)
+    S = int(g['num_stages'])
+    r = float(g['radius'])
+    for i in range(S):
+        pi, li = g[f'points{i}'], g[f'lengths{i}']
+        assert np.array_equal(rn(pi, pi, li, li, r), g[f'neighbors{i}']), f'neighbors{i}'
+        if i < S - 1:
+            pj, lj = g[f'points{i + 1}'], g[f'lengths{i + 1}']
+            assert np.array_equal(rn(pj, pi, lj, li, r), g[f'subsampling{i}']), f'subsampling{i}'
+            assert np.array_equal(rn(pi, pj, li, lj, 2 * r), g[f'upsampling{i}']), f'upsampling{i}'
+        r *= 2
+
+
+def test_tie_order_emulation_matches_live_reference(reference_lib):
+    """Fresh quantised clouds (rows up to ~130 wide, most of them with ties: exercises the introsort path) vs the real cores."""
+    from oracle import neighbors as on
+    rn = on.kdorder_host()
+    for seed, n1, n2, step, radius in ((1, 3000, 2500, 0.01, 0.06), (2, 2000, 2100, 0.02, 0.15), (3, 20000, 18000, 0.001, 0.0625)):
+        s, sl = _quantised_pair(seed, n1, n2, step)
+        want = reference_lib.radius_neighbors(s, s, sl, sl, radius)
+        assert np.array_equal(rn(s, s, sl, sl, radius), want), seed
+        q = np.concatenate([s[:n1:3], s[n1::3]])
+        ql = np.array([len(s[:n1:3]), len(s[n1::3])], dtype=np.int64)
+        assert np.array_equal(rn(q, s, ql, sl, 1.5 * radius), reference_lib.radius_neighbors(q, s, ql, sl, 1.5 * radius)), seed
