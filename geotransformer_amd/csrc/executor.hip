@@ -1,11 +1,13 @@
 // executor.hip -- native (host C++) executor of the whole inference forward (geotr_model_forward, include/geotr.h).
 //
-// Mirrors, launch for launch, what the Python module mirror does (geotransformer_amd/{backbone,model}.py and
-// modules/*): experiments/<exp>/model.py:69-212 -> backbone.py -> modules/kpconv/modules.py, modules/geotransformer/*,
-// modules/transformer/*, modules/sinkhorn, local_global_registration.  Why it exists: one pair is ~260 kernel launches;
-// issued from Python they cost ~5 ms of interpreter time per pair, more than the kernels themselves need.  Here the launch
-// sequence, the intermediates (bump allocator over the caller's workspace) and the data-dependent counts (kept on the
-// device) all stay on the native side: one asynchronous host call per pair, no host<-device read inside.
+// Same kernels and the same arithmetic as the Python module mirror (geotransformer_amd/{backbone,model}.py and modules/*):
+// experiments/<exp>/model.py:69-212 -> backbone.py -> modules/kpconv/modules.py, modules/geotransformer/*, modules/transformer/*,
+// modules/sinkhorn, local_global_registration.  Why it exists: one pair used to be ~420 kernel launches; issued from Python they
+// cost ~5 ms of interpreter time per pair, more than the kernels need, and on a 256-CU part a single small pair is launch-latency
+// bound anyway.  Here one asynchronous host call runs a STACK of up to 16 pairs: the KPConv-FPN once over all stacked points
+// (GroupNorm statistics segmented per pair), the geometric transformer once over all superpoints (row-wise ops one launch per
+// layer, attention cores as ragged grouped launches), the matching heads once per stack with blockIdx.y = pair / cloud.  The
+// intermediates live in a bump allocator over the caller's workspace, the data-dependent counts stay on the device.
 #include <atomic>
 #include <cstring>
 
@@ -180,28 +182,6 @@ static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geo
     lat_ch = l.out;
   }
   return {enc[S - 1], enc_ch[S - 1]};
-}
-
-// multi-head attention core on already projected q (n rows, ld ldq), k/v (m rows); returns hidden (n, C)
-static float* attention(Ctx& c, int H, int64_t C, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                        int64_t n, int64_t m, const float* emb, const geotr_linear* proj_p, float* hidden = nullptr) {
-  const int64_t ch = C / H, mp = (m + 3) / 4 * 4;
-  if (!hidden) hidden = c.alloc<float>((size_t)n * C);
-  const size_t mk = c.mark();
-  float* scores = c.alloc<float>((size_t)H * n * mp);
-  float* qt = emb ? c.alloc<float>((size_t)n * H * C) : nullptr;
-  float* qb = emb ? c.alloc<float>((size_t)n * H) : nullptr;
-  if (c.live()) {
-    c.check(geotr_gemm(q, ldq, k, ldk, 0, scores, mp, n, m, ch, H, ch, ch, n * mp, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-    if (emb) {
-      c.check(geotr_gemm(q, ldq, proj_p->w, C, 1, qt, H * C, n, C, ch, H, ch, ch * C, C, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-      c.check(geotr_gemm(q, ldq, proj_p->b, 1, 1, qb, H, n, 1, ch, H, ch, ch, 1, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-    }
-    c.check(geotr_attn_softmax(scores, mp, emb, qt, qb, n, m, C, H, 1.0f / sqrtf((float)ch), c.stream));
-    c.check(geotr_gemm(scores, mp, v, ldv, 1, hidden, C, n, ch, m, H, n * mp, ch, ch, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-  }
-  c.release(mk);
-  return hidden;
 }
 
 static float* attn_tail(Ctx& c, const geotr_attn_layer& L, const float* hidden, const float* x, int64_t n, int64_t C, float* out = nullptr) {
