@@ -340,14 +340,26 @@ class NativeModel:
                 '_ref_node_corr_indices': o['ref_node_corr_indices'][b], '_src_node_corr_indices': o['src_node_corr_indices'][b],
                 '_ref_corr_points': o['ref_corr_points'][b], '_src_corr_points': o['src_corr_points'][b], '_corr_scores': o['corr_scores'][b],
                 '_counts': (o['num_node_corr'][b], o['num_corr'][b]),
+                '_counts_stack': (o['num_node_corr'], o['num_corr'], b),
             })
         return results
 
     @staticmethod
-    def finalize(out):
+    def finalize_stack(outs):
+        """finalize() for all pairs of one forward_batch call with ONE host<-device read (all counts at once)."""
+        if not outs:
+            return outs
+        num_node, num_corr, _ = outs[0]['_counts_stack']
+        counts = torch.cat([num_node, num_corr], dim=1).tolist()  # (B, 2)
+        return [NativeModel.finalize(o, counts=counts[o['_counts_stack'][2]]) for o in outs]
+
+    @staticmethod
+    def finalize(out, counts=None):
         """Trim the variable-length outputs to their true sizes (the one host<-device read of a pair)."""
         num_node, num_corr = out.pop('_counts')
-        counts = torch.cat([num_node, num_corr]).tolist()
+        out.pop('_counts_stack', None)
+        if counts is None:
+            counts = torch.cat([num_node, num_corr]).tolist()
         p, c = int(counts[0]), int(counts[1])
         out['ref_node_corr_indices'] = out.pop('_ref_node_corr_indices')[:p]
         out['src_node_corr_indices'] = out.pop('_src_node_corr_indices')[:p]

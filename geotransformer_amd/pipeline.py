@@ -78,7 +78,7 @@ class RegistrationPipeline:
         data['batch_size'] = len(pairs)
         if self.model._native is None:
             self.model._native = NativeModel(self.model)
-        outs = [NativeModel.finalize(o) for o in self.model._native.forward_batch(data)]
+        outs = NativeModel.finalize_stack(self.model._native.forward_batch(data))
         for o in outs:
             o['_neighbor_overflow'] = data['_overflow']
         return outs
