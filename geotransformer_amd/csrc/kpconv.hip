@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_c1_kernel(const float* __re
   const int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   if (m >= M) return;
   const bool is_kp = k < kKP;
+  const float inv_sigma = 1.f / sigma;
   const float kx = is_kp ? kp[3 * k] : 0.f, ky = is_kp ? kp[3 * k + 1] : 0.f, kz = is_kp ? kp[3 * k + 2] : 0.f;
   const float qx = qp[3 * m], qy = qp[3 * m + 1], qz = qp[3 * m + 2];
   float acc = 0.f;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_c1_kernel(const float* __re
     cnt += f > 0.f;
     const float rx = sp[3 * idx] - qx, ry = sp[3 * idx + 1] - qy, rz = sp[3 * idx + 2] - qz;
     const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
-    const float w = fmaxf(1.f - sqrtf((dx * dx + dy * dy) + dz * dz) / sigma, 0.f);
+    const float w = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);  // v_sqrt_f32 (1 ulp), * 1/sigma
     acc = fmaf(w, f, acc);
   }
   if (is_kp) out[m * kKP + k] = acc;
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   __shared__ float kps[kKP * 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_sigma = 1.f / sigma;
   const int slots = (ppw * H + 3) & ~3;
   const int per_wave = slots * (kWStride + 3 + 1) + 64;
   if (threadIdx.x < kKP * 3) kps[threadIdx.x] = kp[threadIdx.x];
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
       float v = 0.f;
       if (k < kKP && idx[n] >= 0) {
         const float dx = rel[3 * n] - kps[3 * k], dy = rel[3 * n + 1] - kps[3 * k + 1], dz = rel[3 * n + 2] - kps[3 * k + 2];
-        v = fmaxf(1.f - sqrtf((dx * dx + dy * dy) + dz * dz) / sigma, 0.f);
+        v = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);  // v_sqrt_f32 (1 ulp), * 1/sigma
       }
       w[e] = v;
     }
