@@ -353,7 +353,7 @@ struct SinkhornBatch {  // count == 0: single pair (the plain arguments are used
   int64_t idx_stride, mask_stride, pcount_stride, out_stride;
 };
 template <int K>  // points per patch: 32, 64 or 128
-__global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __restrict__ ref_feats, int64_t nr,
+__global__ __launch_bounds__(K == 128 ? 1024 : 512) void patch_sinkhorn_kernel(const float* __restrict__ ref_feats, int64_t nr,
                                                              const float* __restrict__ src_feats, int64_t ns, int C,
                                                              const int64_t* __restrict__ ref_idx, const int64_t* __restrict__ src_idx,
                                                              const unsigned char* __restrict__ ref_mask,
@@ -373,7 +373,8 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
   constexpr int K1 = K + 1;
   constexpr int LD = K1;               // odd leading dimension: bank = (row + col) mod 32
   constexpr int TILES = K / 32;        // 32x32 MFMA tiles per side
-  constexpr int TPR = K == 32 ? 8 : (K == 64 ? 4 : 2);  // threads per row in the LSE sweeps
+  constexpr int NT = K == 128 ? 1024 : 512, NW = NT / 64;  // K = 128: 16 waves, else the row / column slices spill
+  constexpr int TPR = K == 32 ? 8 : 4;  // threads per row in the LSE sweeps ((K + 1) * TPR <= NT)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* S = smem;                     // [K1][LD]
   float* u = S + K1 * LD;              // [K1]
@@ -391,15 +392,15 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
   if (tid < 2) nvalid[tid] = 0;
 
   // ---- scores on the matrix cores: wave w owns tiles w, w + 8, ... ----
-  f32x16 acc[(TILES * TILES + 7) / 8];
+  f32x16 acc[(TILES * TILES + NW - 1) / NW];
 #pragma unroll
-  for (int t = 0; t < (TILES * TILES + 7) / 8; ++t)
+  for (int t = 0; t < (TILES * TILES + NW - 1) / NW; ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
   const int fr = lane & 31, fk = lane >> 5;
   for (int k0 = 0; k0 < (scores_in ? 0 : C); k0 += 32) {
     __syncthreads();
-    for (int e = tid; e < 2 * K * 8; e += 512) {  // gather rows (pad index -> zeros, like the padded feature row)
+    for (int e = tid; e < 2 * K * 8; e += NT) {  // gather rows (pad index -> zeros, like the padded feature row)
       const int side = e / (K * 8), r = (e / 8) % K, kq = (e % 8) * 4;
       const int64_t row = side == 0 ? ri[r] : si[r];
       const int64_t lim = side == 0 ? nr : ns;
@@ -416,8 +417,8 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < (TILES * TILES + 7) / 8; ++t) {
-      const int tile = wave + 8 * t;
+    for (int t = 0; t < (TILES * TILES + NW - 1) / NW; ++t) {
+      const int tile = wave + NW * t;
       if (tile < TILES * TILES) {
         const int tr = tile / TILES, tc = tile % TILES;
 #pragma unroll 4
@@ -433,14 +434,14 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
   __syncthreads();
   if (scores_in) {  // stand-alone optimal transport: scores were computed by the caller (learnable_sinkhorn.py:20)
     const float* sp = scores_in + (int64_t)p * K * K;
-    for (int e = tid; e < K * K; e += 512) {
+    for (int e = tid; e < K * K; e += NT) {
       const int i = e / K, j = e % K;
       S[i * LD + j] = (rm[i] && sm[j]) ? sp[e] : -kSinkInf;
     }
   }
 #pragma unroll
-  for (int t = 0; t < (scores_in ? 0 : (TILES * TILES + 7) / 8); ++t) {
-    const int tile = wave + 8 * t;
+  for (int t = 0; t < (scores_in ? 0 : (TILES * TILES + NW - 1) / NW); ++t) {
+    const int tile = wave + NW * t;
     if (tile < TILES * TILES) {
       const int tr = tile / TILES, tc = tile % TILES;
 #pragma unroll
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
     }
   }
   // dustbin row / column (learnable_sinkhorn.py:41-48) and marginals (:50-62)
-  for (int e = tid; e < K; e += 512) {
+  for (int e = tid; e < K; e += NT) {
     S[e * LD + K] = rm[e] ? alpha : -kSinkInf;
     S[K * LD + e] = sm[e] ? alpha : -kSinkInf;
     if (rm[e]) atomicAdd(&nvalid[0], 1);
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
   __syncthreads();
   const float nvr = (float)nvalid[0], nvc = (float)nvalid[1];
   const float norm = -logf(nvr + nvc);
-  for (int e = tid; e < K1; e += 512) {
+  for (int e = tid; e < K1; e += NT) {
     lmu[e] = e < K ? (rm[e] ? norm : -kSinkInf) : logf(nvc) + norm;
     lnu[e] = e < K ? (sm[e] ? norm : -kSinkInf) : logf(nvr) + norm;
     u[e] = 0.f;
@@ -474,33 +475,56 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
   // terms are exp(x - max) in [0, 1] and the sums are >= 1, so their ~1e-6 relative error is far below the score tolerance.
   constexpr int NSEG = (K1 + TPR - 1) / TPR;
   const int row = tid / TPR, sub = tid % TPR;
-  float rowv[NSEG], colv[NSEG];
+  // K = 128 keeps no slice in registers (see the sweep below)
+  constexpr bool kColInRegs = K != 128;
+  float rowv[kColInRegs ? NSEG : 1], colv[kColInRegs ? NSEG : 1];
+  if constexpr (kColInRegs) {
 #pragma unroll
-  for (int jj = 0; jj < NSEG; ++jj) {
-    const int j = sub + TPR * jj;
-    const bool ok = row < K1 && j < K1;
-    rowv[jj] = ok ? S[row * LD + j] : -3.0e38f;
-    colv[jj] = ok ? S[j * LD + row] : -3.0e38f;
+    for (int jj = 0; jj < NSEG; ++jj) {
+      const int j = sub + TPR * jj;
+      const bool ok = row < K1 && j < K1;
+      rowv[jj] = ok ? S[row * LD + j] : -3.0e38f;
+      colv[jj] = ok ? S[j * LD + row] : -3.0e38f;
+    }
   }
+  (void)rowv, (void)colv;
   const float my_lmu = row < K1 ? lmu[row] : 0.f, my_lnu = row < K1 ? lnu[row] : 0.f;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       if (row < K1) {
         const float* other = half == 0 ? v : u;
-        float x[NSEG];
-        float mx = -3.4e38f;
+        float mx = -3.4e38f, sum = 0.f;
+        if constexpr (K == 128) {
+          // 129 x 129: register-resident slices would spill in a 1024-thread block, so the slice is streamed from the LDS copy of
+          // S (never modified by the iterations) with a one-pass running (max, sum): sum_j exp(x_j - max) without storing x
+          for (int j = sub; j < K1; j += TPR) {
+            const float x = (half == 0 ? S[row * LD + j] : S[j * LD + row]) + other[j];
+            if (x > mx) {
+              sum = sum * __expf(mx - x) + 1.f;
+              mx = x;
+            } else {
+              sum += __expf(x - mx);
+            }
+          }
+          float mall = mx;
 #pragma unroll
-        for (int jj = 0; jj < NSEG; ++jj) {
-          const int j = sub + TPR * jj;
-          x[jj] = (half == 0 ? rowv[jj] : colv[jj]) + (j < K1 ? other[j] : 0.f);
-          mx = fmaxf(mx, x[jj]);
+          for (int o = TPR / 2; o > 0; o >>= 1) mall = fmaxf(mall, __shfl_xor(mall, o, 64));
+          sum *= __expf(mx - mall);
+          mx = mall;
+        } else {
+          float x[NSEG];
+#pragma unroll
+          for (int jj = 0; jj < NSEG; ++jj) {
+            const int j = sub + TPR * jj;
+            x[jj] = (half == 0 ? rowv[jj] : colv[jj]) + (j < K1 ? other[j] : 0.f);
+            mx = fmaxf(mx, x[jj]);
+          }
+#pragma unroll
+          for (int o = TPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+#pragma unroll
+          for (int jj = 0; jj < NSEG; ++jj) sum += __expf(x[jj] - mx);
         }
-#pragma unroll
-        for (int o = TPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < NSEG; ++jj) sum += __expf(x[jj] - mx);
 #pragma unroll
         for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         const float lse = mx + __logf(sum);
@@ -513,7 +537,7 @@ __global__ __launch_bounds__(512) void patch_sinkhorn_kernel(const float* __rest
     }
   }
   float* o = out + (int64_t)p * K1 * K1;
-  for (int e = tid; e < K1 * K1; e += 512) {
+  for (int e = tid; e < K1 * K1; e += NT) {
     const int i = e / K1, j = e % K1;
     o[e] = ((S[i * LD + j] + u[i]) + v[j]) - norm;
   }
@@ -704,7 +728,7 @@ static int sinkhorn_launch_impl(const float* ref_feats, int64_t nr, const float*
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sinkhorn_kernel<KK>),                        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
       return fail(GEOTR_E_LAUNCH, "patch_sinkhorn: cannot reserve %zu B of LDS", lds);                                           \
-    patch_sinkhorn_kernel<KK><<<dim3((unsigned)p, (unsigned)(sb.count > 0 ? sb.count : 1)), dim3(512), lds, stream>>>(ref_feats, nr, src_feats, ns, (int)c, ref_knn_indices, \
+    patch_sinkhorn_kernel<KK><<<dim3((unsigned)p, (unsigned)(sb.count > 0 ? sb.count : 1)), dim3(KK == 128 ? 1024 : 512), lds, stream>>>(ref_feats, nr, src_feats, ns, (int)c, ref_knn_indices, \
                                                                             src_knn_indices, ref_knn_masks, src_knn_masks, alpha, \
                                                                             (int)num_iterations, scores_in, p_count, matching_scores, sb); \
   } while (0)
