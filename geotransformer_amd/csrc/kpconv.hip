@@ -172,6 +172,24 @@ __global__ void maxpool_kernel(const float* __restrict__ x, const int64_t* __res
   out[e] = best;
 }
 
+// same, four channels per lane (C % 4 == 0): a quarter of the index loads and 16-byte feature loads
+__global__ void maxpool4_kernel(const float* __restrict__ x, const int64_t* __restrict__ nb, int64_t M, int64_t Ns, int H, int C4,
+                                float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * C4) return;
+  const int64_t m = e / C4;
+  const int c4 = (int)(e - m * C4);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4 best = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+#pragma unroll 4
+  for (int h = 0; h < H; ++h) {
+    const int64_t j = nb[m * H + h];
+    const float4 v = j < Ns ? x4[j * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);  // the shadow row is all zeros and takes part in the max
+    best.x = fmaxf(best.x, v.x), best.y = fmaxf(best.y, v.y), best.z = fmaxf(best.z, v.z), best.w = fmaxf(best.w, v.w);
+  }
+  reinterpret_cast<float4*>(out)[e] = best;
+}
+
 __global__ void upsample_concat_kernel(const float* __restrict__ coarse, int64_t nc, int c1, const int64_t* __restrict__ up,
                                        int64_t ld_up, const float* __restrict__ skip, int c2, int64_t M,
                                        float* __restrict__ out) {
@@ -475,10 +493,32 @@ int geotr_maxpool(const float* x, const int64_t* neighbors, int64_t m, int64_t n
   GEOTR_CHECK_ARG(m >= 0 && h >= 1 && c >= 1, "maxpool: bad sizes");
   if (m == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(x && neighbors && out, "maxpool: null pointer");
-  maxpool_kernel<<<dim3((unsigned)((m * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, neighbors, m, ns, (int)h,
+  if (c % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+    maxpool4_kernel<<<dim3((unsigned)((m * (c / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, neighbors, m, ns, (int)h, (int)(c / 4),
+                                                                                                    out);
+  else
+    maxpool_kernel<<<dim3((unsigned)((m * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, neighbors, m, ns, (int)h,
                                                                                               (int)c, out);
   GEOTR_CHECK_LAUNCH("maxpool");
   return GEOTR_OK;
+}
+
+// four channels per lane (c1, c2 multiples of 4)
+__global__ void upsample_concat4_kernel(const float* __restrict__ coarse, int64_t nc, int c1q, const int64_t* __restrict__ up, int64_t ld_up,
+                                        const float* __restrict__ skip, int c2q, int64_t M, float* __restrict__ out) {
+  const int ctq = c1q + c2q;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * ctq) return;
+  const int64_t m = e / ctq;
+  const int c = (int)(e - m * ctq);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < c1q) {
+    const int64_t j = up[m * ld_up];  // column 0 only (functional.py:21)
+    if (j < nc) v = reinterpret_cast<const float4*>(coarse)[j * c1q + c];
+  } else {
+    v = reinterpret_cast<const float4*>(skip)[m * c2q + (c - c1q)];
+  }
+  reinterpret_cast<float4*>(out)[e] = v;
 }
 
 int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int64_t* up_idx, int64_t ld_idx,
@@ -487,8 +527,14 @@ int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int
   if (m == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(coarse && up_idx && out && (skip || c2 == 0), "upsample_concat: null pointer");
   const int64_t tot = m * (c1 + c2);
-  upsample_concat_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-      coarse, nc, (int)c1, up_idx, ld_idx, skip, (int)c2, m, out);
+  const bool vec = c1 % 4 == 0 && c2 % 4 == 0 && ((reinterpret_cast<uintptr_t>(coarse) | reinterpret_cast<uintptr_t>(skip) |
+                                                    reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (vec)
+    upsample_concat4_kernel<<<dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        coarse, nc, (int)(c1 / 4), up_idx, ld_idx, skip, (int)(c2 / 4), m, out);
+  else
+    upsample_concat_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        coarse, nc, (int)c1, up_idx, ld_idx, skip, (int)c2, m, out);
   GEOTR_CHECK_LAUNCH("upsample_concat");
   return GEOTR_OK;
 }
