@@ -463,25 +463,38 @@ __device__ __forceinline__ void attn_pos_softmax_body(float* __restrict__ scores
   float qbv[H];
 #pragma unroll
   for (int h = 0; h < H; ++h) qbv[h] = qb[(int64_t)i * H + h];
-  for (int j = tid; j < m; j += 256) {
+  // eight lanes per key: in every load instruction the 8 lanes of a key read one whole 128-byte line of its embedding row (a lane
+  // per key would touch 64 different lines per instruction and re-fetch each of them 8 times once L1 thrashes); a wave covers 8
+  // keys per instruction, each lane owns the channel chunks l, l + 8, ... and the partial dot products are folded across the 8 lanes
+  const int kl = tid & 7, kg = tid >> 3;  // lane within the key group, key slot (32 per pass)
+  for (int j = kg; j < m; j += 32) {
     const float4* row = reinterpret_cast<const float4*>(emb + ((int64_t)i * m + j) * C);
     float acc[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) acc[h] = 0.f;
-    for (int cb = 0; cb < C / 32; ++cb) {
-      float4 v[8];
+    for (int cb = 0; cb < C / 32; cb += 4) {  // 4 line-loads in flight per lane
+      float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = row[cb * 8 + u];
+      for (int u = 0; u < 4; ++u) v[u] = cb + u < C / 32 ? row[(cb + u) * 8 + kl] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float* w = qt_s + (cb * 32 + u * 4) * H;
+      for (int u = 0; u < 4; ++u) {
+        if (cb + u >= C / 32) break;
+        const float* w = qt_s + (((cb + u) * 8 + kl) * 4) * H;
 #pragma unroll
         for (int h = 0; h < H; ++h)
           acc[h] = fmaf(v[u].w, w[3 * H + h], fmaf(v[u].z, w[2 * H + h], fmaf(v[u].y, w[H + h], fmaf(v[u].x, w[h], acc[h]))));
       }
     }
 #pragma unroll
-    for (int h = 0; h < H; ++h) sc_s[h * m + j] = (scores[((int64_t)h * n + i) * ld + j] + (acc[h] + qbv[h])) * scale;
+    for (int h = 0; h < H; ++h) {
+      acc[h] += __shfl_xor(acc[h], 4, 64);
+      acc[h] += __shfl_xor(acc[h], 2, 64);
+      acc[h] += __shfl_xor(acc[h], 1, 64);
+    }
+    if (kl == 0) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) sc_s[h * m + j] = (scores[((int64_t)h * n + i) * ld + j] + (acc[h] + qbv[h])) * scale;
+    }
   }
   __syncthreads();
   for (int h = wave; h < H; h += 4) {  // wave per head
