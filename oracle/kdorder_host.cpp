@@ -92,3 +92,15 @@ int64_t* kdorder_radius_neighbors(const float* q, const float* s, const int64_t*
 void kdorder_free(void* p) { std::free(p); }
 
 }  // extern "C"
+
+// test hook: libstdc++'s std::sort (distance-only comparator, like IndexDist_Sorter) vs the replay in kdorder.h on the same input;
+// writes the index order each of them produces
+#include <algorithm>
+extern "C" void kdorder_sort_both(int64_t n, const float* dist, int32_t* emulated, int32_t* real) {
+  std::vector<Item> a((size_t)n);
+  std::vector<std::pair<int, float>> b((size_t)n);
+  for (int64_t i = 0; i < n; ++i) a[(size_t)i] = Item{dist[i], (int)i}, b[(size_t)i] = {(int)i, dist[i]};
+  std_sort(a.data(), (int)n);
+  std::sort(b.begin(), b.end(), [](const std::pair<int, float>& x, const std::pair<int, float>& y) { return x.second < y.second; });
+  for (int64_t i = 0; i < n; ++i) emulated[i] = a[(size_t)i].i, real[i] = b[(size_t)i].first;
+}

@@ -143,3 +143,41 @@ def test_tie_order_emulation_matches_live_reference(reference_lib):
         q = np.concatenate([s[:n1:3], s[n1::3]])
         ql = np.array([len(s[:n1:3]), len(s[n1::3])], dtype=np.int64)
         assert np.array_equal(rn(q, s, ql, sl, 1.5 * radius), reference_lib.radius_neighbors(q, s, ql, sl, 1.5 * radius)), seed
+
+
+def test_std_sort_replay_is_libstdcxx_exact():
+    """kdorder.h's introsort replay vs the real std::sort with a distance-only comparator: the PERMUTATION of equal keys must match,
+    including inputs that exhaust the depth limit (heap-sort fallback) and sizes around the insertion-sort threshold."""
+    import ctypes
+    from oracle import neighbors as on
+    on.kdorder_host()
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(on.__file__), 'libkdorder_host.so'))
+    f32p, i32p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+
+    def both(d):
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        a, b = np.zeros(len(d), np.int32), np.zeros(len(d), np.int32)
+        lib.kdorder_sort_both(ctypes.c_int64(len(d)), d.ctypes.data_as(f32p), a.ctypes.data_as(i32p), b.ctypes.data_as(i32p))
+        return a, b
+
+    rng = np.random.default_rng(0)
+    cases = []
+    for n in list(range(0, 40)) + [63, 64, 65, 100, 129, 257, 1000, 4097]:
+        cases.append(rng.random(n))                                   # distinct keys
+        cases.append(rng.integers(0, 4, n).astype(np.float32))        # heavy ties
+        cases.append(rng.integers(0, max(n // 8, 1), n).astype(np.float32))
+        cases.append(np.zeros(n))                                     # all equal
+        cases.append(np.arange(n)[::-1].astype(np.float32))           # descending
+        cases.append(np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]).astype(np.float32))  # organ pipe
+    # median-of-3 killer (Musser): drives quicksort to its depth limit -> heap-sort fallback
+    for n in (64, 256, 2048):
+        k = n // 2
+        killer = np.zeros(n)
+        for i in range(1, k + 1):
+            killer[i - 1] = i if i % 2 else k + i - 1
+            killer[k + i - 1] = 2 * i
+        cases.append(killer)
+        cases.append(np.floor(killer / 3))                            # the same with ties
+    for d in cases:
+        a, b = both(d)
+        assert np.array_equal(a, b), (len(d), d[:16])
