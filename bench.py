@@ -96,6 +96,9 @@ def main():
     ap.add_argument('--lanes', type=int, default=4, help='pairs kept in flight concurrently (host thread + HIP stream each)')
     ap.add_argument('--stack', type=int, default=8, help='pairs stacked into one launch sequence per lane (<= 16; divides --batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32', 'bf16'],
+                    help="matrix-pipe arithmetic: bf16x3 = split-bf16, fp32-grade (default, the headline mode); fp32 = exact fp32 MFMA; "
+                         "bf16 = plain bf16 operands (BASELINE configs[4] 'bf16 features'; not the headline metric)")
     args = ap.parse_args()
 
     from geotransformer_amd import _lib, kernels
@@ -106,6 +109,7 @@ def main():
 
     _lib.require_gpu()
     _lib.load()
+    kernels.set_precision(args.precision)
     rank, world, local = gd.init_from_env()
     assert world == args.gpus or world == 1, f'launched with WORLD_SIZE={world} but --gpus {args.gpus}'
     torch.cuda.set_device(local)
@@ -192,16 +196,18 @@ def main():
         algorithmic = (sum(flops) / sum(durs)) / 1e12 if durs else None
         from geotransformer_amd import kernels as _k
         split = _k.GSE_PRECISION == 1
+        plain_bf16 = _k.GSE_PRECISION == 3
         # split-bf16 path: every product is 3 bf16 MFMA products (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi) -> executed flops = 3x
         executed = (3.0 * algorithmic if split else algorithmic) if algorithmic else None
-        peak = BF16_MATRIX_PEAK_TFLOPS if split else FP32_MATRIX_PEAK_TFLOPS
+        peak = BF16_MATRIX_PEAK_TFLOPS if (split or plain_bf16) else FP32_MATRIX_PEAK_TFLOPS
         line = {
             'metric': {'3dmatch': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)',
                        'kitti': 'registration pairs/sec (120k-pt synthetic KITTI-shape pair)',
                        'modelnet': 'registration pairs/sec (1k-pt synthetic ModelNet-shape pair)'}[args.config],
             'value': round(value, 3), 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if plain_bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[{ {"3dmatch": 1, "kitti": 3, "modelnet": 0}[args.config] }]: synthetic {args.config} pair, {n_points}+{n_points} pts, '
                                    f'{cfg.backbone.num_stages}-stage KPConv-FPN, d={D}, '
                                    f'{info["superpoints"][0]}+{info["superpoints"][1]} superpoints, '
@@ -209,9 +215,10 @@ def main():
                                    f'pyramid + full forward per pair',
                        'pairs_per_step_per_gpu': args.batch, 'lanes_per_gpu': args.lanes, 'pairs_stacked_per_launch_sequence': args.stack,
                        'parallelism': f'pairs sharded over {world} GPU(s), no data-path collective',
-                       'weights': 'random init, seed 7351'},
+                       'weights': 'random init, seed 7351', 'matrix_precision': args.precision},
             'roofline': {'bound': 'mfma',
                          'kernel': ('gse_embed_bf16x3_kernel<256,4> (fused GSE: sinusoid -> split-bf16 MFMA -> max_k)' if split else
+                                    'gse_embed_bf16x3_kernel<256,4,TERMS=1> (fused GSE: sinusoid -> bf16 MFMA -> max_k)' if plain_bf16 else
                                     'gse_embed_kernel<256,4> (fused GSE: sinusoid -> fp32 MFMA -> max_k)'),
                          'achieved': round(executed, 2) if executed else None, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(executed / peak, 4) if executed else None,
@@ -219,7 +226,8 @@ def main():
                          'note': ('algorithmic work = 2*n^2*(1+k)*D^2 flop per launch (fp32-equivalent); achieved counts the 3 bf16 MFMA '
                                   'products executed per algorithmic product; durations are HIP events on the launch stream with '
                                   f'{args.lanes} pair(s) in flight, so co-running kernels of the other lane are included') if split else
-                                 'algorithmic = executed (fp32 MFMA)',
+                                 ('algorithmic = executed (bf16 MFMA, one product per algorithmic product)' if plain_bf16 else
+                                  'algorithmic = executed (fp32 MFMA)'),
                          'traffic': pmc_traffic_bytes('gse_embed'), 'traffic_unit': 'HBM bytes/launch (rocprofv3 PMC '
                          'FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/r01_pmc_hbm_traffic.md)', 'launches': len(durs),
                          'avg_launch_us': round(1e6 * sum(durs) / len(durs), 1) if durs else None,

@@ -65,6 +65,7 @@ SIGNATURES = {
     'geotr_gemm_pack_bytes': (c_size, [c_i64, c_i64]),
     'geotr_gemm_pack': (c_int, [c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_gemm_packed': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
+    'geotr_gemm_packed_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
     'geotr_group_norm_segmented': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geotr_l2_normalize': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_weighted_procrustes': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),

@@ -29,6 +29,7 @@ struct Ctx {
   hipStream_t stream;
   bool dry;  // size-query pass: account for allocations, launch nothing
   int rc = GEOTR_OK;
+  bool gemm_bf16 = false;  // geotr_model.gemm_bf16: packed GEMMs use plain bf16 operands (hi planes only)
   int nseg = 1;                                             // stacked pairs: GroupNorm statistics stay inside a pair
   int64_t seg_rows[GEOTR_MAX_STAGES][GEOTR_MAX_PAIRS] = {};  // rows of pair b at stage s (ref + src)
 
@@ -54,12 +55,18 @@ static inline bool use_packed(const void* packed, const float* a, int64_t lda, i
   return packed && m >= GEOTR_PACKED_MIN_ROWS && k % 32 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0;
 }
 
+// packed GEMM in the model's precision: split-bf16 (default) or plain bf16 operands
+template <typename... Args>
+static int packed_gemm(const Ctx& c, Args... args) {
+  return c.gemm_bf16 ? geotr_gemm_packed_bf16(args...) : geotr_gemm_packed(args...);
+}
+
 static float* linear(Ctx& c, const geotr_linear& l, const float* x, int64_t lda, int64_t m, int act, const float* residual = nullptr,
                      int64_t ldr = 0) {
   float* y = c.alloc<float>((size_t)m * l.out);
   if (c.live()) {
     if (use_packed(l.packed, x, lda, m, l.in))
-      c.check(geotr_gemm_packed(x, lda, l.packed, y, l.out, m, l.out, l.in, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
+      c.check(packed_gemm(c, x, lda, l.packed, y, l.out, m, l.out, l.in, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
     else
       c.check(geotr_gemm(x, lda, l.w, l.in, 0, y, l.out, m, l.out, l.in, 1, 0, 0, 0, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
   }
@@ -97,7 +104,7 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
                                 weighted, nnum, c.stream));
     const int64_t kdim = kp.num_kernel_points * kp.in;
     if (use_packed(kp.packed, weighted, kdim, m, kdim))
-      c.check(geotr_gemm_packed(weighted, kdim, kp.packed, out, kp.out, m, kp.out, kdim, kp.bias, nnum, nullptr, 0, 1.0f, 0, c.stream));
+      c.check(packed_gemm(c, weighted, kdim, kp.packed, out, kp.out, m, kp.out, kdim, kp.bias, nnum, nullptr, 0, 1.0f, 0, c.stream));
     else
       c.check(geotr_gemm(weighted, kdim, kp.weights, kp.out, 1, out, kp.out, m, kp.out, kdim, 1, 0, 0, 0, kp.bias, nnum, nullptr, 0,
                          1.0f, 0, c.stream));
@@ -169,7 +176,7 @@ static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geo
     if (i == net.fine_stage) {  // LastUnaryBlock: straight into the caller's buffer
       if (c.live()) {
         if (use_packed(l.packed, cat, tot, p.n[i], l.in))
-          c.check(geotr_gemm_packed(cat, tot, l.packed, feats_f_out, l.out, p.n[i], l.out, l.in, l.b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+          c.check(packed_gemm(c, cat, tot, l.packed, feats_f_out, l.out, p.n[i], l.out, l.in, l.b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
         else
           c.check(geotr_gemm(cat, tot, l.w, l.in, 0, feats_f_out, l.out, p.n[i], l.out, l.in, 1, 0, 0, 0, l.b, nullptr, nullptr, 0, 1.0f, 0,
                              c.stream));
@@ -199,7 +206,7 @@ static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t 
   int32_t* knn = c.alloc<int32_t>((size_t)n * t.angle_k);
   const size_t gws_bytes = geotr_gse_embed_workspace_bytes(D, t.gse_precision);
   char* gws = shared_ws ? shared_ws : c.alloc<char>(gws_bytes + 16);
-  const int precision = (t.gse_precision == 1 && shared_ws && !first) ? 2 : t.gse_precision;
+  const int precision = ((t.gse_precision == 1 || t.gse_precision == 3) && shared_ws && !first) ? t.gse_precision + 1 : t.gse_precision;
   if (c.live()) {
     c.check(geotr_gse_knn(pts, n, t.angle_k, knn, c.stream));
     int slot = -1;
@@ -329,7 +336,7 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
         float* qkv = c.alloc<float>((size_t)N * 3 * C);
         if (c.live()) {
           if (use_packed(L.qkv_packed, x, C, N, C))
-            c.check(geotr_gemm_packed(x, C, L.qkv_packed, qkv, 3 * C, N, 3 * C, C, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+            c.check(packed_gemm(c, x, C, L.qkv_packed, qkv, 3 * C, N, 3 * C, C, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
           else
             c.check(geotr_gemm(x, C, L.qkv_w, C, 0, qkv, 3 * C, N, 3 * C, C, 1, 0, 0, 0, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
         }
@@ -355,7 +362,7 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
           float* kv = c.alloc<float>((size_t)nm * 2 * C);
           if (c.live()) {
             if (use_packed(L.kv_packed, xm, C, nm, C))
-              c.check(geotr_gemm_packed(xm, C, L.kv_packed, kv, 2 * C, nm, 2 * C, C, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+              c.check(packed_gemm(c, xm, C, L.kv_packed, kv, 2 * C, nm, 2 * C, C, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
             else
               c.check(geotr_gemm(xm, C, L.kv_w, C, 0, kv, 2 * C, nm, 2 * C, C, 1, 0, 0, 0, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
           }
@@ -621,6 +628,7 @@ size_t geotr_model_workspace_bytes(const geotr_model* net, const geotr_pyramid* 
   c.cap = 0;
   c.stream = nullptr;
   c.dry = true;
+  c.gemm_bf16 = net->gemm_bf16 != 0;
   run(c, *net, *pyr, nullptr, nullptr);
   return c.peak + 4096;
 }
@@ -636,6 +644,7 @@ int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const 
   c.cap = ws_bytes;
   c.stream = (hipStream_t)stream;
   c.dry = false;
+  c.gemm_bf16 = net->gemm_bf16 != 0;
   return run(c, *net, *pyr, features, out);
 }
 

@@ -485,6 +485,9 @@ __device__ __forceinline__ void lds_read4(unsigned addr, uint4& r0, uint4& r1, u
       : "v"(addr), "n"(O1), "n"(O2), "n"(O3)
       : "memory");
 }
+__device__ __forceinline__ void lds_read1(unsigned addr, uint4& r0) {
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0) : "v"(addr) : "memory");
+}
 template <int O1>
 __device__ __forceinline__ void lds_read2(unsigned addr, uint4& r0, uint4& r1) {
   asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
@@ -492,12 +495,13 @@ __device__ __forceinline__ void lds_read2(unsigned addr, uint4& r0, uint4& r1) {
                : "v"(addr), "n"(O1)
                : "memory");
 }
-template <int WM, int WN>
+// TERMS = 3: split-bf16 product;  TERMS = 1: plain bf16 operands (hi planes only: the lo plane is neither loaded nor multiplied).
+template <int WM, int WN, int TERMS>
 __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
-  constexpr int BM = 128;
+  constexpr int BM = 128, PLANES = TERMS == 3 ? 2 : 1;
   constexpr int WAVES_M = BM / (32 * WM), WAVES_N = 4 / WAVES_M, NT_BLK = WN * WAVES_N;  // column tiles per block
-  constexpr int A_BYTES = BM * 128, B_BYTES = NT_BLK * 2 * 2 * 1024, STAGE = A_BYTES + B_BYTES;
-  constexpr int B_INSTR = NT_BLK * 4;              // 1 KB weight chunks per stage: (plane, ct, kk)
+  constexpr int A_BYTES = BM * 128, B_BYTES = NT_BLK * PLANES * 2 * 1024, STAGE = A_BYTES + B_BYTES;
+  constexpr int B_INSTR = NT_BLK * PLANES * 2;     // 1 KB weight chunks per stage: (plane, ct, kk)
   constexpr int B_PER_WAVE = (B_INSTR + 3) / 4;    // issued round-robin by the 4 waves
   constexpr int LOADS = 4 + B_PER_WAVE;            // DMA instructions per wave and stage
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
@@ -557,8 +561,13 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
       constexpr int PL = NT_BLK * 2 * 1024, CT = 2 * 1024;
       const unsigned ab = st + A_BYTES + (wctl * 2 + ks) * 1024 + lane * 16;
       uint4 rb[2][2], ra[2][2];
-      if constexpr (WN == 2) lds_read4<PL, CT, PL + CT>(ab, rb[0][0], rb[1][0], rb[0][1], rb[1][1]);
-      else lds_read2<PL>(ab, rb[0][0], rb[1][0]);
+      if constexpr (TERMS == 3) {
+        if constexpr (WN == 2) lds_read4<PL, CT, PL + CT>(ab, rb[0][0], rb[1][0], rb[0][1], rb[1][1]);
+        else lds_read2<PL>(ab, rb[0][0], rb[1][0]);
+      } else {
+        if constexpr (WN == 2) lds_read2<CT>(ab, rb[0][0], rb[0][1]);
+        else lds_read1(ab, rb[0][0]);
+      }
       // A fragment: two swizzled 16-byte chunks of row r (row tile i = 1 sits 32 rows = 4096 B further, same swizzle)
       const int r = wrow + fr, c0 = 4 * ks + 2 * fk;
       const unsigned a0 = st + (r * 8 + (c0 ^ (r & 7))) * 16, a1 = st + (r * 8 + ((c0 + 1) ^ (r & 7))) * 16;
@@ -572,13 +581,16 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           ah[e] = (__bf16)x[e];
-          al[e] = (__bf16)(x[e] - (float)ah[e]);
+          if constexpr (TERMS == 3) al[e] = (__bf16)(x[e] - (float)ah[e]);
         }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, rb[0][j]), bl = __builtin_bit_cast(bf16x8, rb[1][j]);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, rb[0][j]);
+          if constexpr (TERMS == 3) {
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, rb[1][j]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
         }
       }
@@ -647,9 +659,10 @@ extern "C" int geotr_gemm_pack(const float* B, int64_t ldb, int b_is_kn, int64_t
   return GEOTR_OK;
 }
 
-extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                                 const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
-                                 void* stream_) {
+template <int TERMS>
+static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                              const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
+                              void* stream_) {
   GEOTR_CHECK_ARG(M >= 0 && N >= 1 && K >= 1, "gemm_packed: bad sizes");
   if (M == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(A && packed && C, "gemm_packed: null pointer");
@@ -668,11 +681,11 @@ extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed
   GEOTR_CHECK_ARG(gy <= 65535, "gemm_packed: M too large");
 #define GEOTR_PACKED(WM, WN, BN)                                                                                        \
   do {                                                                                                                  \
-    const int lds = std::max(kPStages * (128 * 128 + (BN / 32) * 4096), 4 * 32 * WM * (32 * WN + 4) * 4); /* ring | epilogue slabs */ \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+    const int lds = std::max(kPStages * (128 * 128 + (BN / 32) * (TERMS == 3 ? 4096 : 2048)), 4 * 32 * WM * (32 * WN + 4) * 4); /* ring | epilogue slabs */ \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             lds) != hipSuccess)                                                                         \
       return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);                                      \
-    gemm_packed_kernel<WM, WN><<<dim3((unsigned)((N + BN - 1) / BN), gy), dim3(256), lds, stream>>>(g);                 \
+    gemm_packed_kernel<WM, WN, TERMS><<<dim3((unsigned)((N + BN - 1) / BN), gy), dim3(256), lds, stream>>>(g);                 \
   } while (0)
   if (N > 64) GEOTR_PACKED(2, 2, 128);
   else if (N > 32) GEOTR_PACKED(1, 2, 64);
@@ -680,6 +693,18 @@ extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed
 #undef GEOTR_PACKED
   GEOTR_CHECK_LAUNCH("gemm_packed");
   return GEOTR_OK;
+}
+
+extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                 const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
+                                 void* stream) {
+  return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream);
+}
+
+extern "C" int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N,
+                                      int64_t K, const float* bias, const int32_t* row_div, const float* residual, int64_t ldr,
+                                      float alpha, int act, void* stream) {
+  return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream);
 }
 
 extern "C" int geotr_gemm_grouped(const float* A, const float* B, int b_is_kn, float* C, const geotr_gemm_groups* groups, int64_t heads,

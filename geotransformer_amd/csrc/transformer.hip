@@ -235,7 +235,9 @@ __global__ void split_bf16_swz_kernel(const float* __restrict__ w, int D, unsign
 // matrix pipe works on chunk c; the two waves that share a SIMD (w and w+4 when D = 256) run the two phases in opposite order,
 // so one of them feeds the matrix pipe while the other generates.  B operands come straight from L2 in fragment order, one
 // 16-deep step ahead.  One barrier per 32-deep chunk.
-template <int D, int S>
+// TERMS = 3: the split-bf16 product above;  TERMS = 1: plain bf16 operands (a_hi * b_hi only, "bf16 features" mode -- no lo planes
+// are generated, loaded or multiplied).
+template <int D, int S, int TERMS = 3>
 __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const float* __restrict__ pts, const int* __restrict__ knn, int n,
                                                                          const float* __restrict__ div_term,
                                                                          const unsigned short* __restrict__ wswz,  // [4][D*D]: d_hi, d_lo, a_hi, a_lo (fragment order)
@@ -291,15 +293,18 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
       const float rev = omega * 0.15915494309189535f;
       const float sv = __builtin_amdgcn_sinf(rev), cv = __builtin_amdgcn_cosf(rev);
       const unsigned sh = f32_to_bf16_rne(sv), ch = f32_to_bf16_rne(cv);
-      const unsigned sl = f32_to_bf16_rne(sv - bf16_to_f32(sh)), cl = f32_to_bf16_rne(cv - bf16_to_f32(ch));
       A_hi32[(row * kGseRS) / 2 + t] = sh | (ch << 16);
-      A_lo32[(row * kGseRS) / 2 + t] = sl | (cl << 16);
+      if constexpr (TERMS == 3) {
+        const unsigned sl = f32_to_bf16_rne(sv - bf16_to_f32(sh)), cl = f32_to_bf16_rne(cv - bf16_to_f32(ch));
+        A_lo32[(row * kGseRS) / 2 + t] = sl | (cl << 16);
+      }
     }
   };
   const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wswz);
   auto load_b = [&](int kk, bf16x8(&b)[4]) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) b[v] = wfrag[(((int64_t)v * NW + wave) * KS + kk) * 64 + lane];
+    for (int v = 0; v < 4; ++v)
+      if (TERMS == 3 || (v & 1) == 0) b[v] = wfrag[(((int64_t)v * NW + wave) * KS + kk) * 64 + lane];
   };
 
   f32x16 acc[2][S];
@@ -332,15 +337,19 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
         for (int s = 0; s < S; ++s) {
           const int row = s * kGsePairs + 32 * r + fr;
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A_hi + row * kGseRS + kb);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(A_lo + row * kGseRS + kb);
-          const bf16x8 bh = s == 0 ? bcur[0] : bcur[2], bl = s == 0 ? bcur[1] : bcur[3];
-          acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r][s], 0, 0, 0);
-          acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r][s], 0, 0, 0);
+          const bf16x8 bh = s == 0 ? bcur[0] : bcur[2];
+          if constexpr (TERMS == 3) {
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(A_lo + row * kGseRS + kb);
+            const bf16x8 bl = s == 0 ? bcur[1] : bcur[3];
+            acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r][s], 0, 0, 0);
+            acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r][s], 0, 0, 0);
+          }
           acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r][s], 0, 0, 0);
         }
       }
 #pragma unroll
-      for (int v = 0; v < 4; ++v) bcur[v] = bnext[v];
+      for (int v = 0; v < 4; ++v)
+        if (TERMS == 3 || (v & 1) == 0) bcur[v] = bnext[v];
     }
     if (late_gen && c + 1 < CH) generate(c + 1, buf ^ 1);
     __syncthreads();
@@ -580,7 +589,7 @@ int geotr_gse_knn(const float* points, int64_t n, int64_t k, int32_t* knn, void*
 
 }  // extern "C"
 
-template <int D>
+template <int D, int TERMS>
 static int launch_gse_bf16x3(int k, const float* pts, const int* knn, int n, const float* div_term, const unsigned short* wsplit,
                              const float* bd, const float* ba, float inv_sigma_d, float factor_a, float* out, hipStream_t stream) {
   const int64_t total = (int64_t)n * n;
@@ -596,10 +605,10 @@ static int launch_gse_bf16x3(int k, const float* pts, const int* knn, int n, con
     return GEOTR_OK;
   };
   switch (S) {
-    case 2: return go(gse_embed_bf16x3_kernel<D, 2>);
-    case 3: return go(gse_embed_bf16x3_kernel<D, 3>);
-    case 4: return go(gse_embed_bf16x3_kernel<D, 4>);
-    default: return go(gse_embed_bf16x3_kernel<D, 5>);
+    case 2: return go(gse_embed_bf16x3_kernel<D, 2, TERMS>);
+    case 3: return go(gse_embed_bf16x3_kernel<D, 3, TERMS>);
+    case 4: return go(gse_embed_bf16x3_kernel<D, 4, TERMS>);
+    default: return go(gse_embed_bf16x3_kernel<D, 5, TERMS>);
   }
 }
 
@@ -641,24 +650,29 @@ int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t 
   hipStream_t stream = (hipStream_t)stream_;
   const float inv_sigma_d = 1.0f / sigma_d;
   const float factor_a = (float)(180.0 / ((double)sigma_a * 3.14159265358979323846));  // geotransformer.py:14
-  GEOTR_CHECK_ARG(precision >= 0 && precision <= 2, "gse_embed: precision must be 0 (fp32 MFMA), 1 (split-bf16 MFMA) or 2 (1, workspace reused)");
+  GEOTR_CHECK_ARG(precision >= 0 && precision <= 4,
+                  "gse_embed: precision must be 0 (fp32 MFMA), 1 (split-bf16 MFMA), 3 (bf16 MFMA), or 2 / 4 (1 / 3, workspace reused)");
   if (precision >= 1) {
     GEOTR_CHECK_ARG(ws && ws_bytes >= (size_t)(8 * d * d) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
-                    "gse_embed: split-bf16 path needs a 16-byte aligned workspace of 8*d*d bytes");
+                    "gse_embed: the bf16 paths need a 16-byte aligned workspace of 8*d*d bytes");
     unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
     const int64_t dd = d * d;
     const unsigned nbs = (unsigned)((dd / 8 + 255) / 256);
-    if (precision == 1) {  // precision 2: `ws` still holds the split weights of an earlier call with the same w_d / w_a
+    if (precision == 1 || precision == 3) {  // 2 / 4: `ws` still holds the split weights of an earlier call with the same w_d / w_a
       split_bf16_swz_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_d, (int)d, wsplit, wsplit + dd);
       split_bf16_swz_kernel<<<dim3(nbs), dim3(256), 0, stream>>>(w_a, (int)d, wsplit + 2 * dd, wsplit + 3 * dd);
     }
     int rc2;
+#define GEOTR_GSE_GO(DD)                                                                                                          \
+  (precision <= 2 ? launch_gse_bf16x3<DD, 3>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream) \
+                  : launch_gse_bf16x3<DD, 1>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream))
     switch (d) {
-      case 32: rc2 = launch_gse_bf16x3<32>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream); break;
-      case 64: rc2 = launch_gse_bf16x3<64>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream); break;
-      case 128: rc2 = launch_gse_bf16x3<128>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream); break;
-      default: rc2 = launch_gse_bf16x3<256>((int)k, points, knn, (int)n, div_term, wsplit, b_d, b_a, inv_sigma_d, factor_a, out, stream); break;
+      case 32: rc2 = GEOTR_GSE_GO(32); break;
+      case 64: rc2 = GEOTR_GSE_GO(64); break;
+      case 128: rc2 = GEOTR_GSE_GO(128); break;
+      default: rc2 = GEOTR_GSE_GO(256); break;
     }
+#undef GEOTR_GSE_GO
     if (rc2 != GEOTR_OK) return rc2;
     GEOTR_CHECK_LAUNCH("gse_embed(bf16x3)");
     return GEOTR_OK;

@@ -47,7 +47,8 @@ def gemm(a, b, b_is_kn=False, bias=None, row_div=None, residual=None, alpha=1.0,
     return out
 
 
-GEMM_PACKED = True      # False: exact fp32 MFMA for every backbone contraction
+GEMM_PACKED = True      # True: split-bf16 (fp32-grade) packed GEMMs;  False: exact fp32 MFMA for every backbone contraction;
+                        # 'bf16': plain bf16 operands on the packed GEMMs (BASELINE configs[4] "bf16 features"; see set_precision)
 PACKED_MIN_ROWS = 1024  # activations with at least this many rows use the packed split-bf16 GEMM when a packed weight is given
 
 
@@ -80,8 +81,11 @@ def gemm_pack(weight, b_is_kn=False, view=None):
 
 
 def gemm_packed(a, packed, n, bias=None, row_div=None, residual=None, alpha=1.0, act=None, out=None):
-    """out (M, n) = act(alpha * a @ W^T / row_div + bias + residual) with W given by gemm_pack (split-bf16 MFMA)."""
+    """out (M, n) = act(alpha * a @ W^T / row_div + bias + residual) with W given by gemm_pack (split-bf16 MFMA; plain bf16
+    operands when GEMM_PACKED == 'bf16')."""
     lib = _lib.load()
+    fn, name = ((lib.geotr_gemm_packed_bf16, 'geotr_gemm_packed_bf16') if GEMM_PACKED == 'bf16' else
+                (lib.geotr_gemm_packed, 'geotr_gemm_packed'))
     assert a.dim() == 2 and a.stride(-1) == 1
     M, K = a.shape
     if out is None:
@@ -90,9 +94,8 @@ def gemm_packed(a, packed, n, bias=None, row_div=None, residual=None, alpha=1.0,
     if residual is not None:
         assert residual.stride(-1) == 1
         ldr = residual.stride(0)
-    _lib.check(lib.geotr_gemm_packed(_lib.ptr(a), a.stride(0), _lib.ptr(packed), _lib.ptr(out), out.stride(0), M, n, K, _lib.ptr(bias),
-                                     _lib.ptr(row_div), _lib.ptr(residual), ldr, float(alpha), ACT[act], _lib.stream_ptr()),
-               'geotr_gemm_packed')
+    _lib.check(fn(_lib.ptr(a), a.stride(0), _lib.ptr(packed), _lib.ptr(out), out.stride(0), M, n, K, _lib.ptr(bias),
+                  _lib.ptr(row_div), _lib.ptr(residual), ldr, float(alpha), ACT[act], _lib.stream_ptr()), name)
     return out
 
 
@@ -202,7 +205,23 @@ def gse_knn(points, k):
     return knn
 
 
-GSE_PRECISION = 1  # 0: fp32 MFMA (exact fp32 products); 1: split-bf16 "bf16x3" MFMA (~2^-17 relative error per product)
+GSE_PRECISION = 1  # 0: fp32 MFMA (exact fp32 products); 1: split-bf16 "bf16x3" MFMA (~2^-17 relative error per product);
+                   # 3: plain bf16 operands (~2^-8 per product)
+
+_PRECISIONS = {'fp32': (False, 0), 'bf16x3': (True, 1), 'bf16': ('bf16', 3)}
+
+
+def set_precision(name):
+    """Arithmetic of the two matrix-pipe kernel families (packed GEMMs of the backbone / transformer, GSE embedding):
+    'bf16x3' (default): split-bf16 products, fp32-grade -- the mode every reference-parity claim is made in;
+    'fp32': exact fp32 MFMA products;  'bf16': plain bf16 operands with fp32 accumulation (BASELINE configs[4] "bf16 features").
+    Returns the previous mode's name.  Process-wide; running models pick it up at their next forward."""
+    global GEMM_PACKED, GSE_PRECISION
+    if name not in _PRECISIONS:
+        raise ValueError(f'unknown precision {name!r}: expected one of {sorted(_PRECISIONS)}')
+    prev = next((k for k, v in _PRECISIONS.items() if v == (GEMM_PACKED, GSE_PRECISION)), 'custom')
+    GEMM_PACKED, GSE_PRECISION = _PRECISIONS[name]
+    return prev
 
 
 def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, precision=None):

@@ -74,7 +74,7 @@ class Model(ctypes.Structure):
     _fields_ = [('backbone', Backbone), ('transformer', Transformer), ('alpha', P_F32),
                 ('num_points_in_patch', I64), ('num_correspondences', I64), ('num_sinkhorn_iterations', I64),
                 ('dual_normalization', I32), ('topk', I32), ('mutual', I32), ('correspondence_threshold', I32),
-                ('num_refinement_steps', I32), ('pad_', I32), ('confidence_threshold', F32), ('acceptance_radius', F32)]
+                ('num_refinement_steps', I32), ('gemm_bf16', I32), ('confidence_threshold', F32), ('acceptance_radius', F32)]
 
 
 class Outputs(ctypes.Structure):
@@ -162,7 +162,8 @@ class NativeModel:
         self._lock = threading.Lock()
 
     def _version_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        from . import kernels
+        return (kernels.GEMM_PACKED, kernels.GSE_PRECISION) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
 
     def _build(self):
         m = self.model
@@ -226,6 +227,7 @@ class NativeModel:
         f = m.fine_matching
         d.topk, d.mutual, d.correspondence_threshold = f.k, int(f.mutual), f.correspondence_threshold
         d.num_refinement_steps = f.num_refinement_steps
+        d.gemm_bf16 = int(kernels.GEMM_PACKED == 'bf16')
         d.confidence_threshold, d.acceptance_radius = float(f.confidence_threshold), float(f.acceptance_radius)
         self.desc = d
 

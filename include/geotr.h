@@ -136,6 +136,11 @@ int geotr_gemm_pack(const float* B, int64_t ldb, int b_is_kn, int64_t n, int64_t
 int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                       const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                       void* stream);
+/* The same launch with plain bf16 operands (hi planes of the same packed weight, a_hi*b_hi only, fp32 accumulation; ~2^-8 relative
+ * error per product): the "bf16 features" mode of BASELINE configs[4].  Never the default. */
+int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                           const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K1/K2  KPConv backbone pieces
@@ -192,7 +197,9 @@ int geotr_gse_knn(const float* points, int64_t n, int64_t k, int32_t* knn, void*
 /* precision 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products);  precision 1: split-bf16 ("bf16x3") MFMA --
  * every operand x = hi + lo in bf16, a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, relative error ~2^-17 per product, 3/16 of the
  * fp32 matrix time; needs ws of geotr_gse_embed_workspace_bytes(d, 1) bytes (16-byte aligned);  precision 2: as 1, but `ws` still
- * holds the split weights written by an earlier precision-1 call with the same w_d / w_a (one split per stack of clouds). */
+ * holds the split weights written by an earlier precision-1 call with the same w_d / w_a (one split per stack of clouds);
+ * precision 3: plain bf16 operands (a_hi*b_hi only, relative error ~2^-8 per product: the "bf16 features" mode of BASELINE
+ * configs[4]), same workspace;  precision 4: as 3 with the workspace of an earlier precision-1/3 call reused. */
 size_t geotr_gse_embed_workspace_bytes(int64_t d, int precision);
 int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t k, int64_t d, const float* div_term,
                     const float* w_d, const float* b_d, const float* w_a, const float* b_a, float sigma_d, float sigma_a,
@@ -342,7 +349,7 @@ typedef struct geotr_attn_layer {                                    /* RPETrans
 typedef struct geotr_transformer {                                   /* GeometricTransformer, modules/geotransformer/geotransformer.py:75-155 */
   int32_t num_layers, num_heads, angle_k, pad_;
   float sigma_d, sigma_a;
-  int32_t gse_precision, pad2_;                                      /* 0: fp32 MFMA, 1: split-bf16 MFMA (geotr_gse_embed) */
+  int32_t gse_precision, pad2_;                                      /* 0: fp32 MFMA, 1: split-bf16 MFMA, 3: bf16 MFMA (geotr_gse_embed) */
   const float* div_term;                                             /* (hidden/2) */
   geotr_linear proj_d, proj_a, in_proj, out_proj;
   geotr_attn_layer layers[8];
@@ -352,7 +359,8 @@ typedef struct geotr_model {
   geotr_transformer transformer;
   const float* alpha;                                                /* optimal_transport.alpha (device scalar) */
   int64_t num_points_in_patch, num_correspondences, num_sinkhorn_iterations;
-  int32_t dual_normalization, topk, mutual, correspondence_threshold, num_refinement_steps, pad_;
+  int32_t dual_normalization, topk, mutual, correspondence_threshold, num_refinement_steps;
+  int32_t gemm_bf16;         /* 0: packed GEMMs are split-bf16 (fp32-grade);  1: plain bf16 operands (geotr_gemm_packed_bf16) */
   float confidence_threshold, acceptance_radius;
 } geotr_model;
 typedef struct geotr_outputs {                                       /* caller-allocated device buffers (reference output dict keys) */
