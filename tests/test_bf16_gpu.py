@@ -2,8 +2,8 @@
 kernel families (packed GEMMs, GSE embedding).  Never the default; the reference-parity claims are made in the split-bf16 mode.
 
 Stated tolerances: a packed bf16 GEMM equals the fp64 product of the bf16-ROUNDED operands to fp32-accumulation error (2e-5 of
-the output scale) and the fp64 product of the fp32 operands to 1e-2 of the output scale; GSE rows to 2e-2 of the output scale;
-end to end the feature MSE stays under the north-star bound of 1e-4.
+the output scale; measured 5e-7) and the fp64 product of the fp32 operands to 1e-2 of the output scale (measured 3e-3); GSE rows
+to 2e-2 of the output scale (measured 2.4e-3); end to end the feature MSE stays under the north-star bound of 1e-4 (measured 9e-6).
 """
 import numpy as np
 import pytest
@@ -94,9 +94,8 @@ def test_bf16_mode_end_to_end_lomatch_shape(bf16_mode):
         mse = float(((g - w) ** 2).mean())
         rel = mse / float((w ** 2).mean())
         print(f'bf16 mode {k}: MSE {mse:.3e} (relative {rel:.3e})')
-        assert rel <= 1e-2, (k, rel)
-        if k.endswith('_c'):  # L2-normalised rows: the absolute bound is meaningful
-            assert mse <= 1e-4, (k, mse)
+        assert mse <= 1e-4, (k, mse)   # north-star bound; measured 2e-8 (feats_c) / 9e-6 (feats_f)
+        assert rel <= 1e-3, (k, rel)   # measured 5e-6 / 3e-5
     gi = {tuple(r) for r in torch.stack([got['ref_node_corr_indices'].cpu(), got['src_node_corr_indices'].cpu()], 1).tolist()}
     wi = {tuple(r) for r in torch.stack([want['ref_node_corr_indices'], want['src_node_corr_indices']], 1).tolist()}
     print(f'bf16 mode coarse-selection overlap {len(gi & wi) / max(len(wi), 1):.3f} of {len(wi)}')
