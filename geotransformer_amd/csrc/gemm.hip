@@ -495,6 +495,24 @@ __device__ __forceinline__ void lds_read2(unsigned addr, uint4& r0, uint4& r1) {
                : "v"(addr), "n"(O1)
                : "memory");
 }
+// Split issue / wait versions for the software-pipelined main loop: the reads of step t+1 are issued before the MFMAs of step t and
+// waited for after them (the batched helpers above wait inside the asm block, which serialised read -> convert -> MFMA in every
+// step, profiles/r01_matrix_kernel_breakdown.txt).  Fragment registers are true vector types (a struct like uint4 cannot be a tied
+// asm operand); the wait takes them as in/out operands so no consumer is scheduled ahead of it.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+template <int O1>
+__device__ __forceinline__ void lds_issue2(unsigned addr, u32x4& r0, u32x4& r1) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(r0), "=&v"(r1) : "v"(addr), "n"(O1) : "memory");
+}
+__device__ __forceinline__ void lds_issue1(unsigned addr, u32x4& r0) {
+  asm volatile("ds_read_b128 %0, %1" : "=&v"(r0) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_wait(u32x4& r0) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0) : : "memory"); }
+__device__ __forceinline__ void lds_wait(u32x4& r0, u32x4& r1) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1) : : "memory"); }
+__device__ __forceinline__ void lds_wait(u32x4& r0, u32x4& r1, u32x4& r2, u32x4& r3) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+}
+
 // TERMS = 3: split-bf16 product;  TERMS = 1: plain bf16 operands (hi planes only: the lo plane is neither loaded nor multiplied).
 template <int WM, int WN, int TERMS>
 __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
@@ -545,56 +563,93 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int kt = 0; kt < kPStages - 1 && kt < nkt; ++kt) issue(kt);
-  for (int kt = 0; kt < nkt; ++kt) {
-    // stage kt must have landed; stages kt+1 .. min(kt + kPStages - 2, nkt - 1) may still be in flight
-    const int later = min(kt + kPStages - 2, nkt - 1) - kt;
-    if (later >= 2) GEOTR_WAIT_VMCNT(2 * LOADS);
-    else if (later == 1) GEOTR_WAIT_VMCNT(LOADS);
-    else GEOTR_WAIT_VMCNT(0);
-    __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in LDS, and everyone is done with the slot refilled below
-    if (kt + kPStages - 1 < nkt) issue(kt + kPStages - 1);
+  static_assert(kPStages == 2, "the pipelined loop below assumes a two-slot ring");
+  // fragment registers of the two 16-deep steps of a stage: step ks lives in set ks (constant after unrolling)
+  u32x4 fb[2][2][2];  // [set][plane][column tile]
+  u32x4 fa[2][2][2];  // [set][row tile][16-byte chunk]
+  auto issue_reads = [&](int kt, int ks) {
     const unsigned st = lds_base + (kt % kPStages) * STAGE;
+    constexpr int PL = NT_BLK * 2 * 1024, CT = 2 * 1024;  // (plane, tile) at constant offsets from the wave's first fragment
+    const unsigned ab = st + A_BYTES + (wctl * 2 + ks) * 1024 + lane * 16;
+    if constexpr (TERMS == 3) {
+      lds_issue2<PL>(ab, fb[ks][0][0], fb[ks][1][0]);
+      if constexpr (WN == 2) lds_issue2<PL>(ab + CT, fb[ks][0][1], fb[ks][1][1]);
+    } else {
+      if constexpr (WN == 2) lds_issue2<CT>(ab, fb[ks][0][0], fb[ks][0][1]);
+      else lds_issue1(ab, fb[ks][0][0]);
+    }
+    // A fragment: two swizzled 16-byte chunks of row r (row tile i = 1 sits 32 rows = 4096 B further, same swizzle)
+    const int r = wrow + fr, c0 = 4 * ks + 2 * fk;
+    const unsigned a0 = st + (r * 8 + (c0 ^ (r & 7))) * 16, a1 = st + (r * 8 + ((c0 + 1) ^ (r & 7))) * 16;
+    if constexpr (WM == 2) {
+      lds_issue2<4096>(a0, fa[ks][0][0], fa[ks][1][0]);
+      lds_issue2<4096>(a1, fa[ks][0][1], fa[ks][1][1]);
+    } else {
+      lds_issue1(a0, fa[ks][0][0]);
+      lds_issue1(a1, fa[ks][0][1]);
+    }
+  };
+  auto wait_reads = [&](int ks) {  // one s_waitcnt lgkmcnt(0) covers the step; the further calls only tie the other registers to it
+    if constexpr (WM == 2) lds_wait(fa[ks][0][0], fa[ks][1][0], fa[ks][0][1], fa[ks][1][1]);
+    else lds_wait(fa[ks][0][0], fa[ks][0][1]);
+    if constexpr (TERMS == 3) {
+      if constexpr (WN == 2) lds_wait(fb[ks][0][0], fb[ks][1][0], fb[ks][0][1], fb[ks][1][1]);
+      else lds_wait(fb[ks][0][0], fb[ks][1][0]);
+    } else {
+      if constexpr (WN == 2) lds_wait(fb[ks][0][0], fb[ks][0][1]);
+      else lds_wait(fb[ks][0][0]);
+    }
+  };
+  auto multiply = [&](int ks) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      // B fragments of this wave's WN column tiles: (plane, tile) at constant offsets from the first one
-      constexpr int PL = NT_BLK * 2 * 1024, CT = 2 * 1024;
-      const unsigned ab = st + A_BYTES + (wctl * 2 + ks) * 1024 + lane * 16;
-      uint4 rb[2][2], ra[2][2];
-      if constexpr (TERMS == 3) {
-        if constexpr (WN == 2) lds_read4<PL, CT, PL + CT>(ab, rb[0][0], rb[1][0], rb[0][1], rb[1][1]);
-        else lds_read2<PL>(ab, rb[0][0], rb[1][0]);
-      } else {
-        if constexpr (WN == 2) lds_read2<CT>(ab, rb[0][0], rb[0][1]);
-        else lds_read1(ab, rb[0][0]);
+    for (int i = 0; i < WM; ++i) {
+      const u32x4 q0 = fa[ks][i][0], q1 = fa[ks][i][1];
+      const float x[8] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w),
+                          __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w)};
+      bf16x8 ah, al;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ah[e] = (__bf16)x[e];
+        if constexpr (TERMS == 3) al[e] = (__bf16)(x[e] - (float)ah[e]);
       }
-      // A fragment: two swizzled 16-byte chunks of row r (row tile i = 1 sits 32 rows = 4096 B further, same swizzle)
-      const int r = wrow + fr, c0 = 4 * ks + 2 * fk;
-      const unsigned a0 = st + (r * 8 + (c0 ^ (r & 7))) * 16, a1 = st + (r * 8 + ((c0 + 1) ^ (r & 7))) * 16;
-      lds_read2<4096>(a0, ra[0][0], ra[1][0]);
-      lds_read2<4096>(a1, ra[0][1], ra[1][1]);
 #pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const float x[8] = {__uint_as_float(ra[i][0].x), __uint_as_float(ra[i][0].y), __uint_as_float(ra[i][0].z), __uint_as_float(ra[i][0].w),
-                            __uint_as_float(ra[i][1].x), __uint_as_float(ra[i][1].y), __uint_as_float(ra[i][1].z), __uint_as_float(ra[i][1].w)};
-        bf16x8 ah, al;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          ah[e] = (__bf16)x[e];
-          if constexpr (TERMS == 3) al[e] = (__bf16)(x[e] - (float)ah[e]);
+      for (int j = 0; j < WN; ++j) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[ks][0][j]);
+        if constexpr (TERMS == 3) {
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, fb[ks][1][j]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, rb[0][j]);
-          if constexpr (TERMS == 3) {
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, rb[1][j]);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
-        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
       }
     }
+  };
+
+  // Schedule (two-slot ring, two steps per stage).  The stage barrier sits in the MIDDLE of an iteration:
+  //   wait R(kt,0) | issue R(kt,1) | M(kt,0) | wait R(kt,1) | stage kt+1 landed + barrier | DMA(kt+2) | issue R(kt+1,0) | M(kt,1)
+  // so both steps' LDS reads are in flight under the previous step's MFMAs.  A wave reaches the barrier only after its last read of
+  // stage kt has landed in registers, so the slot of stage kt is free for DMA(kt+2) right after it.
+  issue(0);
+  GEOTR_WAIT_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+  if (1 < nkt) issue(1);
+  issue_reads(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    wait_reads(0);
+    issue_reads(kt, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(0);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_reads(1);
+    if (kt + 1 < nkt) {
+      GEOTR_WAIT_VMCNT(0);           // this wave's part of stage kt+1 (the only DMA it has in flight)
+      __builtin_amdgcn_s_barrier();  // stage kt+1 complete; every wave holds its stage-kt fragments in registers
+      if (kt + 2 < nkt) issue(kt + 2);
+      issue_reads(kt + 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // epilogue through LDS (the ring is free once every wave has read the last stage)

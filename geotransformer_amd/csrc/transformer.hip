@@ -231,6 +231,34 @@ __global__ void split_bf16_swz_kernel(const float* __restrict__ w, int D, unsign
   *reinterpret_cast<uint4*>(lo + v * 8) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+// Split issue / wait of an A fragment (hi plane at `addr` + OFF, lo plane PLANE_B bytes further): the reads are issued one step
+// ahead of the MFMAs that consume them and waited for afterwards.  Inline asm because the compiler sinks plain LDS loads to just
+// before their first use (the read latency was then exposed at every step, profiles/r01_matrix_kernel_breakdown.txt); the wait takes
+// the fragment registers as in/out operands so no consumer can be scheduled ahead of it.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;  // a true vector type: HIP's uint4 is a struct and cannot be a tied asm operand
+template <int OFF, int PLANE_B, bool LO>
+__device__ __forceinline__ void gse_frag_issue(unsigned addr, u32x4& h, u32x4& l) {
+  if constexpr (LO)
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(h), "=&v"(l) : "v"(addr), "n"(OFF), "n"(OFF + PLANE_B) : "memory");
+  else
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(h) : "v"(addr), "n"(OFF) : "memory");
+}
+// wait until at most PENDING LDS reads are outstanding (they return in order, so everything issued before those has landed)
+template <bool LO, int PENDING>
+__device__ __forceinline__ void gse_frag_wait(u32x4& h, u32x4& l) {
+  if constexpr (LO) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(h), "+v"(l) : "n"(PENDING) : "memory");
+  else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(h) : "n"(PENDING) : "memory");
+}
+
+// issue the fragment of step `it` (order: ks, r, s): a switch over the unrolled step index keeps the offsets immediates
+template <int S, int ROW_B, int PLANE_B, bool LO, int IT = 0>
+__device__ __forceinline__ void gse_issue_step(int it, unsigned addr, u32x4& h, u32x4& l) {
+  if constexpr (IT < 4 * S) {
+    if (it == IT) gse_frag_issue<(IT / (2 * S)) * 32 + ((IT % S) * kGsePairs + 32 * ((IT / S) % 2)) * ROW_B, PLANE_B, LO>(addr, h, l);
+    else gse_issue_step<S, ROW_B, PLANE_B, LO, IT + 1>(it, addr, h, l);
+  }
+}
+
 // Schedule: the sinusoid tile of chunk c+1 is generated (VALU + transcendental pipe) into the other LDS buffer while the
 // matrix pipe works on chunk c; the two waves that share a SIMD (w and w+4 when D = 256) run the two phases in opposite order,
 // so one of them feeds the matrix pipe while the other generates.  B operands come straight from L2 in fragment order, one
@@ -248,6 +276,7 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   // [buf 2][hi, lo][S*64 rows][40]
   float* idx_s = reinterpret_cast<float*>(smem16 + 4 * PLANE);  // [S][64]
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)smem16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t total = (int64_t)n * n;
   const int64_t p0 = (int64_t)blockIdx.x * kGsePairs;
@@ -324,32 +353,45 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
   for (int c = 0; c < CH; ++c) {
     const int buf = c & 1;
     if (!late_gen && c + 1 < CH) generate(c + 1, buf ^ 1);
-    const unsigned short* A_hi = smem16 + (2 * buf) * PLANE;
-    const unsigned short* A_lo = A_hi + PLANE;
-#pragma unroll
-    for (int ks = 0; ks < kGseBK2 / 16; ++ks) {
-      const int kk = c * (kGseBK2 / 16) + ks;
-      if (kk + 1 < KS) load_b(kk + 1, bnext);
-      const int kb = ks * 16 + 8 * fk;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-          const int row = s * kGsePairs + 32 * r + fr;
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A_hi + row * kGseRS + kb);
-          const bf16x8 bh = s == 0 ? bcur[0] : bcur[2];
-          if constexpr (TERMS == 3) {
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(A_lo + row * kGseRS + kb);
-            const bf16x8 bl = s == 0 ? bcur[1] : bcur[3];
-            acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r][s], 0, 0, 0);
-            acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r][s], 0, 0, 0);
-          }
-          acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r][s], 0, 0, 0);
-        }
+    // fragment (ks, r, s) of this lane: byte offset ks*32 + (s*64 + 32r)*row stride from the lane's base address in buffer `buf`
+    constexpr int STEPS = (kGseBK2 / 16) * 2 * S, ROW_B = kGseRS * 2, PLANE_B = PLANE * 2;
+    const unsigned a_base = lds_base + buf * (2 * PLANE_B) + fr * ROW_B + fk * 16;
+    // ping-pong on two named register pairs (tied asm operands cannot be array elements): while the MFMAs of step t run, the
+    // fragment of step t+1 is in flight into the other pair.  (A distance of two steps -- three pairs, counted waits -- measured
+    // the same: profiles/r01_gse_pipelined_ab.txt.)
+    u32x4 h0, l0, h1, l1;
+    auto mfma_step = [&](int it, const u32x4& h, const u32x4& l) {
+      const int r = (it / S) % 2, s = it % S;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, h);
+      const bf16x8 bh = s == 0 ? bcur[0] : bcur[2];
+      if constexpr (TERMS == 3) {
+        const bf16x8 al = __builtin_bit_cast(bf16x8, l);
+        const bf16x8 bl = s == 0 ? bcur[1] : bcur[3];
+        acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r][s], 0, 0, 0);
+        acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r][s], 0, 0, 0);
       }
+      acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r][s], 0, 0, 0);
+    };
+    // one step: `cur` holds step t (issued one step ago), `nxt` receives step t+1
+    auto step = [&](int t, u32x4& ch, u32x4& cl, u32x4& nh, u32x4& nl) {
+      const int kk = c * (kGseBK2 / 16) + t / (2 * S);
+      if (t % (2 * S) == 0 && kk + 1 < KS) load_b(kk + 1, bnext);
+      gse_frag_wait<TERMS == 3, 0>(ch, cl);
+      if (t + 1 < STEPS) gse_issue_step<S, ROW_B, PLANE_B, TERMS == 3>(t + 1, a_base, nh, nl);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(t, ch, cl);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t % (2 * S) == 2 * S - 1) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (TERMS == 3 || (v & 1) == 0) bcur[v] = bnext[v];
+        for (int v = 0; v < 4; ++v)
+          if (TERMS == 3 || (v & 1) == 0) bcur[v] = bnext[v];
+      }
+    };
+    gse_frag_issue<0, PLANE_B, TERMS == 3>(a_base, h0, l0);
+#pragma unroll
+    for (int it = 0; it < STEPS; it += 2) {
+      step(it, h0, l0, h1, l1);
+      step(it + 1, h1, l1, h0, l0);
     }
     if (late_gen && c + 1 < CH) generate(c + 1, buf ^ 1);
     __syncthreads();
