@@ -251,11 +251,11 @@ __device__ __forceinline__ void gse_frag_wait(u32x4& h, u32x4& l) {
 }
 
 // issue the fragment of step `it` (order: ks, r, s): a switch over the unrolled step index keeps the offsets immediates
-template <int S, int ROW_B, int PLANE_B, bool LO, int IT = 0>
+template <int S, int R, int ROW_B, int PLANE_B, bool LO, int IT = 0>
 __device__ __forceinline__ void gse_issue_step(int it, unsigned addr, u32x4& h, u32x4& l) {
-  if constexpr (IT < 4 * S) {
-    if (it == IT) gse_frag_issue<(IT / (2 * S)) * 32 + ((IT % S) * kGsePairs + 32 * ((IT / S) % 2)) * ROW_B, PLANE_B, LO>(addr, h, l);
-    else gse_issue_step<S, ROW_B, PLANE_B, LO, IT + 1>(it, addr, h, l);
+  if constexpr (IT < 2 * R * S) {
+    if (it == IT) gse_frag_issue<(IT / (R * S)) * 32 + ((IT % S) * kGsePairs + 32 * ((IT / S) % R)) * ROW_B, PLANE_B, LO>(addr, h, l);
+    else gse_issue_step<S, R, ROW_B, PLANE_B, LO, IT + 1>(it, addr, h, l);
   }
 }
 
@@ -329,24 +329,38 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
       }
     }
   };
+  // Wave tile = R row tiles (32 pairs) x CT column tiles (32 channels), R * CT = 2:  (2, 1) -- a wave owns 32 channels of all 64 pairs;
+  // (1, 2) [GEOTR_GSE_WIDE, D >= 64] -- 64 channels of 32 pairs, so every A fragment read from LDS feeds two MFMA columns (half the
+  // LDS read volume, twice the weight registers).
+#ifdef GEOTR_GSE_WIDE
+  constexpr int CT = D >= 64 ? 2 : 1;
+#else
+  constexpr int CT = 1;
+#endif
+  constexpr int R = 2 / CT, CG = NW / CT;  // CG column groups x (2 / R) row groups = NW waves
+  const int cg = wave % CG, rg = wave / CG;
   const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wswz);
-  auto load_b = [&](int kk, bf16x8(&b)[4]) {
+  auto load_b = [&](int kk, bf16x8(&b)[4][CT]) {
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      if (TERMS == 3 || (v & 1) == 0) b[v] = wfrag[(((int64_t)v * NW + wave) * KS + kk) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+        if (TERMS == 3 || (v & 1) == 0) b[v][j] = wfrag[(((int64_t)v * NW + cg * CT + j) * KS + kk) * 64 + lane];
   };
 
-  f32x16 acc[2][S];
+  f32x16 acc[R][S][CT];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[r][s][q] = 0.f;
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[r][s][j][q] = 0.f;
 
   const int fr = lane & 31, fk = lane >> 5;
   const bool late_gen = NW == 8 && wave >= 4;  // see the schedule note above
-  bf16x8 bcur[4], bnext[4];
+  bf16x8 bcur[4][CT], bnext[4][CT];
   load_b(0, bcur);
   generate(0, 0);
   __syncthreads();
@@ -354,40 +368,46 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
     const int buf = c & 1;
     if (!late_gen && c + 1 < CH) generate(c + 1, buf ^ 1);
     // fragment (ks, r, s) of this lane: byte offset ks*32 + (s*64 + 32r)*row stride from the lane's base address in buffer `buf`
-    constexpr int STEPS = (kGseBK2 / 16) * 2 * S, ROW_B = kGseRS * 2, PLANE_B = PLANE * 2;
-    const unsigned a_base = lds_base + buf * (2 * PLANE_B) + fr * ROW_B + fk * 16;
+    constexpr int STEPS = (kGseBK2 / 16) * R * S, ROW_B = kGseRS * 2, PLANE_B = PLANE * 2;
+    const unsigned a_base = lds_base + buf * (2 * PLANE_B) + (32 * rg * R + fr) * ROW_B + fk * 16;
     // ping-pong on two named register pairs (tied asm operands cannot be array elements): while the MFMAs of step t run, the
     // fragment of step t+1 is in flight into the other pair.  (A distance of two steps -- three pairs, counted waits -- measured
     // the same: profiles/r01_gse_pipelined_ab.txt.)
     u32x4 h0, l0, h1, l1;
     auto mfma_step = [&](int it, const u32x4& h, const u32x4& l) {
-      const int r = (it / S) % 2, s = it % S;
+      const int r = (it / S) % R, s = it % S;
       const bf16x8 ah = __builtin_bit_cast(bf16x8, h);
-      const bf16x8 bh = s == 0 ? bcur[0] : bcur[2];
-      if constexpr (TERMS == 3) {
-        const bf16x8 al = __builtin_bit_cast(bf16x8, l);
-        const bf16x8 bl = s == 0 ? bcur[1] : bcur[3];
-        acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r][s], 0, 0, 0);
-        acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r][s], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const bf16x8 bh = s == 0 ? bcur[0][j] : bcur[2][j];
+        if constexpr (TERMS == 3) {
+          const bf16x8 al = __builtin_bit_cast(bf16x8, l);
+          const bf16x8 bl = s == 0 ? bcur[1][j] : bcur[3][j];
+          acc[r][s][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r][s][j], 0, 0, 0);
+          acc[r][s][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r][s][j], 0, 0, 0);
+        }
+        acc[r][s][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r][s][j], 0, 0, 0);
       }
-      acc[r][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r][s], 0, 0, 0);
     };
     // one step: `cur` holds step t (issued one step ago), `nxt` receives step t+1
     auto step = [&](int t, u32x4& ch, u32x4& cl, u32x4& nh, u32x4& nl) {
-      const int kk = c * (kGseBK2 / 16) + t / (2 * S);
-      if (t % (2 * S) == 0 && kk + 1 < KS) load_b(kk + 1, bnext);
+      const int kk = c * (kGseBK2 / 16) + t / (R * S);
+      if (t % (R * S) == 0 && kk + 1 < KS) load_b(kk + 1, bnext);
       gse_frag_wait<TERMS == 3, 0>(ch, cl);
-      if (t + 1 < STEPS) gse_issue_step<S, ROW_B, PLANE_B, TERMS == 3>(t + 1, a_base, nh, nl);
+      if (t + 1 < STEPS) gse_issue_step<S, R, ROW_B, PLANE_B, TERMS == 3>(t + 1, a_base, nh, nl);
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(t, ch, cl);
       __builtin_amdgcn_sched_barrier(0);
-      if (t % (2 * S) == 2 * S - 1) {
+      if (t % (R * S) == R * S - 1) {
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-          if (TERMS == 3 || (v & 1) == 0) bcur[v] = bnext[v];
+#pragma unroll
+          for (int j = 0; j < CT; ++j)
+            if (TERMS == 3 || (v & 1) == 0) bcur[v][j] = bnext[v][j];
       }
     };
     gse_frag_issue<0, PLANE_B, TERMS == 3>(a_base, h0, l0);
+    static_assert(STEPS % 2 == 0, "the ping-pong below consumes two steps per iteration");
 #pragma unroll
     for (int it = 0; it < STEPS; it += 2) {
       step(it, h0, l0, h1, l1);
@@ -398,19 +418,22 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
   }
   // epilogue d + max_k(a) + biases: the MFMA C layout gives each lane one channel of 16 scattered pairs, so the 64 x D tile is
   // transposed through LDS (the A buffers are free after the loop's last barrier) and every wave writes whole 4*D-byte rows.
-  const int col = 32 * wave + fr;
   constexpr int TS = D + 4;
   float* tile = reinterpret_cast<float*>(smem16);  // [64][D + 4] floats over the (now free) A buffers; the launch reserves max(A, tile)
-  const float bdv = bd[col], bav = ba[col];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int j = 0; j < CT; ++j) {
+    const int col = 32 * (cg * CT + j) + fr;
+    const float bdv = bd[col], bav = ba[col];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float m = acc[r][1][q];
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int s = 2; s < S; ++s) m = fmaxf(m, acc[r][s][q]);
-      tile[(32 * r + (q & 3) + 8 * (q >> 2) + 4 * fk) * TS + col] = (acc[r][0][q] + bdv) + (m + bav);
-    }
+      for (int q = 0; q < 16; ++q) {
+        float m = acc[r][1][j][q];
+#pragma unroll
+        for (int s = 2; s < S; ++s) m = fmaxf(m, acc[r][s][j][q]);
+        tile[(32 * (rg * R + r) + (q & 3) + 8 * (q >> 2) + 4 * fk) * TS + col] = (acc[r][0][j][q] + bdv) + (m + bav);
+      }
+  }
   __syncthreads();
   for (int e = tid; e < kGsePairs * (D / 4); e += T) {
     const int row = e / (D / 4), c4 = e % (D / 4);
