@@ -1,0 +1,1 @@
+from ...pairs import OdometryKittiPairDataset  # noqa: F401

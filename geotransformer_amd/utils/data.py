@@ -165,3 +165,55 @@ def calibrate_neighbors_stack_mode(dataset, collate_fn, num_stages, voxel_size, 
     cum_sum = np.cumsum(neighbor_hists.T, axis=0)
     neighbor_limits = np.sum(cum_sum < (keep_ratio * cum_sum[hist_n - 1, :]), axis=0)
     return neighbor_limits
+
+
+def reset_seed_worker_init_fn(worker_id):
+    """Seed numpy / random of a DataLoader worker from torch's per-worker seed (geotransformer/utils/torch.py:40-45)."""
+    import random
+    seed = torch.initial_seed() % (2 ** 32)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def _identity(batch):
+    return batch
+
+
+class StackModeLoader:
+    """Iterable over collated stack-mode batches.  The torch DataLoader underneath (and its worker processes) only produce lists of
+    host item dicts -- file IO and numpy augmentation; the collate, which builds the neighbour pyramid ON THE DEVICE, runs here in the
+    consuming process as each batch is drawn, so forked workers never touch the GPU."""
+
+    def __init__(self, loader, collate):
+        self.loader = loader
+        self.collate = collate
+        self.dataset = loader.dataset
+        self.sampler = loader.sampler  # DistributedSampler.set_epoch stays reachable, as trainers expect
+        self.batch_size = loader.batch_size
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for items in self.loader:
+            yield self.collate(items)
+
+
+def build_dataloader_stack_mode(dataset, collate_fn, num_stages, voxel_size, search_radius, neighbor_limits, batch_size=1,
+                                num_workers=1, shuffle=False, drop_last=False, distributed=False, precompute_data=True,
+                                device=None, **collate_kwargs):
+    """Mirror of geotransformer/utils/data.py:220-250 (+ utils/torch.py:48-77): same arguments, same batching / sampling / worker
+    seeding; returns an iterable of collated batches.  `device` (default: the current HIP device when there is one) is where the
+    collate places the stacked clouds and builds the pyramid."""
+    from functools import partial
+    if device is None and torch.cuda.is_available():
+        device = torch.device('cuda', torch.cuda.current_device())
+    sampler = torch.utils.data.DistributedSampler(dataset) if distributed else None
+    loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, num_workers=num_workers,
+                                         shuffle=False if distributed else shuffle, sampler=sampler, collate_fn=_identity,
+                                         worker_init_fn=reset_seed_worker_init_fn, pin_memory=False, drop_last=drop_last)
+    if collate_fn is registration_collate_fn_stack_mode:
+        collate_kwargs = dict(collate_kwargs, device=device)
+    collate = partial(collate_fn, num_stages=num_stages, voxel_size=voxel_size, search_radius=search_radius,
+                      neighbor_limits=neighbor_limits, precompute_data=precompute_data, **collate_kwargs)
+    return StackModeLoader(loader, collate)
