@@ -5,18 +5,21 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of the whole hot path over one batch of `--batch` independent synthetic 3DMatch-shape pairs
-(default 4 per GPU, `--lanes` of them in flight at a time on separate HIP streams; BASELINE config 2: ~20k + 20k points,
-4-stage KPConv-FPN, d = 256): the collate-equivalent pyramid (3 grid subsamples + 10 radius searches) plus the full
-GeoTransformer forward through `estimated_transform`.  Inputs (raw xyz) are resident in HBM when the timed region
-starts; weights are random-init (seed 7351), data synthetic.  At N > 1 every rank processes its own pairs (weak
-scaling, pairs are independent): weights are broadcast once from rank 0 over RCCL and the per-pair transforms are
-all-gathered inside the timed region.
+(default 32 per GPU; `--lanes` persistent host threads with a HIP stream each pull stacks of `--stack` pairs from one queue,
+and a stack goes through ONE launch sequence; BASELINE configs[1]: ~20k + 20k points, 4-stage KPConv-FPN, d = 256): the
+collate-equivalent pyramid (3 grid subsamples + 10 radius searches) plus the full GeoTransformer forward through
+`estimated_transform`.  Inputs (raw xyz) are resident in HBM when the timed region starts; weights are random-init
+(seed 7351), data synthetic.  At N > 1 every rank processes its own pairs (weak scaling, pairs are independent): weights are
+broadcast once from rank 0 over RCCL and the per-pair transforms are all-gathered inside the timed region.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     : dominant kernel (fused GSE embedding, MFMA fp32) -- algorithmic FLOPs / launch over the HIP-event
-                 average launch duration measured live in the timed region, vs the 157.3 TFLOP/s fp32-matrix peak
+  roofline     : dominant kernel (fused GSE embedding).  Default split-bf16 path: executed bf16 MFMA FLOPs (3 products per
+                 algorithmic product; `algorithmic_tflops` is reported next to it) over the HIP-event average launch duration
+                 measured live in the timed region, vs the 2.5 PFLOP/s dense bf16 peak; `isolated` = the same kernel with the GPU
+                 otherwise idle.  `--precision fp32`: algorithmic = executed, vs the 157.3 TFLOP/s fp32-matrix peak.
   cpu_baseline : the CPU oracle (reference C++ neighbour cores from oracle/_ref when present, else the restatement,
                  + the torch-fp32 restatement of the model) timed on this box's host cores on ONE pair.
+`--precision bf16` (BASELINE configs[4] arithmetic) and `--config kitti|modelnet` are orientation runs, not the headline metric.
 """
 import argparse
 import json

@@ -72,3 +72,15 @@ def test_ext_rejects_bad_inputs_like_the_reference():
     if not torch.cuda.is_available():  # the product path must fail loudly, never fall back to CPU
         with pytest.raises(RuntimeError, match='no CPU fallback'):
             ext.radius_neighbors(pts, pts, lens, lens, 0.1)
+
+
+def test_integration_doc_indexes_every_entry_point():
+    """INTEGRATION.md section 4 is the audit trail of the boundary: every symbol the header declares must appear there, next to the
+    reference code it replaces and the place it is bound."""
+    import re
+    header = open(os.path.join(ROOT, 'include', 'geotr.h')).read()
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    symbols = sorted(set(re.findall(r'\b(geotr_[a-z0-9_]+)\s*\(', header)))
+    assert len(symbols) >= 49
+    missing = [s for s in symbols if '`' + s + '`' not in doc]
+    assert not missing, missing
