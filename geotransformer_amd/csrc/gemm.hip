@@ -468,37 +468,19 @@ __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b
 // Pipeline: both operands of a 32-deep step are DMA'd straight into LDS (global_load_lds_dwordx4: no register staging) into a ring
 // of kPStages stages -- the activation tile raw fp32 (128 rows x 128 B, 16-byte chunks XOR-swizzled by row so the fragment reads are
 // at most 2-way conflicted), the weight fragments as packed.  The fp32 -> (hi, lo) bf16 split happens when a wave reads its A
-// fragment (v_cvt_pk_bf16_f32).  One barrier per step; each wave issues 4 + WAVES... loads per step and waits on its own
-// vmcnt, then the barrier publishes the stage to the other waves.
+// fragment (v_cvt_pk_bf16_f32).  One barrier per 32-deep stage: each wave issues its share of the stage's DMA (4 activation
+// chunks + its round-robin share of the weight chunks), waits on its own vmcnt, and the barrier publishes the stage to the other
+// waves; see the schedule note at the main loop for where that barrier sits.
 constexpr int kPStages = 2;  // 2 stages = 64-70 KB of LDS: two blocks per CU overlap each other's load / MFMA phases (4 stages with
                              // one block per CU was slower on the tall shapes: 58 vs 45 us for 40000x256x384)
 #define GEOTR_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | (((N) >> 4) << 14) | 0x0F70)
 // LDS reads of DMA-written data go through inline asm: the compiler's own waitcnt insertion would otherwise drain ALL
-// outstanding LDS DMA (vmcnt(0)) before any ds_read it can see.  One asm block = a batch of ds_read_b128 + s_waitcnt lgkmcnt(0),
-// so its outputs are valid when it ends.  Addresses are byte offsets into LDS; OFF* are compile-time immediates.
-template <int O1, int O2, int O3>
-__device__ __forceinline__ void lds_read4(unsigned addr, uint4& r0, uint4& r1, uint4& r2, uint4& r3) {
-  asm volatile(
-      "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-      : "v"(addr), "n"(O1), "n"(O2), "n"(O3)
-      : "memory");
-}
-__device__ __forceinline__ void lds_read1(unsigned addr, uint4& r0) {
-  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0) : "v"(addr) : "memory");
-}
-template <int O1>
-__device__ __forceinline__ void lds_read2(unsigned addr, uint4& r0, uint4& r1) {
-  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(r0), "=&v"(r1)
-               : "v"(addr), "n"(O1)
-               : "memory");
-}
-// Split issue / wait versions for the software-pipelined main loop: the reads of step t+1 are issued before the MFMAs of step t and
-// waited for after them (the batched helpers above wait inside the asm block, which serialised read -> convert -> MFMA in every
-// step, profiles/r01_matrix_kernel_breakdown.txt).  Fragment registers are true vector types (a struct like uint4 cannot be a tied
-// asm operand); the wait takes them as in/out operands so no consumer is scheduled ahead of it.
+// outstanding LDS DMA (vmcnt(0)) before any ds_read it can see.  Addresses are byte offsets into LDS; offsets are immediates.
+// The reads are split into an issue and a wait so that the main loop can software-pipeline them: the reads of step t+1 are issued
+// before the MFMAs of step t and waited for after them (a batched read + wait in one asm block serialised read -> convert -> MFMA in
+// every step, profiles/r01_matrix_kernel_breakdown.txt).  Fragment registers are true vector types (a struct like uint4 cannot be a
+// tied asm operand); the wait takes them as in/out operands so no consumer is scheduled ahead of it
+// (scripts/check_inflight_regs.py proves on the ISA that nothing touches a register while a read may still be filling it).
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 template <int O1>
 __device__ __forceinline__ void lds_issue2(unsigned addr, u32x4& r0, u32x4& r1) {
@@ -521,7 +503,6 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   constexpr int A_BYTES = BM * 128, B_BYTES = NT_BLK * PLANES * 2 * 1024, STAGE = A_BYTES + B_BYTES;
   constexpr int B_INSTR = NT_BLK * PLANES * 2;     // 1 KB weight chunks per stage: (plane, ct, kk)
   constexpr int B_PER_WAVE = (B_INSTR + 3) / 4;    // issued round-robin by the 4 waves
-  constexpr int LOADS = 4 + B_PER_WAVE;            // DMA instructions per wave and stage
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * BM, ct0 = blockIdx.x * NT_BLK;
@@ -547,7 +528,7 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
       __builtin_amdgcn_global_load_lds(a_src[s] + kt * 32, (__attribute__((address_space(3))) void*)(st + (4 * wave + s) * 1024), 16, 0, 0);
 #pragma unroll
     for (int s = 0; s < B_PER_WAVE; ++s) {
-      const int idx = min(wave + 4 * s, B_INSTR - 1);  // (tail duplicates keep LOADS uniform across waves)
+      const int idx = min(wave + 4 * s, B_INSTR - 1);  // (tail duplicates: every wave issues the same number of DMAs)
       const int pl = idx / (NT_BLK * 2), ctl = (idx / 2) % NT_BLK, kq = idx & 1;
       const int ct = min(ct0 + ctl, g.NT - 1);
       const unsigned short* src = g.Bhi + pl * plane_elems + (((int64_t)ct * g.KS + 2 * kt + kq) * 64 + lane) * 8;
