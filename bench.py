@@ -253,7 +253,7 @@ def main():
             line['speedup_vs_cpu_baseline'] = round(value / base['value'], 1)
         print(json.dumps(line))
     runner.close()
-    gd.barrier()
+    gd.shutdown()  # final barrier + process-group teardown
 
 
 if __name__ == '__main__':

@@ -71,3 +71,12 @@ def max_over_ranks(value, device):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shutdown():
+    """Tear the process group down after the last collective (a final barrier keeps a fast rank from leaving while a slow one is
+    still inside one); no-op without a group."""
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_world_size() > 1:
+            dist.barrier()
+        dist.destroy_process_group()

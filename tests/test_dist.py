@@ -28,7 +28,9 @@ def _worker(rank, world, port, ret):
     gd.barrier()
     t = gd.max_over_ranks(1.0 + rank, 'cpu')
     ret[rank] = (checksum, mine, allres.clone(), t)
-    torch.distributed.destroy_process_group()
+    gd.shutdown()
+    assert not torch.distributed.is_initialized()
+    gd.shutdown()  # idempotent
 
 
 def test_two_rank_gloo_broadcast_shard_gather():
@@ -54,3 +56,4 @@ def test_single_process_fast_path():
     assert torch.equal(gd.gather_results(x), x.unsqueeze(0))
     gd.barrier()
     assert gd.max_over_ranks(3.5, 'cpu') == 3.5
+    gd.shutdown()  # no group: nothing to do
