@@ -84,3 +84,25 @@ def test_integration_doc_indexes_every_entry_point():
     assert len(symbols) >= 49
     missing = [s for s in symbols if '`' + s + '`' not in doc]
     assert not missing, missing
+
+
+def test_set_precision_is_host_logic_and_invalidates_model_descriptors():
+    """The precision switch is plain module state (no GPU needed): modes round-trip, unknown names are rejected, and the native
+    model descriptor's cache key includes the mode, so a model that already ran re-derives its packed weights after a switch."""
+    import torch
+    from geotransformer_amd import kernels
+    from geotransformer_amd.native import NativeModel
+    assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == (True, 1)  # the default: split-bf16, the mode parity is claimed in
+    model = NativeModel(torch.nn.Linear(4, 4))
+    default_key = model._version_key()
+    try:
+        assert kernels.set_precision('bf16') == 'bf16x3'
+        assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 3)
+        assert model._version_key() != default_key
+        assert kernels.set_precision('fp32') == 'bf16'
+        assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == (False, 0)
+        with pytest.raises(ValueError):
+            kernels.set_precision('fp8')
+    finally:
+        kernels.set_precision('bf16x3')
+    assert model._version_key() == default_key
