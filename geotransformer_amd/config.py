@@ -3,7 +3,11 @@
 Same tree and field names as the reference's experiments/*/config.py (`cfg.backbone.*`, `cfg.model.*`,
 `cfg.coarse_matching.*`, `cfg.geotransformer.*`, `cfg.fine_matching.*`), restricted to what
 model.py / backbone.py consume at inference (experiments/geotransformer.3dmatch...*/config.py:76-121,
-...kitti...*/config.py:76-121, ...modelnet...*/config.py:82-127).  Unlike the reference, building a config
+...kitti...*/config.py:76-121, ...modelnet...*/config.py:82-127), the `eval` thresholds, and the data-loading
+sections (`cfg.data.*`, `cfg.train.*`, `cfg.test.*`: config.py:31-54) that experiments/*/dataset.py feeds to the pair
+datasets -- so `test_data_loader(cfg)`-style code runs against this cfg.  Training / optimiser / loss / RANSAC sections and
+the output directories are not carried; `data.dataset_root` is a relative default (the reference derives it from its install
+directory).  Every value is pinned to the reference by tests/golden/configs.json.  Unlike the reference, building a config
 has no side effects (no output directories are created).
 """
 import ast
@@ -47,6 +51,10 @@ _EXPERIMENTS = {
         eval=dict(acceptance_overlap=0.0, acceptance_radius=0.1, inlier_ratio_threshold=0.05, rmse_threshold=0.2,
                   rre_threshold=15.0, rte_threshold=0.3),
         neighbor_limits=[38, 36, 36, 38],  # experiments/...3dmatch.../demo.py:52
+        data=dict(dataset_root='data/3DMatch'),
+        train=dict(batch_size=1, num_workers=8, point_limit=30000, use_augmentation=True, augmentation_noise=0.005,
+                   augmentation_rotation=1.0),
+        test=dict(batch_size=1, num_workers=8, point_limit=None),
     ),
     'kitti': dict(
         seed=7351,
@@ -61,6 +69,10 @@ _EXPERIMENTS = {
                            num_refinement_steps=5),
         eval=dict(acceptance_overlap=0.0, acceptance_radius=1.0, inlier_ratio_threshold=0.05, rre_threshold=5.0, rte_threshold=2.0),
         neighbor_limits=[40, 40, 40, 40, 40],
+        data=dict(dataset_root='data/Kitti'),
+        train=dict(batch_size=1, num_workers=8, point_limit=30000, use_augmentation=True, augmentation_noise=0.01,
+                   augmentation_min_scale=0.8, augmentation_max_scale=1.2, augmentation_shift=2.0, augmentation_rotation=1.0),
+        test=dict(batch_size=1, num_workers=8, point_limit=None),
     ),
     'modelnet': dict(
         seed=7351,
@@ -75,6 +87,10 @@ _EXPERIMENTS = {
                            num_refinement_steps=5),
         eval=dict(acceptance_overlap=0.0, acceptance_radius=0.1, inlier_ratio_threshold=0.05, rre_threshold=1.0, rte_threshold=0.1),
         neighbor_limits=[24, 24, 24],
+        data=dict(dataset_root='data/ModelNet', num_points=717, voxel_size=None, rotation_magnitude=45.0, translation_magnitude=0.5,
+                  keep_ratio=0.7, crop_method='plane', asymmetric=True, twice_sample=True, twice_transform=False),
+        train=dict(batch_size=1, num_workers=8, noise_magnitude=0.05, class_indices='all'),
+        test=dict(batch_size=1, num_workers=8, noise_magnitude=0.05, class_indices='all'),
     ),
 }
 
