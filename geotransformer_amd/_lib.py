@@ -76,6 +76,9 @@ SIGNATURES = {
     'geotr_pyramid_build': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_profile_gse': (c_int, [c_ptr, c_ptr, c_ptr, c_i64]),
     'geotr_profile_gse_count': (c_i64, []),
+    'geotr_apply_transform': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    'geotr_pairwise_distance': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    'geotr_index_select': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'geotr_lgr': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_int, c_f32, c_i64,
                           c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
 }

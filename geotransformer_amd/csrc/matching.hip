@@ -171,7 +171,8 @@ constexpr int kTopkChunk = 2048;  // elements per block per sweep
 struct TopkState {                // device, zeroed by the host before the first kernel
   unsigned hist[3][2048];
   unsigned long long cand[kTopkCap];
-  unsigned prefix[3], remaining[3];  // after pass p (written by block 0 of the kernel that consumed hist[p])
+  unsigned prefix[3], remaining[3];  // after pass p (written by block 0 of the kernel that consumed hist[p]);
+                                     // [2] = bit pattern of the k-th largest / how many entries equal to it belong to the top k
   int nvalid, ncand;
 };
 // block-cooperative (256 threads): walk the 2^width bins of `hist` from the top until `rem` elements are covered;
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restri
   unsigned bin, rem;
   topk_select_bin(st->hist[2], 10, st->remaining[1], hist, bin, rem);
   const unsigned thr = st->prefix[1] | bin;  // bit pattern of the k-th largest value
+  if (blockIdx.x == 0 && tid == 0) st->prefix[2] = thr, st->remaining[2] = rem;
   for (int64_t base = (int64_t)blockIdx.x * kTopkChunk; base < total; base += (int64_t)gridDim.x * kTopkChunk) {
     for (int q = 0; q < kTopkChunk / 256; ++q) {
       const int64_t e = base + q * 256 + tid;
@@ -310,19 +312,48 @@ __global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restri
 }
 
 // rank the candidates (larger score first, then smaller flat index) and write the k outputs (zeros past the count)
+// More than kTopkCap candidates means thousands of scores EQUAL to the k-th largest (degenerate inputs, e.g. identical
+// features); the atomically filled list would then hold an arbitrary subset.  In that case the list is rebuilt here in flat-index
+// order: every entry above the threshold plus the first `remaining[2]` entries equal to it -- exactly k, run-to-run identical.
 __global__ __launch_bounds__(1024) void topk_rank_kernel(const TopkState* __restrict__ st, int k, int m, int64_t* __restrict__ rows,
                                                          int64_t* __restrict__ cols, float* __restrict__ vals, int* __restrict__ count_out,
-                                                         SpmBatch sb) {
+                                                         SpmBatch sb, const float* __restrict__ s, int64_t total) {
   if (sb.count > 0) {
     const int b = blockIdx.y;
     m = sb.m[b], st += b;
+    total = (int64_t)sb.n[b] * sb.m[b], s += sb.s_off[b];
     rows += b * sb.out_stride, cols += b * sb.out_stride, vals += b * sb.out_stride, count_out += b * sb.count_stride;
   }
   __shared__ unsigned long long cand[kTopkCap];
+  int* scan_sm = reinterpret_cast<int*>(&cand[kTopkCap - 16]);  // free in the rebuild path: it fills k <= kTopkCap / 2 slots
   const int tid = threadIdx.x;
   const int keff = min(k, st->nvalid);
-  const int c = keff > 0 ? min(st->ncand, kTopkCap) : 0;
-  for (int e = tid; e < c; e += 1024) cand[e] = st->cand[e];
+  int c = keff > 0 ? min(st->ncand, kTopkCap) : 0;
+  if (keff > 0 && st->ncand > kTopkCap) {  // block-uniform
+    const unsigned thr = st->prefix[2];
+    const int want_eq = (int)st->remaining[2];
+    int n_gt = 0, n_eq = 0;  // block-uniform running counts
+    for (int64_t base = 0; base < total; base += 1024) {
+      const int64_t e = base + tid;
+      unsigned u = 0;
+      bool gt = false, eq = false;
+      if (e < total) {
+        const float v = s[e];
+        if (v >= 0.f) u = __float_as_uint(v), gt = u > thr, eq = u == thr;
+      }
+      int tg, te;
+      const int pg = block_exclusive_scan<1024>((int)gt, scan_sm, tg);
+      const int pe = block_exclusive_scan<1024>((int)eq, scan_sm, te);
+      const unsigned long long key = ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)e);
+      // slots [0, keff - want_eq) hold the entries above the threshold, the rest the first want_eq equal ones
+      if (gt && n_gt + pg < keff - want_eq) cand[n_gt + pg] = key;
+      if (eq && n_eq + pe < want_eq) cand[keff - want_eq + n_eq + pe] = key;
+      n_gt += tg, n_eq += te;
+    }
+    c = keff;
+  } else {
+    for (int e = tid; e < c; e += 1024) cand[e] = st->cand[e];
+  }
   __syncthreads();
   for (int e = tid; e < c; e += 1024) {
     const unsigned long long mine = cand[e];
@@ -827,7 +858,7 @@ int spm_stack_launch(float* scores, int pairs, const int64_t* n, const int64_t* 
   topk_pass_kernel<<<dim3(blocks, P), dim3(256), 0, stream>>>(scores, 0, (int)k, 1, st, sb);
   topk_pass_kernel<<<dim3(blocks, P), dim3(256), 0, stream>>>(scores, 0, (int)k, 2, st, sb);
   topk_collect_kernel<<<dim3(blocks, P), dim3(256), 0, stream>>>(scores, 0, (int)k, st, sb);
-  topk_rank_kernel<<<dim3(1, P), dim3(1024), 0, stream>>>(st, (int)k, 0, ref_idx, src_idx, corr_scores, count, sb);
+  topk_rank_kernel<<<dim3(1, P), dim3(1024), 0, stream>>>(st, (int)k, 0, ref_idx, src_idx, corr_scores, count, sb, scores, 0);
   GEOTR_CHECK_LAUNCH("superpoint_match");
   return GEOTR_OK;
 }
@@ -888,7 +919,7 @@ int geotr_superpoint_match(float* scores, int64_t n, int64_t m, const uint8_t* r
   topk_pass_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, 1, st, sb);
   topk_pass_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, 2, st, sb);
   topk_collect_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(scores, total, (int)k, st, sb);
-  topk_rank_kernel<<<dim3(1), dim3(1024), 0, stream>>>(st, (int)k, (int)m, ref_idx, src_idx, corr_scores, count, sb);
+  topk_rank_kernel<<<dim3(1), dim3(1024), 0, stream>>>(st, (int)k, (int)m, ref_idx, src_idx, corr_scores, count, sb, scores, total);
   GEOTR_CHECK_LAUNCH("superpoint_match");
   return GEOTR_OK;
 }

@@ -329,7 +329,8 @@ struct BucketSchedule {  // libstdc++ unordered_map growth: before inserting ele
 
 // Probe the real container once (host): the schedule is a property of the libstdc++ this library
 // is linked against, exactly like the reference extension.
-static const BucketSchedule& bucket_schedule(int64_t upto) {
+// Returned BY VALUE (a copy made under the lock): another lane thread may re-probe for a larger cloud at any time.
+static BucketSchedule bucket_schedule(int64_t upto) {
   static std::mutex mu;
   static BucketSchedule sch;
   static int64_t probed = 0;
@@ -780,7 +781,7 @@ int geotr_grid_subsample(const float* points, const int64_t* len, int64_t batch,
   GsLayout L = gs_layout(ws, n, batch);
   if (ws_bytes < L.bytes)
     return fail(GEOTR_E_WORKSPACE, "grid_subsample: workspace %zu < required %zu", ws_bytes, L.bytes);
-  const BucketSchedule& sch = bucket_schedule(n);
+  const BucketSchedule sch = bucket_schedule(n);
   for (int e = 0; e < sch.n; ++e)  // the bucket tables are carved as 3*len + 64 entries per cloud
     if ((int64_t)sch.bk[e] > 3 * ((int64_t)sch.at[e] + 1) + 64)
       return fail(GEOTR_E_CAPACITY, "grid_subsample: unexpected libstdc++ bucket growth %d at %d", sch.bk[e], sch.at[e]);

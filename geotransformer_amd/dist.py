@@ -12,10 +12,24 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns (rank, world, local)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun; the same variables the reference's
+    launcher convention uses, geotransformer/engine/base_trainer.py:63-78).  Returns (rank, world, local device index).
+
+    One process per GPU: rank r of a node uses device LOCAL_RANK and it is an error if that device does not exist.  Test-only
+    escape hatch (RCCL refuses two ranks on one device -- "Duplicate GPU detected"): GEOTR_DIST_BACKEND=gloo together with
+    GEOTR_ALLOW_SHARED_DEVICE=1 lets several ranks share the one GPU of a test box so that the multi-rank control flow
+    (sharding, broadcast, gather, max-over-ranks) can run on hardware; collectives then go through gloo, not xGMI."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = backend or os.environ.get('GEOTR_DIST_BACKEND') or None
+    if torch.cuda.is_available():
+        have = torch.cuda.device_count()
+        if local >= have:
+            if os.environ.get('GEOTR_ALLOW_SHARED_DEVICE') == '1' and backend == 'gloo':
+                local = local % have
+            else:
+                raise RuntimeError(f'rank {rank}: LOCAL_RANK={local} but only {have} HIP device(s) are visible (one process per GPU)')
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
@@ -27,15 +41,20 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def _active(force):
+    """Collectives are skipped on the world_size-1 fast path unless `force` (loopback communicator: exercises RCCL on one GPU)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
+
+
 def shard_indices(num_items, rank, world):
     """Static round-robin assignment of item indices to ranks (pairs are independent)."""
     return list(range(rank, num_items, world))
 
 
 @torch.no_grad()
-def broadcast_module(module, src=0):
+def broadcast_module(module, src=0, force=False):
     """Make every rank hold rank `src`'s parameters and buffers: ONE broadcast of a flat fp32 buffer."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active(force):
         return
     tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point()]
     if not tensors:
@@ -50,9 +69,9 @@ def broadcast_module(module, src=0):
 
 
 @torch.no_grad()
-def gather_results(local, world=None):
+def gather_results(local, world=None, force=False):
     """All-gather a fixed-size per-rank result tensor (e.g. (pairs_per_rank, 4, 4)) -> (world, ...) on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active(force):
         return local.unsqueeze(0)
     world = dist.get_world_size() if world is None else world
     out = [torch.empty_like(local) for _ in range(world)]
@@ -60,15 +79,15 @@ def gather_results(local, world=None):
     return torch.stack(out, dim=0)
 
 
-def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+def barrier(force=False):
+    if _active(force):
         dist.barrier()
 
 
-def max_over_ranks(value, device):
+def max_over_ranks(value, device, force=False):
     """Max of a python float over all ranks (used for the timed region of bench.py)."""
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active(force):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

@@ -70,10 +70,16 @@ class GeoTransformer(nn.Module):
             from .native import NativeModel
             if self._native is None:
                 self._native = NativeModel(self)
-            out = NativeModel.finalize(self._native.forward(data_dict))
+            out = NativeModel.finalize(self._native.forward(data_dict), overflow=data_dict.get('_overflow'))
             if 'transform' in data_dict:
                 self._ground_truth_node_correspondences(data_dict, out)
             return out
+        if int(data_dict.get('batch_size', 1)) != 1 or len(data_dict['lengths'][0]) != 2:
+            raise ValueError('GeoTransformer.forward registers ONE pair per call, as the reference model does '
+                             '(experiments/*/model.py:76-83); use RegistrationPipeline.register_batch for several pairs')
+        if data_dict.get('_overflow') is not None:
+            from .native import NativeModel
+            NativeModel.raise_on_overflow(data_dict['_overflow'].item())
         out = {}
         fine = self.backbone.fine_stage
         feats = data_dict['features']

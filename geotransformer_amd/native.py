@@ -158,12 +158,20 @@ class NativeModel:
         self.model = model
         self._key = None
         self._keep = []
-        self.desc = None
+        self._gen = None  # (descriptor, [tensors its raw pointers refer to]) -- published and retired as ONE object
         self._lock = threading.Lock()
 
+    @property
+    def desc(self):
+        return None if self._gen is None else self._gen[0]
+
     def _version_key(self):
+        """Everything whose raw device pointer is baked into the descriptor: parameters AND buffers (KPConv.kernel_points,
+        the embedding's div_term), by (data_ptr, version)."""
         from . import kernels
-        return (kernels.GEMM_PACKED, kernels.GSE_PRECISION) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        m = self.model
+        return (kernels.GEMM_PACKED, kernels.GSE_PRECISION) + tuple(
+            (t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
 
     def _build(self):
         m = self.model
@@ -229,17 +237,32 @@ class NativeModel:
         d.num_refinement_steps = f.num_refinement_steps
         d.gemm_bf16 = int(kernels.GEMM_PACKED == 'bf16')
         d.confidence_threshold, d.acceptance_radius = float(f.confidence_threshold), float(f.acceptance_radius)
-        self.desc = d
+        return d, self._keep
 
-    def descriptor(self):
+    def generation(self):
+        """The current (descriptor, keep-alive tensors) generation, re-built when a parameter / buffer changed.
+
+        Lanes share one model.  A re-build never frees memory a concurrent lane may still use: the new generation is built
+        completely (and its producing stream synchronised) before it is published with one reference assignment; the old
+        generation is dropped only after a device-wide synchronise that FOLLOWS the publication, so every kernel launched
+        from it before that point has finished; a lane that launches from an old generation after that point finds itself
+        outdated when its call returns and pins the tensors to its stream (`forward_batch`)."""
         key = self._version_key()
         if key != self._key:
-            with self._lock:  # lanes share one model: build once, and only publish after the derived weights are complete
+            with self._lock:
                 if key != self._key:
-                    self._build()
+                    old = self._gen
+                    gen = self._build()
                     torch.cuda.current_stream().synchronize()  # fused / packed weights are produced on this thread's stream
+                    self._gen = gen
                     self._key = key
-        return self.desc
+                    if old is not None:
+                        torch.cuda.synchronize()
+                    del old
+        return self._gen
+
+    def descriptor(self):
+        return self.generation()[0]
 
     @staticmethod
     def pyramid(data_dict, lengths_host):
@@ -264,7 +287,14 @@ class NativeModel:
 
     @torch.no_grad()
     def forward(self, data_dict):
-        """Whole forward of one pair in one native call.  Returns the output dict (same keys as GeoTransformer.forward)."""
+        """Whole forward of one pair in one native call.  Returns the output dict (same keys as GeoTransformer.forward).
+        The dict must hold exactly one (ref, src) pair: multi-pair stacks have their own layout and entry point
+        (RegistrationPipeline.register_batch -> forward_batch)."""
+        lengths0 = data_dict['lengths_host'][0] if 'lengths_host' in data_dict else data_dict['lengths'][0]
+        if len(lengths0) != 2 or int(data_dict.get('batch_size', 1)) != 1:
+            raise ValueError(f'GeoTransformer.forward registers ONE pair per call (got batch_size={data_dict.get("batch_size", 1)}, '
+                             f'{len(lengths0)} clouds), as the reference model does (experiments/*/model.py:76-83 reads lengths[.][0] '
+                             f'only); use RegistrationPipeline.register_batch for several pairs')
         return self.forward_batch(data_dict)[0]
 
     @torch.no_grad()
@@ -273,7 +303,8 @@ class NativeModel:
         the KPConv-FPN runs once over the whole stack, the heads pair by pair.  Returns B output dicts."""
         lib = _bind()
         m = self.model
-        desc = self.descriptor()
+        gen = self.generation()
+        desc = gen[0]
         lengths = data_dict.get('lengths_host')
         if lengths is None:
             lengths = [l.tolist() for l in data_dict['lengths']]
@@ -324,6 +355,9 @@ class NativeModel:
                                      torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, 'geotr_model_forward')
         ws.record_stream(torch.cuda.current_stream())
+        if gen is not self._gen:  # the model was re-packed while this call was being issued: see generation()
+            for t in gen[1]:
+                t.record_stream(torch.cuda.current_stream())
         points_c, points_f, points = data_dict['points'][-1], data_dict['points'][fine], data_dict['points'][0]
         results = []
         for b in range(B):
@@ -347,21 +381,38 @@ class NativeModel:
         return results
 
     @staticmethod
-    def finalize_stack(outs):
-        """finalize() for all pairs of one forward_batch call with ONE host<-device read (all counts at once)."""
+    def raise_on_overflow(worst):
+        """The fixed-capacity radius search keeps the first `capacity` candidates of a ball in cell-scan order, not the
+        nearest ones: a table built from an overflowed ball is wrong, so this is an error, never a warning."""
+        if int(worst) > 0:
+            raise RuntimeError(f'radius search row capacity exceeded ({int(worst)} neighbours in one ball); '
+                               f'rebuild the pipeline with exact_width=True for such dense clouds')
+
+    @staticmethod
+    def finalize_stack(outs, overflow=None):
+        """finalize() for all pairs of one forward_batch call with ONE host<-device read (all counts at once).
+        `overflow`: the pyramid's device flag (native.build_pyramid); it rides on the same read and raises when set."""
         if not outs:
             return outs
         num_node, num_corr, _ = outs[0]['_counts_stack']
-        counts = torch.cat([num_node, num_corr], dim=1).tolist()  # (B, 2)
+        cols = [num_node, num_corr]
+        if overflow is not None:
+            cols.append(overflow.view(1, 1).expand(num_node.shape[0], 1))
+        counts = torch.cat(cols, dim=1).tolist()  # (B, 2 or 3)
+        if overflow is not None:
+            NativeModel.raise_on_overflow(counts[0][2])
         return [NativeModel.finalize(o, counts=counts[o['_counts_stack'][2]]) for o in outs]
 
     @staticmethod
-    def finalize(out, counts=None):
-        """Trim the variable-length outputs to their true sizes (the one host<-device read of a pair)."""
+    def finalize(out, counts=None, overflow=None):
+        """Trim the variable-length outputs to their true sizes (the one host<-device read of a pair); the pyramid's
+        overflow flag, when given, is read together with the counts and raises when set."""
         num_node, num_corr = out.pop('_counts')
         out.pop('_counts_stack', None)
         if counts is None:
-            counts = torch.cat([num_node, num_corr]).tolist()
+            counts = torch.cat([num_node, num_corr] + ([overflow.view(1)] if overflow is not None else [])).tolist()
+            if overflow is not None:
+                NativeModel.raise_on_overflow(counts[2])
         p, c = int(counts[0]), int(counts[1])
         out['ref_node_corr_indices'] = out.pop('_ref_node_corr_indices')[:p]
         out['src_node_corr_indices'] = out.pop('_src_node_corr_indices')[:p]

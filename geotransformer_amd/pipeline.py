@@ -53,14 +53,38 @@ class RegistrationPipeline:
     def __call__(self, ref_points, src_points, ref_feats=None, src_feats=None):
         """ref/src points: (N,3) fp32 device tensors.  Returns the model's output dict (incl. 'estimated_transform')."""
         data = self.collate(ref_points, src_points, ref_feats, src_feats)
-        out = self.model(data)
-        overflow = data.get('_overflow')
-        if overflow is not None:
-            out['_neighbor_overflow'] = overflow  # device int32: > 0 means a ball held more than 256 points (see check_overflow)
-        return out
+        return self.model(data)  # raises if the fixed-capacity radius search overflowed (flag read together with the counts)
+
+    @staticmethod
+    def pair_pyramid(data, b):
+        """Pair `b`'s pyramid in the reference's single-pair format, cut out of a stacked pyramid (`register_batch(...,
+        return_pyramid=True)`): rows of its two clouds at every stage, neighbour indices re-based to the pair's own rows and
+        the stack-wide pad index replaced by the pair's (= its point count at the indexed stage)."""
+        lengths = data['lengths_host']
+        S = len(lengths)
+        off = [[0] for _ in range(S)]
+        for i in range(S):
+            for l in lengths[i]:
+                off[i].append(off[i][-1] + int(l))
+        lo = [off[i][2 * b] for i in range(S)]
+        hi = [off[i][2 * b + 2] for i in range(S)]
+        tot = [off[i][-1] for i in range(S)]
+
+        def rebase(table, rows, cols):  # rows: stage of the table's rows, cols: stage its entries index
+            t = table[lo[rows]:hi[rows]]
+            return torch.where(t == tot[cols], torch.full_like(t, hi[cols] - lo[cols]), t - lo[cols])
+
+        return {
+            'points': [data['points'][i][lo[i]:hi[i]] for i in range(S)],
+            'lengths': [data['lengths'][i][2 * b:2 * b + 2] for i in range(S)],
+            'neighbors': [rebase(data['neighbors'][i], i, i) for i in range(S)],
+            'subsampling': [rebase(data['subsampling'][i], i + 1, i) for i in range(S - 1)],
+            'upsampling': [rebase(data['upsampling'][i], i, i + 1) for i in range(S - 1)],
+            'lengths_host': [lengths[i][2 * b:2 * b + 2] for i in range(S)],
+        }
 
     @torch.no_grad()
-    def register_batch(self, pairs):
+    def register_batch(self, pairs, return_pyramid=False):
         """Several independent pairs through ONE launch sequence: the clouds are stacked (ref_0, src_0, ref_1, ...), the
         pyramid and the KPConv-FPN run once over the stack (GroupNorm statistics stay per pair), the heads run pair by
         pair.  `pairs` = [(ref_points, src_points), ...] (at most 16); returns one output dict per pair.  Per-pair results
@@ -78,18 +102,9 @@ class RegistrationPipeline:
         data['batch_size'] = len(pairs)
         if self.model._native is None:
             self.model._native = NativeModel(self.model)
-        outs = NativeModel.finalize_stack(self.model._native.forward_batch(data))
-        for o in outs:
-            o['_neighbor_overflow'] = data['_overflow']
-        return outs
-
-    @staticmethod
-    def check_overflow(out):
-        """Raise if the fixed-capacity radius search overflowed for this pair (one host read; call when convenient)."""
-        flag = out.get('_neighbor_overflow')
-        if flag is not None and int(flag.item()) > 0:
-            raise RuntimeError(f'radius search row capacity exceeded ({int(flag.item())} neighbours in one ball); '
-                               f'rebuild the pipeline with exact_width=True for such dense clouds')
+        # the pyramid's overflow flag rides on the one host read of the counts and raises when set
+        outs = NativeModel.finalize_stack(self.model._native.forward_batch(data), overflow=data['_overflow'])
+        return (outs, data) if return_pyramid else outs
 
 
 class ConcurrentRegistration:

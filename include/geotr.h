@@ -386,6 +386,26 @@ int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const 
                         const geotr_outputs* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * T1  free tensor helpers of geotransformer/modules/ops (callers of the hot path use them as functions)
+ *   geotr_apply_transform   : out = P R^T + t (and normals: V R^T)          modules/ops/transformation.py:7-60
+ *       points (batch, n_per_batch, 3); transform (num_transforms, 4, 4) row-major with num_transforms == 1 (one
+ *       transform for every point: the "(*, 3) with (4, 4)" case, pass batch = 1) or == batch (batch-wise case).
+ *       normals / out_normals may both be NULL.
+ *   geotr_pairwise_distance : out (batch, n, m) = max(|x_i|^2 - 2 x_i.y_j + |y_j|^2, 0), or max(2 - 2 x_i.y_j, 0)
+ *       when `normalized`                                                   modules/ops/pairwise_distance.py:4-31
+ *       x (batch, n, c), y (batch, m, c); channel_first: x (batch, c, n), y (batch, c, m).
+ *   geotr_index_select      : out[o, k, :] = data[o, index[k], :] for data viewed as (outer, size, inner_bytes)
+ *       and a flattened index (n_index) -- the caller reshapes to the index's rank    modules/ops/index_select.py:4-31
+ *       *error_flag (device int32, zeroed by the caller) is set to 1 if an index is outside [-size, size).
+ * ---------------------------------------------------------------------------------------------- */
+int geotr_apply_transform(const float* points, const float* normals, const float* transform, int64_t batch, int64_t n_per_batch,
+                          int64_t num_transforms, float* out_points, float* out_normals, void* stream);
+int geotr_pairwise_distance(const float* x, const float* y, int64_t batch, int64_t n, int64_t m, int64_t c, int normalized,
+                            int channel_first, float* out, void* stream);
+int geotr_index_select(const void* data, const int64_t* index, int64_t outer, int64_t size, int64_t n_index, int64_t inner_bytes,
+                       void* out, int32_t* error_flag, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Native pyramid: precompute_data_stack_mode (geotransformer/utils/data.py:13-77) as one host call: (S-1) grid
  * subsamples, one radius grid per stage, 3S-2 radius searches with fixed widths `limits[i]` (pad = support count).
  * Stage buffers have capacity n0 rows (a stage never has more points than the input); the true row counts are returned

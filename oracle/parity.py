@@ -1,0 +1,89 @@
+"""TEST INFRASTRUCTURE ONLY -- the pair-level parity comparison shared by bench.py's `parity` block, __graft_entry__.smoke()
+and tests/test_bench_config_gpu.py: HIP output dict of one pair vs the CPU oracle's (oracle/model_oracle.py forward on the
+oracle's own pyramid, oracle/neighbors.py) for the same pair and the same weights.
+
+Tolerances (BASELINE.json north_star: neighbour indices bit-exact, feature MSE <= 1e-4):
+  pyramid tables            byte-identical
+  features (4 tensors)      MSE <= 1e-6 (two orders inside the north-star bound)
+  coarse correspondences    a global top-k over nearly flat scores under random weights: reported as set overlap; when the
+                            selection is identical everything downstream is compared one to one
+  matching scores           |d| <= 5e-3 on patches whose point order is identical
+  transform                 |d| <= 5e-3 per entry, rotation / translation error reported
+"""
+import numpy as np
+import torch
+
+FEATURE_MSE_BOUND = 1e-6
+SCORE_ATOL = 5e-3
+TRANSFORM_ATOL = 5e-3
+
+
+def oracle_pair(cfg, state_dict, item, lib=None):
+    """(pyramid dict of numpy arrays, oracle output dict) for one item {'ref_points', 'src_points'[, 'transform']}."""
+    from . import model_oracle as mo
+    from . import neighbors as on
+    lib = lib or on.restated()
+    pts = np.concatenate([item['ref_points'], item['src_points']])
+    lens = np.array([len(item['ref_points']), len(item['src_points'])], dtype=np.int64)
+    b = cfg.backbone
+    pyr = on.precompute_pyramid(lib, pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, list(cfg.neighbor_limits))
+    data = {k: [torch.from_numpy(np.ascontiguousarray(a)) for a in v] for k, v in pyr.items()}
+    data['features'] = torch.ones((pts.shape[0], 1))
+    want = mo.forward(state_dict, mo.config_from_reference(cfg), data)
+    return pyr, want
+
+
+def pyramid_identical(got, want):
+    """got: dict of lists of tensors / arrays (the HIP pyramid of ONE pair, reference format); want: oracle pyramid."""
+    for key in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling'):
+        if len(got[key]) != len(want[key]):
+            return False
+        for g, w in zip(got[key], want[key]):
+            g = g.detach().cpu().numpy() if torch.is_tensor(g) else np.asarray(g)
+            if g.shape != w.shape or np.ascontiguousarray(g).tobytes() != np.ascontiguousarray(w).tobytes():
+                return False
+    return True
+
+
+def rotation_translation_error(a, b):
+    """(degrees, metres) between two 4x4 rigid transforms."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    c = (np.trace(a[:3, :3].T @ b[:3, :3]) - 1.0) / 2.0
+    return float(np.degrees(np.arccos(np.clip(c, -1.0, 1.0)))), float(np.linalg.norm(a[:3, 3] - b[:3, 3]))
+
+
+def compare_pair(got, want):
+    """Returns a JSON-able report; report['ok'] is the verdict under the tolerances in this file's header."""
+    rep = {}
+    ok = True
+    for k in ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f'):
+        g, w = got[k].detach().cpu(), want[k]
+        same_shape = tuple(g.shape) == tuple(w.shape)
+        mse = float(((g - w) ** 2).mean()) if same_shape else float('inf')
+        rep['mse_' + k] = mse
+        ok &= same_shape and mse <= FEATURE_MSE_BOUND
+    gi = torch.stack([got['ref_node_corr_indices'].cpu(), got['src_node_corr_indices'].cpu()], 1)
+    wi = torch.stack([want['ref_node_corr_indices'], want['src_node_corr_indices']], 1)
+    gs, ws = {tuple(r) for r in gi.tolist()}, {tuple(r) for r in wi.tolist()}
+    rep['coarse_pairs'] = len(ws)
+    rep['coarse_set_overlap'] = len(gs & ws) / max(len(ws), 1)
+    rep['coarse_identical'] = bool(gi.shape == wi.shape and torch.equal(gi, wi))
+    ok &= gi.shape == wi.shape and rep['coarse_set_overlap'] >= 0.95
+    rep['matching_scores_max_err'] = rep['transform_max_abs_diff'] = rep['rre_deg_vs_oracle'] = rep['rte_m_vs_oracle'] = None
+    rep['correspondences'] = [int(got['corr_scores'].shape[0]), int(want['corr_scores'].shape[0])]
+    if rep['coarse_identical']:
+        same = (torch.eq(got['ref_node_corr_knn_points'].cpu(), want['ref_node_corr_knn_points']).flatten(1).all(1) &
+                torch.eq(got['src_node_corr_knn_points'].cpu(), want['src_node_corr_knn_points']).flatten(1).all(1))
+        rep['patches_in_identical_point_order'] = float(same.float().mean())
+        gm, wm = got['matching_scores'].cpu()[same], want['matching_scores'][same]
+        live = wm > -1e11  # masked entries are -1e12 + O(ulp(1e12)) noise in any implementation
+        masks_equal = bool(torch.equal(live, gm > -1e11))
+        rep['matching_scores_max_err'] = float((gm[live] - wm[live]).abs().max()) if masks_equal and bool(live.any()) else None
+        ok &= masks_equal and (rep['matching_scores_max_err'] or 0.0) <= SCORE_ATOL and rep['patches_in_identical_point_order'] >= 0.75
+        T, Tw = got['estimated_transform'].cpu().numpy(), want['estimated_transform'].numpy()
+        rep['transform_max_abs_diff'] = float(np.abs(T - Tw).max())
+        rep['rre_deg_vs_oracle'], rep['rte_m_vs_oracle'] = rotation_translation_error(T, Tw)
+        ok &= rep['transform_max_abs_diff'] <= TRANSFORM_ATOL
+    ok &= bool(torch.isfinite(got['estimated_transform']).all())
+    rep['ok'] = bool(ok)
+    return rep

@@ -1,0 +1,121 @@
+"""GPU: the multi-rank path on real hardware, as far as a 1-GPU box allows.
+
+* RCCL itself (backend 'nccl' IS RCCL on ROCm): a loopback communicator (world_size 1) runs the exact collectives of the data
+  path -- the flat parameter broadcast, the all-gather of the (steps, batch, 4, 4) transforms, the MAX all-reduce -- on device
+  buffers.  RCCL refuses two ranks on one device ("Duplicate GPU detected"), so a 2-rank RCCL run needs 2 GPUs: the driver's
+  scaling bench covers that; here the refusal is pinned so a silent fallback cannot hide behind it.
+* bench.py with TWO ranks on the one device (collectives over gloo, test-only switch): sharding, broadcast, gather and the
+  max-over-ranks timing run end to end on the GPU, and both ranks' pairs enter the result.
+* `bench.py --gpus 2` on a node with fewer devices exits loudly instead of printing a 1-GPU line (reference launcher convention:
+  geotransformer/engine/base_trainer.py:63-78).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _env(**kw):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'GEOTR_DIST_BACKEND', 'GEOTR_ALLOW_SHARED_DEVICE'):
+        env.pop(k, None)
+    env.update({k: str(v) for k, v in kw.items()})
+    return env
+
+
+LOOPBACK = r'''
+import torch, torch.distributed as dist
+from geotransformer_amd import dist as gd
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1)
+assert dist.get_backend() == 'nccl'
+torch.manual_seed(3)
+net = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.LayerNorm(512)).cuda()
+before = [p.clone() for p in net.parameters()]
+gd.broadcast_module(net, src=0, force=True)                      # one flat RCCL broadcast
+assert all(torch.equal(a, b) for a, b in zip(before, net.parameters()))
+res = torch.randn(5, 32, 4, 4, device='cuda')
+out = gd.gather_results(res, force=True)                         # RCCL all-gather
+assert out.shape == (1, 5, 32, 4, 4) and torch.equal(out[0], res)
+gd.barrier(force=True)
+assert gd.max_over_ranks(2.5, torch.device('cuda', 0), force=True) == 2.5   # RCCL all-reduce MAX
+gd.shutdown()
+print('RCCL-LOOPBACK-OK')
+'''
+
+DUPLICATE = r'''
+import os, sys, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=int(os.environ['RANK']), world_size=2)
+try:
+    t = torch.ones(4, device='cuda')
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    print('TWO-RANKS-ONE-DEVICE-WORKED', float(t[0]))
+except Exception as exc:  # RCCL: "Duplicate GPU detected"
+    print('TWO-RANKS-ONE-DEVICE-REFUSED', type(exc).__name__)
+os._exit(0)
+'''
+
+
+def test_rccl_loopback_collectives_on_device():
+    res = subprocess.run([sys.executable, '-c', LOOPBACK], env=_env(MASTER_ADDR='127.0.0.1', MASTER_PORT=_port()), cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert 'RCCL-LOOPBACK-OK' in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_rccl_refuses_two_ranks_on_one_device_or_runs_them():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('multi-GPU node: the real N>1 path is the driver\'s scaling bench')
+    port = _port()
+    procs = [subprocess.Popen([sys.executable, '-c', DUPLICATE], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=_env(RANK=r, WORLD_SIZE=2, LOCAL_RANK=0, MASTER_ADDR='127.0.0.1', MASTER_PORT=port)) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=180)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(p.communicate()[0] + '\nTIMEOUT')
+    joined = '\n'.join(outs)
+    # either outcome is a defined one; what must not happen is a hang or a silent wrong answer
+    assert 'TWO-RANKS-ONE-DEVICE-REFUSED' in joined or 'TWO-RANKS-ONE-DEVICE-WORKED 2.0' in joined, joined[-3000:]
+
+
+def test_bench_two_ranks_share_the_device_over_gloo():
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '8',
+           '--pairs', '2', '--points', '6000', '--lanes', '2', '--stack', '4']
+    res = subprocess.run(cmd, env=_env(GEOTR_DIST_BACKEND='gloo', GEOTR_ALLOW_SHARED_DEVICE=1), cwd=ROOT, capture_output=True, text=True,
+                         timeout=900)
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-3000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['collective_backend'] == 'gloo' and line['scaling'] == 'weak'
+    assert abs(line['value'] - 2 * 2 * 8 / (line['ms_per_step'] * 2 / 1e3)) < 1e-2 * line['value']  # both ranks' pairs counted
+    assert 'cpu_baseline' not in line and 'parity' not in line  # rank 0 at N = 1 only
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    n = torch.cuda.device_count() + 1
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'], env=_env(),
+                         cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and not any(l.startswith('{') for l in res.stdout.splitlines())
+    assert f'--gpus {n}' in (res.stderr + res.stdout)
+    # and under a launcher that starts fewer ranks than --gpus says
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         env=_env(WORLD_SIZE=1, RANK=0, LOCAL_RANK=0), cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and 'WORLD_SIZE=1' in (res.stderr + res.stdout)

@@ -61,6 +61,33 @@ def test_superpoint_matching_respects_masks_and_small_k():
     assert torch.allclose(sc.cpu(), wsc, rtol=1e-5)
 
 
+def test_superpoint_matching_degenerate_ties_are_deterministic():
+    """Identical features: every score equals the k-th largest, far more candidates than the collection list holds.  The
+    selection must then be the first k entries in flat-index order (ties: smaller flat index first), run after run."""
+    from geotransformer_amd import kernels
+    n, m, k = 150, 130, 256  # 19 500 equal scores > the 8192-entry candidate list
+    f = torch.zeros((1, 64), device='cuda')
+    f[0, 3] = 1.0
+    ref, src = f.expand(n, 64).contiguous(), f.expand(m, 64).contiguous()
+    ones_r, ones_s = torch.ones(n, dtype=torch.bool, device='cuda'), torch.ones(m, dtype=torch.bool, device='cuda')
+    runs = []
+    for _ in range(3):
+        ri, si, v, cnt = kernels.superpoint_match(ref, src, ones_r, ones_s, k)
+        assert int(cnt.item()) == k
+        runs.append((ri.cpu(), si.cpu(), v.cpu()))
+    flat = torch.arange(k)
+    assert torch.equal(runs[0][0], flat // m) and torch.equal(runs[0][1], flat % m)
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+    # a row of strictly larger scores in front of the tie plateau: those first, then the plateau in flat-index order
+    ref2 = (0.5 * ref).contiguous()
+    ref2[5] = ref[5]
+    ri, si, v, cnt = kernels.superpoint_match(ref2, src, ones_r, ones_s, k, dual_normalization=False)
+    want = torch.cat([torch.arange(5 * m, 6 * m), torch.arange(k - m)])
+    assert int(cnt.item()) == k and torch.equal(ri.cpu(), want // m) and torch.equal(si.cpu(), want % m)
+    assert bool((v[:m] > v[m]).all()) and bool((v[m:] == v[m]).all())
+
+
 @pytest.mark.parametrize('K,C', [(32, 32), (64, 256), (128, 64)])
 def test_sinkhorn_matches_oracle(K, C):
     from geotransformer_amd.modules.sinkhorn import LearnableLogOptimalTransport

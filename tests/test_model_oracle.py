@@ -67,3 +67,57 @@ def test_oracle_against_live_reference_larger_dims():
     for k in ('ref_feats_c', 'src_feats_f', 'matching_scores', 'corr_scores', 'estimated_transform'):
         assert torch.allclose(got[k], ref[k], atol=1e-5), k
     assert torch.equal(got['ref_node_corr_indices'], ref['ref_node_corr_indices'])
+
+
+def test_oracle_matches_reference_on_the_demo_pair():
+    """The reference's only real-data fixture (data/demo, experiments/*3dmatch*/demo.py:24-60) at FULL model widths: golden produced
+    by executing the reference (tests/golden/make_demo_golden.py).  Pins (a) the neighbour restatements on tie-heavy 1 mm-grid
+    clouds, including the reference's order of equal-distance neighbours, (b) the seeded weights of the drop-in model,
+    (c) the torch restatement of the whole forward at d = 256 on a pair of the benchmarked size."""
+    from geotransformer_amd.config import make_cfg
+    from geotransformer_amd.model import create_model
+    from oracle import model_oracle as mo
+    from oracle import neighbors as on
+    from util import check_outputs_against_demo_golden, check_pyramid_against_demo_golden, load_demo_golden, state_dict_sha
+    g = load_demo_golden()
+    cfg = make_cfg('3dmatch')
+    torch.manual_seed(cfg.seed)
+    np.random.seed(cfg.seed)
+    model = create_model(cfg).eval()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    assert state_dict_sha(sd) == str(g['sd/sha256']), 'seeded weights differ from the reference model built under the same seeds'
+    pts = np.concatenate([g['in/ref_points'], g['in/src_points']])
+    lens = np.array([len(g['in/ref_points']), len(g['in/src_points'])], dtype=np.int64)
+    b = cfg.backbone
+    limits = [int(x) for x in g['in/limits']]
+
+    class TieOrderLib:  # restated grid subsampling + the product's tie-order header built for the host
+        grid_subsampling = staticmethod(on.restated().grid_subsampling)
+        radius_neighbors = staticmethod(on.kdorder_host())
+
+    pyr = on.precompute_pyramid(TieOrderLib, pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, limits)
+    check_pyramid_against_demo_golden(pyr, g)
+    data = {k: [torch.from_numpy(np.ascontiguousarray(a)) for a in v] for k, v in pyr.items()}
+    data['features'] = torch.ones((pts.shape[0], 1))
+    data['transform'] = torch.from_numpy(g['in/transform'])
+    got = mo.forward(sd, mo.config_from_reference(cfg), data)
+    report = check_outputs_against_demo_golden(got, g)
+    assert report['correspondences'] == 'identical list'
+    assert np.array_equal(got['gt_node_corr_indices'].numpy(), g['out/gt_node_corr_indices'])
+    assert np.allclose(got['gt_node_corr_overlaps'].numpy(), g['out/gt_node_corr_overlaps'], atol=1e-6)
+
+
+def test_t1_helpers_match_reference_golden():
+    """oracle restatements of modules/ops/{transformation,pairwise_distance,index_select}.py vs outputs of the reference's own
+    functions (tests/golden/ops_t1.npz)."""
+    import os
+    from oracle import model_oracle as mo
+    from util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'ops_t1.npz'))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    assert torch.allclose(mo.apply_transform(g['at/any/points'], g['at/any/transform']), g['at/any/out'], atol=1e-6)
+    assert torch.allclose(mo.apply_transform(g['at/batch/points'], g['at/batch/transform']), g['at/batch/out_points'], atol=1e-5)
+    assert torch.allclose(mo.pairwise_distance(g['pd/xyz/x'], g['pd/xyz/y']), g['pd/xyz/out'], atol=1e-5)
+    assert torch.allclose(mo.pairwise_distance(g['pd/feat/x'], g['pd/feat/y']), g['pd/feat/out'], rtol=1e-5, atol=1e-3)
+    for name, dim in (('f32_dim0', 0), ('f32_dim1', 1), ('f32_dim2', 2), ('i64', 0), ('bool', 0)):
+        assert torch.equal(mo.index_select(g[f'is/{name}/data'], g[f'is/{name}/index'], dim), g[f'is/{name}/out'])

@@ -78,6 +78,103 @@ def load_model_golden(name):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# the reference's demo pair (tests/golden/demo_3dmatch.npz, generator tests/golden/make_demo_golden.py)
+# ----------------------------------------------------------------------------------------------------------------------
+def sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def state_dict_sha(sd):
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k].detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def demo_projection(c, seed=20250924, width=8):
+    """Fixed random (c, width) matrix: the fine features are stored as `feats @ projection` (9 222 x 256 floats would be 9 MB)."""
+    return np.random.RandomState(seed).standard_normal((c, width)).astype(np.float32)
+
+
+def demo_sample_rows(n, seed=20250925, count=512):
+    return np.sort(np.random.RandomState(seed).permutation(n)[:count]).astype(np.int64)
+
+
+def load_demo_golden():
+    g = np.load(os.path.join(GOLDEN, 'demo_3dmatch.npz'))
+    return {k: g[k] for k in g.files}
+
+
+def check_pyramid_against_demo_golden(pyr, g):
+    """`pyr`: dict of lists of numpy arrays (points / lengths / neighbors / subsampling / upsampling) -> asserts bit equality."""
+    for key in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling'):
+        for i, a in enumerate(pyr[key]):
+            a = np.ascontiguousarray(a)
+            assert tuple(a.shape) == tuple(g[f'pyr/{key}/{i}/shape']), (key, i, a.shape)
+            full = g.get(f'pyr/{key}/{i}/full')
+            if full is not None:
+                assert np.array_equal(a, full.astype(a.dtype)), (key, i)
+            assert sha(a) == str(g[f'pyr/{key}/{i}/sha256']), (key, i)
+
+
+def check_outputs_against_demo_golden(out, g, atol=3e-4, mse=1e-8, transform_atol=1e-3, exact_selection=True):
+    """`out`: model output dict of torch tensors (any device).  Features within `atol` / `mse` of the reference's, identical
+    coarse correspondences, and -- given those -- identical correspondence lists and the reference's transform.
+    `exact_selection=False` (other arithmetic than the golden's CPU BLAS): the coarse top-k may swap near-equal scores; the
+    selected SET must overlap >= 97 % and the downstream comparison only runs when the selection is identical."""
+    import torch
+    o = {k: v.detach().cpu().numpy() for k, v in out.items() if torch.is_tensor(v)}
+    report = {}
+    for k in ('ref_feats_c', 'src_feats_c'):
+        d = o[k] - g['out/' + k]
+        report[k] = float((d ** 2).mean())
+        assert o[k].shape == g['out/' + k].shape and report[k] <= mse and float(np.abs(d).max()) <= atol, (k, report[k], float(np.abs(d).max()))
+    for k in ('ref_feats_f', 'src_feats_f'):
+        f = o[k]
+        assert tuple(f.shape) == tuple(g[f'out/{k}/shape']), k
+        d = f[g[f'out/{k}/rows']] - g[f'out/{k}/sampled']
+        report[k] = float((d ** 2).mean())
+        assert report[k] <= mse and float(np.abs(d).max()) <= atol, (k, report[k], float(np.abs(d).max()))
+        dp = f @ demo_projection(f.shape[1]) - g[f'out/{k}/projected']  # every row, through a fixed random projection
+        assert float(np.abs(dp).max()) <= 50 * atol, (k, float(np.abs(dp).max()))
+    identical = (np.array_equal(o['ref_node_corr_indices'], g['out/ref_node_corr_indices']) and
+                 np.array_equal(o['src_node_corr_indices'], g['out/src_node_corr_indices']))
+    report['coarse_identical'] = identical
+    if not identical:
+        assert not exact_selection, 'coarse correspondences differ from the reference\'s'
+        a = set(zip(o['ref_node_corr_indices'].tolist(), o['src_node_corr_indices'].tolist()))
+        b = set(zip(g['out/ref_node_corr_indices'].tolist(), g['out/src_node_corr_indices'].tolist()))
+        report['coarse_set_overlap'] = len(a & b) / len(b)
+        assert report['coarse_set_overlap'] >= 0.97, report
+        return report
+    assert tuple(o['matching_scores'].shape) == tuple(g['out/matching_scores/shape'])
+    # a near-tie in point-to-node distances may permute two points of a patch: compare patches in identical point order
+    same = [p for p in range(16) if np.array_equal(o['ref_node_corr_knn_points'][p], g['out/ref_node_corr_knn_points/first16'][p]) and
+            np.array_equal(o['src_node_corr_knn_points'][p], g['out/src_node_corr_knn_points/first16'][p])]
+    assert len(same) >= 14, same
+    gm, wm = o['matching_scores'][same], g['out/matching_scores/first16'][same]
+    live = wm > -1e11
+    assert np.array_equal(live, gm > -1e11)
+    report['matching_scores_max_err'] = float(np.abs(gm[live] - wm[live]).max())
+    assert report['matching_scores_max_err'] <= 5e-3
+    if o['corr_scores'].shape == g['out/corr_scores'].shape and np.array_equal(o['ref_corr_points'], g['out/ref_corr_points']):
+        report['correspondences'] = 'identical list'
+        assert np.array_equal(o['src_corr_points'], g['out/src_corr_points'])
+        assert float(np.abs(o['corr_scores'] - g['out/corr_scores']).max()) <= 1e-3
+    else:  # a score within rounding of the 0.05 confidence threshold / of a top-3 boundary may add or drop a correspondence
+        a = {tuple(r) for r in np.concatenate([o['ref_corr_points'], o['src_corr_points']], 1).tolist()}
+        b = {tuple(r) for r in np.concatenate([g['out/ref_corr_points'], g['out/src_corr_points']], 1).tolist()}
+        report['correspondences'] = f'{len(a & b)} common of {len(b)}'
+        assert len(a & b) >= 0.995 * len(b), report['correspondences']
+    report['transform_max_abs_diff'] = float(np.abs(o['estimated_transform'] - g['out/estimated_transform']).max())
+    assert report['transform_max_abs_diff'] <= transform_atol, report
+    return report
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # synthetic benchmark trees for the dataset loaders (shared by tests/golden/make_dataset_golden.py and tests/test_datasets.py)
 # ----------------------------------------------------------------------------------------------------------------------
 def _random_rigid(rng):
