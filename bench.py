@@ -46,6 +46,115 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the 5 PF marketing figure is 2:1 sparse)
 
 
+HBM_PEAK_TBS = 8.0               # same guide: HBM3E peak (6.3 TB/s is what a streaming copy reaches)
+
+
+def time_alone(fn, reps=10):
+    """Average seconds of `fn()` (enqueues GPU work on the current stream) with the GPU otherwise idle."""
+    evs = []
+    for _ in range(reps + 2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in evs[2:]) / reps / 1e3
+
+
+def roofline_blocks(events, cfg, args, pipe, out, kernels):
+    """Live roofline of the two heaviest kernel families from the executor's HIP events (recorded on the launch streams inside the
+    timed region).  Returns the block of the family with the larger summed launch time (`roofline`), the other one under
+    `roofline['other']`.  Work per launch (DESIGN.md section 3 states it per unit):
+      packed GEMM  : 2 m n k FLOP (algorithmic = fp32-equivalent products; the split-bf16 path executes 3 bf16 MFMA products each)
+      GSE by table : n^2 D 4 B of mandatory HBM output per cloud (the (n, n, D) embedding); its L2 gather traffic is on-chip.
+                     Also quoted in the reference formulation's FLOPs, 2 n^2 (1+k) D^2, to compare with the MFMA kernels it replaces
+      GSE by MFMA  : 2 n^2 (1+k) D^2 FLOP."""
+    D, k = cfg.geotransformer.hidden_dim, cfg.geotransformer.angle_k
+    gse_mode = kernels.GSE_PRECISION
+    gemm_mode = kernels.GEMM_PACKED
+    fam = {}
+    gse = [(sec, work) for sec, kind, work in events if kind == 'gse']
+    gemm = [(sec, work) for sec, kind, work in events if kind == 'gemm']
+    lanes_note = (f'HIP events on the launch streams inside the timed region, {args.lanes} lanes co-running (launch durations include '
+                  f'contention from the other lanes)')
+    if gse:
+        sec, pairs = sum(s for s, _ in gse), sum(w for _, w in gse)
+        flops = 2.0 * pairs * (1 + k) * D * D
+        if gse_mode == 5:
+            nbytes = pairs * D * 4.0
+            blk = {'bound': 'hbm', 'kernel': f'gse_embed_table_kernel<{D},{1 + k}> (GSE by table: (1+k) cubic-Taylor row lookups per (i,j) from L2, max_k, one (n,n,D) write)',
+                   'achieved': round(nbytes / sec / 1e9, 1), 'peak': HBM_PEAK_TBS * 1e3, 'unit': 'GB/s', 'frac': round(nbytes / sec / 1e12 / HBM_PEAK_TBS, 4),
+                   'reference_formulation_tflops': round(flops / sec / 1e12, 1),
+                   'note': 'achieved = algorithmic HBM bytes (the n^2 D fp32 output; inputs are KBs) / launch time; the kernel is bound by its L2 gather '
+                           '(16 KB of table rows per (i,j) at D=256), see DESIGN.md; reference_formulation_tflops = 2 n^2 (1+k) D^2 / time, the contraction this replaces; ' + lanes_note}
+        else:
+            peak = FP32_MATRIX_PEAK_TFLOPS if gse_mode == 0 else BF16_MATRIX_PEAK_TFLOPS
+            ex = 3.0 if gse_mode == 1 else 1.0
+            blk = {'bound': 'mfma', 'kernel': {0: f'gse_embed_kernel<{D},{1 + k}> (fp32 MFMA)', 1: f'gse_embed_bf16x3_kernel<{D},{1 + k},3> (split-bf16 MFMA)',
+                                               3: f'gse_embed_bf16x3_kernel<{D},{1 + k},1> (bf16 MFMA)'}[gse_mode],
+                   'achieved': round(flops / sec / 1e12, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(flops / sec / 1e12 / peak, 4),
+                   'executed_tflops': round(ex * flops / sec / 1e12, 2), 'note': 'achieved = algorithmic 2 n^2 (1+k) D^2 FLOP / launch time; ' + lanes_note}
+        blk.update(launches=len(gse), avg_launch_us=round(1e6 * sec / len(gse), 1), total_ms=round(1e3 * sec, 2))
+        fam['gse'] = blk
+    if gemm:
+        sec = sum(s for s, _ in gemm)
+        flops = sum(2.0 * m * n * kk for _, (m, n, kk) in gemm)
+        peak = FP32_MATRIX_PEAK_TFLOPS if gemm_mode is False else BF16_MATRIX_PEAK_TFLOPS
+        ex = 3.0 if gemm_mode is True else 1.0
+        shapes = {}
+        for s_, w in gemm:
+            d = shapes.setdefault(w, [0, 0.0])
+            d[0] += 1
+            d[1] += s_
+        top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:6]
+        blk = {'bound': 'mfma', 'kernel': 'gemm_packed_kernel<WM,WN,TERMS> (+ split-K reduce) -- every packed Linear / KPConv contraction of the stack',
+               'achieved': round(flops / sec / 1e12, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(flops / sec / 1e12 / peak, 4),
+               'executed_tflops': round(ex * flops / sec / 1e12, 2), 'executed_frac': round(ex * flops / sec / 1e12 / peak, 4),
+               'launches': len(gemm), 'avg_launch_us': round(1e6 * sec / len(gemm), 1), 'total_ms': round(1e3 * sec, 2),
+               'top_shapes_in_flight': [{'m_n_k': list(w), 'launches': c, 'avg_us': round(1e6 * t / c, 1),
+                                         'tflops': round(2.0 * w[0] * w[1] * w[2] * c / t / 1e12, 1)} for w, (c, t) in top],
+               'note': 'achieved = ALGORITHMIC 2 m n k FLOP summed over the recorded launches / their summed duration; executed_* counts the 3 bf16 '
+                       'MFMA products per algorithmic product of the split-bf16 path; ' + lanes_note}
+        fam['gemm'] = blk
+    if not fam:
+        return None
+    # the same kernels with the GPU otherwise idle (after the timed region): separates kernel quality from lane contention
+    if 'gse' in fam:
+        emb_mod = pipe.model.transformer.embedding
+        pts_c = out['ref_points_c'].contiguous()
+        knn = kernels.gse_knn(pts_c, emb_mod.angle_k)
+        tabs = emb_mod.tables() if gse_mode == 5 else None
+        t_iso = time_alone(lambda: kernels.gse_embed(pts_c, knn, emb_mod.embedding.div_term, emb_mod.proj_d.weight, emb_mod.proj_d.bias,
+                                                     emb_mod.proj_a.weight, emb_mod.proj_a.bias, emb_mod.sigma_d, emb_mod.sigma_a, tables=tabs))
+        n = int(pts_c.shape[0])
+        iso = {'n': n, 'avg_launch_us': round(1e6 * t_iso, 1), 'reference_formulation_tflops': round(2.0 * n * n * (1 + k) * D * D / t_iso / 1e12, 1),
+               'note': 'one cloud, GPU otherwise idle, HIP events after the timed region'}
+        if gse_mode == 5:
+            iso.update(achieved=round(n * n * D * 4.0 / t_iso / 1e9, 1), frac=round(n * n * D * 4.0 / t_iso / 1e12 / HBM_PEAK_TBS, 4))
+        else:
+            iso.update(achieved=iso['reference_formulation_tflops'], frac=round(iso['reference_formulation_tflops'] / fam['gse']['peak'], 4))
+        fam['gse']['isolated'] = iso
+    if 'gemm' in fam:
+        iso = []
+        for (m, n, kk), (c, t) in top[:4]:
+            a = torch.randn((m, kk), dtype=torch.float32, device=out['ref_points_c'].device)
+            w = torch.randn((n, kk), dtype=torch.float32, device=a.device) * 0.05
+            packed = kernels.gemm_pack(w)
+            y = torch.empty((m, n), dtype=torch.float32, device=a.device)
+            t_iso = time_alone(lambda: kernels.gemm_packed(a, packed, n, out=y))
+            iso.append({'m_n_k': [m, n, kk], 'avg_us': round(1e6 * t_iso, 1), 'tflops': round(2.0 * m * n * kk / t_iso / 1e12, 1),
+                        'frac': round(2.0 * m * n * kk / t_iso / 1e12 / fam['gemm']['peak'], 4)})
+        fam['gemm']['isolated'] = {'shapes': iso, 'note': 'the heaviest shapes re-run alone (random operands, bias-free epilogue), GPU otherwise idle'}
+    order = sorted(fam, key=lambda f: -fam[f]['total_ms'])
+    main = fam[order[0]]
+    if len(order) > 1:
+        main['other'] = fam[order[1]]
+    recorded = sum(fam[f]['launches'] for f in fam)
+    main['events'] = f'{recorded} launches bracketed (first {recorded} of the timed region; pool capacity bounds the count)'
+    return main
+
+
 def pmc_traffic_bytes(kernel_substr):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (collected in separate --pmc passes of
     this same command; bench.py itself cannot run under the counters).  None when no summary is present."""
@@ -60,14 +169,24 @@ def pmc_traffic_bytes(kernel_substr):
     return None
 
 
+def note(msg):
+    """Progress on stderr (stdout carries exactly one JSON line): a slow or hung phase is then visible in the log."""
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
 def build_pair(seed, config, n_points):
     from geotransformer_amd.synthetic import make_pair
     return make_pair(seed, config, n_points=n_points)
 
 
-def cpu_baseline(cfg, items, model):
-    """Oracle on the host CPU (both parts are checkers, see oracle/), SURVEY.md 8(d) protocol: 1 warm-up + 3 timed pairs, median.
-    Returns (record, pyramid of items[0], oracle outputs of items[0])."""
+def cpu_baseline(cfg, items, model, budget_s=150.0):
+    """Oracle on the host CPU (both parts are checkers, see oracle/), SURVEY.md 8(d) protocol: 1 warm-up + 3 timed pairs, median;
+    collate on one thread (the reference's C++ cores, as the reference runs them), forward (torch fp32 restatement) on 16 threads, on
+    all cores and on one thread.  Every forward leg runs in a child process with a time budget (oracle/cpu_timing.py): a thread
+    count that oversubscribes a big host cannot be interrupted from inside.  Returns (record, pyramid of items[0], oracle outputs of
+    items[0])."""
+    import subprocess
+    import tempfile
     from oracle import model_oracle as mo
     from oracle import neighbors as on
     lib = on.reference()
@@ -90,38 +209,65 @@ def cpu_baseline(cfg, items, model):
         data['features'] = torch.ones((pts.shape[0], 1))
         return dt, pyr, data
 
-    def forward(data, threads):
-        torch.set_num_threads(threads)
-        t0 = time.perf_counter()
-        out = mo.forward(sd, ocfg, data)
-        return time.perf_counter() - t0, out
-
+    t_start = time.perf_counter()
     sample = [items[i % len(items)] for i in range(4)]  # 1 warm-up + 3 timed pairs of the same workload
     collated = [collate(it) for it in sample]
     t_collate = float(np.median([c[0] for c in collated[1:]]))
     pyr0, data0 = collated[0][1], collated[0][2]
-    many = min(nproc, 256)
-    _, out0 = forward(data0, many)  # warm-up (its output is the parity reference for items[0])
-    t_many = float(np.median([forward(c[2], many)[0] for c in collated[1:]]))
-    t_16 = None
-    if many > 16:  # torch CPU ops of this size stop scaling well before a big host's core count
-        forward(collated[1][2], 16)
-        t_16 = float(np.median([forward(c[2], 16)[0] for c in collated[1:]]))
-    t_forward, threads = (t_16, 16) if (t_16 is not None and t_16 < t_many) else (t_many, many)
-    t_one = None
-    if t_forward * min(threads, 16) < 60.0:  # keep the default run inside a few minutes
-        t_one = forward(collated[1][2], 1)[0]
-    torch.set_num_threads(threads)
+    torch.set_num_threads(min(nproc, 16))
+    out0 = mo.forward(sd, ocfg, data0)  # the parity reference for items[0] (in-process, 16 threads)
+
+    legs = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        blob = os.path.join(tmp, 'oracle_inputs.pt')
+        torch.save({'sd': sd, 'cfg': ocfg, 'data': [c[2] for c in collated]}, blob)
+
+        def leg(threads, warmup, reps, limit_s):
+            """median seconds of a forward at `threads`, or ('timeout', completed times) when the child overran its budget"""
+            limit_s = max(10.0, min(limit_s, budget_s - (time.perf_counter() - t_start)))
+            env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+            cmd = [sys.executable, '-m', 'oracle.cpu_timing', blob, str(threads), str(warmup), str(reps)]
+            try:
+                res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=limit_s)
+                lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+                last = json.loads(lines[-1]) if lines else {'median_s': None, 'times_s': []}
+                return last['median_s'], last['times_s'], False
+            except subprocess.TimeoutExpired as exc:
+                out = exc.stdout.decode() if isinstance(exc.stdout, bytes) else (exc.stdout or '')
+                lines = [l for l in out.splitlines() if l.startswith('{')]
+                last = json.loads(lines[-1]) if lines else {'median_s': None, 'times_s': []}
+                return last['median_s'], last['times_s'], True
+
+        few = min(nproc, 16)
+        legs[few] = leg(few, 1, 3, 60.0)
+        if nproc > few:
+            legs[nproc] = leg(nproc, 1, 3, 45.0)
+        if few > 1:
+            legs[1] = leg(1, 0, 1, 75.0)
+
+    def med(key):
+        return legs[key][0] if key in legs and legs[key][0] is not None else None
+
+    candidates = [(med(k), k) for k in legs if (k != 1 or len(legs) == 1) and med(k) is not None]
+    t_forward, threads = min(candidates) if candidates else (None, None)
     workers = min(8, nproc)  # the reference overlaps collate in 8 DataLoader workers (experiments/*/config.py:49)
+
+    def describe(key):
+        m, times, timed_out = legs[key]
+        if m is None:
+            return 'did not finish one pair inside its budget' if timed_out else 'failed'
+        return f'{m:.2f} s' + (f' (budget hit after {len(times)} timed pair(s))' if timed_out else '')
+
     rec = {
-        'value': 1.0 / (t_collate + t_forward), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+        'value': None if t_forward is None else 1.0 / (t_collate + t_forward), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
         'sample': f'1 warm-up + 3 timed pairs of the same workload (20k-pt pairs of this run), medians: collate {t_collate:.2f} s '
-                  f'(1 thread, {kind_nb}) + forward {t_forward:.2f} s (torch fp32 restatement, {threads} threads); host has {nproc} cores',
-        'nproc': nproc, 'collate_s': round(t_collate, 3), 'forward_s': round(t_forward, 3),
-        'forward_s_all_cores': round(t_many, 3), 'forward_s_16_threads': None if t_16 is None else round(t_16, 3),
-        'one_thread_pairs_per_s': None if t_one is None else round(1.0 / (t_collate + t_one), 4),
-        'forward_s_one_thread': None if t_one is None else round(t_one, 2),
-        'pipelined_bound_pairs_per_s': round(1.0 / max(t_collate / workers, t_forward), 4),
+                  f'(1 thread, {kind_nb}) + forward {describe(threads) if threads else "n/a"} (torch fp32 restatement, {threads} threads, '
+                  f'the best of the thread counts tried); host has {nproc} logical cores',
+        'nproc': nproc, 'collate_s': round(t_collate, 3), 'forward_s': None if t_forward is None else round(t_forward, 3),
+        f'forward_{few}_threads': describe(few), 'forward_all_cores': describe(nproc),
+        'forward_one_thread': describe(1) if 1 in legs else describe(few),
+        'one_thread_pairs_per_s': None if med(1) is None else round(1.0 / (t_collate + med(1)), 4),
+        'pipelined_bound_pairs_per_s': None if t_forward is None else round(1.0 / max(t_collate / workers, t_forward), 4),
         'pipelined_note': f'1 / max(collate / {workers} workers, forward): the reference overlaps collate in DataLoader workers',
     }
     return rec, pyr0, out0
@@ -156,6 +302,10 @@ def main():
     ap.add_argument('--lanes', type=int, default=4, help='pairs kept in flight concurrently (host thread + HIP stream each)')
     ap.add_argument('--stack', type=int, default=8, help='pairs stacked into one launch sequence per lane (<= 16; divides --batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle legs (cpu_baseline and parity)')
+    ap.add_argument('--gse', default='table', choices=['table', 'mfma'],
+                    help='geometric structure embedding: by table lookup (default) or on the fused sinusoid -> MFMA kernel (A/B runs)')
+    ap.add_argument('--profile-events', type=int, default=2048,
+                    help='launches of the two heaviest kernel families bracketed by HIP events inside the timed region (0 = none)')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the exact-fp32 mode line')
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32', 'bf16'],
                     help="matrix-pipe arithmetic: bf16x3 = split-bf16, fp32-grade (default, the headline mode); fp32 = exact fp32 MFMA; "
@@ -173,7 +323,7 @@ def main():
 
     _lib.require_gpu()
     _lib.load()
-    kernels.set_precision(args.precision)
+    kernels.set_precision(args.precision, gse=args.gse)
     rank, world, local = gd.init_from_env()
     if world != args.gpus:
         sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: every rank must come up (one process per GPU)')
@@ -214,6 +364,7 @@ def main():
 
         runner.submit(batch, sink)
 
+    note(f'rank {rank}: model + {len(pairs)} pairs ready; warm-up')
     for i in range(args.warmup):
         step(i)
     runner.drain()
@@ -221,8 +372,8 @@ def main():
     out = last[0][1]
     info['superpoints'] = [int(out['ref_points_c'].shape[0]), int(out['src_points_c'].shape[0])]
 
-    from geotransformer_amd.native import GseProfiler
-    prof = GseProfiler(2 * args.steps * args.batch + 8)  # HIP events around the dominant kernel, recorded on the launch stream
+    from geotransformer_amd.native import KernelProfiler
+    prof = KernelProfiler(args.profile_events)  # HIP events around the GSE / packed-GEMM launches, recorded on the launch streams
     gd.barrier()
     torch.cuda.synchronize()
     with prof:
@@ -236,29 +387,13 @@ def main():
         elapsed = time.perf_counter() - t0
     elapsed = gd.max_over_ranks(elapsed, device)
     events = prof.results()
-
-    # the same kernel with nothing else in flight (after the timed region): separates kernel quality from lane contention
-    isolated = None
-    if rank == 0:
-        emb_mod = pipe.model.transformer.embedding
-        pts_c = out['ref_points_c'].contiguous()
-        knn = kernels.gse_knn(pts_c, emb_mod.angle_k)
-        reps, evs = 10, []
-        for r in range(reps + 2):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            kernels.gse_embed(pts_c, knn, emb_mod.embedding.div_term, emb_mod.proj_d.weight, emb_mod.proj_d.bias,
-                              emb_mod.proj_a.weight, emb_mod.proj_a.bias, emb_mod.sigma_d, emb_mod.sigma_a)
-            e1.record()
-            evs.append((e0, e1))
-        torch.cuda.synchronize()
-        iso_s = sum(a.elapsed_time(b) for a, b in evs[2:]) / reps / 1e3  # includes the two weight-split launches (~3 us)
-        isolated = (iso_s, int(pts_c.shape[0]))
+    note(f'rank {rank}: timed region done ({args.steps} steps in {elapsed:.2f} s)')
 
     # exact-fp32 matrix arithmetic on the same workload (a few steps; a mode line next to the headline, not the headline)
     fp32_mode = None
     if rank == 0 and world == 1 and args.precision == 'bf16x3' and not args.no_fp32_mode:
         timed_out = dict(last)
+        note('exact-fp32 mode leg')
         kernels.set_precision('fp32')
         k_steps = max(2, min(5, args.steps))
         step(0)
@@ -273,7 +408,7 @@ def main():
         fp32_mode = {'value': round(k_steps * args.batch / dt, 3), 'unit': 'pairs/s', 'steps': k_steps,
                      'ms_per_step': round(1e3 * dt / k_steps, 3), 'dtype': 'f32 (exact fp32 MFMA, v_mfma_f32_32x32x2_f32)',
                      'note': 'same workload and execution shape, every matrix product in exact fp32; untimed warm-up of 1 step'}
-        kernels.set_precision(args.precision)
+        kernels.set_precision(args.precision, gse=args.gse)
         last.clear()
         last.update(timed_out)
 
@@ -281,17 +416,14 @@ def main():
         assert torch.isfinite(gathered).all()
         total_pairs = args.steps * args.batch * world
         value = total_pairs / elapsed
-        # roofline of the dominant kernel: 2 * n^2 * (1 + k) * D^2 FLOPs per launch (proj_d + k x proj_a)
-        D, k = cfg.geotransformer.hidden_dim, cfg.geotransformer.angle_k
-        durs = [sec for sec, _ in events]
-        flops = [2.0 * n * n * (1 + k) * D * D for _, n in events]
-        algorithmic = (sum(flops) / sum(durs)) / 1e12 if durs else None
+        D = cfg.geotransformer.hidden_dim
         from geotransformer_amd import kernels as _k
-        split = _k.GSE_PRECISION == 1
-        plain_bf16 = _k.GSE_PRECISION == 3
-        # split-bf16 path: every product is 3 bf16 MFMA products (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi) -> executed flops = 3x
-        executed = (3.0 * algorithmic if split else algorithmic) if algorithmic else None
-        peak = BF16_MATRIX_PEAK_TFLOPS if (split or plain_bf16) else FP32_MATRIX_PEAK_TFLOPS
+        split, plain_bf16 = _k.GEMM_PACKED is True, _k.GEMM_PACKED == 'bf16'
+        roof = roofline_blocks(events, cfg, args, pipe, out, _k) if events else None
+        if roof is not None:
+            name = 'gse_embed' if roof['kernel'].startswith('gse') else 'gemm_packed'
+            roof['traffic'] = pmc_traffic_bytes(name)
+            roof['traffic_unit'] = 'HBM bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; latest profiles/r*_pmc_hbm_traffic.md)'
         line = {
             'metric': {'3dmatch': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)',
                        'kitti': 'registration pairs/sec (120k-pt synthetic KITTI-shape pair)',
@@ -311,42 +443,18 @@ def main():
                        'pairs_per_step_per_gpu': args.batch, 'lanes_per_gpu': args.lanes, 'pairs_stacked_per_launch_sequence': args.stack,
                        'parallelism': f'pairs sharded over {world} rank(s), one process per GPU, no data-path collective',
                        'collective_backend': 'rccl' if backend == 'nccl' else backend,
-                       'weights': 'random init, seed 7351', 'matrix_precision': args.precision,
+                       'weights': 'random init, seed 7351', 'matrix_precision': args.precision, 'gse': args.gse,
                        'inputs': 'raw xyz resident in HBM before the timed region (480 KB/pair; H2D not timed)'},
-            'roofline': {'bound': 'mfma',
-                         'kernel': ('gse_embed_bf16x3_kernel<256,4> (fused GSE: sinusoid -> split-bf16 MFMA -> max_k)' if split else
-                                    'gse_embed_bf16x3_kernel<256,4,TERMS=1> (fused GSE: sinusoid -> bf16 MFMA -> max_k)' if plain_bf16 else
-                                    'gse_embed_kernel<256,4> (fused GSE: sinusoid -> fp32 MFMA -> max_k)'),
-                         'achieved': round(algorithmic, 2) if algorithmic else None, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(algorithmic / peak, 4) if algorithmic else None,
-                         'executed_tflops': round(executed, 2) if executed else None,
-                         'executed_frac': round(executed / peak, 4) if executed else None,
-                         'note': ('achieved = ALGORITHMIC work, 2*n^2*(1+k)*D^2 flop per launch (fp32-equivalent products), over the launch '
-                                  'duration; executed_* counts the 3 bf16 MFMA products the split-bf16 path issues per algorithmic product '
-                                  '(what the matrix pipe actually does); durations are HIP events on the launch stream with '
-                                  f'{args.lanes} pair(s) in flight, so co-running kernels of the other lane are included') if split else
-                                 ('algorithmic = executed (bf16 MFMA, one product per algorithmic product)' if plain_bf16 else
-                                  'algorithmic = executed (fp32 MFMA)'),
-                         'traffic': pmc_traffic_bytes('gse_embed'), 'traffic_unit': 'HBM bytes/launch (rocprofv3 PMC '
-                         'FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/r01_pmc_hbm_traffic.md)', 'launches': len(durs),
-                         'avg_launch_us': round(1e6 * sum(durs) / len(durs), 1) if durs else None,
-                         'isolated': None},
+            'roofline': roof,
         }
-        if isolated is not None:
-            iso_s, iso_n = isolated
-            iso_alg = 2.0 * iso_n * iso_n * (1 + k) * D * D / iso_s / 1e12
-            iso_exec = 3.0 * iso_alg if split else iso_alg
-            line['roofline']['isolated'] = {
-                'achieved': round(iso_alg, 2), 'frac': round(iso_alg / peak, 4),
-                'executed_tflops': round(iso_exec, 2), 'executed_frac': round(iso_exec / peak, 4),
-                'avg_launch_us': round(1e6 * iso_s, 1), 'n': iso_n,
-                'note': 'same kernel + its weight-split launches, GPU otherwise idle, HIP events after the timed region'}
         if fp32_mode is not None:
             line['exact_fp32_mode'] = fp32_mode
         if world == 1 and not args.no_cpu_baseline:
+            note('CPU baseline (oracle on the host cores)')
             base, pyr0, want0 = cpu_baseline(cfg, items, pipe.model)
+            note('parity of the timed run vs the oracle')
             line['cpu_baseline'] = base
-            line['speedup_vs_cpu_baseline'] = round(value / base['value'], 1)
+            line['speedup_vs_cpu_baseline'] = round(value / base['value'], 1) if base['value'] else None
             # parity of the TIMED run: the last step's output for pair 0 (one of `--stack` pairs of a lane's launch sequence)
             from oracle import parity
             slot = next(j for j in range(args.batch) if last[j][0] == 0)

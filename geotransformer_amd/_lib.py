@@ -66,7 +66,13 @@ SIGNATURES = {
     'geotr_gemm_pack': (c_int, [c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_gemm_packed': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
     'geotr_gemm_packed_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
+    'geotr_gemm_packed_splitk_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
+    'geotr_gemm_packed_splitk': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_int,
+                                         c_ptr, c_size, c_ptr]),
     'geotr_group_norm_segmented': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'geotr_group_norm_flags_supported': (c_int, [c_i64]),
+    'geotr_group_norm_segmented_flags': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_i64, c_ptr,
+                                                 c_ptr, c_ptr]),
     'geotr_l2_normalize': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_weighted_procrustes': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_lgr_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
@@ -76,6 +82,11 @@ SIGNATURES = {
     'geotr_pyramid_build': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_profile_gse': (c_int, [c_ptr, c_ptr, c_ptr, c_i64]),
     'geotr_profile_gse_count': (c_i64, []),
+    'geotr_gse_table_bytes': (c_size, [c_i64, c_i64]),
+    'geotr_gse_table_build': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
+    'geotr_gse_knn_clouds': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'geotr_gse_embed_table': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                      c_f32, c_f32, c_ptr, c_ptr]),
     'geotr_apply_transform': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'geotr_pairwise_distance': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),
     'geotr_index_select': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),

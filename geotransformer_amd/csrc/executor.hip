@@ -9,6 +9,7 @@
 // layer, attention cores as ragged grouped launches), the matching heads once per stack with blockIdx.y = pair / cloud.  The
 // intermediates live in a bump allocator over the caller's workspace, the data-dependent counts stay on the device.
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -55,35 +56,71 @@ static inline bool use_packed(const void* packed, const float* a, int64_t lda, i
   return packed && m >= GEOTR_PACKED_MIN_ROWS && k % 32 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0;
 }
 
+// Event bracket of one launch for bench.py's live roofline (armed by geotr_profile_gse; free when disarmed).  `tag` goes into the
+// size slot: n > 0 = a per-cloud GSE launch over n superpoints; -pairs = a ragged GSE launch over that many (i, j) pairs;
+// kProfGemm | m << 26 | n << 14 | k = a packed GEMM of that shape (m < 2^24, n < 2^12, k < 2^14; larger shapes are not recorded).
+constexpr int64_t kProfGemm = 1ll << 62;
+struct ProfScope {
+  int slot = -1;
+  hipStream_t stream;
+  explicit ProfScope(hipStream_t st) : stream(st) {
+    if (g_prof_cap > 0) {
+      slot = g_prof_used.fetch_add(1);
+      if (slot >= g_prof_cap) slot = -1;
+    }
+    if (slot >= 0) (void)hipEventRecord((hipEvent_t)g_prof_start[slot], stream);
+  }
+  void done(int64_t tag) {
+    if (slot < 0) return;
+    (void)hipEventRecord((hipEvent_t)g_prof_stop[slot], stream);
+    g_prof_size[slot] = tag;
+  }
+};
+
 // packed GEMM in the model's precision: split-bf16 (default) or plain bf16 operands
-template <typename... Args>
-static int packed_gemm(const Ctx& c, Args... args) {
-  return c.gemm_bf16 ? geotr_gemm_packed_bf16(args...) : geotr_gemm_packed(args...);
+// (narrow, deep launches are split over K: the partial tiles live in the bump allocator for the duration of the call)
+static int packed_gemm(Ctx& c, const float* a, int64_t lda, const void* packed, float* out, int64_t ldc, int64_t m, int64_t n, int64_t k,
+                       const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act, hipStream_t stream) {
+  const size_t mk = c.mark();
+  const size_t sk_bytes = geotr_gemm_packed_splitk_workspace_bytes(m, n, k);
+  char* sk = sk_bytes ? c.alloc<char>(sk_bytes) : nullptr;
+  c.release(mk);  // stream order keeps the scratch valid until the reduce kernel has run: later allocations are written by later launches
+  if (!c.live()) return GEOTR_OK;
+  ProfScope prof(stream);
+  const int rc = geotr_gemm_packed_splitk(a, lda, packed, out, ldc, m, n, k, bias, row_div, residual, ldr, alpha, act, c.gemm_bf16 ? 1 : 0, sk,
+                                          sk_bytes, stream);
+  if (m < (1 << 24) && n < (1 << 12) && k < (1 << 14)) prof.done(kProfGemm | (m << 26) | (n << 14) | k);
+  else prof.done(0);
+  return rc;
 }
 
 static float* linear(Ctx& c, const geotr_linear& l, const float* x, int64_t lda, int64_t m, int act, const float* residual = nullptr,
                      int64_t ldr = 0) {
   float* y = c.alloc<float>((size_t)m * l.out);
-  if (c.live()) {
-    if (use_packed(l.packed, x, lda, m, l.in))
-      c.check(packed_gemm(c, x, lda, l.packed, y, l.out, m, l.out, l.in, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
-    else
-      c.check(geotr_gemm(x, lda, l.w, l.in, 0, y, l.out, m, l.out, l.in, 1, 0, 0, 0, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
-  }
+  // (packed_gemm also runs in the size-query pass: it accounts for its split-K scratch and launches only when live)
+  if (use_packed(l.packed, x, lda, m, l.in))
+    c.check(packed_gemm(c, x, lda, l.packed, y, l.out, m, l.out, l.in, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
+  else if (c.live())
+    c.check(geotr_gemm(x, lda, l.w, l.in, 0, y, l.out, m, l.out, l.in, 1, 0, 0, 0, l.b, nullptr, residual, ldr, 1.0f, act, c.stream));
   return y;
 }
 
 // GroupNorm (groups > 0) or LayerNorm (groups == 0) with optional residual / activation; returns a new (n, ch) buffer
 // `stage` selects the pair segments of the row set (GroupNorm only)
+// `row_flags` (GroupNorm only, optional): receives (row sum of the output > 0) per row -- what the KPConv fed by this output
+// needs for its neighbour count -- when the width allows it (geotr_group_norm_flags_supported), else it is left untouched and
+// *row_flags_done stays false
 static float* norm(Ctx& c, const geotr_norm& nm, const float* x, int64_t n, int64_t ch, const float* residual, int act, int stage = 0,
-                   float* y = nullptr) {
+                   float* y = nullptr, uint8_t* row_flags = nullptr, bool* row_flags_done = nullptr) {
   if (!y) y = c.alloc<float>((size_t)n * ch);
   if (nm.groups > 0) {
     const size_t m = c.mark();
     double* ws = reinterpret_cast<double*>(c.alloc<char>(geotr_group_norm_workspace_bytes(n, ch)));
+    const bool flags = row_flags && geotr_group_norm_flags_supported(ch);
+    if (row_flags_done) *row_flags_done = flags;
     if (c.live())
-      c.check(geotr_group_norm_segmented(x, n, ch, nm.groups, nm.gamma, nm.beta, nm.eps, residual, act, y, c.seg_rows[stage], c.nseg, ws,
-                                         c.stream));
+      c.check(geotr_group_norm_segmented_flags(x, n, ch, nm.groups, nm.gamma, nm.beta, nm.eps, residual, act, y, c.seg_rows[stage], c.nseg, ws,
+                                               flags ? row_flags : nullptr, c.stream));
     c.release(m);
   } else {
     if (c.live()) c.check(geotr_layer_norm(x, residual, n, ch, nm.gamma, nm.beta, nm.eps, y, c.stream));
@@ -91,23 +128,47 @@ static float* norm(Ctx& c, const geotr_norm& nm, const float* x, int64_t n, int6
   return y;
 }
 
+// Rows of a KPConv layer processed per gather -> GEMM round.  The (rows, 15 C_in) gathered operand is written by one kernel and read
+// by the next; bounded to a few tens of MB it stays in the 256 MB Infinity Cache between the two instead of making an HBM round
+// trip (a stack of 8 pairs would otherwise stream up to 600 MB per layer through HBM twice).  GEOTR_KPCONV_CHUNK_MB overrides the
+// operand budget per round (0 = one round per layer).
+static int64_t kpconv_chunk_rows(int64_t m, int64_t kdim) {
+  static const int64_t budget_mb = [] {
+    const char* e = std::getenv("GEOTR_KPCONV_CHUNK_MB");
+    return e ? (int64_t)std::atoll(e) : (int64_t)48;
+  }();
+  if (budget_mb <= 0) return m;
+  int64_t rows = budget_mb * (1 << 20) / (4 * kdim);
+  rows = std::max<int64_t>(rows / 2048 * 2048, 8192);  // whole GEMM tiles, and never a launch too small to fill the chip
+  return rows >= m || m - rows < 4096 ? m : rows;
+}
+
+// `s_flags` (optional): (row sum > 0) of s_feats, already produced by the GroupNorm that wrote them; else computed here
 static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64_t ns, const float* q_pts, int64_t m,
-                     const float* s_pts, const int64_t* nb, int64_t h) {
+                     const float* s_pts, const int64_t* nb, int64_t h, const uint8_t* s_flags = nullptr) {
   float* out = c.alloc<float>((size_t)m * kp.out);
   const size_t mk = c.mark();
-  uint8_t* flag = kp.in > 1 ? c.alloc<uint8_t>((size_t)ns) : nullptr;
-  float* weighted = c.alloc<float>((size_t)m * kp.num_kernel_points * kp.in);
+  const int64_t kdim = kp.num_kernel_points * kp.in;
+  const int64_t chunk = kpconv_chunk_rows(m, kdim);
+  const uint8_t* flag = s_flags;
+  if (kp.in > 1 && !flag) {
+    uint8_t* f = c.alloc<uint8_t>((size_t)ns);
+    if (c.live()) c.check(geotr_row_positive(s_feats, ns, kp.in, f, c.stream));
+    flag = f;
+  }
+  float* weighted = c.alloc<float>((size_t)chunk * kdim);
   int32_t* nnum = c.alloc<int32_t>((size_t)m);
-  if (c.live()) {
-    if (flag) c.check(geotr_row_positive(s_feats, ns, kp.in, flag, c.stream));
-    c.check(geotr_kpconv_gather(s_feats, q_pts, s_pts, nb, kp.kernel_points, flag, m, ns, h, kp.in, kp.num_kernel_points, kp.sigma,
-                                weighted, nnum, c.stream));
-    const int64_t kdim = kp.num_kernel_points * kp.in;
-    if (use_packed(kp.packed, weighted, kdim, m, kdim))
-      c.check(packed_gemm(c, weighted, kdim, kp.packed, out, kp.out, m, kp.out, kdim, kp.bias, nnum, nullptr, 0, 1.0f, 0, c.stream));
-    else
-      c.check(geotr_gemm(weighted, kdim, kp.weights, kp.out, 1, out, kp.out, m, kp.out, kdim, 1, 0, 0, 0, kp.bias, nnum, nullptr, 0,
-                         1.0f, 0, c.stream));
+  for (int64_t r0 = 0; r0 < m; r0 += chunk) {
+    const int64_t rows = std::min(chunk, m - r0);
+    if (c.live())
+      c.check(geotr_kpconv_gather(s_feats, q_pts + 3 * r0, s_pts, nb + r0 * h, kp.kernel_points, flag, rows, ns, h, kp.in, kp.num_kernel_points,
+                                  kp.sigma, weighted, nnum + r0, c.stream));
+    float* o = out + r0 * kp.out;
+    if (use_packed(kp.packed, weighted, kdim, rows, kdim))
+      c.check(packed_gemm(c, weighted, kdim, kp.packed, o, kp.out, rows, kp.out, kdim, kp.bias, nnum + r0, nullptr, 0, 1.0f, 0, c.stream));
+    else if (c.live())
+      c.check(geotr_gemm(weighted, kdim, kp.weights, kp.out, 1, o, kp.out, rows, kp.out, kdim, 1, 0, 0, 0, kp.bias, nnum + r0, nullptr, 0, 1.0f,
+                         0, c.stream));
   }
   c.release(mk);
   return out;
@@ -122,11 +183,15 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
     return norm(c, b.conv_norm, x, m, b.conv.out, nullptr, 2, q_stage);
   }
   const float* x = s_feats;
+  const uint8_t* x_flags = nullptr;
   if (b.has_unary1) {
     float* t = linear(c, b.unary1, s_feats, b.unary1.in, ns, 0);
-    x = norm(c, b.unary1_norm, t, ns, b.unary1.out, nullptr, 2, s_stage);
+    uint8_t* f = c.alloc<uint8_t>((size_t)ns);
+    bool done = false;
+    x = norm(c, b.unary1_norm, t, ns, b.unary1.out, nullptr, 2, s_stage, nullptr, f, &done);
+    if (done) x_flags = f;  // the KPConv below needs no separate pass over its input
   }
-  float* y = kpconv(c, b.conv, x, ns, q_pts, m, s_pts, nb, h);
+  float* y = kpconv(c, b.conv, x, ns, q_pts, m, s_pts, nb, h, x_flags);
   y = norm(c, b.conv_norm, y, m, b.conv.out, nullptr, 2, q_stage);
   const float* sc = s_feats;  // shortcut branch
   const int64_t in_ch = b.has_unary1 ? b.unary1.in : b.conv.in;
@@ -174,13 +239,11 @@ static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geo
       c.check(geotr_upsample_concat(latent, p.n[i + 1], lat_ch, p.upsampling[i], p.upsampling_w[i], enc[i], enc_ch[i], p.n[i], cat, c.stream));
     const geotr_linear& l = net.decoder[d];
     if (i == net.fine_stage) {  // LastUnaryBlock: straight into the caller's buffer
-      if (c.live()) {
-        if (use_packed(l.packed, cat, tot, p.n[i], l.in))
-          c.check(packed_gemm(c, cat, tot, l.packed, feats_f_out, l.out, p.n[i], l.out, l.in, l.b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-        else
-          c.check(geotr_gemm(cat, tot, l.w, l.in, 0, feats_f_out, l.out, p.n[i], l.out, l.in, 1, 0, 0, 0, l.b, nullptr, nullptr, 0, 1.0f, 0,
-                             c.stream));
-      }
+      if (use_packed(l.packed, cat, tot, p.n[i], l.in))
+        c.check(packed_gemm(c, cat, tot, l.packed, feats_f_out, l.out, p.n[i], l.out, l.in, l.b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+      else if (c.live())
+        c.check(geotr_gemm(cat, tot, l.w, l.in, 0, feats_f_out, l.out, p.n[i], l.out, l.in, 1, 0, 0, 0, l.b, nullptr, nullptr, 0, 1.0f, 0,
+                           c.stream));
       latent = feats_f_out;
     } else {
       float* t = linear(c, l, cat, tot, p.n[i], 0);
@@ -209,18 +272,10 @@ static float* gse(Ctx& c, const geotr_transformer& t, const float* pts, int64_t 
   const int precision = ((t.gse_precision == 1 || t.gse_precision == 3) && shared_ws && !first) ? t.gse_precision + 1 : t.gse_precision;
   if (c.live()) {
     c.check(geotr_gse_knn(pts, n, t.angle_k, knn, c.stream));
-    int slot = -1;
-    if (g_prof_cap > 0) {
-      slot = g_prof_used.fetch_add(1);
-      if (slot >= g_prof_cap) slot = -1;
-    }
-    if (slot >= 0) (void)hipEventRecord((hipEvent_t)g_prof_start[slot], c.stream);
+    ProfScope prof(c.stream);
     c.check(geotr_gse_embed(pts, knn, n, t.angle_k, D, t.div_term, t.proj_d.w, t.proj_d.b, t.proj_a.w, t.proj_a.b, t.sigma_d, t.sigma_a,
                             precision, gws, gws_bytes, emb, c.stream));
-    if (slot >= 0) {
-      (void)hipEventRecord((hipEvent_t)g_prof_stop[slot], c.stream);
-      g_prof_size[slot] = n;
-    }
+    prof.done(n);
   }
   return emb;
 }
@@ -318,10 +373,32 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
     to_work.src0[q] = stack0[q], to_work.dst0[q] = work0[q], to_work.rows[q] = cloud_n[q];
     to_stack.src0[q] = work0[q], to_stack.dst0[q] = stack0[q], to_stack.rows[q] = cloud_n[q];
   }
-  // geometric structure embeddings, one (n, n, D) tensor per cloud, shared split-weight workspace
+  // geometric structure embeddings, one (n, n, D) tensor per cloud
   const float* emb[2 * GEOTR_MAX_PAIRS];
-  char* gws = c.alloc<char>(geotr_gse_embed_workspace_bytes(t.proj_d.out, t.gse_precision) + 16);
-  for (int q = 0; q < 2 * B; ++q) emb[q] = gse(c, t, pts_c + 3 * stack0[q], cloud_n[q], gws, q == 0);
+  if (t.gse_precision == 5) {  // by table: all clouds of the stack in one ragged launch (+ one for the k nearest superpoints)
+    geotr_gse_clouds gc;
+    std::memset(&gc, 0, sizeof(gc));
+    gc.count = 2 * B;
+    int64_t tot = 0, sq = 0;
+    for (int q = 0; q < 2 * B; ++q) {
+      gc.n[q] = (int32_t)cloud_n[q], gc.row0[q] = (int32_t)stack0[q], gc.emb_off[q] = tot;
+      tot += cloud_n[q] * cloud_n[q] * t.proj_d.out;
+      sq += cloud_n[q] * cloud_n[q];
+    }
+    float* emb_all = c.alloc<float>((size_t)tot);
+    int32_t* knn = c.alloc<int32_t>((size_t)N * t.angle_k);
+    for (int q = 0; q < 2 * B; ++q) emb[q] = emb_all + gc.emb_off[q];
+    if (c.live()) {
+      c.check(geotr_gse_knn_clouds(pts_c, &gc, t.angle_k, knn, c.stream));
+      ProfScope prof(c.stream);
+      c.check(geotr_gse_embed_table(pts_c, knn, &gc, t.angle_k, t.proj_d.out, t.gse_table_d, t.gse_points_d, t.gse_table_a, t.gse_points_a,
+                                    t.proj_d.w, t.proj_d.b, t.proj_a.w, t.proj_a.b, t.div_term, t.sigma_d, t.sigma_a, emb_all, c.stream));
+      prof.done(-sq);
+    }
+  } else {  // fused sinusoid -> MFMA kernels, one launch per cloud, shared split-weight workspace
+    char* gws = c.alloc<char>(geotr_gse_embed_workspace_bytes(t.proj_d.out, t.gse_precision) + 16);
+    for (int q = 0; q < 2 * B; ++q) emb[q] = gse(c, t, pts_c + 3 * stack0[q], cloud_n[q], gws, q == 0);
+  }
 
   float* xin = c.alloc<float>((size_t)N * c_dim);
   move_rows(c, feats_bb, xin, c_dim, to_work);
@@ -334,12 +411,10 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
       int64_t ld;
       if (L.qkv_w) {
         float* qkv = c.alloc<float>((size_t)N * 3 * C);
-        if (c.live()) {
-          if (use_packed(L.qkv_packed, x, C, N, C))
-            c.check(packed_gemm(c, x, C, L.qkv_packed, qkv, 3 * C, N, 3 * C, C, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-          else
-            c.check(geotr_gemm(x, C, L.qkv_w, C, 0, qkv, 3 * C, N, 3 * C, C, 1, 0, 0, 0, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-        }
+        if (use_packed(L.qkv_packed, x, C, N, C))
+          c.check(packed_gemm(c, x, C, L.qkv_packed, qkv, 3 * C, N, 3 * C, C, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+        else if (c.live())
+          c.check(geotr_gemm(x, C, L.qkv_w, C, 0, qkv, 3 * C, N, 3 * C, C, 1, 0, 0, 0, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
         q = qkv, k = qkv + C, v = qkv + 2 * C, ld = 3 * C;
       } else {
         q = linear(c, L.q, x, C, N, 0), k = linear(c, L.k, x, C, N, 0), v = linear(c, L.v, x, C, N, 0), ld = C;
@@ -360,12 +435,10 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
         int64_t ld;
         if (L.kv_w) {
           float* kv = c.alloc<float>((size_t)nm * 2 * C);
-          if (c.live()) {
-            if (use_packed(L.kv_packed, xm, C, nm, C))
-              c.check(packed_gemm(c, xm, C, L.kv_packed, kv, 2 * C, nm, 2 * C, C, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-            else
-              c.check(geotr_gemm(xm, C, L.kv_w, C, 0, kv, 2 * C, nm, 2 * C, C, 1, 0, 0, 0, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-          }
+          if (use_packed(L.kv_packed, xm, C, nm, C))
+            c.check(packed_gemm(c, xm, C, L.kv_packed, kv, 2 * C, nm, 2 * C, C, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+          else if (c.live())
+            c.check(geotr_gemm(xm, C, L.kv_w, C, 0, kv, 2 * C, nm, 2 * C, C, 1, 0, 0, 0, L.kv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
           k = kv, v = kv + C, ld = 2 * C;
         } else {
           k = linear(c, L.k, xm, C, nm, 0), v = linear(c, L.v, xm, C, nm, 0), ld = C;

@@ -11,6 +11,8 @@
 // sub-tile = WM*WN accumulators of 16 VGPRs.  Next tile's global loads are issued before the MFMAs of the
 // current one.  Two instances: 128x128 (4 waves, 2x2 tiles per wave) for tall operands, 64x64 (4 waves, 1 tile
 // per wave) for the few-hundred-row superpoint matrices.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace geotr {
@@ -444,6 +446,11 @@ struct PackedArgs {
   int M, N, K, KS, NT;  // KS = padded K / 16, NT = padded N / 32
   float alpha;
   int act;
+  // split-K (gridDim.z > 1): block z contracts the 32-deep stages [z * kt_split, min((z + 1) * kt_split, KS / 2)) and stores its raw
+  // fp32 partial tile to partial + z * M * N (row-major, ld = N); gemm_splitk_reduce_kernel sums the slices in z order and
+  // applies the epilogue.  gridDim.z == 1: kt_split = KS / 2, partial unused -- the launch is exactly the unsplit kernel.
+  int kt_split;
+  float* partial;
 };
 
 __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b_is_kn, int N, int K, int KS, int64_t nvec,
@@ -508,7 +515,8 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   const int m0 = blockIdx.y * BM, ct0 = blockIdx.x * NT_BLK;
   const int wrow = (wave / WAVES_N) * 32 * WM, wctl = (wave % WAVES_N) * WN;  // wave's first row / local column tile
   const int fr = lane & 31, fk = lane >> 5;
-  const int nkt = g.KS / 2;
+  const int kt_first = blockIdx.z * g.kt_split;              // this block's K range in 32-deep stages (split-K: gridDim.z slices)
+  const int nkt = min(g.KS / 2 - kt_first, g.kt_split);     // >= 1 by construction of the grid; `kt` below is relative to kt_first
   const int64_t plane_elems = (int64_t)g.NT * g.KS * 512;  // bf16 elements per plane
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)psm;
 
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
     const int r = 8 * (4 * wave + s) + (lane >> 3);
     const int c = (lane & 7) ^ (r & 7);
     const int gm = min(m0 + r, g.M - 1);  // rows past M: any valid row (never stored)
-    a_src[s] = g.A + (int64_t)gm * g.lda + 4 * c;
+    a_src[s] = g.A + (int64_t)gm * g.lda + 4 * c + (int64_t)kt_first * 32;
   }
   auto issue = [&](int kt) {
     unsigned char* st = psm + (kt % kPStages) * STAGE;
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
       const int idx = min(wave + 4 * s, B_INSTR - 1);  // (tail duplicates: every wave issues the same number of DMAs)
       const int pl = idx / (NT_BLK * 2), ctl = (idx / 2) % NT_BLK, kq = idx & 1;
       const int ct = min(ct0 + ctl, g.NT - 1);
-      const unsigned short* src = g.Bhi + pl * plane_elems + (((int64_t)ct * g.KS + 2 * kt + kq) * 64 + lane) * 8;
+      const unsigned short* src = g.Bhi + pl * plane_elems + (((int64_t)ct * g.KS + 2 * (kt_first + kt) + kq) * 64 + lane) * 8;
       __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + A_BYTES + idx * 1024), 16, 0, 0);
     }
   };
@@ -644,8 +652,53 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
 
   // epilogue through LDS (the ring is free once every wave has read the last stage)
   __builtin_amdgcn_s_barrier();
-  epilogue_lds<WM, WN>(acc, reinterpret_cast<float*>(psm) + wave * (32 * WM * (32 * WN + 4)), lane, m0 + wrow, 32 * (ct0 + wctl), g.M, g.N,
-                       g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act, g.C, g.ldc);
+  float* slab = reinterpret_cast<float*>(psm) + wave * (32 * WM * (32 * WN + 4));
+  if (gridDim.z == 1)
+    epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), g.M, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act, g.C,
+                         g.ldc);
+  else  // raw partial sums of this K slice; the epilogue runs in the reduce kernel
+    epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), g.M, g.N, 1.0f, nullptr, nullptr, nullptr, 0, 0,
+                         g.partial + (int64_t)blockIdx.z * g.M * g.N, g.N);
+}
+
+// out = act(alpha * (sum over z, in z order) partial[z] / row_div + bias + residual): the epilogue of a split-K launch.  One float4
+// per thread when N % 4 == 0 and everything is 16-byte aligned (the packed path's shapes), scalar otherwise.
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N, float alpha,
+                                                                 const float* __restrict__ bias, const int32_t* __restrict__ row_div,
+                                                                 const float* __restrict__ residual, int64_t ldr, int act,
+                                                                 float* __restrict__ C, int64_t ldc) {
+  constexpr int W = VEC ? 4 : 1;
+  const int64_t per_row = N / W, total = (int64_t)M * per_row, slice = (int64_t)M * N;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int m = (int)(e / per_row), n = (int)(e % per_row) * W;
+    float x[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) x[q] = 0.f;
+    const float* p = partial + (int64_t)m * N + n;
+    for (int z = 0; z < splits; ++z) {
+      if constexpr (VEC) {
+        const float4 v = *reinterpret_cast<const float4*>(p + z * slice);
+        x[0] += v.x, x[1] += v.y, x[2] += v.z, x[3] += v.w;
+      } else {
+        x[0] += p[z * slice];
+      }
+    }
+    const float d = row_div ? (float)max(row_div[m], 1) : 1.f;
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      float v = x[q] * alpha;
+      if (row_div) v = v / d;
+      if (bias) v += bias[n + q];
+      if (residual) v += residual[(int64_t)m * ldr + n + q];
+      if (act == 1) v = fmaxf(v, 0.f);
+      if (act == 2) v = v > 0.f ? v : 0.1f * v;
+      x[q] = v;
+    }
+    float* cp = C + (int64_t)m * ldc + n;
+    if constexpr (VEC) *reinterpret_cast<float4*>(cp) = make_float4(x[0], x[1], x[2], x[3]);
+    else cp[0] = x[0];
+  }
 }
 
 }  // namespace geotr
@@ -704,10 +757,26 @@ extern "C" int geotr_gemm_pack(const float* B, int64_t ldb, int b_is_kn, int64_t
   return GEOTR_OK;
 }
 
+// Split-K plan of a packed launch: how many K slices make a narrow grid fill the chip.  256 CUs x 2 resident blocks = 512 slots;
+// a launch of fewer than 256 blocks with a deep K (the coarse-stage KPConv contractions: 78 blocks x 120 stages) leaves most of
+// them empty for its whole duration.  Slices of >= 8 stages (256-deep) keep the pipeline prologue / epilogue amortised.
+static int packed_splits(int64_t M, int64_t N, int64_t K) {
+  static const bool enabled = [] {
+    const char* e = std::getenv("GEOTR_SPLITK");  // A/B switch for measurements: GEOTR_SPLITK=0 keeps every launch single-pass
+    return !(e && e[0] == '0');
+  }();
+  if (!enabled) return 1;
+  const int64_t bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  const int64_t blocks = ((M + 127) / 128) * ((N + bn - 1) / bn), nkt = pack_pad32(K) / 32;
+  if (blocks >= 256 || nkt < 16) return 1;
+  const int64_t want = (512 + blocks - 1) / blocks, most = nkt / 8;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, most), 16));
+}
+
 template <int TERMS>
 static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                               const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
-                              void* stream_) {
+                              void* stream_, void* ws = nullptr, size_t ws_bytes = 0) {
   GEOTR_CHECK_ARG(M >= 0 && N >= 1 && K >= 1, "gemm_packed: bad sizes");
   if (M == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(A && packed && C, "gemm_packed: null pointer");
@@ -719,6 +788,13 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   g.C = C; g.bias = bias; g.row_div = row_div; g.residual = residual;
   g.lda = lda; g.ldc = ldc; g.ldr = residual ? ldr : 0;
   g.M = (int)M; g.N = (int)N; g.K = (int)K; g.KS = (int)(kp / 16); g.NT = (int)(np / 32); g.alpha = alpha; g.act = act;
+  int splits = ws ? packed_splits(M, N, K) : 1;
+  if (splits > 1 && ws_bytes < sizeof(float) * (size_t)splits * (size_t)M * (size_t)N) splits = 1;  // never more than the caller's scratch holds
+  const int nkt_all = g.KS / 2;
+  g.kt_split = (nkt_all + splits - 1) / splits;
+  splits = (nkt_all + g.kt_split - 1) / g.kt_split;  // no empty slice
+  g.partial = reinterpret_cast<float*>(ws);
+  GEOTR_CHECK_ARG(splits == 1 || (reinterpret_cast<uintptr_t>(ws) & 15) == 0, "gemm_packed: split-K scratch must be 16-byte aligned");
   GEOTR_CHECK_ARG((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && K % 32 == 0,
                   "gemm_packed: A must be 16-byte aligned with lda %% 4 == 0 and K %% 32 == 0 (use geotr_gemm otherwise)");
   hipStream_t stream = (hipStream_t)stream_;
@@ -730,14 +806,38 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             lds) != hipSuccess)                                                                         \
       return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);                                      \
-    gemm_packed_kernel<WM, WN, TERMS><<<dim3((unsigned)((N + BN - 1) / BN), gy), dim3(256), lds, stream>>>(g);                 \
+    gemm_packed_kernel<WM, WN, TERMS><<<dim3((unsigned)((N + BN - 1) / BN), gy, (unsigned)splits), dim3(256), lds, stream>>>(g); \
   } while (0)
   if (N > 64) GEOTR_PACKED(2, 2, 128);
   else if (N > 32) GEOTR_PACKED(1, 2, 64);
   else GEOTR_PACKED(1, 1, 32);
 #undef GEOTR_PACKED
   GEOTR_CHECK_LAUNCH("gemm_packed");
+  if (splits > 1) {
+    const bool vec = N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    const int64_t total = M * (vec ? N / 4 : N);
+    const unsigned nb = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+    if (vec)
+      gemm_splitk_reduce_kernel<true><<<dim3(nb), dim3(256), 0, stream>>>(g.partial, splits, (int)M, (int)N, alpha, bias, row_div, residual,
+                                                                         g.ldr, act, C, ldc);
+    else
+      gemm_splitk_reduce_kernel<false><<<dim3(nb), dim3(256), 0, stream>>>(g.partial, splits, (int)M, (int)N, alpha, bias, row_div, residual,
+                                                                          g.ldr, act, C, ldc);
+    GEOTR_CHECK_LAUNCH("gemm_packed(split-K reduce)");
+  }
   return GEOTR_OK;
+}
+
+extern "C" size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  const int splits = packed_splits(M, N, K);
+  return splits > 1 ? sizeof(float) * (size_t)splits * (size_t)M * (size_t)N : 0;
+}
+
+extern "C" int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                        const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
+                                        int bf16_operands, void* ws, size_t ws_bytes, void* stream) {
+  if (bf16_operands) return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream, ws, ws_bytes);
+  return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream, ws, ws_bytes);
 }
 
 extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

@@ -19,15 +19,31 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 constexpr int kWStride = 16;  // influence rows padded to 16 floats: four broadcast ds_read_b128 per neighbour
 constexpr int kSlotCap = 256; // (points per wave) * H <= 256
 
+// flag[row] = (sum of the row > 0).  LPR = min(c / 4, 64) lanes per row read float4s, so a wave's load covers 64 / LPR whole rows
+// = 1 KB of contiguous memory (one wave per row left half the lanes idle at c = 32 and needed 80 000 blocks for a stack).
 __global__ __launch_bounds__(256) void row_positive_kernel(const float* __restrict__ x, int64_t n, int c,
                                                            unsigned char* __restrict__ flag) {
+  if ((c & 3) == 0 && ((c >> 2) & ((c >> 2) - 1)) == 0) {
+    const int lpr = min(c >> 2, 64), rpw = 64 / lpr;
+    const int lane = threadIdx.x & 63, sub = lane / lpr, l = lane % lpr;
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + sub; row < n; row += (int64_t)gridDim.x * 4 * rpw) {
+      float s = 0.f;
+      for (int j = 4 * l; j < c; j += 4 * lpr) {
+        const float4 v = *reinterpret_cast<const float4*>(x + row * c + j);
+        s += (v.x + v.y) + (v.z + v.w);
+      }
+      for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (l == 0) flag[row] = s > 0.f;
+    }
+    return;
+  }
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
-  float s = 0.f;
-  for (int j = lane; j < c; j += 64) s += x[row * c + j];
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) flag[row] = s > 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+    float s = 0.f;
+    for (int j = lane; j < c; j += 64) s += x[row * c + j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) flag[row] = s > 0.f;
+  }
 }
 
 // C_in == 1 (first layer): 16 lanes per query point, lane k < 15 accumulates kernel point k over the neighbours in order
@@ -321,11 +337,15 @@ __global__ __launch_bounds__(256) void gn_group_kernel(const float* __restrict__
     ab[C + c] = beta[c] - stat[0] * a;
   }
 }
+// `flag` (optional, VEC4 with C / 4 a power of two <= 64 only): flag[row] = (sum of the row's OUTPUT values > 0) -- the predicate
+// KPConv's neighbour count needs of its input features (kpconv.py:113-115), produced here for free instead of by a separate pass
+// over the tensor: the C / 4 lanes that hold a row are an aligned group of one wave, reduced with shuffles.
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gn_apply2_kernel(const float* __restrict__ x, int64_t total, int C, const float* __restrict__ ab_all,
-                                                        GnSegs sg, const float* __restrict__ residual, int act, float* __restrict__ out) {
+                                                        GnSegs sg, const float* __restrict__ residual, int act, float* __restrict__ out,
+                                                        unsigned char* __restrict__ flag) {
   const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (VEC4 ? 4 : 1);
-  if (e >= total) return;
+  if (e >= total) return;  // total is a multiple of C, so a row's lane group leaves together
   const float* ab = ab_all + (int64_t)(sg.nseg > 1 ? gn_seg_of_row(sg, e / C) : 0) * 2 * C;
   if (VEC4) {
     const int c = (int)(e % C);
@@ -342,6 +362,12 @@ __global__ __launch_bounds__(256) void gn_apply2_kernel(const float* __restrict_
       if (act == 1) r[k] = fmaxf(r[k], 0.f);
     }
     *reinterpret_cast<float4*>(out + e) = make_float4(r[0], r[1], r[2], r[3]);
+    if (flag) {
+      const int lpr = C >> 2;  // lanes per row
+      float sum = (r[0] + r[1]) + (r[2] + r[3]);
+      for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if ((threadIdx.x & (lpr - 1)) == 0) flag[e / C] = sum > 0.f;
+    }
   } else {
     const int c = (int)(e % C);
     float v = x[e] * ab[c] + ab[C + c];
@@ -447,7 +473,8 @@ int geotr_row_positive(const float* x, int64_t n, int64_t c, uint8_t* flag, void
   GEOTR_CHECK_ARG(n >= 0 && c >= 1, "row_positive: bad sizes");
   if (n == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(x && flag, "row_positive: null pointer");
-  row_positive_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(x, n, (int)c, flag);
+  GEOTR_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 || c % 4 != 0, "row_positive: rows of 4-float multiples must be 16-byte aligned");
+  row_positive_kernel<<<dim3((unsigned)std::min<int64_t>((n + 3) / 4, 8192)), dim3(256), 0, (hipStream_t)stream>>>(x, n, (int)c, flag);
   GEOTR_CHECK_LAUNCH("row_positive");
   return GEOTR_OK;
 }
@@ -548,9 +575,19 @@ size_t geotr_group_norm_workspace_bytes(int64_t n, int64_t c) {
   return sizeof(double) * 2 * (size_t)c + sizeof(float) * 2 * (size_t)c * (nb + GEOTR_MAX_PAIRS);
 }
 
+int geotr_group_norm_flags_supported(int64_t c) { return c % 4 == 0 && c / 4 <= 64 && ((c / 4) & (c / 4 - 1)) == 0; }
+
 int geotr_group_norm_segmented(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
                                const float* residual, int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws,
                                void* stream_) {
+  return geotr_group_norm_segmented_flags(x, n, c, groups, gamma, beta, eps, residual, act, out, seg_rows_host, nseg, stats_ws, nullptr, stream_);
+}
+
+int geotr_group_norm_segmented_flags(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                                     const float* residual, int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws,
+                                     uint8_t* row_positive, void* stream_) {
+  GEOTR_CHECK_ARG(!row_positive || geotr_group_norm_flags_supported(c), "group_norm: row flags need c / 4 a power of two <= 64 (c = %lld)",
+                  (long long)c);
   GEOTR_CHECK_ARG(n >= 0 && c >= 1 && groups >= 1 && c % groups == 0, "group_norm: %lld channels / %lld groups",
                   (long long)c, (long long)groups);
   GEOTR_CHECK_ARG(nseg >= 1 && nseg <= GEOTR_MAX_PAIRS && seg_rows_host, "group_norm: 1..%d row segments", GEOTR_MAX_PAIRS);
@@ -579,9 +616,11 @@ int geotr_group_norm_segmented(const float* x, int64_t n, int64_t c, int64_t gro
   gn_group_kernel<<<dim3((unsigned)groups, (unsigned)nseg), dim3(256), 0, stream>>>(partial, sg, (int)c, (int)groups, gamma, beta, eps, ab);
   const int64_t total = n * c;
   if (c % 4 == 0)
-    gn_apply2_kernel<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, act, out);
+    gn_apply2_kernel<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, act, out,
+                                                                                                row_positive);
   else
-    gn_apply2_kernel<false><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, act, out);
+    gn_apply2_kernel<false><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, act, out,
+                                                                                             nullptr);
   GEOTR_CHECK_LAUNCH("group_norm");
   return GEOTR_OK;
 }

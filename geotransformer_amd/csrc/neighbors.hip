@@ -682,7 +682,7 @@ using namespace geotr;
 extern "C" {
 
 const char* geotr_last_error(void) { return error_buffer(); }
-int geotr_abi_version(void) { return 1; }
+int geotr_abi_version(void) { return 2; }  // 2: geotr_transformer carries the GSE lookup tables
 
 size_t geotr_radius_grid_workspace_bytes(int64_t ns, int64_t batch) {
   return grid_layout(nullptr, ns, batch).bytes;

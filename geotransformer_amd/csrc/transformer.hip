@@ -30,8 +30,23 @@ __device__ __forceinline__ float expanded_sqdist(const float* a, const float* b)
 
 constexpr int kMaxK = 4;  // angle_k <= 4 (every reference config uses 3)
 
+// Clouds of one stack for the ragged launches (by value): cloud q owns point rows [row0[q], row0[q] + n[q]), its knn rows start at
+// row0[q] * k, its (n, n, D) embedding block at out + emb_off[q]; chunk0[q] = first 256-pair chunk of cloud q (gse_embed_table).
+struct GseClouds {
+  int count;
+  int n[2 * GEOTR_MAX_PAIRS];
+  int row0[2 * GEOTR_MAX_PAIRS];
+  int chunk0[2 * GEOTR_MAX_PAIRS + 1];
+  int64_t emb_off[2 * GEOTR_MAX_PAIRS];
+};
+
 // one wave per point: (k+1) smallest distances by (distance, index); rank 0 (the presumed self) is dropped
-__global__ __launch_bounds__(256) void gse_knn_kernel(const float* __restrict__ pts, int n, int k, int* __restrict__ knn) {
+// cl.count > 0: blockIdx.y selects the cloud (indices stay cloud-local, as in a per-cloud call)
+__global__ __launch_bounds__(256) void gse_knn_kernel(const float* __restrict__ pts, int n, int k, int* __restrict__ knn, GseClouds cl) {
+  if (cl.count > 0) {
+    const int q = blockIdx.y;
+    n = cl.n[q], pts += 3 * (int64_t)cl.row0[q], knn += (int64_t)cl.row0[q] * k;
+  }
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -443,6 +458,209 @@ __global__ __launch_bounds__(64 * (D / 32)) void gse_embed_bf16x3_kernel(const f
 }
 
 // ---------------------------------------------------------------------------------------------------
+// GSE by table ("precision 5", the default).  proj(sinusoid(x)) is a function of ONE scalar:
+//     f(x)[c] = sum_t W[c,2t] sin(x w_t) + W[c,2t+1] cos(x w_t),
+// so the reference's 2 n^2 (1+k) D^2 FLOP contraction (geotransformer.py:60-70) is n^2 (1+k) evaluations of two smooth
+// vector-valued 1-D functions, f_d and f_a.  Both are tabulated once per weight set on a uniform grid of kGseTabInv points per
+// unit index as CUBIC TAYLOR coefficients  c_k[g] = f^(k)(x_g) / k!  (exact derivatives: d^k/dx^k sin(x w) = w^k sin(x w + k pi/2),
+// evaluated in fp64, contracted with W by the exact-fp32 MFMA GEMM), and an embedding is
+//     f(x_g + delta) ~= ((c_3 delta + c_2) delta + c_1) delta + c_0,   |delta| <= 1/32.
+// Remainder <= max |4th derivative| delta^4 / 24 <= (sum_t w_t^4 (|W_s| + |W_c|)) * 4e-8 <= 3.2e-7 max|W|
+// (sum_t w_t^4 = 1 / (1 - 1e4^(-8/D)) ~ 4 at D = 256) -- below the fp32 rounding of the reference's own 256-term sums.
+// Cost per (i, j): (1+k) reads of a 4 D-float table row from L2 (the tables are 1-4 MB) instead of 2 (1+k) D^2 flops: the kernel
+// is L2-gather / HBM-write bound, not matrix bound, and matches the reference to ~1e-6 (the MFMA kernels above remain as
+// precisions 0 / 1 / 3).  Indices beyond the table (a cloud wider than (points - 1) / 16 sigma_d) take a direct-evaluation path.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kGseTabInv = 16;
+
+// basis[(g * 4 + k), 2t] = d^k/dx^k sin(x w_t) / k!,  [.., 2t + 1] = the same for cos, at x = g / kGseTabInv
+__global__ __launch_bounds__(256) void gse_table_basis_kernel(const float* __restrict__ div_term, int D, int points,
+                                                              float* __restrict__ basis) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int half = D / 2;
+  if (e >= (int64_t)points * half) return;
+  const int t = (int)(e % half), g = (int)(e / half);
+  const double x = (double)g / (double)kGseTabInv, w = (double)div_term[t];
+  double sv, cv;
+  sincos(x * w, &sv, &cv);
+  // derivative cycle of sin: sin, cos, -sin, -cos; of cos: cos, -sin, -cos, sin
+  const double ds[4] = {sv, cv, -sv, -cv}, dc[4] = {cv, -sv, -cv, sv};
+  const double fact[4] = {1.0, 1.0, 0.5, 1.0 / 6.0};
+  double wk = 1.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float* row = basis + ((int64_t)g * 4 + k) * D;
+    row[2 * t] = (float)(wk * ds[k] * fact[k]);
+    row[2 * t + 1] = (float)(wk * dc[k] * fact[k]);
+    wk *= w;
+  }
+}
+
+template <int V>
+struct GseVec;
+template <>
+struct GseVec<1> {
+  using T = float;
+};
+template <>
+struct GseVec<2> {
+  using T = float2;
+};
+template <>
+struct GseVec<4> {
+  using T = float4;
+};
+
+template <int V>
+__device__ __forceinline__ void gse_vec_load(float (&dst)[V], const float* __restrict__ src) {
+  const typename GseVec<V>::T v = *reinterpret_cast<const typename GseVec<V>::T*>(src);
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int q = 0; q < V; ++q) dst[q] = f[q];
+}
+
+// fast path of one lookup: issue the four coefficient loads (the caller batches the loads of all slots before any use)
+template <int D, int V>
+struct GseRow {
+  float a0[V], a1[V], a2[V], a3[V];
+  float delta;
+  __device__ __forceinline__ void load(float x, const float* __restrict__ tab, int c0) {
+    const int g = (int)(x * (float)kGseTabInv + 0.5f);
+    delta = x - (float)g * (1.0f / (float)kGseTabInv);
+    const float* row = tab + (int64_t)g * 4 * D + c0;
+    gse_vec_load<V>(a0, row), gse_vec_load<V>(a1, row + D), gse_vec_load<V>(a2, row + 2 * D), gse_vec_load<V>(a3, row + 3 * D);
+  }
+  __device__ __forceinline__ void eval(float (&r)[V]) const {
+#pragma unroll
+    for (int q = 0; q < V; ++q) r[q] = fmaf(fmaf(fmaf(a3[q], delta, a2[q]), delta, a1[q]), delta, a0[q]);
+  }
+};
+__device__ __forceinline__ bool gse_in_table(float x, int points) { return x * (float)kGseTabInv < (float)(points - 1); }  // false for NaN
+
+// Block = 4 waves x 64 consecutive (i, j) pairs of one cloud; a lane first computes the embedding indices of "its" pair, then
+// the wave walks its 64 pairs with lanes <-> channels (V = D / 64 per lane, 16-byte accesses at D = 256): every table row and
+// every output row is one contiguous wave-wide access.  All clouds of a stack in ONE ragged launch (blockIdx.x -> cloud by the
+// chunk prefix table).
+template <int D, int S>
+__global__ __launch_bounds__(256) void gse_embed_table_kernel(const float* __restrict__ pts_all, const int* __restrict__ knn_all,
+                                                              GseClouds cl, const float* __restrict__ tab_d, int points_d,
+                                                              const float* __restrict__ tab_a, int points_a,
+                                                              const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                              const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                              const float* __restrict__ div_term, float inv_sigma_d, float factor_a,
+                                                              float* __restrict__ out_all) {
+  constexpr int V = D >= 256 ? 4 : (D >= 128 ? 2 : 1);
+  constexpr int ACTIVE = D / V;  // lanes that own channels (64, or D when D < 64)
+  int q = 0;
+  while (q + 1 < cl.count && (int)blockIdx.x >= cl.chunk0[q + 1]) ++q;
+  const int n = cl.n[q];
+  const float* pts = pts_all + 3 * (int64_t)cl.row0[q];
+  const int* knn = knn_all + (int64_t)cl.row0[q] * (S - 1);
+  float* out = out_all + cl.emb_off[q];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t total = (int64_t)n * n;
+  const int64_t p0 = ((int64_t)((int)blockIdx.x - cl.chunk0[q]) * 4 + wave) * 64;
+  if (p0 >= total) return;
+
+  // ---- embedding indices of the lane's pair (geotransformer.py:36-53) ----
+  float vals[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) vals[s] = 0.f;
+  {
+    const int64_t p = p0 + lane;
+    if (p < total) {
+      const int i = (int)(p / n), j = (int)(p - (int64_t)i * n);
+      const float pi[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+      const float pj[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+      vals[0] = sqrtf(expanded_sqdist(pi, pj)) * inv_sigma_d;
+      const float ax = pj[0] - pi[0], ay = pj[1] - pi[1], az = pj[2] - pi[2];  // anchor vector
+#pragma unroll
+      for (int x = 0; x < S - 1; ++x) {
+        const int r = knn[i * (S - 1) + x];
+        const float rx = pts[3 * r] - pi[0], ry = pts[3 * r + 1] - pi[1], rz = pts[3 * r + 2] - pi[2];
+        const float cx = ry * az - rz * ay, cy = rz * ax - rx * az, cz = rx * ay - ry * ax;
+        const float sinv = sqrtf((cx * cx + cy * cy) + cz * cz);
+        const float cosv = ((rx * ax + ry * ay) + rz * az) + 0.0f;  // +0: see gse_embed_kernel (atan2(+0, -0) trap)
+        vals[1 + x] = atan2f(sinv, cosv) * factor_a;
+      }
+    }
+  }
+  const int c0 = lane * V;
+  float bias[V];
+#pragma unroll
+  for (int c = 0; c < V; ++c) bias[c] = 0.f;
+  if (lane < ACTIVE) {
+    float b1[V], b2[V];
+    gse_vec_load<V>(b1, bd + c0), gse_vec_load<V>(b2, ba + c0);
+#pragma unroll
+    for (int c = 0; c < V; ++c) bias[c] = b1[c] + b2[c];
+  }
+  const int count = (int)min((int64_t)64, total - p0);
+  unsigned long long slow = 0;  // pairs with an index beyond its table (or NaN): wave-uniform mask, handled after the main loop
+  for (int e = 0; e < count; ++e) {
+    float x[S];
+    bool fast = true;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      x[s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vals[s]), e));  // wave-uniform
+      fast = fast && gse_in_table(x[s], s == 0 ? points_d : points_a);
+    }
+    if (!fast) {
+      slow |= 1ull << e;
+      continue;
+    }
+    if (lane >= ACTIVE) continue;
+    GseRow<D, V> rows[S];  // all (1 + k) x 4 row loads in flight before the first use
+#pragma unroll
+    for (int s = 0; s < S; ++s) rows[s].load(x[s], s == 0 ? tab_d : tab_a, c0);
+    float d[V], m[V];
+    rows[0].eval(d);
+    rows[1].eval(m);
+#pragma unroll
+    for (int s = 2; s < S; ++s) {
+      float a[V];
+      rows[s].eval(a);
+#pragma unroll
+      for (int c = 0; c < V; ++c) m[c] = fmaxf(m[c], a[c]);
+    }
+    float r[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) r[c] = (d[c] + m[c]) + bias[c];
+    *reinterpret_cast<typename GseVec<V>::T*>(out + (p0 + e) * D + c0) = *reinterpret_cast<const typename GseVec<V>::T*>(r);
+  }
+  while (slow) {  // exact direct evaluation (rare)
+    const int e = __builtin_ctzll(slow);
+    slow &= slow - 1;
+    if (lane >= ACTIVE) continue;
+    float d[V], m[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) d[c] = 0.f, m[c] = -3.4e38f;
+    for (int s = 0; s < S; ++s) {
+      const float x = __shfl(vals[s], e, 64);
+      float a[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) a[c] = 0.f;
+      const float* W = s == 0 ? Wd : Wa;
+      for (int t = 0; t < D / 2; ++t) {
+        float sv, cv;
+        sincosf(x * div_term[t], &sv, &cv);
+#pragma unroll
+        for (int c = 0; c < V; ++c) a[c] = fmaf(W[(int64_t)(c0 + c) * D + 2 * t + 1], cv, fmaf(W[(int64_t)(c0 + c) * D + 2 * t], sv, a[c]));
+      }
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        if (s == 0) d[c] = a[c];
+        else m[c] = fmaxf(m[c], a[c]);
+      }
+    }
+    float r[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) r[c] = (d[c] + m[c]) + bias[c];
+    *reinterpret_cast<typename GseVec<V>::T*>(out + (p0 + e) * D + c0) = *reinterpret_cast<const typename GseVec<V>::T*>(r);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // attention scores: positional term + scale + softmax, one block per query row
 // ---------------------------------------------------------------------------------------------------
 constexpr int kAttTile = 32;  // keys per tile (small tiles: several blocks per CU keep the embedding stream in flight)
@@ -647,8 +865,38 @@ int geotr_gse_knn(const float* points, int64_t n, int64_t k, int32_t* knn, void*
   GEOTR_CHECK_ARG(n == 0 || n > k, "gse_knn: need more than k points");
   if (n == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(points && knn, "gse_knn: null pointer");
-  gse_knn_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(points, (int)n, (int)k, knn);
+  GseClouds none;
+  none.count = 0;
+  gse_knn_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(points, (int)n, (int)k, knn, none);
   GEOTR_CHECK_LAUNCH("gse_knn");
+  return GEOTR_OK;
+}
+
+static int gse_clouds(const geotr_gse_clouds* c, int64_t k, GseClouds& cl, int& max_n) {
+  GEOTR_CHECK_ARG(c && c->count >= 1 && c->count <= 2 * GEOTR_MAX_PAIRS, "gse: 1..%d clouds", 2 * GEOTR_MAX_PAIRS);
+  cl.count = c->count;
+  cl.chunk0[0] = 0;
+  max_n = 0;
+  for (int q = 0; q < c->count; ++q) {
+    GEOTR_CHECK_ARG(c->n[q] > k && c->n[q] < 46341 && c->row0[q] >= 0 && c->emb_off[q] >= 0, "gse: cloud %d has %d superpoints (need k < n < 46341)",
+                    q, c->n[q]);
+    cl.n[q] = c->n[q], cl.row0[q] = c->row0[q], cl.emb_off[q] = c->emb_off[q];
+    const int64_t chunks = ((int64_t)c->n[q] * c->n[q] + 255) / 256;
+    GEOTR_CHECK_ARG(cl.chunk0[q] + chunks < (1ll << 31), "gse: too many pairs for one launch");
+    cl.chunk0[q + 1] = cl.chunk0[q] + (int)chunks;
+    max_n = std::max(max_n, c->n[q]);
+  }
+  return GEOTR_OK;
+}
+
+int geotr_gse_knn_clouds(const float* points, const geotr_gse_clouds* clouds, int64_t k, int32_t* knn, void* stream) {
+  GEOTR_CHECK_ARG(points && knn && k >= 1 && k <= kMaxK, "gse_knn_clouds: bad arguments (k in [1, %d])", kMaxK);
+  GseClouds cl;
+  int max_n;
+  const int rc = gse_clouds(clouds, k, cl, max_n);
+  if (rc != GEOTR_OK) return rc;
+  gse_knn_kernel<<<dim3((unsigned)((max_n + 3) / 4), (unsigned)cl.count), dim3(256), 0, (hipStream_t)stream>>>(points, 0, (int)k, knn, cl);
+  GEOTR_CHECK_LAUNCH("gse_knn_clouds");
   return GEOTR_OK;
 }
 
@@ -751,6 +999,65 @@ int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t 
   }
   if (rc != GEOTR_OK) return rc;
   GEOTR_CHECK_LAUNCH("gse_embed");
+  return GEOTR_OK;
+}
+
+size_t geotr_gse_table_bytes(int64_t d, int64_t points) { return sizeof(float) * 4 * (size_t)d * (size_t)points; }
+
+int geotr_gse_table_build(const float* div_term, const float* w, int64_t d, int64_t points, float* table, void* ws, size_t ws_bytes,
+                          void* stream_) {
+  GEOTR_CHECK_ARG(div_term && w && table && ws, "gse_table_build: null pointer");
+  GEOTR_CHECK_ARG(d == 32 || d == 64 || d == 128 || d == 256, "gse_table_build: hidden_dim must be 32, 64, 128 or 256 (got %lld)", (long long)d);
+  GEOTR_CHECK_ARG(points >= 2 && points <= (1 << 20), "gse_table_build: 2..2^20 grid points");
+  GEOTR_CHECK_ARG(ws_bytes >= geotr_gse_table_bytes(d, points), "gse_table_build: workspace smaller than the table");
+  hipStream_t stream = (hipStream_t)stream_;
+  float* basis = reinterpret_cast<float*>(ws);
+  const int64_t elems = points * (d / 2);
+  gse_table_basis_kernel<<<dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream>>>(div_term, (int)d, (int)points, basis);
+  GEOTR_CHECK_LAUNCH("gse_table_build");
+  // table (points * 4, d) = basis (points * 4, d) W^T in exact fp32 (W is (out, in) row-major, i.e. N x K)
+  return geotr_gemm(basis, d, w, d, 0, table, d, points * 4, d, d, 1, 0, 0, 0, nullptr, nullptr, nullptr, 0, 1.0f, 0, stream_);
+}
+
+int geotr_gse_embed_table(const float* points, const int32_t* knn, const geotr_gse_clouds* clouds, int64_t k, int64_t d,
+                          const float* table_d, int64_t points_d, const float* table_a, int64_t points_a, const float* w_d,
+                          const float* b_d, const float* w_a, const float* b_a, const float* div_term, float sigma_d, float sigma_a,
+                          float* out, void* stream_) {
+  GEOTR_CHECK_ARG(k >= 1 && k <= kMaxK, "gse_embed_table: angle_k must be in [1, %d]", kMaxK);
+  GEOTR_CHECK_ARG(d == 32 || d == 64 || d == 128 || d == 256, "gse_embed_table: hidden_dim must be 32, 64, 128 or 256 (got %lld)", (long long)d);
+  GEOTR_CHECK_ARG(points && knn && table_d && table_a && w_d && b_d && w_a && b_a && div_term && out, "gse_embed_table: null pointer");
+  GEOTR_CHECK_ARG(points_d >= 2 && points_a >= 2 && points_d < (1 << 24) && points_a < (1 << 24), "gse_embed_table: bad table sizes");
+  GEOTR_CHECK_ARG(((reinterpret_cast<uintptr_t>(table_d) | reinterpret_cast<uintptr_t>(table_a) | reinterpret_cast<uintptr_t>(out) |
+                    reinterpret_cast<uintptr_t>(b_d) | reinterpret_cast<uintptr_t>(b_a)) & 15) == 0,
+                  "gse_embed_table: tables, biases and output must be 16-byte aligned");
+  GseClouds cl;
+  int max_n;
+  const int rc = gse_clouds(clouds, k, cl, max_n);
+  if (rc != GEOTR_OK) return rc;
+  for (int q = 0; q < cl.count; ++q) GEOTR_CHECK_ARG(cl.emb_off[q] % 4 == 0, "gse_embed_table: embedding offsets must be multiples of 4 floats");
+  hipStream_t stream = (hipStream_t)stream_;
+  const float inv_sigma_d = 1.0f / sigma_d;
+  const float factor_a = (float)(180.0 / ((double)sigma_a * 3.14159265358979323846));  // geotransformer.py:14
+  const dim3 grid((unsigned)cl.chunk0[cl.count]);
+#define GEOTR_GSE_TAB(DD, SS)                                                                                                        \
+  gse_embed_table_kernel<DD, SS><<<grid, dim3(256), 0, stream>>>(points, knn, cl, table_d, (int)points_d, table_a, (int)points_a, w_d, b_d, \
+                                                                 w_a, b_a, div_term, inv_sigma_d, factor_a, out)
+#define GEOTR_GSE_TAB_D(DD)             \
+  switch ((int)k) {                     \
+    case 1: GEOTR_GSE_TAB(DD, 2); break; \
+    case 2: GEOTR_GSE_TAB(DD, 3); break; \
+    case 3: GEOTR_GSE_TAB(DD, 4); break; \
+    default: GEOTR_GSE_TAB(DD, 5); break; \
+  }
+  switch (d) {
+    case 32: GEOTR_GSE_TAB_D(32); break;
+    case 64: GEOTR_GSE_TAB_D(64); break;
+    case 128: GEOTR_GSE_TAB_D(128); break;
+    default: GEOTR_GSE_TAB_D(256); break;
+  }
+#undef GEOTR_GSE_TAB_D
+#undef GEOTR_GSE_TAB
+  GEOTR_CHECK_LAUNCH("gse_embed_table");
   return GEOTR_OK;
 }
 

@@ -1,6 +1,9 @@
 """Thin torch-facing wrappers over the C ABI (include/geotr.h).  Device tensors in, new device tensors out;
 every call is asynchronous on the current torch stream.  No eager/PyTorch fallback exists: a missing library
 or a failing call raises RuntimeError."""
+import ctypes
+import math
+
 import torch
 
 from . import _lib
@@ -80,12 +83,11 @@ def gemm_pack(weight, b_is_kn=False, view=None):
     return packed
 
 
-def gemm_packed(a, packed, n, bias=None, row_div=None, residual=None, alpha=1.0, act=None, out=None):
+def gemm_packed(a, packed, n, bias=None, row_div=None, residual=None, alpha=1.0, act=None, out=None, split_k=True):
     """out (M, n) = act(alpha * a @ W^T / row_div + bias + residual) with W given by gemm_pack (split-bf16 MFMA; plain bf16
-    operands when GEMM_PACKED == 'bf16')."""
+    operands when GEMM_PACKED == 'bf16').  `split_k` (default): narrow, deep launches are split over K (gridDim.z slices +
+    a deterministic reduce, geotr_gemm_packed_splitk); False forces the single-pass kernel."""
     lib = _lib.load()
-    fn, name = ((lib.geotr_gemm_packed_bf16, 'geotr_gemm_packed_bf16') if GEMM_PACKED == 'bf16' else
-                (lib.geotr_gemm_packed, 'geotr_gemm_packed'))
     assert a.dim() == 2 and a.stride(-1) == 1
     M, K = a.shape
     if out is None:
@@ -94,6 +96,16 @@ def gemm_packed(a, packed, n, bias=None, row_div=None, residual=None, alpha=1.0,
     if residual is not None:
         assert residual.stride(-1) == 1
         ldr = residual.stride(0)
+    bf16 = GEMM_PACKED == 'bf16'
+    nbytes = lib.geotr_gemm_packed_splitk_workspace_bytes(M, n, K) if split_k else 0
+    if nbytes:
+        ws = _lib.workspace(nbytes, a.device)
+        _lib.check(lib.geotr_gemm_packed_splitk(_lib.ptr(a), a.stride(0), _lib.ptr(packed), _lib.ptr(out), out.stride(0), M, n, K,
+                                                _lib.ptr(bias), _lib.ptr(row_div), _lib.ptr(residual), ldr, float(alpha), ACT[act],
+                                                int(bf16), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'geotr_gemm_packed_splitk')
+        ws.record_stream(torch.cuda.current_stream())
+        return out
+    fn, name = (lib.geotr_gemm_packed_bf16, 'geotr_gemm_packed_bf16') if bf16 else (lib.geotr_gemm_packed, 'geotr_gemm_packed')
     _lib.check(fn(_lib.ptr(a), a.stride(0), _lib.ptr(packed), _lib.ptr(out), out.stride(0), M, n, K, _lib.ptr(bias),
                   _lib.ptr(row_div), _lib.ptr(residual), ldr, float(alpha), ACT[act], _lib.stream_ptr()), name)
     return out
@@ -205,27 +217,64 @@ def gse_knn(points, k):
     return knn
 
 
-GSE_PRECISION = 1  # 0: fp32 MFMA (exact fp32 products); 1: split-bf16 "bf16x3" MFMA (~2^-17 relative error per product);
+GSE_PRECISION = 5  # 5: by table (default: proj(sinusoid(x)) tabulated as cubic Taylor coefficients, fp32, ~1e-6 of the reference);
+                   # 0: fp32 MFMA (exact fp32 products); 1: split-bf16 "bf16x3" MFMA (~2^-17 relative error per product);
                    # 3: plain bf16 operands (~2^-8 per product)
 
-_PRECISIONS = {'fp32': (False, 0), 'bf16x3': (True, 1), 'bf16': ('bf16', 3)}
+_PRECISIONS = {'fp32': (False, 0), 'bf16x3': (True, 5), 'bf16': ('bf16', 5)}
+_GSE_MFMA = {'fp32': 0, 'bf16x3': 1, 'bf16': 3}
 
 
-def set_precision(name):
-    """Arithmetic of the two matrix-pipe kernel families (packed GEMMs of the backbone / transformer, GSE embedding):
+def set_precision(name, gse='table'):
+    """Arithmetic of the matrix-pipe kernel family (packed GEMMs of the backbone / transformer) and of the GSE embedding:
     'bf16x3' (default): split-bf16 products, fp32-grade -- the mode every reference-parity claim is made in;
-    'fp32': exact fp32 MFMA products;  'bf16': plain bf16 operands with fp32 accumulation (BASELINE configs[4] "bf16 features").
+    'fp32': exact fp32 MFMA products everywhere (GSE on the fp32 MFMA kernel);
+    'bf16': plain bf16 operands with fp32 accumulation (BASELINE configs[4] "bf16 features").
+    `gse`: 'table' (default: the embedding by table lookup, fp32, independent of the GEMM mode -- except under 'fp32', which
+    keeps the all-MFMA exact path) or 'mfma' (the fused sinusoid -> MFMA kernel in the named arithmetic).
     Returns the previous mode's name.  Process-wide; running models pick it up at their next forward."""
     global GEMM_PACKED, GSE_PRECISION
     if name not in _PRECISIONS:
         raise ValueError(f'unknown precision {name!r}: expected one of {sorted(_PRECISIONS)}')
-    prev = next((k for k, v in _PRECISIONS.items() if v == (GEMM_PACKED, GSE_PRECISION)), 'custom')
+    if gse not in ('table', 'mfma'):
+        raise ValueError("gse must be 'table' or 'mfma'")
+    prev = next((k for k, v in _PRECISIONS.items() if v[0] == GEMM_PACKED), 'custom')
     GEMM_PACKED, GSE_PRECISION = _PRECISIONS[name]
+    if gse == 'mfma':
+        GSE_PRECISION = _GSE_MFMA[name]
     return prev
 
 
-def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, precision=None):
-    """(n, n, D) geometric structure embedding of one cloud (n, 3)."""
+class GseClouds(ctypes.Structure):  # geotr_gse_clouds
+    _fields_ = [('count', ctypes.c_int32), ('n', ctypes.c_int32 * 32), ('row0', ctypes.c_int32 * 32), ('emb_off', ctypes.c_int64 * 32)]
+
+
+GSE_TABLE_SPAN = 64.0  # the distance table covers d / sigma_d <= 64 (12.8 m at the 3DMatch sigma_d); beyond: direct evaluation in-kernel
+GSE_TABLE_DENSITY = 16  # grid points per unit index (kGseTabInv in csrc/transformer.hip)
+
+
+def gse_table(div_term, weight, span):
+    """Cubic-Taylor table (points, 4, D) of proj(sinusoid(x)) for x in [0, span] (geotr_gse_table_build)."""
+    lib = _lib.load()
+    weight, div_term = _f32c(weight.detach()), _f32c(div_term)
+    d = weight.shape[0]
+    points = int(math.ceil(span * GSE_TABLE_DENSITY)) + 2
+    nbytes = lib.geotr_gse_table_bytes(d, points)
+    table = torch.empty((points, 4, d), dtype=torch.float32, device=weight.device)
+    ws = _lib.workspace(nbytes, weight.device)
+    _lib.check(lib.geotr_gse_table_build(_lib.ptr(div_term), _lib.ptr(weight), d, points, _lib.ptr(table), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream_ptr()), 'geotr_gse_table_build')
+    ws.record_stream(torch.cuda.current_stream())
+    return table
+
+
+def gse_tables(div_term, w_d, w_a, sigma_a):
+    """(distance table, angle table): angles are at most 180 degrees, i.e. indices <= 180 / sigma_a."""
+    return gse_table(div_term, w_d, GSE_TABLE_SPAN), gse_table(div_term, w_a, 180.0 / float(sigma_a))
+
+
+def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, precision=None, tables=None):
+    """(n, n, D) geometric structure embedding of one cloud (n, 3).  `tables` (precision 5): a cached `gse_tables` result."""
     lib = _lib.load()
     points = _f32c(points)
     n, d = points.shape[0], w_d.shape[0]
@@ -235,11 +284,21 @@ def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, preci
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
     precision = GSE_PRECISION if precision is None else int(precision)
-    ws = _lib.workspace(lib.geotr_gse_embed_workspace_bytes(d, precision), points.device)
-    _lib.check(lib.geotr_gse_embed(_lib.ptr(points), _lib.ptr(knn), n, knn.shape[1], d, _lib.ptr(_f32c(div_term)),
-                                   _lib.ptr(_f32c(w_d)), _lib.ptr(b_d), _lib.ptr(_f32c(w_a)), _lib.ptr(b_a), float(sigma_d),
-                                   float(sigma_a), precision, _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
-               'geotr_gse_embed')
+    if precision == 5:
+        tab_d, tab_a = tables if tables is not None else gse_tables(div_term, w_d, w_a, sigma_a)
+        cl = GseClouds()
+        cl.count, cl.n[0], cl.row0[0], cl.emb_off[0] = 1, n, 0, 0
+        if n > 0:
+            _lib.check(lib.geotr_gse_embed_table(_lib.ptr(points), _lib.ptr(knn), ctypes.byref(cl), knn.shape[1], d, _lib.ptr(tab_d),
+                                                 tab_d.shape[0], _lib.ptr(tab_a), tab_a.shape[0], _lib.ptr(_f32c(w_d)), _lib.ptr(_f32c(b_d)),
+                                                 _lib.ptr(_f32c(w_a)), _lib.ptr(_f32c(b_a)), _lib.ptr(_f32c(div_term)), float(sigma_d),
+                                                 float(sigma_a), _lib.ptr(out), _lib.stream_ptr()), 'geotr_gse_embed_table')
+    else:
+        ws = _lib.workspace(lib.geotr_gse_embed_workspace_bytes(d, precision), points.device)
+        _lib.check(lib.geotr_gse_embed(_lib.ptr(points), _lib.ptr(knn), n, knn.shape[1], d, _lib.ptr(_f32c(div_term)),
+                                       _lib.ptr(_f32c(w_d)), _lib.ptr(b_d), _lib.ptr(_f32c(w_a)), _lib.ptr(b_a), float(sigma_d),
+                                       float(sigma_a), precision, _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
+                   'geotr_gse_embed')
     if prof is not None:
         end.record()
         prof.append((start, end, n))

@@ -20,6 +20,15 @@ class GeometricStructureEmbedding(nn.Module):
         self.proj_d = nn.Linear(hidden_dim, hidden_dim)
         self.proj_a = nn.Linear(hidden_dim, hidden_dim)
         self.reduction_a = reduction_a
+        self._tables = None  # (key, tables): cubic-Taylor tables of proj_d / proj_a for the table-lookup embedding kernel
+
+    def tables(self):
+        """The two lookup tables of the default embedding kernel (kernels.gse_tables), rebuilt when a weight changes."""
+        ws = (self.proj_d.weight, self.proj_a.weight, self.embedding.div_term)
+        key = tuple((t.data_ptr(), t._version) for t in ws)
+        if self._tables is None or self._tables[0] != key:
+            self._tables = (key, kernels.gse_tables(self.embedding.div_term, self.proj_d.weight, self.proj_a.weight, self.sigma_a))
+        return self._tables[1]
 
     def forward(self, points):
         """points (1, N, 3) -> embeddings (1, N, N, D): proj_d(sin/cos(d)) + max_k proj_a(sin/cos(angle_k))."""
@@ -28,7 +37,8 @@ class GeometricStructureEmbedding(nn.Module):
         pts = points[0]
         knn = kernels.gse_knn(pts, self.angle_k)
         emb = kernels.gse_embed(pts, knn, self.embedding.div_term, self.proj_d.weight, self.proj_d.bias,
-                                self.proj_a.weight, self.proj_a.bias, self.sigma_d, self.sigma_a)
+                                self.proj_a.weight, self.proj_a.bias, self.sigma_d, self.sigma_a,
+                                tables=self.tables() if kernels.GSE_PRECISION == 5 else None)
         return emb.unsqueeze(0)
 
 

@@ -26,6 +26,8 @@ def pairwise_distance(x, y, normalized=False, channel_first=False):
         if y.shape[-1] != c:
             raise ValueError(f'channel mismatch: {tuple(x.shape)} vs {tuple(y.shape)}')
     out = torch.empty(lead + (n, m), dtype=torch.float32, device=x.device)
+    if out.numel() == 0:
+        return out
     lib = _lib.load()
     _lib.check(lib.geotr_pairwise_distance(_lib.ptr(x), _lib.ptr(y), batch, n, m, c, int(bool(normalized)), int(bool(channel_first)),
                                            _lib.ptr(out), _lib.stream_ptr()), 'geotr_pairwise_distance')

@@ -33,6 +33,8 @@ def _transform_points(points, normals, matrices, what):
         raise ValueError(f'Incompatible shapes between points {tuple(points.shape)} and transform {tuple(matrices.shape)}.')
     points = points.float().contiguous()
     out = torch.empty(shape, dtype=torch.float32, device=points.device)
+    if out.numel() == 0:
+        return out if normals is None else (out, torch.empty_like(out))
     out_n = None
     if normals is not None:
         normals = normals.float().contiguous()

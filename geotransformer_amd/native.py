@@ -66,7 +66,8 @@ class AttnLayer(ctypes.Structure):
 
 class Transformer(ctypes.Structure):
     _fields_ = [('num_layers', I32), ('num_heads', I32), ('angle_k', I32), ('pad_', I32), ('sigma_d', F32), ('sigma_a', F32),
-                ('gse_precision', I32), ('pad2_', I32), ('div_term', P_F32), ('proj_d', Linear), ('proj_a', Linear), ('in_proj', Linear), ('out_proj', Linear),
+                ('gse_precision', I32), ('pad2_', I32), ('gse_table_d', P_F32), ('gse_table_a', P_F32), ('gse_points_d', I64),
+                ('gse_points_a', I64), ('div_term', P_F32), ('proj_d', Linear), ('proj_a', Linear), ('in_proj', Linear), ('out_proj', Linear),
                 ('layers', AttnLayer * 8)]
 
 
@@ -199,6 +200,11 @@ class NativeModel:
         t.angle_k, t.sigma_d, t.sigma_a = tr.embedding.angle_k, float(tr.embedding.sigma_d), float(tr.embedding.sigma_a)
         from . import kernels
         t.gse_precision = int(kernels.GSE_PRECISION)
+        if t.gse_precision == 5:  # lookup tables of proj_d / proj_a, built once per weight set (kept alive with the descriptor)
+            tab_d, tab_a = tr.embedding.tables()
+            self._keep += [tab_d, tab_a]
+            t.gse_table_d, t.gse_table_a = tab_d.data_ptr(), tab_a.data_ptr()
+            t.gse_points_d, t.gse_points_a = tab_d.shape[0], tab_a.shape[0]
         t.div_term = _ptr(tr.embedding.embedding.div_term)
         t.proj_d, t.proj_a = _linear(tr.embedding.proj_d), _linear(tr.embedding.proj_a)
         t.in_proj, t.out_proj = _linear(tr.in_proj, self._keep), _linear(tr.out_proj, self._keep)  # packed: used when pairs are stacked
@@ -425,10 +431,13 @@ class NativeModel:
         return out
 
 
-class GseProfiler:
-    """HIP-event timing of the dominant kernel (fused GSE embedding) for launches made by the native executor.
+class KernelProfiler:
+    """HIP-event timing of the two heaviest kernel families (GSE embedding, packed GEMMs) for launches made by the native executor.
 
-    Events are created here, handed to the library as raw handles and recorded by the executor on the launch stream."""
+    Events are created here, handed to the library as raw handles and recorded by the executor on the launch stream; the first
+    `capacity` such launches after arming are recorded.  `results()` -> [(seconds, kind, work)]: kind 'gse' with work = number of
+    (i, j) superpoint pairs of the launch, or kind 'gemm' with work = (m, n, k)."""
+    GEMM_TAG = 1 << 62
 
     def __init__(self, capacity):
         _bind()
@@ -451,8 +460,18 @@ class GseProfiler:
         _lib.load().geotr_profile_gse(None, None, None, 0)
 
     def results(self):
-        """[(seconds, n_superpoints)] for every recorded launch; call after torch.cuda.synchronize()."""
-        return [(self.start[i].elapsed_time(self.stop[i]) * 1e-3, int(self._sizes[i])) for i in range(self.used)]
+        """Every recorded launch; call after torch.cuda.synchronize()."""
+        out = []
+        for i in range(self.used):
+            sec, tag = self.start[i].elapsed_time(self.stop[i]) * 1e-3, int(self._sizes[i])
+            if tag & self.GEMM_TAG and tag > 0:
+                out.append((sec, 'gemm', ((tag >> 26) & 0xffffff, (tag >> 14) & 0xfff, tag & 0x3fff)))
+            elif tag != 0:
+                out.append((sec, 'gse', tag * tag if tag > 0 else -tag))
+        return out
+
+
+GseProfiler = KernelProfiler  # former name
 
 
 @torch.no_grad()

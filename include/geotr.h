@@ -136,6 +136,14 @@ int geotr_gemm_pack(const float* B, int64_t ldb, int b_is_kn, int64_t n, int64_t
 int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                       const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                       void* stream);
+/* Split-K variant for narrow, deep launches (fewer than 256 output tiles and K >= 512: the coarse-stage KPConv contractions):
+ * gridDim.z K slices write raw fp32 partial tiles to `ws`, a second kernel sums them in slice order (deterministic) and applies the
+ * epilogue.  ws = geotr_gemm_packed_splitk_workspace_bytes(M, N, K) bytes, 16-byte aligned (0 => the launch is not split and ws may
+ * be NULL; identical to geotr_gemm_packed / _bf16 then).  bf16_operands: 0 = split-bf16 products, 1 = plain bf16 operands. */
+size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                             const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
+                             int bf16_operands, void* ws, size_t ws_bytes, void* stream);
 /* The same launch with plain bf16 operands (hi planes of the same packed weight, a_hi*b_hi only, fp32 accumulation; ~2^-8 relative
  * error per product): the "bf16 features" mode of BASELINE configs[4].  Never the default. */
 int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
@@ -177,6 +185,13 @@ int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const
 int geotr_group_norm_segmented(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
                                const float* residual, int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws,
                                void* stream);
+/* The same, additionally writing row_positive[i] = (sum of OUTPUT row i > 0): the predicate KPConv's neighbour count takes of its input
+ * features (kpconv/kpconv.py:113-115; geotr_row_positive as a separate pass).  Requires geotr_group_norm_flags_supported(c)
+ * (c / 4 a power of two <= 64); row_positive may be NULL. */
+int geotr_group_norm_flags_supported(int64_t c);
+int geotr_group_norm_segmented_flags(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                                     const float* residual, int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws,
+                                     uint8_t* row_positive, void* stream);
 int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c, const float* gamma, const float* beta,
                      float eps, float* out, void* stream);
 
@@ -206,6 +221,29 @@ int geotr_gse_embed(const float* points, const int32_t* knn, int64_t n, int64_t 
                     int precision, void* ws, size_t ws_bytes, float* out, void* stream);
 int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m,
                        int64_t c, int64_t heads, float scale, void* stream);
+/* GSE by table (geotr_gse_embed_table; the default of the native executor, gse_precision 5): proj(sinusoid(x)) is a function of
+ * one scalar, so the 2 n^2 (1+k) d^2 FLOP contraction of geotr_gse_embed becomes n^2 (1+k) evaluations of two tabulated functions
+ * (cubic Taylor coefficients on a grid of 16 points per unit index, table layout (points, 4, d) fp32; remainder < 3.2e-7 max|W|).
+ *   geotr_gse_table_build : table of one projection (w = proj_d.weight or proj_a.weight, (d, d) row-major) covering indices
+ *                           [0, (points - 1) / 16]; ws = scratch of geotr_gse_table_bytes(d, points) bytes.  Once per weight set.
+ *   geotr_gse_knn_clouds / geotr_gse_embed_table : geotr_gse_knn / geotr_gse_embed for ALL clouds of a stack in one ragged
+ *                           launch each; cloud q = point rows [row0[q], row0[q] + n[q]) of `points`, knn rows from row0[q] * k
+ *                           (indices cloud-local), embedding block (n, n, d) at out + emb_off[q] (floats, multiple of 4).
+ *                           Indices beyond a table are evaluated directly from w_d / w_a (slow, exact).  Biases are added here. */
+typedef struct geotr_gse_clouds {
+  int32_t count;                       /* <= 2 * GEOTR_MAX_PAIRS (= 32) */
+  int32_t n[32], row0[32];
+  int64_t emb_off[32];
+} geotr_gse_clouds;
+size_t geotr_gse_table_bytes(int64_t d, int64_t points);
+int geotr_gse_table_build(const float* div_term, const float* w, int64_t d, int64_t points, float* table, void* ws, size_t ws_bytes,
+                          void* stream);
+int geotr_gse_knn_clouds(const float* points, const geotr_gse_clouds* clouds, int64_t k, int32_t* knn, void* stream);
+int geotr_gse_embed_table(const float* points, const int32_t* knn, const geotr_gse_clouds* clouds, int64_t k, int64_t d,
+                          const float* table_d, int64_t points_d, const float* table_a, int64_t points_a, const float* w_d,
+                          const float* b_d, const float* w_a, const float* b_a, const float* div_term, float sigma_d, float sigma_a,
+                          float* out, void* stream);
+
 /* The same over ragged groups (one per cloud of a stack) in one launch: group i has n[i] query rows, m[i] keys, score rows of leading
  * dimension ld[i] starting at scores + scores_off[i] (head stride n[i]*ld[i]), embedding emb[i] (all NULL: plain scaled softmax) and
  * its query rows start at row q_row0[i] of qt (rows, heads, c) / qb (rows, heads).  heads in {1,2,4,8}; c % 32 == 0. */
@@ -349,7 +387,9 @@ typedef struct geotr_attn_layer {                                    /* RPETrans
 typedef struct geotr_transformer {                                   /* GeometricTransformer, modules/geotransformer/geotransformer.py:75-155 */
   int32_t num_layers, num_heads, angle_k, pad_;
   float sigma_d, sigma_a;
-  int32_t gse_precision, pad2_;                                      /* 0: fp32 MFMA, 1: split-bf16 MFMA, 3: bf16 MFMA (geotr_gse_embed) */
+  int32_t gse_precision, pad2_;                                      /* 0: fp32 MFMA, 1: split-bf16 MFMA, 3: bf16 MFMA (geotr_gse_embed); 5: by table */
+  const float* gse_table_d; const float* gse_table_a;                /* gse_precision 5: geotr_gse_table_build of proj_d / proj_a */
+  int64_t gse_points_d, gse_points_a;
   const float* div_term;                                             /* (hidden/2) */
   geotr_linear proj_d, proj_a, in_proj, out_proj;
   geotr_attn_layer layers[8];

@@ -5,8 +5,9 @@ oracle's own pyramid, oracle/neighbors.py) for the same pair and the same weight
 Tolerances (BASELINE.json north_star: neighbour indices bit-exact, feature MSE <= 1e-4):
   pyramid tables            byte-identical
   features (4 tensors)      MSE <= 1e-6 (two orders inside the north-star bound)
-  coarse correspondences    a global top-k over nearly flat scores under random weights: reported as set overlap; when the
-                            selection is identical everything downstream is compared one to one
+  coarse correspondences    a global top-k over nearly flat scores under random weights: reported as set overlap (>= 0.95); when
+                            the selected SET is identical the patches are aligned pair by pair (equal scores may swap ranks) and
+                            everything downstream is compared one to one
   matching scores           |d| <= 5e-3 on patches whose point order is identical
   transform                 |d| <= 5e-3 per entry, rotation / translation error reported
 """
@@ -71,11 +72,17 @@ def compare_pair(got, want):
     ok &= gi.shape == wi.shape and rep['coarse_set_overlap'] >= 0.95
     rep['matching_scores_max_err'] = rep['transform_max_abs_diff'] = rep['rre_deg_vs_oracle'] = rep['rte_m_vs_oracle'] = None
     rep['correspondences'] = [int(got['corr_scores'].shape[0]), int(want['corr_scores'].shape[0])]
-    if rep['coarse_identical']:
-        same = (torch.eq(got['ref_node_corr_knn_points'].cpu(), want['ref_node_corr_knn_points']).flatten(1).all(1) &
-                torch.eq(got['src_node_corr_knn_points'].cpu(), want['src_node_corr_knn_points']).flatten(1).all(1))
+    rep['coarse_same_set'] = bool(gi.shape == wi.shape and gs == ws and len(gs) == gi.shape[0])
+    if rep['coarse_same_set']:
+        # the same superpoint pairs, possibly listed in another order (scores equal to rounding swap ranks): align patch p of the
+        # oracle with the patch of the same (ref, src) pair here, then compare patch by patch
+        where = {pair: i for i, pair in enumerate(map(tuple, gi.tolist()))}
+        perm = torch.tensor([where[pair] for pair in map(tuple, wi.tolist())], dtype=torch.long)
+        g_ref, g_src = got['ref_node_corr_knn_points'].cpu()[perm], got['src_node_corr_knn_points'].cpu()[perm]
+        same = (torch.eq(g_ref, want['ref_node_corr_knn_points']).flatten(1).all(1) &
+                torch.eq(g_src, want['src_node_corr_knn_points']).flatten(1).all(1))
         rep['patches_in_identical_point_order'] = float(same.float().mean())
-        gm, wm = got['matching_scores'].cpu()[same], want['matching_scores'][same]
+        gm, wm = got['matching_scores'].cpu()[perm][same], want['matching_scores'][same]
         live = wm > -1e11  # masked entries are -1e12 + O(ulp(1e12)) noise in any implementation
         masks_equal = bool(torch.equal(live, gm > -1e11))
         rep['matching_scores_max_err'] = float((gm[live] - wm[live]).abs().max()) if masks_equal and bool(live.any()) else None
@@ -83,7 +90,10 @@ def compare_pair(got, want):
         T, Tw = got['estimated_transform'].cpu().numpy(), want['estimated_transform'].numpy()
         rep['transform_max_abs_diff'] = float(np.abs(T - Tw).max())
         rep['rre_deg_vs_oracle'], rep['rte_m_vs_oracle'] = rotation_translation_error(T, Tw)
-        ok &= rep['transform_max_abs_diff'] <= TRANSFORM_ATOL
+        # the pose is a function of the correspondence SET except for ties between equally supported hypotheses, which the patch
+        # order breaks (first maximum): required to agree when the order is identical, reported otherwise
+        if rep['coarse_identical']:
+            ok &= rep['transform_max_abs_diff'] <= TRANSFORM_ATOL
     ok &= bool(torch.isfinite(got['estimated_transform']).all())
     rep['ok'] = bool(ok)
     return rep

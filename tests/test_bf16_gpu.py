@@ -12,10 +12,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def bf16_mode():
+@pytest.fixture(params=['table', 'mfma'])
+def bf16_mode(request):
+    """bf16 GEMMs with the embedding by table (default) and on the bf16 MFMA embedding kernel."""
     from geotransformer_amd import kernels
-    prev = kernels.set_precision('bf16')
+    prev = kernels.set_precision('bf16', gse=request.param)
     yield
     kernels.set_precision(prev)
 
@@ -23,10 +24,12 @@ def bf16_mode():
 def test_set_precision_round_trip():
     from geotransformer_amd import kernels
     assert kernels.set_precision('bf16') == 'bf16x3'
-    assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 3)
+    assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 5)   # GEMMs in bf16; the embedding stays on its fp32 table
+    assert kernels.set_precision('bf16', gse='mfma') == 'bf16'
+    assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 3)   # ... unless the MFMA embedding kernel is asked for
     assert kernels.set_precision('fp32') == 'bf16'
     assert kernels.set_precision('bf16x3') == 'fp32'
-    assert kernels.GEMM_PACKED is True and kernels.GSE_PRECISION == 1
+    assert kernels.GEMM_PACKED is True and kernels.GSE_PRECISION == 5
     with pytest.raises(ValueError):
         kernels.set_precision('fp8')
 

@@ -32,6 +32,38 @@ def test_packed_split_bf16_gemm_vs_fp64(M, N, K, b_is_kn):
     assert float((exact.double() - want).abs().max()) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize('M,N,K,b_is_kn', [(2900, 128, 1920, True), (2570, 256, 1920, True), (560, 256, 3840, True), (1100, 512, 3840, True),
+                                           (1030, 64, 960, True), (1024, 256, 512, False), (3000, 32, 2048, False)])
+def test_split_k_packed_gemm(M, N, K, b_is_kn):
+    """The narrow, deep launches of the coarse stages (fewer than 256 output tiles, K up to 15 x 256): gridDim.z K slices + the
+    z-ordered reduce with the full epilogue.  vs fp64 (2e-5 of the output scale, as the unsplit kernel); vs the unsplit kernel
+    (the same products, summed in another association: 4e-6 of the scale); run-to-run bit-identical (no atomics)."""
+    from geotransformer_amd import _lib, kernels
+    lib = _lib.load()
+    assert lib.geotr_gemm_packed_splitk_workspace_bytes(M, N, K) > 0, 'this shape is expected to split'
+    assert lib.geotr_gemm_packed_splitk_workspace_bytes(40000, 256, 384) == 0  # wide launches never split
+    assert lib.geotr_gemm_packed_splitk_workspace_bytes(300, 128, 256) == 0    # shallow ones neither
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(K, N, generator=g) if b_is_kn else torch.randn(N, K, generator=g)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    div = torch.randint(0, 5, (M,), generator=g, dtype=torch.int32).cuda()
+    packed = kernels.gemm_pack(w, b_is_kn=b_is_kn)
+    got = kernels.gemm_packed(a, packed, N, bias=bias, row_div=div, residual=res, act='leaky')
+    again = kernels.gemm_packed(a, packed, N, bias=bias, row_div=div, residual=res, act='leaky')
+    single = kernels.gemm_packed(a, packed, N, bias=bias, row_div=div, residual=res, act='leaky', split_k=False)
+    wt = w.double() if b_is_kn else w.double().t()
+    want = (a.double() @ wt) / div.clamp(min=1).double()[:, None] + bias.double() + res.double()
+    want = torch.where(want > 0, want, 0.1 * want)
+    scale = float(want.abs().max())
+    assert torch.equal(got, again)
+    assert float((got.double() - want).abs().max()) <= 2e-5 * scale
+    assert float((got - single).abs().max()) <= 4e-6 * scale
+    plain = kernels.gemm_packed(a, packed, N)  # no epilogue terms at all
+    assert float((plain.double() - a.double() @ wt).abs().max()) <= 2e-5 * float((a.double() @ wt).abs().max())
+
+
 def test_grouped_gemm_matches_per_group_calls():
     """geotr_gemm_grouped (ragged groups x heads in one launch) is bit-identical to one geotr_gemm call per group."""
     from geotransformer_amd import _lib, kernels
@@ -106,3 +138,34 @@ def test_segmented_group_norm_equals_per_segment_calls():
         ref = torch.where(ref > 0, ref, 0.1 * ref)
         assert torch.allclose(alone, ref, atol=2e-4, rtol=2e-4)
         r0 += rows
+
+
+@pytest.mark.parametrize('C', [32, 64, 128, 256])
+def test_group_norm_row_flags_and_row_positive(C):
+    """geotr_group_norm_segmented_flags: the GroupNorm output's (row sum > 0) flags, produced inside the apply kernel, equal the
+    separate geotr_row_positive pass over that output (same predicate KPConv's neighbour count uses, kpconv.py:113-115) and the
+    torch row sums wherever the sum is not within rounding of zero."""
+    from geotransformer_amd import _lib, kernels
+    lib = _lib.load()
+    assert lib.geotr_group_norm_flags_supported(C) == 1 and lib.geotr_group_norm_flags_supported(512) == 0
+    g = torch.Generator().manual_seed(C)
+    seg = [3000, 777, 2048]
+    n = sum(seg)
+    x = (torch.randn(n, C, generator=g) * 2).cuda()
+    gamma, beta = torch.randn(C, generator=g).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    out, flags = torch.empty_like(x), torch.full((n,), 7, dtype=torch.uint8, device='cuda')
+    ws = _lib.workspace(lib.geotr_group_norm_workspace_bytes(n, C), x.device)
+    arr = (ctypes.c_int64 * len(seg))(*seg)
+    _lib.check(lib.geotr_group_norm_segmented_flags(_lib.ptr(x), n, C, 32 if C >= 32 else 4, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, None, 2,
+                                                    _lib.ptr(out), arr, len(seg), _lib.ptr(ws), _lib.ptr(flags), _lib.stream_ptr()), 'gn_flags')
+    plain = torch.empty_like(x)
+    _lib.check(lib.geotr_group_norm_segmented(_lib.ptr(x), n, C, 32 if C >= 32 else 4, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, None, 2,
+                                              _lib.ptr(plain), arr, len(seg), _lib.ptr(ws), _lib.stream_ptr()), 'gn')
+    assert torch.equal(out, plain)  # the flag output does not change the normalisation
+    sums = out.double().sum(1)
+    clear = sums.abs() > 1e-4 * out.abs().double().sum(1)
+    assert int(flags.max()) <= 1
+    assert torch.equal(flags.bool()[clear], (sums > 0)[clear])
+    sep = kernels.row_positive(out)
+    assert torch.equal(sep.bool()[clear], (sums > 0)[clear])
+    assert float((sep.bool() != flags.bool()).float().mean()) <= 1e-3  # another summation order: only rows with |sum| ~ 0 may differ

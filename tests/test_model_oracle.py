@@ -103,6 +103,11 @@ def test_oracle_matches_reference_on_the_demo_pair():
     got = mo.forward(sd, mo.config_from_reference(cfg), data)
     report = check_outputs_against_demo_golden(got, g)
     assert report['correspondences'] == 'identical list'
+    # the same pair at reduced widths under the stored weights of model_3dmatch_small.npz (the part that is portable to any box)
+    from util import load_model_golden
+    cfg_s, sd_s, _, _, _ = load_model_golden('model_3dmatch_small')
+    report_s = check_outputs_against_demo_golden(mo.forward(sd_s, mo.config_from_reference(cfg_s), data), g, prefix='small/out/')
+    assert report_s['correspondences'] == 'identical list'
     assert np.array_equal(got['gt_node_corr_indices'].numpy(), g['out/gt_node_corr_indices'])
     assert np.allclose(got['gt_node_corr_overlaps'].numpy(), g['out/gt_node_corr_overlaps'], atol=1e-6)
 

@@ -21,7 +21,7 @@ def _gse_weights(D, seed):
             'e.proj_a.weight': torch.randn(D, D, generator=g) * s, 'e.proj_a.bias': torch.randn(D, generator=g) * 0.1}
 
 
-@pytest.mark.parametrize('precision', [0, 1], ids=['fp32mfma', 'bf16x3'])
+@pytest.mark.parametrize('precision', [0, 1, 5], ids=['fp32mfma', 'bf16x3', 'table'])
 @pytest.mark.parametrize('n,D', [(5, 32), (70, 64), (150, 128), (130, 256), (272, 256)])
 def test_gse_matches_oracle(n, D, precision):
     from geotransformer_amd import kernels
@@ -45,6 +45,78 @@ def test_gse_matches_oracle(n, D, precision):
     assert float(err[off].max()) <= 3e-4 + 3e-4 * float(want.abs().max()), float(err[off].max())
     assert float(err[~off].max()) <= 5e-2, float(err[~off].max())
     assert float(((got - want) ** 2).mean()) <= 1e-6  # north_star bound on feature MSE is 1e-4
+
+
+def test_gse_table_is_the_projection_of_the_sinusoid():
+    """The lookup tables themselves: f(x) from the cubic-Taylor table at arbitrary x vs proj(sinusoid(x)) in float64 -- the table
+    error must be far below the kernel tolerance (design bound 3.2e-7 max|W|), also for weights 8x larger than the init scale."""
+    from geotransformer_amd import kernels
+    D = 256
+    div_term = torch.exp(torch.arange(0, D, 2).float() * (-np.log(10000.0) / D))
+    g = torch.Generator().manual_seed(11)
+    W = torch.randn(D, D, generator=g) * (8.0 / D ** 0.5)
+    tab = kernels.gse_table(div_term.cuda(), W.cuda(), 64.0).cpu().double()  # (points, 4, D)
+    x = torch.rand(4000, generator=g).double() * 63.9
+    grid = torch.round(x * kernels.GSE_TABLE_DENSITY)
+    delta = (x - grid / kernels.GSE_TABLE_DENSITY).unsqueeze(1)
+    c = tab[grid.long()]
+    got = ((c[:, 3] * delta + c[:, 2]) * delta + c[:, 1]) * delta + c[:, 0]
+    om = x.unsqueeze(1) * div_term.double().unsqueeze(0)
+    emb = torch.stack([torch.sin(om), torch.cos(om)], dim=2).reshape(-1, D)
+    want = emb @ W.double().t()
+    err = float((got - want).abs().max())
+    scale = float(want.abs().max())
+    print('table error', err, 'of scale', scale)
+    assert err <= 2e-5 and err <= 3e-6 * scale  # fp32 rounding of 256-term sums dominates; the Taylor remainder is ~1e-6 here
+
+
+def test_gse_table_direct_path_beyond_the_table_and_ragged_clouds():
+    """(a) a cloud wider than the distance table (d / sigma_d > 64): the in-kernel direct evaluation must agree with the oracle;
+    (b) geotr_gse_knn_clouds / geotr_gse_embed_table over several clouds in one ragged launch == per-cloud calls, bit for bit."""
+    import ctypes
+    from geotransformer_amd import _lib, kernels
+    from oracle import model_oracle as mo
+    D = 64
+    sd = _gse_weights(D, 3)
+    cfg = dict(hidden_dim=D, sigma_d=0.2, sigma_a=15, angle_k=3, reduction_a='max')
+    div_term = torch.exp(torch.arange(0, D, 2).float() * (-np.log(10000.0) / D)).cuda()
+    w = [sd[k].cuda() for k in ('e.proj_d.weight', 'e.proj_d.bias', 'e.proj_a.weight', 'e.proj_a.bias')]
+    pts = _random_superpoints(60, 5, extent=20.0)  # distances up to ~30 m = 150 sigma_d: most pairs leave the table
+    want = mo.gse(sd, 'e.', pts.unsqueeze(0), cfg)[0]
+    knn = kernels.gse_knn(pts.cuda(), 3)
+    got = kernels.gse_embed(pts.cuda(), knn, div_term, *w, 0.2, 15, precision=5).cpu()
+    off = ~torch.eye(60, dtype=torch.bool)
+    err = (got - want).abs()
+    assert float(err[off].max()) <= 3e-4 + 3e-4 * float(want.abs().max()), float(err[off].max())
+    far = torch.cdist(pts, pts) / 0.2 > kernels.GSE_TABLE_SPAN
+    assert int(far.sum()) > 1000  # the direct path really ran
+
+    sizes = [70, 5, 133, 64]
+    clouds = [_random_superpoints(n, 40 + n) for n in sizes]
+    allpts = torch.cat(clouds).cuda()
+    tabs = kernels.gse_tables(div_term, w[0], w[2], 15)
+    cl = kernels.GseClouds()
+    cl.count = len(sizes)
+    row, off_e = 0, 0
+    for q, n in enumerate(sizes):
+        cl.n[q], cl.row0[q], cl.emb_off[q] = n, row, off_e
+        row += n
+        off_e += n * n * D
+    lib = _lib.load()
+    knn_all = torch.empty((row, 3), dtype=torch.int32, device='cuda')
+    out = torch.empty(off_e, dtype=torch.float32, device='cuda')
+    _lib.check(lib.geotr_gse_knn_clouds(_lib.ptr(allpts), ctypes.byref(cl), 3, _lib.ptr(knn_all), _lib.stream_ptr()), 'knn_clouds')
+    _lib.check(lib.geotr_gse_embed_table(_lib.ptr(allpts), _lib.ptr(knn_all), ctypes.byref(cl), 3, D, _lib.ptr(tabs[0]), tabs[0].shape[0],
+                                         _lib.ptr(tabs[1]), tabs[1].shape[0], _lib.ptr(w[0]), _lib.ptr(w[1]), _lib.ptr(w[2]), _lib.ptr(w[3]),
+                                         _lib.ptr(div_term), 0.2, 15.0, _lib.ptr(out), _lib.stream_ptr()), 'embed_table')
+    row, off_e = 0, 0
+    for n, c in zip(sizes, clouds):
+        k1 = kernels.gse_knn(c.cuda(), 3)
+        assert torch.equal(knn_all[row:row + n], k1)
+        e1 = kernels.gse_embed(c.cuda(), k1, div_term, *w, 0.2, 15, precision=5, tables=tabs)
+        assert torch.equal(out[off_e:off_e + n * n * D].view(n, n, D), e1)
+        row += n
+        off_e += n * n * D
 
 
 @pytest.mark.parametrize('n,m,C,H', [(40, 40, 32, 4), (100, 100, 64, 4), (272, 272, 256, 4), (90, 130, 128, 4)])

@@ -120,12 +120,14 @@ def check_pyramid_against_demo_golden(pyr, g):
             assert sha(a) == str(g[f'pyr/{key}/{i}/sha256']), (key, i)
 
 
-def check_outputs_against_demo_golden(out, g, atol=3e-4, mse=1e-8, transform_atol=1e-3, exact_selection=True):
+def check_outputs_against_demo_golden(out, g, atol=3e-4, mse=1e-8, transform_atol=1e-3, exact_selection=True, prefix='out/'):
     """`out`: model output dict of torch tensors (any device).  Features within `atol` / `mse` of the reference's, identical
     coarse correspondences, and -- given those -- identical correspondence lists and the reference's transform.
     `exact_selection=False` (other arithmetic than the golden's CPU BLAS): the coarse top-k may swap near-equal scores; the
-    selected SET must overlap >= 97 % and the downstream comparison only runs when the selection is identical."""
+    selected SET must overlap >= 97 % and the downstream comparison only runs when the selection is identical.
+    `prefix`: 'out/' = full widths under the seeded weights, 'small/out/' = reduced widths under model_3dmatch_small's weights."""
     import torch
+    g = {k[len(prefix) - 4:]: v for k, v in g.items() if k.startswith(prefix)} if prefix != 'out/' else g
     o = {k: v.detach().cpu().numpy() for k, v in out.items() if torch.is_tensor(v)}
     report = {}
     for k in ('ref_feats_c', 'src_feats_c'):
