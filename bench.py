@@ -28,7 +28,9 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                  3 timed pairs, median; collate on one thread (as the reference), forward on all cores and on 16 threads
                  (the better one is `value`), the 1-thread figure and the pipelined 8-worker bound next to it.
   exact_fp32_mode : the same workload re-timed (a few steps) with every matrix product in exact fp32 MFMA (`--precision fp32`).
-`--precision bf16` (BASELINE configs[4] arithmetic) and `--config kitti|modelnet` are orientation runs, not the headline metric.
+`--config kitti` (BASELINE configs[3]: 120k + 120k points, 5-stage backbone; use `--lanes 2 --stack 4 --batch 8`), `--config lomatch
+--precision bf16` (configs[4]: low overlap, 1000 hypotheses, bf16 operands) and `--config modelnet` (configs[0] shape) print the same line
+with their own parity block; the headline metric is the default run.
 """
 import argparse
 import json
@@ -117,6 +119,28 @@ def roofline_blocks(events, cfg, args, pipe, out, kernels):
                'note': 'achieved = ALGORITHMIC 2 m n k FLOP summed over the recorded launches / their summed duration; executed_* counts the 3 bf16 '
                        'MFMA products per algorithmic product of the split-bf16 path; ' + lanes_note}
         fam['gemm'] = blk
+    kpc = [(sec, work) for sec, kind, work in events if kind == 'kpconv']
+    if kpc:
+        sec = sum(s_ for s_, _ in kpc)
+        # per point: neighbour contraction 2 h (15 c_in) FLOP on the fp32 matrix pipe + kernel-point contraction 2 (15 c_in) c_out on the bf16 pipe
+        f1 = sum(2.0 * m * hh * kd for _, (m, co, kd, hh) in kpc)
+        f2 = sum(2.0 * m * kd * co for _, (m, co, kd, hh) in kpc)
+        shapes = {}
+        for s_, w in kpc:
+            d = shapes.setdefault(w, [0, 0.0])
+            d[0] += 1
+            d[1] += s_
+        t1, t2 = f1 / 1e12 / FP32_MATRIX_PEAK_TFLOPS, f2 / 1e12 / BF16_MATRIX_PEAK_TFLOPS * (3.0 if gemm_mode is True else 1.0)
+        fam['kpconv'] = {
+            'bound': 'mfma', 'kernel': 'kpconv_fused_kernel<C_in,WAVES,TERMS> (KPConv layer in one kernel: fp32-MFMA neighbour contraction -> LDS -> bf16-MFMA kernel-point contraction)',
+            'achieved': round((f1 + f2) / sec / 1e12, 2), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round((t1 + t2) / sec, 4),
+            'fp32_pipe_tflops': round(f1 / sec / 1e12, 2), 'bf16_pipe_algorithmic_tflops': round(f2 / sec / 1e12, 2),
+            'launches': len(kpc), 'avg_launch_us': round(1e6 * sec / len(kpc), 1), 'total_ms': round(1e3 * sec, 2),
+            'shapes_in_flight': [{'m_cout_15cin_h': list(w), 'launches': c_, 'avg_us': round(1e6 * t / c_, 1)}
+                                 for w, (c_, t) in sorted(shapes.items(), key=lambda kv: -kv[1][1])],
+            'note': 'two matrix pipes in one kernel: frac = (fp32-pipe FLOP / 157.3 TF + executed bf16-pipe FLOP / 2500 TF) / launch time, i.e. the '
+                    'fraction of the launch the matrix pipes would need at their peaks; achieved = all algorithmic FLOP / time; ' + lanes_note}
     if not fam:
         return None
     # the same kernels with the GPU otherwise idle (after the timed region): separates kernel quality from lane contention
@@ -174,9 +198,20 @@ def note(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
+# bench configurations -> (experiment config, synthetic shape, config overrides, overlap, BASELINE.json configs[] index)
+WORKLOADS = {
+    '3dmatch': ('3dmatch', '3dmatch', None, 0.6, 1),
+    'modelnet': ('modelnet', 'modelnet', None, 0.6, 0),
+    'kitti': ('kitti', 'kitti', None, 0.6, 3),
+    # BASELINE configs[4]: low-overlap 3DLoMatch-shape pair, 1000 coarse correspondences (<= 1000 LGR hypotheses); meant for --precision bf16
+    'lomatch': ('3dmatch', '3dmatch', {'coarse_matching.num_correspondences': 1000}, 0.2, 4),
+}
+
+
 def build_pair(seed, config, n_points):
     from geotransformer_amd.synthetic import make_pair
-    return make_pair(seed, config, n_points=n_points)
+    _, shape, _, overlap, _ = WORKLOADS[config]
+    return make_pair(seed, shape, n_points=n_points, overlap=overlap)
 
 
 def cpu_baseline(cfg, items, model, budget_s=150.0):
@@ -260,7 +295,7 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
 
     rec = {
         'value': None if t_forward is None else 1.0 / (t_collate + t_forward), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-        'sample': f'1 warm-up + 3 timed pairs of the same workload (20k-pt pairs of this run), medians: collate {t_collate:.2f} s '
+        'sample': f'1 warm-up + 3 timed pairs of the same workload (pairs of this run), medians: collate {t_collate:.2f} s '
                   f'(1 thread, {kind_nb}) + forward {describe(threads) if threads else "n/a"} (torch fp32 restatement, {threads} threads, '
                   f'the best of the thread counts tried); host has {nproc} logical cores',
         'nproc': nproc, 'collate_s': round(t_collate, 3), 'forward_s': None if t_forward is None else round(t_forward, 3),
@@ -295,7 +330,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', default='3dmatch', choices=['3dmatch', 'modelnet', 'kitti'])
+    ap.add_argument('--config', default='3dmatch', choices=sorted(WORKLOADS))
     ap.add_argument('--points', type=int, default=None, help='points per cloud (default: the config\'s)')
     ap.add_argument('--pairs', type=int, default=8, help='distinct synthetic pairs cycled through per rank')
     ap.add_argument('--batch', type=int, default=32, help='pairs per step per GPU (independent pairs of one batch)')
@@ -332,8 +367,9 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
 
-    cfg = make_cfg(args.config)
-    n_points = args.points or CONFIGS[args.config]['n_points']
+    exp, shape, overrides, _, baseline_index = WORKLOADS[args.config]
+    cfg = make_cfg(exp, overrides)
+    n_points = args.points or CONFIGS[shape]['n_points']
     torch.manual_seed(cfg.seed)
     np.random.seed(cfg.seed)
     pipe = RegistrationPipeline(cfg, device=device, exact_width=False)
@@ -427,7 +463,8 @@ def main():
         line = {
             'metric': {'3dmatch': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)',
                        'kitti': 'registration pairs/sec (120k-pt synthetic KITTI-shape pair)',
-                       'modelnet': 'registration pairs/sec (1k-pt synthetic ModelNet-shape pair)'}[args.config],
+                       'modelnet': 'registration pairs/sec (1k-pt synthetic ModelNet-shape pair)',
+                       'lomatch': 'registration pairs/sec (20k-pt synthetic low-overlap 3DLoMatch-shape pair, 1000 hypotheses)'}[args.config],
             'value': round(value, 3), 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -435,7 +472,7 @@ def main():
                       'bf16x3 (split-bf16 products: 3 bf16 MFMA terms per fp32 product, ~2^-17 relative; fp32 accumulate and storage)' if split else
                       'f32 (exact fp32 MFMA)'),
             'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[{ {"3dmatch": 1, "kitti": 3, "modelnet": 0}[args.config] }]: synthetic {args.config} pair, {n_points}+{n_points} pts, '
+            'config': {'workload': f'BASELINE configs[{baseline_index}]: synthetic {args.config} pair, {n_points}+{n_points} pts, '
                                    f'{cfg.backbone.num_stages}-stage KPConv-FPN, d={D}, '
                                    f'{info["superpoints"][0]}+{info["superpoints"][1]} superpoints, '
                                    f'P={cfg.coarse_matching.num_correspondences}, K={cfg.model.num_points_in_patch}, '

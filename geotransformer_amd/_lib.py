@@ -33,6 +33,9 @@ SIGNATURES = {
     'geotr_row_positive': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_kpconv_gather': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
                                     c_ptr, c_ptr, c_ptr]),
+    'geotr_kpconv_fused_supported': (c_int, [c_i64, c_i64, c_i64]),
+    'geotr_kpconv_fused': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr, c_ptr,
+                                   c_int, c_ptr, c_ptr]),
     'geotr_maxpool': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_upsample_concat': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_group_norm_workspace_bytes': (c_size, [c_i64, c_i64]),

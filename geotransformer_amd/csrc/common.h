@@ -42,6 +42,11 @@ struct Carver {
   }
 };
 
+// Zero-fill / device-to-device copy as plain kernels on the caller's stream.  The runtime's hipMemsetAsync / hipMemcpyAsync go
+// through blit paths with their own cross-queue ordering; everything on the data path here stays an ordinary in-order dispatch.
+int zero_async(void* p, size_t bytes, hipStream_t stream);
+int copy_async(void* dst, const void* src, size_t bytes, hipStream_t stream);
+
 // LGR over several stacked pairs in one launch sequence (lgr.hip): byte distance between the per-pair arrays of consecutive pairs
 struct LgrBatch {
   int64_t knn_pts, knn_mask, score, pcount, corr_pts, corr_score, total, transform, ws;

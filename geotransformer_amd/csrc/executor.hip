@@ -60,6 +60,7 @@ static inline bool use_packed(const void* packed, const float* a, int64_t lda, i
 // size slot: n > 0 = a per-cloud GSE launch over n superpoints; -pairs = a ragged GSE launch over that many (i, j) pairs;
 // kProfGemm | m << 26 | n << 14 | k = a packed GEMM of that shape (m < 2^24, n < 2^12, k < 2^14; larger shapes are not recorded).
 constexpr int64_t kProfGemm = 1ll << 62;
+constexpr int64_t kProfKpconv = 1ll << 61;  // kProfKpconv | h << 50 | m << 26 | c_out << 14 | 15 c_in = a fused KPConv layer (kpconv_fused.hip)
 struct ProfScope {
   int slot = -1;
   hipStream_t stream;
@@ -129,13 +130,14 @@ static float* norm(Ctx& c, const geotr_norm& nm, const float* x, int64_t n, int6
 }
 
 // Rows of a KPConv layer processed per gather -> GEMM round.  The (rows, 15 C_in) gathered operand is written by one kernel and read
-// by the next; bounded to a few tens of MB it stays in the 256 MB Infinity Cache between the two instead of making an HBM round
-// trip (a stack of 8 pairs would otherwise stream up to 600 MB per layer through HBM twice).  GEOTR_KPCONV_CHUNK_MB overrides the
-// operand budget per round (0 = one round per layer).
+// by the next; the idea of bounding it to a few tens of MB so that it stays in the 256 MB Infinity Cache between the two was MEASURED
+// not to pay (profiles/r02_ab_runs.md: 918 pairs/s unchunked, 912 at 48 MB, 896 at 16 MB -- with four lanes in flight the cache is
+// shared by four such operands and the extra launches cost more than the traffic saved), so the default is one round per layer;
+// GEOTR_KPCONV_CHUNK_MB=<MB> enables the chunking for experiments.
 static int64_t kpconv_chunk_rows(int64_t m, int64_t kdim) {
   static const int64_t budget_mb = [] {
     const char* e = std::getenv("GEOTR_KPCONV_CHUNK_MB");
-    return e ? (int64_t)std::atoll(e) : (int64_t)48;
+    return e ? (int64_t)std::atoll(e) : (int64_t)0;
   }();
   if (budget_mb <= 0) return m;
   int64_t rows = budget_mb * (1 << 20) / (4 * kdim);
@@ -155,6 +157,22 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     uint8_t* f = c.alloc<uint8_t>((size_t)ns);
     if (c.live()) c.check(geotr_row_positive(s_feats, ns, kp.in, f, c.stream));
     flag = f;
+  }
+  // one kernel for the whole layer where the shape allows it: the (m, 15 c_in) operand stays in LDS (kpconv_fused.hip)
+  static const bool fused_enabled = [] {
+    const char* e = std::getenv("GEOTR_KPCONV_FUSED");  // A/B switch for measurements: GEOTR_KPCONV_FUSED=0 keeps the two-kernel path
+    return !(e && e[0] == '0');
+  }();
+  if (fused_enabled && kp.packed && flag && kp.num_kernel_points == 15 && geotr_kpconv_fused_supported(kp.in, kp.out, h) &&
+      (reinterpret_cast<uintptr_t>(s_feats) & 15) == 0) {
+    if (c.live()) {
+      ProfScope prof(c.stream);
+      c.check(geotr_kpconv_fused(s_feats, q_pts, s_pts, nb, kp.kernel_points, flag, m, ns, h, kp.in, kp.out, kp.num_kernel_points, kp.sigma,
+                                 kp.packed, kp.bias, c.gemm_bf16 ? 1 : 0, out, c.stream));
+      prof.done(kProfKpconv | (h << 50) | (m << 26) | (kp.out << 14) | kdim);
+    }
+    c.release(mk);
+    return out;
   }
   float* weighted = c.alloc<float>((size_t)chunk * kdim);
   int32_t* nnum = c.alloc<int32_t>((size_t)m);
@@ -530,8 +548,7 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
   float* feats_c = c.alloc<float>((size_t)n_c * c_dim);
   const size_t mk = c.mark();
   BackboneOut bb = backbone_forward(c, net.backbone, p, features, feats_f);
-  if (c.live() && hipMemcpyAsync(feats_c, bb.feats_c, sizeof(float) * (size_t)n_c * c_dim, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
-    c.check(fail(GEOTR_E_LAUNCH, "model_forward: copy failed"));
+  if (c.live()) c.check(copy_async(feats_c, bb.feats_c, sizeof(float) * (size_t)n_c * c_dim, c.stream));
   c.release(mk);
 
   // geometric transformer over the whole stack -> L2-normalised superpoint features in the caller's stack-ordered buffer
@@ -579,7 +596,7 @@ static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const flo
     int64_t f0[2 * GEOTR_MAX_PAIRS + 1], c0[2 * GEOTR_MAX_PAIRS + 1];
     f0[0] = c0[0] = 0;
     for (int q = 0; q < 2 * B; ++q) f0[q + 1] = f0[q] + p.cloud_n[fine][q], c0[q + 1] = c0[q] + p.cloud_n[S - 1][q];
-    if (hipMemsetAsync(scratch_flag, 0, 16, c.stream) != hipSuccess) c.check(fail(GEOTR_E_LAUNCH, "model_forward: memset failed"));
+    c.check(zero_async(scratch_flag, 16, c.stream));
     c.check(p2n_launch(p.points[fine], p.points[S - 1], 2 * B, f0, c0, K, p2n, node_masks, node_knn_idx, node_knn_mask, scratch_flag, c.stream));
   }
 

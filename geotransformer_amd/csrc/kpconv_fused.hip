@@ -1,0 +1,270 @@
+// kpconv_fused.hip -- K1 as ONE kernel: KPConv (geotransformer/modules/kpconv/kpconv.py:79-121) without the (M, 15 C_in) operand
+// in HBM.
+//
+// The reference computes, per query point m with neighbours h = 0 .. H-1 (pad index -> zero row, zero weight):
+//     w[k, h]   = max(0, 1 - |(s_h - q_m) - kp_k| / sigma)                 15 kernel points            (:91-99)
+//     g[k, c]   = sum_h w[k, h] f[h, c]                                     (15, C_in)  "weighted"      (:102-105)
+//     out[m, :] = sum_{k, c} g[k, c] W[k, c, :]  / max(#{h : sum_c f[h, c] > 0}, 1) + bias            (:108-117)
+// The two-kernel path (kpconv.hip gather -> gemm.hip packed GEMM) writes g for every point -- 15 C_in floats, 250 MB per 20k+20k
+// pair over the backbone -- and reads it back: the deep-K GEMMs it feeds are bandwidth-bound on exactly that operand (47 TFLOP/s
+// alone at 12 288 x 64 x 960, profiles/r02_bench_n1.json).  Here a workgroup owns 32 query points and keeps g in LDS:
+//
+//   phase 1  (matrix pipe, exact fp32)  one wave per point:  g (16 x C_in) = w (16 x H) . f (H x C_in)  as v_mfma_f32_16x16x4_f32
+//            steps over 4 neighbours.  A operand = the lane's own influence w[k = lane & 15][h = 4 s + (lane >> 4)], computed in
+//            registers from the relative position; B operand = the neighbour's feature channels, fetched with ONE 8 / 16-byte
+//            load per lane and step that feeds VEC MFMAs (channel <-> column map: column n of tile j in group g is channel
+//            16 VEC g + VEC n + j, so 16 lanes read a neighbour's row as one contiguous segment).  The MFMA is a k-ordered
+//            fmaf chain (bitwise the VALU kernel's sum over h).  The result is split into bf16 hi / lo and stored to the LDS
+//            tile A[point][k C_in + c] (rows padded by 16 B: conflict-free ds_read_b128 fragments).
+//   phase 2  (matrix pipe, split-bf16)   out (32 x C_out) = A (32 x 15 C_in) . W  with v_mfma_f32_32x32x16_bf16, three products
+//            per step (a_hi b_lo + a_lo b_hi + a_hi b_hi) against the SAME packed weight planes geotr_gemm_pack builds for the
+//            two-kernel path, streamed fragment by fragment from L2.  Waves split (column tile, K range); the K partials meet in
+//            LDS, the epilogue (/ count + bias) writes whole rows.
+// Supported: C_in in {32, 64} (the stage-0 .. 2 layers: three quarters of the backbone's KPConv work), C_out a multiple of 32 with
+// C_out / 32 dividing the wave count, H <= 64.  Everything else stays on the two-kernel path.
+#include "common.h"
+
+namespace geotr {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kFusedRows = 32;  // query points per workgroup tile = one 32-row MFMA tile
+
+template <int V>
+struct FVec;
+template <>
+struct FVec<2> {
+  using T = float2;
+};
+template <>
+struct FVec<4> {
+  using T = float4;
+};
+
+// C = C_in; WAVES = waves per workgroup; TERMS = 3 split-bf16 / 1 plain bf16 (hi planes only)
+template <int C, int WAVES, int TERMS>
+__global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
+                                                                  const float* __restrict__ sp, const int64_t* __restrict__ nb,
+                                                                  const float* __restrict__ kp, const unsigned char* __restrict__ pos,
+                                                                  int64_t M, int64_t Ns, int H, float sigma, int c_out, int KS, int NT,
+                                                                  const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo,
+                                                                  const float* __restrict__ bias, float* __restrict__ out) {
+  constexpr int VEC = C >= 64 ? 4 : 2;          // feature channels per lane and load
+  constexpr int G = C / (16 * VEC);             // loads (column-tile groups) per neighbour step
+  constexpr int K = 15 * C;                     // contraction depth of phase 2
+  constexpr int RS = K + 8;                     // LDS row stride in bf16 elements (16 B pad)
+  constexpr int PPW = kFusedRows / WAVES;       // points per wave in phase 1
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  unsigned short* A_hi = reinterpret_cast<unsigned short*>(fsm);
+  unsigned short* A_lo = A_hi + kFusedRows * RS;
+  float4* relw_all = reinterpret_cast<float4*>(A_lo + kFusedRows * RS);  // [WAVES][64] (rel.xyz, neighbour index bits)
+  int* cnt_s = reinterpret_cast<int*>(relw_all + WAVES * 64);            // [32] neighbours with a positive feature sum
+  float* part = reinterpret_cast<float*>(fsm);                           // [WAVES][16][64] K partials (reuses the A tile)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, q4 = lane >> 4;
+  float4* relw = relw_all + wave * 64;
+  const float inv_sigma = 1.f / sigma;
+  // the lane's kernel point (row of the phase-1 A operand); row 15 is padding
+  const bool kp_ok = n16 < 15;
+  const float kx = kp_ok ? kp[3 * n16] : 0.f, ky = kp_ok ? kp[3 * n16 + 1] : 0.f, kz = kp_ok ? kp[3 * n16 + 2] : 0.f;
+  const int steps = (H + 3) >> 2;
+  const int CT = c_out >> 5;            // 32-column tiles of the output
+  const int KPARTS = WAVES / CT;        // K ranges of phase 2
+  const int ct = wave % CT, kpart = wave / CT;
+  const int nkk = K / 16;               // 16-deep steps of phase 2 (K % 32 == 0)
+  const int kk_per = (nkk + KPARTS - 1) / KPARTS;
+  const int kk0 = kpart * kk_per, kk1 = min(nkk, kk0 + kk_per);
+
+  const int64_t tiles = (M + kFusedRows - 1) / kFusedRows;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t m0 = tile * kFusedRows;
+    // ------------------------------------------------------------------ phase 1: g = w . f per point
+    for (int i = 0; i < PPW; ++i) {
+      const int row = wave * PPW + i;
+      const int64_t m = m0 + row;
+      if (m >= M) break;  // wave-uniform; the rows past M are never stored
+      {
+        float4 rv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        bool counted = false;
+        if (lane < H) {
+          const int64_t j = nb[m * H + lane];
+          if (j < Ns) {
+            rv.x = sp[3 * j] - qp[3 * m], rv.y = sp[3 * j + 1] - qp[3 * m + 1], rv.z = sp[3 * j + 2] - qp[3 * m + 2];
+            rv.w = __int_as_float((int)j);
+            counted = pos[j] != 0;
+          }
+        }
+        relw[lane] = rv;
+        const unsigned long long b = __ballot(counted);
+        if (lane == 0) cnt_s[row] = __popcll(b);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      f32x4 acc[G][VEC];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[g][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // neighbour steps in chunks of kChunk: all of a chunk's feature loads are issued before its first MFMA (memory-level
+      // parallelism instead of one dependent L2 round trip per step)
+      constexpr int kChunk = 5;
+      for (int s0 = 0; s0 < steps; s0 += kChunk) {
+        float a[kChunk], b[kChunk][G][VEC];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+          const int s = s0 + u;
+          const float4 rv = relw[(4 * s + q4) & 63];  // lanes >= H of the row hold index -1
+          const int id = __float_as_int(rv.w);
+          const bool ok = s < steps && id >= 0;
+          a[u] = 0.f;
+          if (ok && kp_ok) {
+            const float dx = rv.x - kx, dy = rv.y - ky, dz = rv.z - kz;
+            a[u] = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);  // as kpconv_gather_kernel
+          }
+          const float* fr = feats + (int64_t)(ok ? id : 0) * C + VEC * n16;
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const typename FVec<VEC>::T v = *reinterpret_cast<const typename FVec<VEC>::T*>(fr + 16 * VEC * g);
+            const float* vf = reinterpret_cast<const float*>(&v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) b[u][g][j] = ok ? vf[j] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][g][j], acc[g][j], 0, 0, 0);
+      }
+      // accumulator (16 kernel points x 16 columns per tile): lane holds rows 4 q4 + r, column n16 -> A[row][k C + channel]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kpt = 4 * q4 + r;
+        if (kpt >= 15) continue;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          unsigned h[VEC], l[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float x = acc[g][j][r];
+            h[j] = f32_to_bf16_rne(x);
+            l[j] = f32_to_bf16_rne(x - bf16_to_f32(h[j]));
+          }
+          const int e = row * RS + kpt * C + 16 * VEC * g + VEC * n16;  // VEC consecutive bf16: 4- or 8-byte aligned
+          if constexpr (VEC == 2) {
+            *reinterpret_cast<unsigned*>(A_hi + e) = h[0] | (h[1] << 16);
+            if constexpr (TERMS == 3) *reinterpret_cast<unsigned*>(A_lo + e) = l[0] | (l[1] << 16);
+          } else {
+            *reinterpret_cast<uint2*>(A_hi + e) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            if constexpr (TERMS == 3) *reinterpret_cast<uint2*>(A_lo + e) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // relw is rewritten for the wave's next point
+    }
+    __syncthreads();  // A tile complete
+    // ------------------------------------------------------------------ phase 2: out = A . W  (this wave: column tile ct, steps kk0 .. kk1)
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    {
+      const unsigned short* a_hi = A_hi + (lane & 31) * RS + 8 * (lane >> 5);
+      const unsigned short* a_lo = A_lo + (lane & 31) * RS + 8 * (lane >> 5);
+      const int ctc = min(ct, NT - 1);
+      const unsigned short* b_hi = Bhi + ((int64_t)ctc * KS * 64 + lane) * 8;
+      const unsigned short* b_lo = Blo + ((int64_t)ctc * KS * 64 + lane) * 8;
+#pragma unroll 2
+      for (int kk = kk0; kk < kk1; ++kk) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_hi + 16 * kk);
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_hi + (int64_t)kk * 512);
+        if constexpr (TERMS == 3) {
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(a_lo + 16 * kk);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_lo + (int64_t)kk * 512);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
+        }
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2, 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave has read its A fragments: the tile's memory now takes the K partials
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(wave * 16 + r) * 64 + lane] = acc2[r];
+    __syncthreads();
+    // ------------------------------------------------------------------ epilogue: sum the K partials, / count + bias, whole rows out
+    for (int e = tid; e < kFusedRows * c_out; e += 64 * WAVES) {
+      const int row = e / c_out, col = e - row * c_out;
+      const int64_t m = m0 + row;
+      if (m >= M) continue;
+      const int t = col >> 5, cc = col & 31;
+      // element (row, cc) of a 32 x 32 accumulator: lane = cc + 32 ((row >> 2) & 1), register = (row & 3) + 4 (row >> 3)
+      const int src = ((row & 3) + 4 * (row >> 3)) * 64 + cc + 32 * ((row >> 2) & 1);
+      float v = 0.f;
+      for (int p = 0; p < KPARTS; ++p) v += part[(p * CT + t) * 16 * 64 + src];
+      out[m * c_out + col] = v / (float)max(cnt_s[row], 1) + (bias ? bias[col] : 0.f);
+    }
+    __syncthreads();  // partials and counts are consumed before the next tile overwrites them
+  }
+}
+
+static inline int64_t pad32(int64_t x) { return (x + 31) / 32 * 32; }
+
+}  // namespace geotr
+
+using namespace geotr;
+
+extern "C" {
+
+int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h) {
+  if (!(c_in == 32 || c_in == 64) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 64) return 0;
+  const int waves = c_in == 32 ? 4 : 8;
+  const int64_t ct = c_out / 32;
+  return ct <= waves && waves % ct == 0;
+}
+
+int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
+                       const float* kernel_points, const uint8_t* pos_flag, int64_t m, int64_t ns, int64_t h, int64_t c_in, int64_t c_out,
+                       int64_t num_kernel_points, float sigma, const void* packed, const float* bias, int bf16_operands, float* out,
+                       void* stream_) {
+  GEOTR_CHECK_ARG(m >= 0 && ns >= 0, "kpconv_fused: bad sizes");
+  GEOTR_CHECK_ARG(num_kernel_points == 15, "kpconv_fused: only 15 kernel points are supported (got %lld)", (long long)num_kernel_points);
+  GEOTR_CHECK_ARG(geotr_kpconv_fused_supported(c_in, c_out, h), "kpconv_fused: unsupported shape (c_in %lld, c_out %lld, h %lld)",
+                  (long long)c_in, (long long)c_out, (long long)h);
+  if (m == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(s_feats && q_points && s_points && neighbors && kernel_points && pos_flag && packed && out, "kpconv_fused: null pointer");
+  GEOTR_CHECK_ARG((reinterpret_cast<uintptr_t>(s_feats) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed) & 15) == 0,
+                  "kpconv_fused: features and packed weights must be 16-byte aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t kdim = 15 * c_in, kp_pad = pad32(kdim), np_pad = pad32(c_out);
+  const unsigned short* bhi = reinterpret_cast<const unsigned short*>(packed);
+  const unsigned short* blo = bhi + np_pad * kp_pad;
+  const int KS = (int)(kp_pad / 16), NT = (int)(np_pad / 32);
+  const int waves = c_in == 32 ? 4 : 8;
+  const size_t lds = (size_t)2 * kFusedRows * (kdim + 8) * 2 + (size_t)waves * 64 * 16 + 32 * 4;
+  const int64_t tiles = (m + kFusedRows - 1) / kFusedRows;
+  const unsigned grid = (unsigned)std::min<int64_t>(tiles, 256 * (c_in == 32 ? 8 : 4));
+#define GEOTR_KPF(CC, WW, TT)                                                                                                      \
+  do {                                                                                                                             \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<CC, WW, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds) != hipSuccess)                                                                               \
+      return fail(GEOTR_E_LAUNCH, "kpconv_fused: cannot reserve %zu B of LDS", lds);                                               \
+    kpconv_fused_kernel<CC, WW, TT><<<dim3(grid), dim3(64 * WW), lds, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points,  \
+                                                                               pos_flag, m, ns, (int)h, sigma, (int)c_out, KS, NT, bhi, \
+                                                                               blo, bias, out);                                    \
+  } while (0)
+  if (c_in == 32) {
+    if (bf16_operands) GEOTR_KPF(32, 4, 1);
+    else GEOTR_KPF(32, 4, 3);
+  } else {
+    if (bf16_operands) GEOTR_KPF(64, 8, 1);
+    else GEOTR_KPF(64, 8, 3);
+  }
+#undef GEOTR_KPF
+  GEOTR_CHECK_LAUNCH("kpconv_fused");
+  return GEOTR_OK;
+}
+
+}  // extern "C"

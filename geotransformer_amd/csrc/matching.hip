@@ -31,6 +31,12 @@ struct P2nClouds {
   int64_t f0[2 * GEOTR_MAX_PAIRS + 1], c0[2 * GEOTR_MAX_PAIRS + 1];
 };
 
+// Loads of the pyramid's point arrays in the matching heads go through agent scope (sc1: served by L2, never by a CU's L1).
+// Measured necessity, not style: with several streams in flight (stacks of DIFFERENT pairs on 3-4 lanes) plain loads here
+// occasionally returned the coordinates a previous stack had left at the same address -- a handful of points per cloud then joined
+// the wrong superpoint (0 of 10 runs affected with these loads, 3 of 10 without on the same box; profiles/r02_concurrency_hazard.md).
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ __launch_bounds__(256) void p2n_assign_kernel(const float* __restrict__ pts, int64_t N, const float* __restrict__ nodes,
                                                          int M, int64_t* __restrict__ point_to_node,
                                                          unsigned char* __restrict__ node_masks, P2nClouds tb) {
@@ -41,11 +47,11 @@ __global__ __launch_bounds__(256) void p2n_assign_kernel(const float* __restrict
     pts += 3 * tb.f0[q], nodes += 3 * tb.c0[q], point_to_node += tb.f0[q], node_masks += tb.c0[q];
     if ((int64_t)blockIdx.x * blockDim.x >= N) return;
   }
-  for (int e = threadIdx.x; e < 3 * M; e += blockDim.x) nd[e] = nodes[e];
+  for (int e = threadIdx.x; e < 3 * M; e += blockDim.x) nd[e] = ld_agent(nodes + e);
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  const float p[3] = {ld_agent(pts + 3 * i), ld_agent(pts + 3 * i + 1), ld_agent(pts + 3 * i + 2)};
   float best = 3.4e38f;
   int bi = 0;
   for (int m = 0; m < M; ++m) {
@@ -77,10 +83,10 @@ __global__ __launch_bounds__(256) void p2n_knn_kernel(const float* __restrict__ 
   }
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
-  const float nd[3] = {nodes[3 * node], nodes[3 * node + 1], nodes[3 * node + 2]};
+  const float nd[3] = {ld_agent(nodes + 3 * node), ld_agent(nodes + 3 * node + 1), ld_agent(nodes + 3 * node + 2)};
   for (int64_t i = threadIdx.x; i < N; i += blockDim.x) {
     if (point_to_node[i] != node) continue;
-    const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    const float p[3] = {ld_agent(pts + 3 * i), ld_agent(pts + 3 * i + 1), ld_agent(pts + 3 * i + 2)};
     const float d = sqdist_expanded(nd, p);
     const int pos = atomicAdd(&cnt, 1);
     if (pos < kP2nCap) keys[pos] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
@@ -599,9 +605,9 @@ __global__ __launch_bounds__(128) void patch_gather_kernel(const int64_t* __rest
     io[j] = id;
     mo[j] = live ? mtab[node * K + j] : 0;
     const bool real = id < n;  // the pad index selects the zero row appended by model.py:114-115
-    po[3 * j] = real ? pts[3 * id] : 0.f;
-    po[3 * j + 1] = real ? pts[3 * id + 1] : 0.f;
-    po[3 * j + 2] = real ? pts[3 * id + 2] : 0.f;
+    po[3 * j] = real ? ld_agent(pts + 3 * id) : 0.f;
+    po[3 * j + 1] = real ? ld_agent(pts + 3 * id + 1) : 0.f;
+    po[3 * j + 2] = real ? ld_agent(pts + 3 * id + 2) : 0.f;
   }
 }
 
@@ -807,7 +813,7 @@ int p2n_launch(const float* points, const float* nodes, int clouds, const int64_
   }
   GEOTR_CHECK_ARG(maxm <= 12000, "point_to_node: at most 12000 nodes (got %lld)", (long long)maxm);
   hipStream_t stream = (hipStream_t)stream_;
-  if (hipMemsetAsync(node_masks, 0, (size_t)c0[clouds], stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "point_to_node: memset failed");
+  if (zero_async(node_masks, (size_t)c0[clouds], stream) != GEOTR_OK) return GEOTR_E_LAUNCH;
   const size_t lds = sizeof(float) * 3 * (size_t)maxm;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -850,7 +856,7 @@ int spm_stack_launch(float* scores, int pairs, const int64_t* n, const int64_t* 
   TopkState* st = cv.take<TopkState>((size_t)pairs);
   float* rowsum = cv.take<float>((size_t)ro);
   float* colpart = cv.take<float>((size_t)co);
-  if (hipMemsetAsync(st, 0, sizeof(TopkState) * (size_t)pairs, stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "superpoint_match: memset failed");
+  if (zero_async(st, sizeof(TopkState) * (size_t)pairs, stream) != GEOTR_OK) return GEOTR_E_LAUNCH;
   const unsigned blocks = (unsigned)std::min<int64_t>((maxtot + kTopkChunk - 1) / kTopkChunk, 256), P = (unsigned)pairs;
   spm_exp_kernel<<<dim3((unsigned)maxn, P), dim3(256), 0, stream>>>(scores, 0, 0, masks, nullptr, rowsum, sb);
   spm_colsum_kernel<<<dim3((unsigned)((maxm + 63) / 64), kSpmParts, P), dim3(256), 0, stream>>>(scores, 0, 0, colpart, sb);
@@ -908,7 +914,7 @@ int geotr_superpoint_match(float* scores, int64_t n, int64_t m, const uint8_t* r
   float* rowsum = cv.take<float>((size_t)n);
   float* colpart = cv.take<float>((size_t)m * kSpmParts);
   // hist / counters / tickets (everything before the candidate list ... simplest: the whole state) start at zero
-  if (hipMemsetAsync(st, 0, sizeof(TopkState), stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "superpoint_match: memset failed");
+  if (zero_async(st, sizeof(TopkState), stream) != GEOTR_OK) return GEOTR_E_LAUNCH;
   const int64_t total = n * m;
   const unsigned blocks = (unsigned)std::min<int64_t>((total + kTopkChunk - 1) / kTopkChunk, 256);
   SpmBatch sb;

@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
 // N1 grid subsampling
 // ================================================================================================
 constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr unsigned long long kKeyFlip = 1ull << 63;  // table keys = voxel key ^ kKeyFlip (see gs_insert_kernel)
 
 // Table words that other lanes update with global atomics (performed at L2) inside the same launch are
 // read back with agent-scope relaxed loads (sc1: served by L2), never through a possibly stale L1 line.
@@ -488,10 +489,16 @@ __global__ void gs_insert_kernel(const float* __restrict__ pts, int64_t n, int b
   const int b = gs_cloud_of_point(L.hdr, batch, i);
   const GsCloud g = L.hdr[b];
   const float* p = pts + 3 * i;
-  const unsigned long long ix = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(p[0], g.org[0]), voxel));
-  const unsigned long long iy = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(p[1], g.org[1]), voxel));
-  const unsigned long long iz = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(p[2], g.org[2]), voxel));
-  const unsigned long long key = ix + g.nx * iy + g.nxy * iz;
+  // (size_t)floor(x) as the reference's x86-64 build evaluates it (grid_subsampling_cpu.cpp:32-34): origin = floor(min * inv) * v can
+  // round to slightly ABOVE min, so a point on the low face gets floor(...) = -1, and cvttss2si + reinterpretation turns that into
+  // 2^64 - 1 -- a voxel of its own whose key wraps modulo 2^64 (observed on the reference's own demo pair, whose 1 mm-grid
+  // coordinates sit exactly on voxel faces).  The GPU's float -> unsigned conversion saturates negatives to 0 instead, so the
+  // conversion goes through a signed 64-bit integer here.  Keys are stored in the table with the top bit flipped so that the
+  // empty-slot sentinel (~0) cannot collide with such a wrapped key (-1 + 0 + 0); vkey gets the true key back.
+  const unsigned long long ix = (unsigned long long)(long long)floorf(__fdiv_rn(__fsub_rn(p[0], g.org[0]), voxel));
+  const unsigned long long iy = (unsigned long long)(long long)floorf(__fdiv_rn(__fsub_rn(p[1], g.org[1]), voxel));
+  const unsigned long long iz = (unsigned long long)(long long)floorf(__fdiv_rn(__fsub_rn(p[2], g.org[2]), voxel));
+  const unsigned long long key = (ix + g.nx * iy + g.nxy * iz) ^ kKeyFlip;
   const unsigned long long size = 2ull * (unsigned long long)g.len;
   unsigned long long slot = ((key * 0x9E3779B97F4A7C15ull) >> 24) % size;
   const unsigned long long base = 2ull * (unsigned long long)g.start;
@@ -587,7 +594,7 @@ __global__ void gs_bary_kernel(const float* __restrict__ pts, int64_t n, int bat
   o[0] = __fmul_rn(sx, w);
   o[1] = __fmul_rn(sy, w);
   o[2] = __fmul_rn(sz, w);
-  L.vkey[g.start + r] = L.keys[slot];
+  L.vkey[g.start + r] = L.keys[slot] ^ kKeyFlip;
 }
 
 // one block per cloud: replay of the libstdc++ hashtable order.
@@ -699,8 +706,7 @@ int geotr_radius_grid_build(const float* s_points, const int64_t* s_len, int64_t
   GridLayout L = grid_layout(grid_ws, ns, batch);
   if (grid_ws_bytes < L.bytes)
     return fail(GEOTR_E_WORKSPACE, "radius_grid_build: workspace %zu < required %zu", grid_ws_bytes, L.bytes);
-  if (hipMemsetAsync(L.cell_cnt, 0, sizeof(int) * (size_t)L.cells, stream) != hipSuccess)
-    return fail(GEOTR_E_LAUNCH, "radius_grid_build: memset failed");
+  if (zero_async(L.cell_cnt, sizeof(int) * (size_t)L.cells, stream) != GEOTR_OK) return GEOTR_E_LAUNCH;
   rg_bbox_kernel<<<dim3((unsigned)batch), dim3(1024), 0, stream>>>(s_points, s_len, (int)batch, radius,
                                                                     (int)L.cells_per_cloud, L.hdr);
   if (ns > 0) {

@@ -106,6 +106,43 @@ __global__ __launch_bounds__(256) void index_select_kernel(const char* __restric
   }
 }
 
+// ---- zero_async / copy_async: 16-byte lanes when both ends allow it, bytes otherwise -------------------------------------------
+__global__ __launch_bounds__(256) void fill_zero_kernel(unsigned char* __restrict__ p, size_t bytes, int vec) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  if (vec) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    for (size_t e = i; e < bytes / 16; e += stride) q[e] = make_uint4(0, 0, 0, 0);
+    for (size_t e = bytes / 16 * 16 + i; e < bytes; e += stride) p[e] = 0;
+  } else {
+    for (size_t e = i; e < bytes; e += stride) p[e] = 0;
+  }
+}
+__global__ __launch_bounds__(256) void copy_bytes_kernel(unsigned char* __restrict__ d, const unsigned char* __restrict__ s, size_t bytes, int vec) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  if (vec) {
+    for (size_t e = i; e < bytes / 16; e += stride) reinterpret_cast<uint4*>(d)[e] = reinterpret_cast<const uint4*>(s)[e];
+    for (size_t e = bytes / 16 * 16 + i; e < bytes; e += stride) d[e] = s[e];
+  } else {
+    for (size_t e = i; e < bytes; e += stride) d[e] = s[e];
+  }
+}
+
+int zero_async(void* p, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return GEOTR_OK;
+  const int vec = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  const size_t units = vec ? (bytes + 15) / 16 : bytes;
+  fill_zero_kernel<<<dim3((unsigned)std::min<size_t>((units + 255) / 256, 2048)), dim3(256), 0, stream>>>(reinterpret_cast<unsigned char*>(p), bytes, vec);
+  return hipGetLastError() == hipSuccess ? GEOTR_OK : fail(GEOTR_E_LAUNCH, "zero fill launch failed");
+}
+int copy_async(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return GEOTR_OK;
+  const int vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+  const size_t units = vec ? (bytes + 15) / 16 : bytes;
+  copy_bytes_kernel<<<dim3((unsigned)std::min<size_t>((units + 255) / 256, 4096)), dim3(256), 0, stream>>>(
+      reinterpret_cast<unsigned char*>(dst), reinterpret_cast<const unsigned char*>(src), bytes, vec);
+  return hipGetLastError() == hipSuccess ? GEOTR_OK : fail(GEOTR_E_LAUNCH, "copy launch failed");
+}
+
 }  // namespace geotr
 
 using namespace geotr;

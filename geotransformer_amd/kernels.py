@@ -135,6 +135,29 @@ def row_positive(feats):
     return flag
 
 
+KPCONV_FUSED = True  # layers whose shape geotr_kpconv_fused supports run as one kernel (no (M, 15 C) operand in HBM)
+
+
+def kpconv_fused_supported(c_in, c_out, h):
+    return bool(KPCONV_FUSED and GEMM_PACKED and _lib.load().geotr_kpconv_fused_supported(int(c_in), int(c_out), int(h)))
+
+
+def kpconv_fused(s_feats, q_points, s_points, neighbor_indices, kernel_points, sigma, packed, c_out, bias=None):
+    """Whole KPConv layer in one kernel (csrc/kpconv_fused.hip): -> (M, c_out).  `packed` = gemm_pack of the (15 C_in, c_out) weights."""
+    lib = _lib.load()
+    s_feats, q_points, s_points = _f32c(s_feats), _f32c(q_points), _f32c(s_points)
+    nb = neighbor_indices if neighbor_indices.is_contiguous() else neighbor_indices.contiguous()
+    assert nb.dtype == torch.int64
+    M, H = nb.shape
+    Ns, C = s_feats.shape
+    flag = row_positive(s_feats)
+    out = torch.empty((M, c_out), dtype=torch.float32, device=s_feats.device)
+    _lib.check(lib.geotr_kpconv_fused(_lib.ptr(s_feats), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(nb), _lib.ptr(_f32c(kernel_points)),
+                                      _lib.ptr(flag), M, Ns, H, C, int(c_out), kernel_points.shape[0], float(sigma), _lib.ptr(packed),
+                                      _lib.ptr(bias), int(GEMM_PACKED == 'bf16'), _lib.ptr(out), _lib.stream_ptr()), 'geotr_kpconv_fused')
+    return out
+
+
 def kpconv_gather(s_feats, q_points, s_points, neighbor_indices, kernel_points, sigma):
     """-> weighted (M, 15*C) fp32, nnum (M,) int32."""
     lib = _lib.load()

@@ -2,8 +2,9 @@
 
 Same constructor, parameters (`weights`, `bias`), buffer (`kernel_points`), initialisation order and forward
 signature as the reference, so reference checkpoints load unchanged and a model built under the same seeds has
-identical weights.  forward = geotr_kpconv_gather (gather + kernel-point influences + weighted sums) followed by
-one MFMA GEMM (M, 15*C_in) x (15*C_in, C_out) with the neighbour-count division and bias fused in its epilogue.
+identical weights.  forward = ONE kernel for the mid-width layers (geotr_kpconv_fused: influences + neighbour contraction on the
+fp32 matrix pipe into LDS, kernel-point contraction on the bf16 matrix pipe, count division + bias), else geotr_kpconv_gather
+followed by one MFMA GEMM (M, 15*C_in) x (15*C_in, C_out) with the neighbour-count division and bias fused in its epilogue.
 """
 import math
 
@@ -44,6 +45,11 @@ class KPConv(nn.Module):
 
     def forward(self, s_feats, q_points, s_points, neighbor_indices):
         """s_feats (N, C_in), q_points (M, 3), s_points (N, 3), neighbor_indices (M, H) int64 -> (M, C_out)."""
+        if (neighbor_indices.shape[0] >= kernels.PACKED_MIN_ROWS and
+                kernels.kpconv_fused_supported(self.in_channels, self.out_channels, neighbor_indices.shape[1])):
+            packed = kernels.gemm_pack(self.weights, b_is_kn=True, view=(self.kernel_size * self.in_channels, self.out_channels))
+            return kernels.kpconv_fused(s_feats, q_points, s_points, neighbor_indices, self.kernel_points, self.sigma, packed,
+                                        self.out_channels, bias=self.bias)
         weighted, nnum = kernels.kpconv_gather(s_feats, q_points, s_points, neighbor_indices, self.kernel_points, self.sigma)
         w2d = self.weights.view(self.kernel_size * self.in_channels, self.out_channels)  # (15*C_in, C_out), K-major
         if kernels.use_packed(weighted):  # same dispatch as the native executor

@@ -11,6 +11,9 @@ import torch
 
 from . import _lib, kernels
 
+import os
+
+_POISON = os.environ.get('GEOTR_POISON_WS') == '1'  # fill workspaces / output buffers with 0xFF before every forward (debug)
 MAX_STAGES = 5
 MAX_PAIRS = 16  # GEOTR_MAX_PAIRS
 P_F32 = ctypes.c_void_p
@@ -357,6 +360,10 @@ class NativeModel:
         if nbytes == 0:
             raise RuntimeError('geotr_model_workspace_bytes failed: ' + lib.geotr_last_error().decode('utf-8', 'replace'))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if _POISON:  # debugging aid: a kernel that reads workspace / output memory it never wrote then shows up as NaNs
+            ws.fill_(0xFF)
+            for t in o.values():
+                t.view(torch.uint8).fill_(0xFF)
         rc = lib.geotr_model_forward(ctypes.byref(desc), ctypes.byref(pyr), feats.data_ptr(), outs, ws.data_ptr(), nbytes,
                                      torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, 'geotr_model_forward')
@@ -436,8 +443,10 @@ class KernelProfiler:
 
     Events are created here, handed to the library as raw handles and recorded by the executor on the launch stream; the first
     `capacity` such launches after arming are recorded.  `results()` -> [(seconds, kind, work)]: kind 'gse' with work = number of
-    (i, j) superpoint pairs of the launch, or kind 'gemm' with work = (m, n, k)."""
+    (i, j) superpoint pairs of the launch, kind 'gemm' with work = (m, n, k), or kind 'kpconv' (a fused KPConv layer) with
+    work = (m, c_out, 15 c_in, h)."""
     GEMM_TAG = 1 << 62
+    KPCONV_TAG = 1 << 61
 
     def __init__(self, capacity):
         _bind()
@@ -466,6 +475,8 @@ class KernelProfiler:
             sec, tag = self.start[i].elapsed_time(self.stop[i]) * 1e-3, int(self._sizes[i])
             if tag & self.GEMM_TAG and tag > 0:
                 out.append((sec, 'gemm', ((tag >> 26) & 0xffffff, (tag >> 14) & 0xfff, tag & 0x3fff)))
+            elif tag & self.KPCONV_TAG and tag > 0:
+                out.append((sec, 'kpconv', ((tag >> 26) & 0xffffff, (tag >> 14) & 0xfff, tag & 0x3fff, (tag >> 50) & 0x7ff)))
             elif tag != 0:
                 out.append((sec, 'gse', tag * tag if tag > 0 else -tag))
         return out
@@ -497,6 +508,8 @@ def build_pyramid(points, lengths, num_stages, voxel_size, radius, neighbor_limi
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
     nbytes = lib.geotr_pyramid_workspace_bytes(n0, B, S)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if _POISON:
+        ws.fill_(0xFF)
     rc = lib.geotr_pyramid_build(points.data_ptr(), lengths.data_ptr(), B, n0, S, float(voxel_size), float(radius), limits,
                                  ctypes.byref(buf), host, overflow.data_ptr(), ws.data_ptr(), nbytes,
                                  torch.cuda.current_stream().cuda_stream)

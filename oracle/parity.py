@@ -35,13 +35,31 @@ def oracle_pair(cfg, state_dict, item, lib=None):
 
 
 def pyramid_identical(got, want):
-    """got: dict of lists of tensors / arrays (the HIP pyramid of ONE pair, reference format); want: oracle pyramid."""
-    for key in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling'):
+    """got: dict of lists of tensors / arrays (the HIP pyramid of ONE pair, reference format); want: oracle pyramid.
+    Points and lengths byte-identical; neighbour tables identical entry for entry.  The two sides may differ in WIDTH only: the
+    reference emits min(longest row, limit) columns (radius_search.py:24-27), the fixed-width device tables always `limit`;
+    the surplus columns must then hold nothing but the pad index (= the support cloud's point count)."""
+    def arr(t):
+        return np.ascontiguousarray(t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t))
+
+    for key in ('points', 'lengths'):
         if len(got[key]) != len(want[key]):
             return False
         for g, w in zip(got[key], want[key]):
-            g = g.detach().cpu().numpy() if torch.is_tensor(g) else np.asarray(g)
-            if g.shape != w.shape or np.ascontiguousarray(g).tobytes() != np.ascontiguousarray(w).tobytes():
+            g, w = arr(g), arr(w)
+            if g.shape != w.shape or g.tobytes() != w.tobytes():
+                return False
+    sizes = [arr(p).shape[0] for p in want['points']]
+    for key, support in (('neighbors', 0), ('subsampling', 0), ('upsampling', 1)):
+        if len(got[key]) != len(want[key]):
+            return False
+        for i, (g, w) in enumerate(zip(got[key], want[key])):
+            g, w = arr(g), arr(w)
+            if g.shape[0] != w.shape[0]:
+                return False
+            common = min(g.shape[1], w.shape[1])
+            pad = sizes[i + support]
+            if not (np.array_equal(g[:, :common], w[:, :common]) and (g[:, common:] == pad).all() and (w[:, common:] == pad).all()):
                 return False
     return True
 

@@ -70,6 +70,50 @@ def test_kpconv_layer_matches_oracle(C):
     assert _mse(got, want) <= 1e-8
 
 
+@pytest.mark.parametrize('C,CO,H', [(32, 32, 36), (64, 64, 36), (32, 64, 38), (64, 128, 24), (32, 128, 40), (64, 256, 33)])
+def test_kpconv_fused_matches_oracle_and_the_two_kernel_path(C, CO, H):
+    """geotr_kpconv_fused (one kernel: fp32-MFMA neighbour contraction into LDS + split-bf16 kernel-point contraction) vs the
+    oracle and vs gather -> packed GEMM, on a strided layer (queries = coarser cloud), with pad neighbours, rows of negative
+    feature sum (neighbour-count rule) and a row count that is not a multiple of the 32-point tile."""
+    from geotransformer_amd import kernels
+    from geotransformer_amd.modules.kpconv import KPConv
+    from oracle import model_oracle as mo
+    g = np.load('tests/golden/neighbors_3dmatch_small_s2.npz')
+    fine = torch.from_numpy(g['points1'])
+    nb_self = torch.from_numpy(g['neighbors1'].astype(np.int64))
+    reps = 1 + 1500 // fine.shape[0]
+    # tall enough for the packed / fused dispatch: the same cloud repeated with an index offset (a stack of identical pairs)
+    pts = torch.cat([fine + 10.0 * r for r in range(reps)])
+    n1 = fine.shape[0]
+    nb = torch.cat([torch.where(nb_self < n1, nb_self + r * n1, torch.full_like(nb_self, n1 * reps)) for r in range(reps)])
+    width = nb.shape[1]
+    nb = nb[:, :H].contiguous() if width >= H else torch.cat([nb, torch.full((nb.shape[0], H - width), n1 * reps)], 1).contiguous()
+    nb = nb[: nb.shape[0] - 5].contiguous()  # M not a multiple of 32, fewer queries than supports
+    q = pts[: nb.shape[0]].contiguous()
+    torch.manual_seed(C + CO)
+    np.random.seed(C + CO)
+    layer = KPConv(C, CO, 15, 0.125, 0.1, bias=True)
+    feats = torch.randn(pts.shape[0], C)
+    feats[::7] = -feats[::7].abs()
+    sd = {'x.' + k: v for k, v in layer.state_dict().items()}
+    want = mo.kpconv(sd, 'x.', feats, q, pts, nb, 0.1)
+    assert kernels.kpconv_fused_supported(C, CO, H) and nb.shape[0] >= kernels.PACKED_MIN_ROWS
+    layer = layer.cuda()
+    got = layer(feats.cuda(), q.cuda(), pts.cuda(), nb.cuda()).cpu()
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, **TOL), float((got - want).abs().max())
+    assert _mse(got, want) <= 1e-8
+    kernels.KPCONV_FUSED = False
+    try:
+        two = layer(feats.cuda(), q.cuda(), pts.cuda(), nb.cuda()).cpu()
+    finally:
+        kernels.KPCONV_FUSED = True
+    # same products (the neighbour contraction is bitwise the VALU kernel's fmaf chain), K summed in wave-split partials
+    assert float((got - two).abs().max()) <= 2e-5 * float(want.abs().max()), float((got - two).abs().max())
+    again = layer(feats.cuda(), q.cuda(), pts.cuda(), nb.cuda()).cpu()
+    assert torch.equal(got, again)
+
+
 def test_strided_kpconv_and_maxpool_and_upsample():
     from geotransformer_amd import kernels
     from oracle import model_oracle as mo

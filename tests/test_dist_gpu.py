@@ -64,9 +64,9 @@ try:
     t = torch.ones(4, device='cuda')
     dist.all_reduce(t)
     torch.cuda.synchronize()
-    print('TWO-RANKS-ONE-DEVICE-WORKED', float(t[0]))
+    print('TWO-RANKS-ONE-DEVICE-WORKED', float(t[0]), flush=True)
 except Exception as exc:  # RCCL: "Duplicate GPU detected"
-    print('TWO-RANKS-ONE-DEVICE-REFUSED', type(exc).__name__)
+    print('TWO-RANKS-ONE-DEVICE-REFUSED', type(exc).__name__, flush=True)
 os._exit(0)
 '''
 

@@ -80,6 +80,26 @@ def test_edge_cases_gpu():
     assert ext.radius_neighbors(s2[:1].contiguous(), s2, one, torch.tensor([2]), 0.5).tolist() == [[0]]
 
 
+def test_grid_subsample_points_below_the_rounded_origin(oracle_lib):
+    """origin = floor(min * inv) * v can round to slightly ABOVE min (e.g. min = 0.45, 0.65, 0.9 at v = 0.05): the reference then
+    evaluates (size_t)floor(-tiny) on x86-64 as 2^64 - 1 -- such points form voxels of their own whose keys wrap modulo 2^64
+    (found on the reference's demo pair: same barycentres, other hash order).  Values AND order must match the oracle, also for
+    the corner case key = -1 + 0 + 0 = 2^64 - 1 (the bit pattern of the table's empty-slot sentinel)."""
+    from geotransformer_amd import ext
+    rng = np.random.default_rng(12)
+    for lo in (0.45, 0.65, 0.9, 1.05, 2.35):
+        cloud = (rng.integers(0, 900, size=(6000, 3)) * 0.001 + lo).astype(np.float32)
+        cloud[:40] = np.float32(lo)                       # corner: all three indices negative
+        cloud[40:80, 0] = np.float32(lo)                  # low x face only
+        cloud[80:120, 1:] = np.float32(lo)                # low y and z faces: key = ix - nx - nx * ny (wraps)
+        cloud[120] = [lo, lo + 0.0005, lo + 0.0005]       # ix = -1, iy = iz = 0 when lo + 0.0005 is above the origin
+        lens = np.array([3500, 2500], dtype=np.int64)
+        want, wl = oracle_lib.grid_subsampling(cloud, lens, 0.05)
+        got, gl = ext.grid_subsampling(torch.from_numpy(cloud), torch.from_numpy(lens), 0.05)
+        assert gl.tolist() == wl.tolist(), lo
+        assert got.numpy().tobytes() == want.tobytes(), lo
+
+
 def test_full_size_3dmatch_pair_properties(oracle_lib):
     """BASELINE config 2 size (20k+20k points): GPU pyramid == oracle exactly, plus size-independent
     properties (sorted rows, self first, symmetry of the neighbour relation)."""
