@@ -21,7 +21,7 @@
 //            two-kernel path, streamed fragment by fragment from L2.  Waves split (column tile, K range); the K partials meet in
 //            LDS, the epilogue (/ count + bias) writes whole rows.
 // Supported: C_in in {32, 64} (the stage-0 .. 2 layers: three quarters of the backbone's KPConv work), C_out a multiple of 32 with
-// C_out / 32 dividing the wave count, H <= 64.  Everything else stays on the two-kernel path.
+// C_out / 32 dividing the wave count, H <= 40.  Everything else stays on the two-kernel path.
 #include "common.h"
 
 namespace geotr {
@@ -30,6 +30,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kFusedRows = 32;  // query points per workgroup tile = one 32-row MFMA tile
+constexpr int kMaxSteps = 10;   // neighbour steps of 4 held in registers: H <= 40 (every reference config: 24 .. 40)
 
 template <int V>
 struct FVec;
@@ -58,13 +59,13 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   unsigned short* A_hi = reinterpret_cast<unsigned short*>(fsm);
   unsigned short* A_lo = A_hi + kFusedRows * RS;
-  float4* relw_all = reinterpret_cast<float4*>(A_lo + kFusedRows * RS);  // [WAVES][64] (rel.xyz, neighbour index bits)
-  int* cnt_s = reinterpret_cast<int*>(relw_all + WAVES * 64);            // [32] neighbours with a positive feature sum
+  float4* relw_all = reinterpret_cast<float4*>(A_lo + kFusedRows * RS);  // [WAVES][2][64] (rel.xyz, neighbour index bits), two slots per wave
+  int* cnt_s = reinterpret_cast<int*>(relw_all + WAVES * 128);           // [32] neighbours with a positive feature sum
   float* part = reinterpret_cast<float*>(fsm);                           // [WAVES][16][64] K partials (reuses the A tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, q4 = lane >> 4;
-  float4* relw = relw_all + wave * 64;
+  float4* relw = relw_all + wave * 128;
   const float inv_sigma = 1.f / sigma;
   // the lane's kernel point (row of the phase-1 A operand); row 15 is padding
   const bool kp_ok = n16 < 15;
@@ -80,67 +81,70 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   const int64_t tiles = (M + kFusedRows - 1) / kFusedRows;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t m0 = tile * kFusedRows;
-    // ------------------------------------------------------------------ phase 1: g = w . f per point
-    for (int i = 0; i < PPW; ++i) {
-      const int row = wave * PPW + i;
-      const int64_t m = m0 + row;
-      if (m >= M) break;  // wave-uniform; the rows past M are never stored
-      {
-        float4 rv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        bool counted = false;
-        if (lane < H) {
-          const int64_t j = nb[m * H + lane];
-          if (j < Ns) {
-            rv.x = sp[3 * j] - qp[3 * m], rv.y = sp[3 * j + 1] - qp[3 * m + 1], rv.z = sp[3 * j + 2] - qp[3 * m + 2];
-            rv.w = __int_as_float((int)j);
-            counted = pos[j] != 0;
-          }
-        }
-        relw[lane] = rv;
-        const unsigned long long b = __ballot(counted);
-        if (lane == 0) cnt_s[row] = __popcll(b);
+    // ------------------------------------------------------------------ phase 1: g = w . f per point, software-pipelined over the wave's points
+    // Three dependent global round trips lead to a point's first MFMA (neighbour index -> support position -> feature row); done
+    // one point after the other they cost ~2 us each and the kernel was latency-bound at 3.7x its matrix-pipe time.  Pipeline:
+    //   stage A1(i)  load the neighbour index               stage A2(i)  load position + flag, write (rel, index) to LDS slot i & 1
+    //   stage B1(i)  influences + feature loads (registers)  stage B2(i)  MFMAs, split, A-tile stores
+    // iteration i runs A2(i+1), A1(i+2), B1(i+1) BEFORE B2(i): the loads of the next point are in flight under this point's MFMAs.
+    // Rows past M are computed on a clamped index and never stored.
+    auto stage_a1 = [&](int i) -> int64_t {  // -> the lane's neighbour index of the wave's i-th point (lanes >= H: pad)
+      const int64_t m = min(m0 + wave * PPW + i, M - 1);
+      return lane < H ? nb[m * H + lane] : Ns;
+    };
+    auto stage_a2 = [&](int i, int64_t j) {
+      const int64_t m = min(m0 + wave * PPW + i, M - 1);
+      float4 rv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+      bool counted = false;
+      if (j < Ns) {
+        rv.x = sp[3 * j] - qp[3 * m], rv.y = sp[3 * j + 1] - qp[3 * m + 1], rv.z = sp[3 * j + 2] - qp[3 * m + 2];
+        rv.w = __int_as_float((int)j);
+        counted = pos[j] != 0;
       }
+      relw[(i & 1) * 64 + lane] = rv;
+      const unsigned long long bal = __ballot(counted);
+      if (lane == 0) cnt_s[wave * PPW + i] = __popcll(bal);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    float a_cur[kMaxSteps], a_nxt[kMaxSteps];
+    float b_cur[kMaxSteps][G][VEC], b_nxt[kMaxSteps][G][VEC];
+    auto stage_b1 = [&](int i, float (&a)[kMaxSteps], float (&b)[kMaxSteps][G][VEC]) {
+#pragma unroll
+      for (int u = 0; u < kMaxSteps; ++u) {
+        const float4 rv = relw[(i & 1) * 64 + ((4 * u + q4) & 63)];  // lanes >= H of the slot hold index -1
+        const int id = __float_as_int(rv.w);
+        const bool ok = u < steps && id >= 0;
+        a[u] = 0.f;
+        if (ok && kp_ok) {
+          const float dx = rv.x - kx, dy = rv.y - ky, dz = rv.z - kz;
+          a[u] = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);  // as kpconv_gather_kernel
+        }
+        const float* fr = feats + (int64_t)(ok ? id : 0) * C + VEC * n16;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const typename FVec<VEC>::T v = *reinterpret_cast<const typename FVec<VEC>::T*>(fr + 16 * VEC * g);
+          const float* vf = reinterpret_cast<const float*>(&v);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) b[u][g][j] = ok ? vf[j] : 0.f;
+        }
+      }
+    };
+    auto stage_b2 = [&](int i, const float (&a)[kMaxSteps], const float (&b)[kMaxSteps][G][VEC]) {
       f32x4 acc[G][VEC];
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[g][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // neighbour steps in chunks of kChunk: all of a chunk's feature loads are issued before its first MFMA (memory-level
-      // parallelism instead of one dependent L2 round trip per step)
-      constexpr int kChunk = 5;
-      for (int s0 = 0; s0 < steps; s0 += kChunk) {
-        float a[kChunk], b[kChunk][G][VEC];
 #pragma unroll
-        for (int u = 0; u < kChunk; ++u) {
-          const int s = s0 + u;
-          const float4 rv = relw[(4 * s + q4) & 63];  // lanes >= H of the row hold index -1
-          const int id = __float_as_int(rv.w);
-          const bool ok = s < steps && id >= 0;
-          a[u] = 0.f;
-          if (ok && kp_ok) {
-            const float dx = rv.x - kx, dy = rv.y - ky, dz = rv.z - kz;
-            a[u] = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);  // as kpconv_gather_kernel
-          }
-          const float* fr = feats + (int64_t)(ok ? id : 0) * C + VEC * n16;
+      for (int u = 0; u < kMaxSteps; ++u)  // steps past `steps` multiply zeros (their operands are 0): the order of the sum over h is kept
 #pragma unroll
-          for (int g = 0; g < G; ++g) {
-            const typename FVec<VEC>::T v = *reinterpret_cast<const typename FVec<VEC>::T*>(fr + 16 * VEC * g);
-            const float* vf = reinterpret_cast<const float*>(&v);
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) b[u][g][j] = ok ? vf[j] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kChunk; ++u)
-#pragma unroll
-          for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][g][j], acc[g][j], 0, 0, 0);
-      }
+          for (int j = 0; j < VEC; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][g][j], acc[g][j], 0, 0, 0);
       // accumulator (16 kernel points x 16 columns per tile): lane holds rows 4 q4 + r, column n16 -> A[row][k C + channel]
+      const int row = wave * PPW + i;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kpt = 4 * q4 + r;
@@ -164,7 +168,23 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
           }
         }
       }
-      __builtin_amdgcn_wave_barrier();  // relw is rewritten for the wave's next point
+    };
+    {
+      int64_t j_next = stage_a1(0);
+      stage_a2(0, j_next);
+      j_next = stage_a1(1 < PPW ? 1 : 0);
+      stage_b1(0, a_cur, b_cur);
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        if (i + 1 < PPW) {
+          stage_a2(i + 1, j_next);
+          if (i + 2 < PPW) j_next = stage_a1(i + 2);
+          if (i & 1) stage_b1(i + 1, a_cur, b_cur);
+          else stage_b1(i + 1, a_nxt, b_nxt);
+        }
+        if (i & 1) stage_b2(i, a_nxt, b_nxt);
+        else stage_b2(i, a_cur, b_cur);
+      }
     }
     __syncthreads();  // A tile complete
     // ------------------------------------------------------------------ phase 2: out = A . W  (this wave: column tile ct, steps kk0 .. kk1)
@@ -219,7 +239,7 @@ using namespace geotr;
 extern "C" {
 
 int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h) {
-  if (!(c_in == 32 || c_in == 64) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 64) return 0;
+  if (!(c_in == 32 || c_in == 64) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 4 * kMaxSteps) return 0;
   const int waves = c_in == 32 ? 4 : 8;
   const int64_t ct = c_out / 32;
   return ct <= waves && waves % ct == 0;
@@ -243,7 +263,7 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
   const unsigned short* blo = bhi + np_pad * kp_pad;
   const int KS = (int)(kp_pad / 16), NT = (int)(np_pad / 32);
   const int waves = c_in == 32 ? 4 : 8;
-  const size_t lds = (size_t)2 * kFusedRows * (kdim + 8) * 2 + (size_t)waves * 64 * 16 + 32 * 4;
+  const size_t lds = (size_t)2 * kFusedRows * (kdim + 8) * 2 + (size_t)waves * 128 * 16 + 32 * 4;
   const int64_t tiles = (m + kFusedRows - 1) / kFusedRows;
   const unsigned grid = (unsigned)std::min<int64_t>(tiles, 256 * (c_in == 32 ? 8 : 4));
 #define GEOTR_KPF(CC, WW, TT)                                                                                                      \

@@ -45,8 +45,7 @@ class KPConv(nn.Module):
 
     def forward(self, s_feats, q_points, s_points, neighbor_indices):
         """s_feats (N, C_in), q_points (M, 3), s_points (N, 3), neighbor_indices (M, H) int64 -> (M, C_out)."""
-        if (neighbor_indices.shape[0] >= kernels.PACKED_MIN_ROWS and
-                kernels.kpconv_fused_supported(self.in_channels, self.out_channels, neighbor_indices.shape[1])):
+        if kernels.kpconv_fused_supported(self.in_channels, self.out_channels, neighbor_indices.shape[1]):  # as the native executor
             packed = kernels.gemm_pack(self.weights, b_is_kn=True, view=(self.kernel_size * self.in_channels, self.out_channels))
             return kernels.kpconv_fused(s_feats, q_points, s_points, neighbor_indices, self.kernel_points, self.sigma, packed,
                                         self.out_channels, bias=self.bias)

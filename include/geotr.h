@@ -170,7 +170,7 @@ int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* packed, floa
  * and the neighbour contraction on the fp32 matrix pipe into an LDS tile, the kernel-point contraction on the bf16 matrix pipe against
  * `packed` = geotr_gemm_pack(weights viewed (15 c_in, c_out), b_is_kn = 1), epilogue / max(count, 1) + bias (kpconv/kpconv.py:79-121).
  * pos_flag (ns) as for geotr_kpconv_gather (required).  Shapes: geotr_kpconv_fused_supported(c_in, c_out, h) -- c_in in {32, 64},
- * c_out a multiple of 32 (<= 128 / 256), h <= 64; other layers use the two-kernel path.  bf16_operands as geotr_gemm_packed_splitk. */
+ * c_out a multiple of 32 (<= 128 / 256), h <= 40; other layers use the two-kernel path.  bf16_operands as geotr_gemm_packed_splitk. */
 int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h);
 int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
                        const float* kernel_points, const uint8_t* pos_flag, int64_t m, int64_t ns, int64_t h, int64_t c_in, int64_t c_out,

@@ -63,7 +63,7 @@ def test_stacked_pairs_match_single_pair_runs():
             assert torch.equal(w[k], g[k]), k
         for k in ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f'):
             assert w[k].shape == g[k].shape
-            assert float((w[k] - g[k]).abs().max()) <= 2e-5, (k, float((w[k] - g[k]).abs().max()))
+            assert float((w[k] - g[k]).abs().max()) <= 5e-5, (k, float((w[k] - g[k]).abs().max()))  # other tilings / K splits: fp32 rounding
         # the discrete stages may flip on near-ties when the GEMM tiling differs; with equal selections the rest must agree
         if torch.equal(w['ref_node_corr_indices'], g['ref_node_corr_indices']) and torch.equal(w['src_node_corr_indices'], g['src_node_corr_indices']):
             assert torch.allclose(w['matching_scores'], g['matching_scores'], atol=1e-3, rtol=1e-3)
