@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
           const float dx = rv.x - kx, dy = rv.y - ky, dz = rv.z - kz;
           a[u] = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);  // as kpconv_gather_kernel
         }
-        const float* fr = feats + (int64_t)(ok ? id : 0) * C + VEC * n16;
+        const float* fr = feats + (unsigned)((ok ? id : 0) * C + VEC * n16);  // < 2^31 elements (checked by the host)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const typename FVec<VEC>::T v = *reinterpret_cast<const typename FVec<VEC>::T*>(fr + 16 * VEC * g);
@@ -153,10 +153,12 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
         for (int g = 0; g < G; ++g) {
           unsigned h[VEC], l[VEC];
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
+          for (int j = 0; j < VEC; ++j) {  // hi = bf16(x), lo = bf16(x - hi), round to nearest even (v_cvt_pk_bf16_f32, as gemm.hip)
             const float x = acc[g][j][r];
-            h[j] = f32_to_bf16_rne(x);
-            l[j] = f32_to_bf16_rne(x - bf16_to_f32(h[j]));
+            const __bf16 hb = (__bf16)x;
+            const __bf16 lb = (__bf16)(x - (float)hb);
+            h[j] = (unsigned)__builtin_bit_cast(unsigned short, hb);
+            l[j] = (unsigned)__builtin_bit_cast(unsigned short, lb);
           }
           const int e = row * RS + kpt * C + 16 * VEC * g + VEC * n16;  // VEC consecutive bf16: 4- or 8-byte aligned
           if constexpr (VEC == 2) {
@@ -240,7 +242,7 @@ extern "C" {
 
 int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h) {
   if (!(c_in == 32 || c_in == 64) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 4 * kMaxSteps) return 0;
-  const int waves = c_in == 32 ? 4 : 8;
+  const int waves = 8;
   const int64_t ct = c_out / 32;
   return ct <= waves && waves % ct == 0;
 }
@@ -257,15 +259,16 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
   GEOTR_CHECK_ARG(s_feats && q_points && s_points && neighbors && kernel_points && pos_flag && packed && out, "kpconv_fused: null pointer");
   GEOTR_CHECK_ARG((reinterpret_cast<uintptr_t>(s_feats) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed) & 15) == 0,
                   "kpconv_fused: features and packed weights must be 16-byte aligned");
+  GEOTR_CHECK_ARG(ns * c_in < (1ll << 31), "kpconv_fused: more than 2^31 feature elements");
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t kdim = 15 * c_in, kp_pad = pad32(kdim), np_pad = pad32(c_out);
   const unsigned short* bhi = reinterpret_cast<const unsigned short*>(packed);
   const unsigned short* blo = bhi + np_pad * kp_pad;
   const int KS = (int)(kp_pad / 16), NT = (int)(np_pad / 32);
-  const int waves = c_in == 32 ? 4 : 8;
+  const int waves = 8;
   const size_t lds = (size_t)2 * kFusedRows * (kdim + 8) * 2 + (size_t)waves * 128 * 16 + 32 * 4;
   const int64_t tiles = (m + kFusedRows - 1) / kFusedRows;
-  const unsigned grid = (unsigned)std::min<int64_t>(tiles, 256 * (c_in == 32 ? 8 : 4));
+  const unsigned grid = (unsigned)std::min<int64_t>(tiles, 256 * (c_in == 32 ? 8 : 4));  // persistent: a few tiles per resident workgroup
 #define GEOTR_KPF(CC, WW, TT)                                                                                                      \
   do {                                                                                                                             \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<CC, WW, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -275,9 +278,9 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
                                                                                pos_flag, m, ns, (int)h, sigma, (int)c_out, KS, NT, bhi, \
                                                                                blo, bias, out);                                    \
   } while (0)
-  if (c_in == 32) {
-    if (bf16_operands) GEOTR_KPF(32, 4, 1);
-    else GEOTR_KPF(32, 4, 3);
+  if (c_in == 32) {  // 8 waves in both widths: two resident workgroups at c_in = 32 give 4 waves per SIMD, the LDS tile allows no more
+    if (bf16_operands) GEOTR_KPF(32, 8, 1);
+    else GEOTR_KPF(32, 8, 3);
   } else {
     if (bf16_operands) GEOTR_KPF(64, 8, 1);
     else GEOTR_KPF(64, 8, 3);

@@ -1,17 +1,35 @@
 #!/bin/bash
-# Round artifacts on the GPU box: bench line (with CPU baseline), rocprofv3 kernel stats of the same command, PMC passes.
-# usage (from the repo root, via gpurun): bash scripts/refresh_artifacts.sh r01
+# Round artifacts on the GPU box: full GPU suite, bench line (with CPU baseline + parity), rocprofv3 kernel stats of the same
+# command (4 lanes and 1 lane), PMC passes (HBM traffic), A/B runs of the round's switches.
+# usage (from the repo root, via gpurun): bash scripts/refresh_artifacts.sh r02
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/artifacts_$TAG
 mkdir -p $OUT
+cd $ROOT
+timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 > $OUT/gputests.log 2>&1
+echo "pytest rc=$?" >> $OUT/gputests.log
+tail -4 $OUT/gputests.log
 cd /tmp && export TMPDIR=/tmp
-python $ROOT/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>/dev/null
+timeout 600 python $ROOT/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+echo "bench rc=$?"; head -c 200 $OUT/bench_n1.json; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode > $OUT/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_l1 -o bench -- python $ROOT/bench.py --steps 6 --warmup 2 --lanes 1 --no-cpu-baseline --no-fp32-mode > $OUT/bench_l1_under_rocprof.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --lanes 1 --batch 8 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --lanes 1 --batch 8 --no-cpu-baseline --no-fp32-mode > /dev/null 2>&1
 done
 python $ROOT/scripts/pmc_summary.py $OUT $OUT/pmc_hbm_traffic.md $OUT/pmc_hbm_traffic.json "python bench.py --steps 2 --warmup 1 --lanes 1 --batch 8"
-ls -la $OUT $OUT/stats | head -30
-tail -c 600 $OUT/bench_n1.json
+ab() { name=$1; shift; timeout 300 env "$@" python $ROOT/bench.py --no-cpu-baseline --no-fp32-mode ${EXTRA:-} > $OUT/ab_$name.json 2> $OUT/ab_$name.err; python -c "
+import json
+try:
+    d=json.load(open('$OUT/ab_$name.json')); print('$name', d['value'], 'pairs/s', d['ms_per_step'],'ms/step')
+except Exception as e: print('$name FAILED', e)" | tee -a $OUT/ab_runs.txt; }
+EXTRA="" ab default X=1
+EXTRA="" ab two_kernel_kpconv GEOTR_KPCONV_FUSED=0
+EXTRA="--gse mfma" ab gse_mfma_kernel X=1
+EXTRA="" ab no_split_k GEOTR_SPLITK=0
+EXTRA="--lanes 1" ab one_lane X=1
+EXTRA="--lanes 2" ab two_lanes X=1
+EXTRA="--lanes 6" ab six_lanes X=1
+ls -la $OUT | head -40
