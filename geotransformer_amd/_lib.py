@@ -34,6 +34,7 @@ SIGNATURES = {
     'geotr_kpconv_gather': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
                                     c_ptr, c_ptr, c_ptr]),
     'geotr_kpconv_fused_supported': (c_int, [c_i64, c_i64, c_i64]),
+    'geotr_kpconv_c1_fused': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     'geotr_kpconv_fused': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr, c_ptr,
                                    c_int, c_ptr, c_ptr]),
     'geotr_maxpool': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr]),

@@ -163,6 +163,17 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     const char* e = std::getenv("GEOTR_KPCONV_FUSED");  // A/B switch for measurements: GEOTR_KPCONV_FUSED=0 keeps the two-kernel path
     return !(e && e[0] == '0');
   }();
+  static const bool c1_fused_enabled = [] {
+    const char* e = std::getenv("GEOTR_KPCONV_C1_FUSED");  // A/B switch of the first-layer kernel alone
+    return !(e && e[0] == '0');
+  }();
+  if (fused_enabled && c1_fused_enabled && kp.in == 1 && kp.num_kernel_points == 15 && h <= 64) {  // first layer: exact fp32, bitwise the two-kernel result
+    if (c.live())
+      c.check(geotr_kpconv_c1_fused(s_feats, q_pts, s_pts, nb, kp.kernel_points, m, ns, h, kp.out, kp.num_kernel_points, kp.sigma, kp.weights,
+                                    kp.bias, out, c.stream));
+    c.release(mk);
+    return out;
+  }
   if (fused_enabled && kp.packed && flag && kp.num_kernel_points == 15 && geotr_kpconv_fused_supported(kp.in, kp.out, h) &&
       (reinterpret_cast<uintptr_t>(s_feats) & 15) == 0) {
     if (c.live()) {
@@ -788,13 +799,16 @@ int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t bat
     r *= 2.0f;
   }
   r = radius;
+  // Row capacity of the fixed-width searches: after grid subsampling a ball of 2.5 voxels holds at most the voxels within
+  // 2.5 + sqrt(3) voxel sizes of its centre (~320), so 512 cannot overflow from stage 1 on; stage 0 (raw input) raises if it does.
+  const int64_t kRowCap = 512;
   for (int i = 0; i < S; ++i) {
-    int rc = geotr_radius_query(grids[i], n[i], pts[i], len[i], batch, n[i], r, limits_host[i], 0, buf->neighbors[i], overflow, stream);
+    int rc = geotr_radius_query(grids[i], n[i], pts[i], len[i], batch, n[i], r, limits_host[i], kRowCap, buf->neighbors[i], overflow, stream);
     if (rc != GEOTR_OK) return rc;
     if (i < S - 1) {
-      rc = geotr_radius_query(grids[i], n[i], pts[i + 1], len[i + 1], batch, n[i + 1], r, limits_host[i], 0, buf->subsampling[i], overflow, stream);
+      rc = geotr_radius_query(grids[i], n[i], pts[i + 1], len[i + 1], batch, n[i + 1], r, limits_host[i], kRowCap, buf->subsampling[i], overflow, stream);
       if (rc != GEOTR_OK) return rc;
-      rc = geotr_radius_query(grids[i + 1], n[i + 1], pts[i], len[i], batch, n[i], 2.0f * r, limits_host[i + 1], 0, buf->upsampling[i], overflow,
+      rc = geotr_radius_query(grids[i + 1], n[i + 1], pts[i], len[i], batch, n[i], 2.0f * r, limits_host[i + 1], kRowCap, buf->upsampling[i], overflow,
                               stream);
       if (rc != GEOTR_OK) return rc;
     }

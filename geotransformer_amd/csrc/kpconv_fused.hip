@@ -232,6 +232,88 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   }
 }
 
+// ---- first layer (C_in = 1, kpconv.py:79-121 with a one-channel feature): the whole layer per point is 15 influence-weighted sums
+// and a 15 x C_out product.  The two-kernel path ran a 16-lanes-per-point gather whose inner loop waited on two dependent global loads
+// per neighbour, wrote (M, 15) to HBM and launched an exact-fp32 GEMM over it.  Here a wave takes 4 points at a time:
+//   (1) all 4 H neighbour records (relative position, feature) are loaded with lanes <-> neighbours and parked in LDS;
+//   (2) lanes <-> (point, kernel point): g[p][k] = sum_h w f as an fmaf chain over h in order (bitwise the gather kernel's sum);
+//   (3) lanes <-> output channels: out[c] = (sum_k g[k] W[k][c] as an fmaf chain over k in order -- bitwise the fp32 MFMA GEMM's)
+//       / max(#positive neighbours, 1) + bias, one coalesced row store per point.
+constexpr int kC1Points = 4;  // points per wave iteration (16 lanes each in step 2)
+__global__ __launch_bounds__(256) void kpconv_c1_fused_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
+                                                              const float* __restrict__ sp, const int64_t* __restrict__ nb,
+                                                              const float* __restrict__ kp, int64_t M, int64_t Ns, int H, float sigma,
+                                                              const float* __restrict__ W, const float* __restrict__ bias, int c_out,
+                                                              float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char c1sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int recs = kC1Points * H;                                   // <= 256
+  float4* rec = reinterpret_cast<float4*>(c1sm) + wave * (256 + 16 + 4);  // [recs] (relative position, feature)
+  float* g_s = reinterpret_cast<float*>(rec + 256);                 // [4][16] weighted sums
+  int* cnt_s = reinterpret_cast<int*>(g_s + 64);                    // [4] positive-feature neighbour counts
+  const float inv_sigma = 1.f / sigma;
+  const int p16 = lane >> 4, k16 = lane & 15;
+  const bool is_kp = k16 < 15;
+  const float kx = is_kp ? kp[3 * k16] : 0.f, ky = is_kp ? kp[3 * k16 + 1] : 0.f, kz = is_kp ? kp[3 * k16 + 2] : 0.f;
+  const int64_t groups = (M + kC1Points - 1) / kC1Points;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t m0 = grp * kC1Points;
+    // (1) neighbour records; an absent neighbour (pad index, or a point past M) is marked by an infinite x offset
+    for (int e = lane; e < recs; e += 64) {
+      const int p = e / H, h = e - p * H;
+      const int64_t m = m0 + p;
+      float4 r = make_float4(__int_as_float(0x7f800000), 0.f, 0.f, 0.f);
+      if (m < M) {
+        const int64_t j = nb[m * H + h];
+        if (j < Ns) {
+          r.x = sp[3 * j] - qp[3 * m], r.y = sp[3 * j + 1] - qp[3 * m + 1], r.z = sp[3 * j + 2] - qp[3 * m + 2];
+          r.w = feats[j];
+        }
+      }
+      rec[e] = r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (2) lane (p16, k16): kernel point k16 of point p16; lane k16 == 15 counts the neighbours with a positive feature instead
+    {
+      float acc = 0.f;
+      int cnt = 0;
+      const float4* rp = rec + p16 * H;
+      for (int h = 0; h < H; ++h) {
+        const float4 r = rp[h];
+        if (r.x == __int_as_float(0x7f800000)) continue;  // absent: skipped as in the gather kernel, the order of the others is kept
+        cnt += r.w > 0.f;
+        const float dx = r.x - kx, dy = r.y - ky, dz = r.z - kz;
+        const float w = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);
+        acc = fmaf(w, r.w, acc);
+      }
+      if (is_kp) g_s[p16 * 16 + k16] = acc;
+      else cnt_s[p16] = cnt;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (3) lanes <-> output channels
+    for (int c = lane; c < c_out; c += 64) {
+      float wk[15];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) wk[k] = W[k * c_out + c];
+      const float b = bias ? bias[c] : 0.f;
+#pragma unroll
+      for (int p = 0; p < kC1Points; ++p) {
+        const int64_t m = m0 + p;
+        if (m >= M) break;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) v = fmaf(g_s[p * 16 + k], wk[k], v);
+        out[m * c_out + c] = v / (float)max(cnt_s[p], 1) + b;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 static inline int64_t pad32(int64_t x) { return (x + 31) / 32 * 32; }
 
 }  // namespace geotr
@@ -245,6 +327,22 @@ int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h) {
   const int waves = 8;
   const int64_t ct = c_out / 32;
   return ct <= waves && waves % ct == 0;
+}
+
+int geotr_kpconv_c1_fused(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
+                          const float* kernel_points, int64_t m, int64_t ns, int64_t h, int64_t c_out, int64_t num_kernel_points, float sigma,
+                          const float* weights, const float* bias, float* out, void* stream_) {
+  GEOTR_CHECK_ARG(m >= 0 && ns >= 0 && h >= 1 && h <= 64 && c_out >= 1, "kpconv_c1_fused: bad sizes (h <= 64)");
+  GEOTR_CHECK_ARG(num_kernel_points == 15, "kpconv_c1_fused: only 15 kernel points are supported (got %lld)", (long long)num_kernel_points);
+  if (m == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(s_feats && q_points && s_points && neighbors && kernel_points && weights && out, "kpconv_c1_fused: null pointer");
+  const size_t lds = 4 * (256 + 16 + 4) * sizeof(float4);
+  const int64_t groups = (m + kC1Points - 1) / kC1Points;
+  const unsigned grid = (unsigned)std::min<int64_t>((groups + 3) / 4, 256 * 16);
+  kpconv_c1_fused_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream_>>>(s_feats, q_points, s_points, neighbors, kernel_points, m, ns, (int)h,
+                                                                             sigma, weights, bias, (int)c_out, out);
+  GEOTR_CHECK_LAUNCH("kpconv_c1_fused");
+  return GEOTR_OK;
 }
 
 int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,

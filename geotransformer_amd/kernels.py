@@ -158,6 +158,21 @@ def kpconv_fused(s_feats, q_points, s_points, neighbor_indices, kernel_points, s
     return out
 
 
+def kpconv_c1_fused(s_feats, q_points, s_points, neighbor_indices, kernel_points, sigma, weights, bias=None):
+    """First layer (C_in = 1) in one exact-fp32 kernel: weights (15, 1, c_out) -> (M, c_out)."""
+    lib = _lib.load()
+    s_feats, q_points, s_points, weights = _f32c(s_feats), _f32c(q_points), _f32c(s_points), _f32c(weights.detach())
+    nb = neighbor_indices if neighbor_indices.is_contiguous() else neighbor_indices.contiguous()
+    assert nb.dtype == torch.int64 and s_feats.shape[1] == 1
+    M, H = nb.shape
+    c_out = weights.shape[-1]
+    out = torch.empty((M, c_out), dtype=torch.float32, device=s_feats.device)
+    _lib.check(lib.geotr_kpconv_c1_fused(_lib.ptr(s_feats), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(nb), _lib.ptr(_f32c(kernel_points)),
+                                         M, s_feats.shape[0], H, c_out, kernel_points.shape[0], float(sigma), _lib.ptr(weights), _lib.ptr(bias),
+                                         _lib.ptr(out), _lib.stream_ptr()), 'geotr_kpconv_c1_fused')
+    return out
+
+
 def kpconv_gather(s_feats, q_points, s_points, neighbor_indices, kernel_points, sigma):
     """-> weighted (M, 15*C) fp32, nnum (M,) int32."""
     lib = _lib.load()

@@ -45,6 +45,9 @@ class KPConv(nn.Module):
 
     def forward(self, s_feats, q_points, s_points, neighbor_indices):
         """s_feats (N, C_in), q_points (M, 3), s_points (N, 3), neighbor_indices (M, H) int64 -> (M, C_out)."""
+        if self.in_channels == 1 and kernels.KPCONV_FUSED and self.kernel_size == 15 and neighbor_indices.shape[1] <= 64:
+            return kernels.kpconv_c1_fused(s_feats, q_points, s_points, neighbor_indices, self.kernel_points, self.sigma, self.weights,
+                                           bias=self.bias)
         if kernels.kpconv_fused_supported(self.in_channels, self.out_channels, neighbor_indices.shape[1]):  # as the native executor
             packed = kernels.gemm_pack(self.weights, b_is_kn=True, view=(self.kernel_size * self.in_channels, self.out_channels))
             return kernels.kpconv_fused(s_feats, q_points, s_points, neighbor_indices, self.kernel_points, self.sigma, packed,

@@ -172,6 +172,11 @@ int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* packed, floa
  * pos_flag (ns) as for geotr_kpconv_gather (required).  Shapes: geotr_kpconv_fused_supported(c_in, c_out, h) -- c_in in {32, 64},
  * c_out a multiple of 32 (<= 128 / 256), h <= 40; other layers use the two-kernel path.  bf16_operands as geotr_gemm_packed_splitk. */
 int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h);
+/* The first layer (c_in = 1: s_feats is (ns,)), whole layer in one kernel, exact fp32: weights (15, 1, c_out) row-major as the
+ * reference's parameter, h <= 64.  Bitwise the two-kernel path's result (the same fmaf chains over h and over k). */
+int geotr_kpconv_c1_fused(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
+                          const float* kernel_points, int64_t m, int64_t ns, int64_t h, int64_t c_out, int64_t num_kernel_points, float sigma,
+                          const float* weights, const float* bias, float* out, void* stream);
 int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
                        const float* kernel_points, const uint8_t* pos_flag, int64_t m, int64_t ns, int64_t h, int64_t c_in, int64_t c_out,
                        int64_t num_kernel_points, float sigma, const void* packed, const float* bias, int bf16_operands, float* out,

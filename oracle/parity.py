@@ -8,7 +8,8 @@ Tolerances (BASELINE.json north_star: neighbour indices bit-exact, feature MSE <
   coarse correspondences    a global top-k over nearly flat scores under random weights: reported as set overlap (>= 0.95); when
                             the selected SET is identical the patches are aligned pair by pair (equal scores may swap ranks) and
                             everything downstream is compared one to one
-  matching scores           |d| <= 5e-3 on patches whose point order is identical
+  matching scores           |d| <= 5e-3 on every patch holding the same point set (>= 75% of them; points re-aligned one to one
+                            when equal-to-rounding distances list them in another order)
   transform                 |d| <= 5e-3 per entry when the patch and point order is identical throughout (else reported only: equally
                             supported hypotheses are ranked by position); rotation / translation error always reported
 """
@@ -72,16 +73,27 @@ def rotation_translation_error(a, b):
     return float(np.degrees(np.arccos(np.clip(c, -1.0, 1.0)))), float(np.linalg.norm(a[:3, 3] - b[:3, 3]))
 
 
-def compare_pair(got, want):
-    """Returns a JSON-able report; report['ok'] is the verdict under the tolerances in this file's header."""
-    rep = {}
+def _same_points(g, w):
+    """g, w: (K, 3) patch points.  `take` with g[take] == w row for row when both hold the same multiset of points, else None."""
+    og, ow = np.lexsort(g.T[::-1]), np.lexsort(w.T[::-1])
+    if not np.array_equal(g[og], w[ow]):
+        return None
+    take = np.empty(len(ow), dtype=np.int64)
+    take[ow] = og
+    return take
+
+
+def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND):
+    """Returns a JSON-able report; report['ok'] is the verdict under the tolerances in this file's header.
+    `feature_mse_bound`: the default is for the fp32-grade modes; plain-bf16 operands are held to the north-star bound (1e-4)."""
+    rep = {'feature_mse_bound': feature_mse_bound}
     ok = True
     for k in ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f'):
         g, w = got[k].detach().cpu(), want[k]
         same_shape = tuple(g.shape) == tuple(w.shape)
         mse = float(((g - w) ** 2).mean()) if same_shape else float('inf')
         rep['mse_' + k] = mse
-        ok &= same_shape and mse <= FEATURE_MSE_BOUND
+        ok &= same_shape and mse <= feature_mse_bound
     gi = torch.stack([got['ref_node_corr_indices'].cpu(), got['src_node_corr_indices'].cpu()], 1)
     wi = torch.stack([want['ref_node_corr_indices'], want['src_node_corr_indices']], 1)
     gs, ws = {tuple(r) for r in gi.tolist()}, {tuple(r) for r in wi.tolist()}
@@ -97,15 +109,32 @@ def compare_pair(got, want):
         # oracle with the patch of the same (ref, src) pair here, then compare patch by patch
         where = {pair: i for i, pair in enumerate(map(tuple, gi.tolist()))}
         perm = torch.tensor([where[pair] for pair in map(tuple, wi.tolist())], dtype=torch.long)
-        g_ref, g_src = got['ref_node_corr_knn_points'].cpu()[perm], got['src_node_corr_knn_points'].cpu()[perm]
-        same = (torch.eq(g_ref, want['ref_node_corr_knn_points']).flatten(1).all(1) &
-                torch.eq(g_src, want['src_node_corr_knn_points']).flatten(1).all(1))
-        rep['patches_in_identical_point_order'] = float(same.float().mean())
-        gm, wm = got['matching_scores'].cpu()[perm][same], want['matching_scores'][same]
-        live = wm > -1e11  # masked entries are -1e12 + O(ulp(1e12)) noise in any implementation
-        masks_equal = bool(torch.equal(live, gm > -1e11))
-        rep['matching_scores_max_err'] = float((gm[live] - wm[live]).abs().max()) if masks_equal and bool(live.any()) else None
-        ok &= masks_equal and (rep['matching_scores_max_err'] or 0.0) <= SCORE_ATOL and rep['patches_in_identical_point_order'] >= 0.75
+        g_ref, g_src = got['ref_node_corr_knn_points'].cpu()[perm].numpy(), got['src_node_corr_knn_points'].cpu()[perm].numpy()
+        w_ref, w_src = want['ref_node_corr_knn_points'].numpy(), want['src_node_corr_knn_points'].numpy()
+        gm_all, wm_all = got['matching_scores'].cpu()[perm].numpy(), want['matching_scores'].numpy()
+        same_order = same_set = 0
+        masks_equal, worst = True, 0.0
+        for p in range(len(perm)):
+            # the K nearest points of a superpoint: squared distances that agree to rounding (|x|^2 + |y|^2 - 2xy at scene-scale
+            # coordinates) may list the same points in another order; align the patch point by point before comparing scores
+            tr, ts = _same_points(g_ref[p], w_ref[p]), _same_points(g_src[p], w_src[p])
+            if tr is None or ts is None:
+                continue
+            same_set += 1
+            same_order += int(np.array_equal(g_ref[p], w_ref[p]) and np.array_equal(g_src[p], w_src[p]))
+            if gm_all.shape[1] == len(tr) + 1:  # the slack row / column of the optimal-transport scores stays last
+                tr, ts = np.append(tr, len(tr)), np.append(ts, len(ts))
+            gm, wm = gm_all[p][tr][:, ts], wm_all[p]
+            live = wm > -1e11  # masked entries are -1e12 + O(ulp(1e12)) noise in any implementation
+            if not np.array_equal(live, gm > -1e11):
+                masks_equal = False
+            elif live.any():
+                worst = max(worst, float(np.abs(gm[live] - wm[live]).max()))
+        n_patch = max(len(perm), 1)
+        rep['patches_with_identical_point_set'] = same_set / n_patch
+        rep['patches_in_identical_point_order'] = same_order / n_patch
+        rep['matching_scores_max_err'] = worst if masks_equal and same_set else None
+        ok &= masks_equal and worst <= SCORE_ATOL and rep['patches_with_identical_point_set'] >= 0.75
         T, Tw = got['estimated_transform'].cpu().numpy(), want['estimated_transform'].numpy()
         rep['transform_max_abs_diff'] = float(np.abs(T - Tw).max())
         rep['rre_deg_vs_oracle'], rep['rte_m_vs_oracle'] = rotation_translation_error(T, Tw)

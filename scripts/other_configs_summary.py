@@ -1,0 +1,34 @@
+"""Summarise the bench lines of the non-headline configurations (BASELINE configs[0], [3], [4]) into a profiles/ markdown table.
+usage: python scripts/other_configs_summary.py OUT.md name=path.json [name=path.json ...]"""
+import json
+import sys
+
+
+def main():
+    out, items = sys.argv[1], [a.split('=', 1) for a in sys.argv[2:]]
+    rows, details = [], []
+    for name, path in items:
+        try:
+            d = json.load(open(path))
+        except Exception as e:  # a failed run is part of the record
+            rows.append(f'| {name} | FAILED ({type(e).__name__}) | | | | | |')
+            continue
+        c, p, b = d['config'], d.get('parity') or {}, d.get('cpu_baseline') or {}
+        shape = f"{c['lanes_per_gpu']} x {c['pairs_stacked_per_launch_sequence']}"
+        mse = max((p.get(k) or 0.0) for k in ('mse_ref_feats_c', 'mse_src_feats_c', 'mse_ref_feats_f', 'mse_src_feats_f')) if p else None
+        rows.append(f"| {name} | {d['value']} | {d['ms_per_step']} | {shape} | {c['matrix_precision']} | "
+                    f"{'ok' if p.get('ok') else ('-' if not p else 'NOT ok')} (max feature MSE {mse:.2e}, bound {p.get('feature_mse_bound')}) | "
+                    f"{b.get('value', '-')} |" if p else
+                    f"| {name} | {d['value']} | {d['ms_per_step']} | {shape} | {c['matrix_precision']} | not run | - |")
+        details.append(f"### {name}\n\n`{c['workload']}`\n\n```json\n{json.dumps({'parity': p, 'cpu_baseline': b, 'roofline': {k: v for k, v in (d.get('roofline') or {}).items() if k in ('kernel', 'achieved', 'peak', 'frac', 'executed_tflops', 'avg_launch_us', 'launches')}}, indent=1)}\n```\n")
+    with open(out, 'w') as f:
+        f.write('# Round 2: the other BASELINE configurations through the same `bench.py` line\n\n'
+                'Each run: `python bench.py --config <name> [--precision bf16]` on one MI355X (synthetic pairs of the configuration\'s shape, '
+                'random weights); `parity` = pair 0 of the last timed step vs the CPU oracle (oracle/parity.py), `cpu` = the CPU baseline '
+                'of the same workload (pairs/s, collate + forward).  The headline metric is the default run (profiles/r02_bench_n1.json).\n\n'
+                '| run | pairs/s | ms/step | lanes x stacked pairs | matrix precision | parity | cpu pairs/s |\n|---|---|---|---|---|---|---|\n')
+        f.write('\n'.join(rows) + '\n\n' + '\n'.join(details))
+
+
+if __name__ == '__main__':
+    main()

@@ -123,7 +123,7 @@ def test_documents_reference_existing_files():
         text = open(os.path.join(ROOT, doc)).read()
         pattern = r'`((?:profiles|scripts|tests|oracle|include|geotransformer_amd)/[\w./\-]+?\.(?:md|json|txt|csv|py|sh|h|hip|npz|cpp))`'
         cited = [m.group(1) for m in re.finditer(pattern, text)]
-        cited += ['profiles/' + m.group(1) for m in re.finditer(r'`(r01_[\w.\-]+\.(?:md|json|txt|csv))`', text)]
+        cited += ['profiles/' + m.group(1) for m in re.finditer(r'`(r0\d_[\w.\-]+\.(?:md|json|txt|csv))`', text)]
         assert cited or doc == 'README.md'
         missing += [(doc, path) for path in cited if not os.path.exists(os.path.join(ROOT, path))]
     assert not missing, missing

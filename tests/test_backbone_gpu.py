@@ -114,6 +114,34 @@ def test_kpconv_fused_matches_oracle_and_the_two_kernel_path(C, CO, H):
     assert torch.equal(got, again)
 
 
+def test_first_layer_fused_kernel_is_bitwise_the_two_kernel_path():
+    """geotr_kpconv_c1_fused (C_in = 1: neighbour records in LDS, fmaf chains over h and over k) == kpconv_gather_c1 + exact fp32 GEMM."""
+    from geotransformer_amd import kernels
+    from geotransformer_amd.modules.kpconv import KPConv
+    from oracle import model_oracle as mo
+    g = np.load('tests/golden/neighbors_3dmatch_small_s2.npz')
+    pts = torch.from_numpy(g['points1'])
+    nb = torch.from_numpy(g['neighbors1'].astype(np.int64))[:, :38].contiguous()
+    nb = nb[: nb.shape[0] - 3].contiguous()  # not a multiple of 4 points
+    q = pts[: nb.shape[0]].contiguous()
+    torch.manual_seed(3)
+    np.random.seed(3)
+    layer = KPConv(1, 64, 15, 0.0625, 0.05, bias=True).cuda()
+    feats = torch.ones(pts.shape[0], 1)
+    feats[::5] = -1.0  # non-positive features do not count as neighbours
+    args = (feats.cuda(), q.cuda(), pts.cuda(), nb.cuda())
+    fused = layer(*args)
+    kernels.KPCONV_FUSED = False
+    try:
+        two = layer(*args)
+    finally:
+        kernels.KPCONV_FUSED = True
+    assert torch.equal(fused, two)
+    sd = {'x.' + k: v.cpu() for k, v in layer.state_dict().items()}
+    want = mo.kpconv(sd, 'x.', feats, q, pts, nb, 0.05)
+    assert torch.allclose(fused.cpu(), want, **TOL)
+
+
 def test_strided_kpconv_and_maxpool_and_upsample():
     from geotransformer_amd import kernels
     from oracle import model_oracle as mo

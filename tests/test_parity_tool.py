@@ -1,0 +1,95 @@
+"""oracle/parity.py's pair comparison (the checker bench.py, smoke() and the GPU parity tests share) on hand-made outputs: a pair
+whose patches list the same points in another order passes once aligned; a wrong score, a wrong mask or a wrong point set fails."""
+import copy
+
+import numpy as np
+import torch
+
+from oracle import parity
+
+
+def _pair(seed=0, P=6, K=5, N=40, M=30):
+    g = torch.Generator().manual_seed(seed)
+    out = {k: torch.randn(n, 8, generator=g) for k, n in (('ref_feats_c', 7), ('src_feats_c', 9), ('ref_feats_f', N), ('src_feats_f', M))}
+    out['ref_node_corr_indices'] = torch.arange(P)
+    out['src_node_corr_indices'] = torch.arange(P).flip(0)
+    out['ref_node_corr_knn_points'] = torch.randn(P, K, 3, generator=g)
+    out['src_node_corr_knn_points'] = torch.randn(P, K, 3, generator=g)
+    scores = torch.randn(P, K + 1, K + 1, generator=g)
+    scores[:, 2, :] = -1e12  # a masked point in every patch
+    out['matching_scores'] = scores
+    out['corr_scores'] = torch.rand(11, generator=g)
+    out['estimated_transform'] = torch.eye(4)
+    return out
+
+
+def _shuffled(out, patch, seed=1):
+    """The same pair with the points of `patch` listed in another order on both sides (scores permuted with them)."""
+    got = copy.deepcopy(out)
+    K = out['ref_node_corr_knn_points'].shape[1]
+    g = torch.Generator().manual_seed(seed)
+    pr, ps = torch.randperm(K, generator=g), torch.randperm(K, generator=g)
+    got['ref_node_corr_knn_points'][patch] = out['ref_node_corr_knn_points'][patch][pr]
+    got['src_node_corr_knn_points'][patch] = out['src_node_corr_knn_points'][patch][ps]
+    full_r, full_s = torch.cat([pr, torch.tensor([K])]), torch.cat([ps, torch.tensor([K])])
+    got['matching_scores'][patch] = out['matching_scores'][patch][full_r][:, full_s]
+    return got
+
+
+def test_identical_outputs_pass_and_the_transform_is_compared():
+    want = _pair()
+    rep = parity.compare_pair(copy.deepcopy(want), want)
+    assert rep['ok'] and rep['coarse_identical'] and rep['transform_compared']
+    assert rep['patches_in_identical_point_order'] == 1.0 and rep['matching_scores_max_err'] == 0.0
+
+
+def test_patches_listing_the_same_points_in_another_order_are_aligned():
+    want = _pair()
+    got = _shuffled(_shuffled(want, 1), 4, seed=5)
+    rep = parity.compare_pair(got, want)
+    assert rep['ok'], rep
+    assert rep['patches_with_identical_point_set'] == 1.0 and rep['patches_in_identical_point_order'] < 1.0
+    assert rep['matching_scores_max_err'] == 0.0 and not rep['transform_compared']
+
+
+def test_coarse_pairs_listed_in_another_order_are_aligned():
+    want = _pair()
+    got = copy.deepcopy(want)
+    order = torch.tensor([3, 0, 5, 1, 4, 2])
+    for k in ('ref_node_corr_indices', 'src_node_corr_indices', 'ref_node_corr_knn_points', 'src_node_corr_knn_points', 'matching_scores'):
+        got[k] = want[k][order]
+    rep = parity.compare_pair(got, want)
+    assert rep['ok'] and rep['coarse_same_set'] and not rep['coarse_identical'] and rep['matching_scores_max_err'] == 0.0
+
+
+def test_a_wrong_score_mask_point_set_or_feature_fails():
+    want = _pair()
+    bad = _shuffled(want, 2)
+    bad['matching_scores'][2, 0, 0] += 0.1
+    assert not parity.compare_pair(bad, want)['ok']
+    bad = copy.deepcopy(want)
+    bad['matching_scores'][3, 2, 1] = 0.5  # a masked entry came out live
+    assert not parity.compare_pair(bad, want)['ok']
+    bad = copy.deepcopy(want)
+    bad['ref_node_corr_knn_points'][:3, 0] += 1.0  # half of the patches hold another point
+    rep = parity.compare_pair(bad, want)
+    assert not rep['ok'] and rep['patches_with_identical_point_set'] == 0.5
+    bad = copy.deepcopy(want)
+    bad['ref_feats_f'] = bad['ref_feats_f'] + 0.01
+    assert not parity.compare_pair(bad, want)['ok']
+    assert parity.compare_pair(bad, want, feature_mse_bound=1e-3)['ok']
+    bad = copy.deepcopy(want)
+    bad['estimated_transform'][0, 3] = 0.1
+    assert not parity.compare_pair(bad, want)['ok']
+
+
+def test_pyramid_tables_may_differ_in_width_only():
+    pts = [np.random.RandomState(0).rand(6, 3).astype(np.float32)]
+    lens = [np.array([3, 3])]
+    nb = np.array([[0, 1, 6], [1, 0, 6], [2, 6, 6], [3, 4, 6], [4, 3, 6], [5, 6, 6]], dtype=np.int64)
+    want = {'points': pts, 'lengths': lens, 'neighbors': [nb], 'subsampling': [], 'upsampling': []}
+    wide = np.concatenate([nb, np.full((6, 2), 6, dtype=np.int64)], 1)
+    assert parity.pyramid_identical({**want, 'neighbors': [wide]}, want)
+    wrong = wide.copy()
+    wrong[0, 3] = 2
+    assert not parity.pyramid_identical({**want, 'neighbors': [wrong]}, want)
