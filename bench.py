@@ -187,10 +187,11 @@ def pmc_traffic_bytes(kernel_substr):
     if not found:
         return None
     data = json.load(open(found[-1]))  # the latest round's summary
-    for name, rec in data.items():
-        if kernel_substr in name:
-            return round(rec['hbm_mb_per_launch'] * 1024 * 1024)
-    return None
+    hits = [rec for name, rec in data.items() if kernel_substr in name and isinstance(rec, dict) and rec.get('launches')]
+    if not hits:
+        return None
+    launches = sum(r['launches'] for r in hits)  # every instantiation of the family, weighted by its launches
+    return round(sum(r['hbm_mb_per_launch'] * r['launches'] for r in hits) / launches * 1024 * 1024)
 
 
 def note(msg):

@@ -25,6 +25,7 @@ SIGNATURES = {
     'geotr_grid_subsample': (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_radius_grid_workspace_bytes': (c_size, [c_i64, c_i64]),
     'geotr_radius_grid_build': (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_f32, c_ptr, c_size, c_ptr]),
+    'geotr_radius_grid_order': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_radius_count': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_f32, c_ptr, c_ptr, c_ptr]),
     'geotr_radius_query': (ctypes.c_int,
                            [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_f32, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
@@ -34,10 +35,11 @@ SIGNATURES = {
     'geotr_kpconv_gather': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
                                     c_ptr, c_ptr, c_ptr]),
     'geotr_kpconv_fused_supported': (c_int, [c_i64, c_i64, c_i64]),
-    'geotr_kpconv_c1_fused': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'geotr_kpconv_c1_fused': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'geotr_kpconv_fused': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr, c_ptr,
-                                   c_int, c_ptr, c_ptr]),
+                                   c_int, c_ptr, c_ptr, c_ptr]),
     'geotr_maxpool': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    'geotr_maxpool_ordered': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'geotr_upsample_concat': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_group_norm_workspace_bytes': (c_size, [c_i64, c_i64]),
     'geotr_group_norm': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),

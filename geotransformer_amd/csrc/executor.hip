@@ -33,6 +33,7 @@ struct Ctx {
   bool gemm_bf16 = false;  // geotr_model.gemm_bf16: packed GEMMs use plain bf16 operands (hi planes only)
   int nseg = 1;                                             // stacked pairs: GroupNorm statistics stay inside a pair
   int64_t seg_rows[GEOTR_MAX_STAGES][GEOTR_MAX_PAIRS] = {};  // rows of pair b at stage s (ref + src)
+  const int32_t* order[GEOTR_MAX_STAGES] = {};               // grid order of each stage's rows (geotr_pyramid.order; null = row order)
 
   template <typename T>
   T* alloc(size_t count) {
@@ -146,8 +147,9 @@ static int64_t kpconv_chunk_rows(int64_t m, int64_t kdim) {
 }
 
 // `s_flags` (optional): (row sum > 0) of s_feats, already produced by the GroupNorm that wrote them; else computed here
+// `order`: visiting order of the m query rows (the grid order of their stage) or null
 static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64_t ns, const float* q_pts, int64_t m,
-                     const float* s_pts, const int64_t* nb, int64_t h, const uint8_t* s_flags = nullptr) {
+                     const float* s_pts, const int64_t* nb, int64_t h, const int32_t* order, const uint8_t* s_flags = nullptr) {
   float* out = c.alloc<float>((size_t)m * kp.out);
   const size_t mk = c.mark();
   const int64_t kdim = kp.num_kernel_points * kp.in;
@@ -170,7 +172,7 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
   if (fused_enabled && c1_fused_enabled && kp.in == 1 && kp.num_kernel_points == 15 && h <= 64) {  // first layer: exact fp32, bitwise the two-kernel result
     if (c.live())
       c.check(geotr_kpconv_c1_fused(s_feats, q_pts, s_pts, nb, kp.kernel_points, m, ns, h, kp.out, kp.num_kernel_points, kp.sigma, kp.weights,
-                                    kp.bias, out, c.stream));
+                                    kp.bias, order, out, c.stream));
     c.release(mk);
     return out;
   }
@@ -179,7 +181,7 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     if (c.live()) {
       ProfScope prof(c.stream);
       c.check(geotr_kpconv_fused(s_feats, q_pts, s_pts, nb, kp.kernel_points, flag, m, ns, h, kp.in, kp.out, kp.num_kernel_points, kp.sigma,
-                                 kp.packed, kp.bias, c.gemm_bf16 ? 1 : 0, out, c.stream));
+                                 kp.packed, kp.bias, c.gemm_bf16 ? 1 : 0, order, out, c.stream));
       prof.done(kProfKpconv | (h << 50) | (m << 26) | (kp.out << 14) | kdim);
     }
     c.release(mk);
@@ -208,7 +210,7 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
 static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t ns, const float* q_pts, int64_t m, const float* s_pts,
                     const int64_t* nb, int64_t h, int s_stage, int q_stage) {
   if (b.is_conv_block) {
-    float* x = kpconv(c, b.conv, s_feats, ns, q_pts, m, s_pts, nb, h);
+    float* x = kpconv(c, b.conv, s_feats, ns, q_pts, m, s_pts, nb, h, c.order[q_stage]);
     return norm(c, b.conv_norm, x, m, b.conv.out, nullptr, 2, q_stage);
   }
   const float* x = s_feats;
@@ -220,13 +222,13 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
     x = norm(c, b.unary1_norm, t, ns, b.unary1.out, nullptr, 2, s_stage, nullptr, f, &done);
     if (done) x_flags = f;  // the KPConv below needs no separate pass over its input
   }
-  float* y = kpconv(c, b.conv, x, ns, q_pts, m, s_pts, nb, h, x_flags);
+  float* y = kpconv(c, b.conv, x, ns, q_pts, m, s_pts, nb, h, c.order[q_stage], x_flags);
   y = norm(c, b.conv_norm, y, m, b.conv.out, nullptr, 2, q_stage);
   const float* sc = s_feats;  // shortcut branch
   const int64_t in_ch = b.has_unary1 ? b.unary1.in : b.conv.in;
   if (b.strided) {
     float* pooled = c.alloc<float>((size_t)m * in_ch);
-    if (c.live()) c.check(geotr_maxpool(s_feats, nb, m, ns, h, in_ch, pooled, c.stream));
+    if (c.live()) c.check(geotr_maxpool_ordered(s_feats, nb, m, ns, h, in_ch, c.order[q_stage], pooled, c.stream));
     sc = pooled;
   }
   if (b.has_shortcut) {
@@ -548,6 +550,11 @@ static int64_t uniform_stride(const geotr_outputs* outs, int B, F field) {
 static int run(Ctx& c, const geotr_model& net, const geotr_pyramid& p, const float* features, const geotr_outputs* outs) {
   const int S = net.backbone.num_stages, fine = net.backbone.fine_stage, B = p.num_pairs;
   c.nseg = B;
+  static const bool spatial_order = [] {
+    const char* e = std::getenv("GEOTR_SPATIAL_ORDER");  // A/B switch for measurements: GEOTR_SPATIAL_ORDER=0 visits rows in row order
+    return !(e && e[0] == '0');
+  }();
+  for (int s = 0; s < p.num_stages; ++s) c.order[s] = spatial_order ? p.order[s] : nullptr;
   for (int s = 0; s < S; ++s)
     for (int b = 0; b < B; ++b) c.seg_rows[s][b] = p.cloud_n[s][2 * b] + p.cloud_n[s][2 * b + 1];
   const int64_t n_c = p.n[S - 1];
@@ -795,6 +802,7 @@ int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t bat
   for (int i = 0; i < S; ++i) {
     grids[i] = base + gs_bytes + (size_t)i * grid_bytes;
     int rc = geotr_radius_grid_build(pts[i], len[i], batch, n[i], r, grids[i], grid_bytes, stream);
+    if (rc == GEOTR_OK && buf->order[i]) rc = geotr_radius_grid_order(grids[i], n[i], batch, buf->order[i], stream);
     if (rc != GEOTR_OK) return rc;
     r *= 2.0f;
   }

@@ -192,13 +192,18 @@ __global__ void maxpool_kernel(const float* __restrict__ x, const int64_t* __res
   out[e] = best;
 }
 
-// same, four channels per lane (C % 4 == 0): a quarter of the index loads and 16-byte feature loads
+// same, four channels per lane (C % 4 == 0): a quarter of the index loads and 16-byte feature loads.  `order` (optional): the query rows
+// are visited in this order (the pyramid's grid order: consecutive rows are spatial neighbours and gather mostly the same support
+// rows); blocks are renumbered so that each XCD (block b runs on XCD b % 8) sweeps one contiguous eighth of the order and finds those
+// shared rows in its own L2.  Row m's result lands in row m either way.
 __global__ void maxpool4_kernel(const float* __restrict__ x, const int64_t* __restrict__ nb, int64_t M, int64_t Ns, int H, int C4,
-                                float* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                const int* __restrict__ order, float* __restrict__ out) {
+  const int64_t lblock = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // gridDim.x % 8 == 0 (host)
+  const int64_t e = lblock * blockDim.x + threadIdx.x;
   if (e >= M * C4) return;
-  const int64_t m = e / C4;
-  const int c4 = (int)(e - m * C4);
+  const int64_t t = e / C4;
+  const int c4 = (int)(e - t * C4);
+  const int64_t m = order ? (int64_t)order[t] : t;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   float4 best = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
 #pragma unroll 4
@@ -207,7 +212,7 @@ __global__ void maxpool4_kernel(const float* __restrict__ x, const int64_t* __re
     const float4 v = j < Ns ? x4[j * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);  // the shadow row is all zeros and takes part in the max
     best.x = fmaxf(best.x, v.x), best.y = fmaxf(best.y, v.y), best.z = fmaxf(best.z, v.z), best.w = fmaxf(best.w, v.w);
   }
-  reinterpret_cast<float4*>(out)[e] = best;
+  reinterpret_cast<float4*>(out)[m * C4 + c4] = best;
 }
 
 __global__ void upsample_concat_kernel(const float* __restrict__ coarse, int64_t nc, int c1, const int64_t* __restrict__ up,
@@ -229,7 +234,11 @@ __global__ void upsample_concat_kernel(const float* __restrict__ coarse, int64_t
 }
 
 // ---- GroupNorm over (N, C): statistics span all N stacked points (modules.py:47-50) -------------------------
-constexpr int kGnRows = 32;  // rows per block in the statistics pass (many small blocks: the pass is latency-bound)
+constexpr int kGnRows = 32;  // rows per block in the statistics pass of a small segment (many small blocks: that pass is latency-bound)
+constexpr int kGnRowsLong = 128;          // ... of a segment of >= kGnLongSegment rows: 4x fewer partials to write and to re-read
+constexpr int64_t kGnLongSegment = 8192;  // (the finalize pass reads 16-byte pieces of 2C-float records: its traffic is ~4x its payload)
+// Rows per statistics block depend on the segment's OWN row count only: a pair's statistics are the same bits alone or in any stack.
+static inline int gn_rows_per_block(int64_t seg_rows) { return seg_rows >= kGnLongSegment ? kGnRowsLong : kGnRows; }
 
 // pass 1: per-block, per-channel partial (sum, sum of squares) over kGnRows rows -- no atomics
 // Row segments (one per stacked pair: statistics never mix pairs).  Statistics blocks start at segment starts, so a
@@ -237,6 +246,7 @@ constexpr int kGnRows = 32;  // rows per block in the statistics pass (many smal
 struct GnSegs {
   int nseg;
   int blk0[GEOTR_MAX_PAIRS + 1];      // first statistics block of each segment
+  int rpb[GEOTR_MAX_PAIRS];           // rows per statistics block of each segment (gn_rows_per_block)
   int64_t row0[GEOTR_MAX_PAIRS + 1];  // first row of each segment
 };
 __device__ __forceinline__ int gn_seg_of_block(const GnSegs& sg, int b) {
@@ -253,8 +263,9 @@ __device__ __forceinline__ int gn_seg_of_row(const GnSegs& sg, int64_t r) {
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, GnSegs sg, int C, float* __restrict__ partial) {
   extern __shared__ float red[];  // [phases][2][C] when C < 256
   const int seg = gn_seg_of_block(sg, blockIdx.x);
-  const int64_t r0 = sg.row0[seg] + (int64_t)(blockIdx.x - sg.blk0[seg]) * kGnRows;
-  const int64_t r1 = r0 + kGnRows < sg.row0[seg + 1] ? r0 + kGnRows : sg.row0[seg + 1];
+  const int rpb = sg.rpb[seg];
+  const int64_t r0 = sg.row0[seg] + (int64_t)(blockIdx.x - sg.blk0[seg]) * rpb;
+  const int64_t r1 = r0 + rpb < sg.row0[seg + 1] ? r0 + rpb : sg.row0[seg + 1];
   float* out = partial + (int64_t)blockIdx.x * 2 * C;
   if (C >= 256) {
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -521,15 +532,21 @@ int geotr_kpconv_gather(const float* s_feats, const float* q_points, const float
 
 int geotr_maxpool(const float* x, const int64_t* neighbors, int64_t m, int64_t ns, int64_t h, int64_t c, float* out,
                   void* stream) {
-  GEOTR_CHECK_ARG(m >= 0 && h >= 1 && c >= 1, "maxpool: bad sizes");
+  return geotr_maxpool_ordered(x, neighbors, m, ns, h, c, nullptr, out, stream);
+}
+
+int geotr_maxpool_ordered(const float* x, const int64_t* neighbors, int64_t m, int64_t ns, int64_t h, int64_t c, const int32_t* order,
+                          float* out, void* stream) {
+  GEOTR_CHECK_ARG(m >= 0 && m < (1ll << 31) && h >= 1 && c >= 1, "maxpool: bad sizes");
   if (m == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(x && neighbors && out, "maxpool: null pointer");
-  if (c % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
-    maxpool4_kernel<<<dim3((unsigned)((m * (c / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, neighbors, m, ns, (int)h, (int)(c / 4),
-                                                                                                    out);
-  else
+  if (c % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int64_t blocks = ((m * (c / 4) + 255) / 256 + 7) / 8 * 8;  // a multiple of 8: one contiguous share of the rows per XCD
+    maxpool4_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(x, neighbors, m, ns, (int)h, (int)(c / 4), order, out);
+  } else {  // odd widths: natural order (no reference configuration takes this path)
     maxpool_kernel<<<dim3((unsigned)((m * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, neighbors, m, ns, (int)h,
                                                                                               (int)c, out);
+  }
   GEOTR_CHECK_LAUNCH("maxpool");
   return GEOTR_OK;
 }
@@ -601,8 +618,9 @@ int geotr_group_norm_segmented_flags(const float* x, int64_t n, int64_t c, int64
     GEOTR_CHECK_ARG(seg_rows_host[s] >= 1, "group_norm: empty row segment %d", s);
     sg.row0[s] = row;
     sg.blk0[s] = blk;
+    sg.rpb[s] = gn_rows_per_block(seg_rows_host[s]);
     row += seg_rows_host[s];
-    blk += (int)((seg_rows_host[s] + kGnRows - 1) / kGnRows);
+    blk += (int)((seg_rows_host[s] + sg.rpb[s] - 1) / sg.rpb[s]);
   }
   sg.row0[nseg] = row;
   sg.blk0[nseg] = blk;

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
                                                                   const float* __restrict__ kp, const unsigned char* __restrict__ pos,
                                                                   int64_t M, int64_t Ns, int H, float sigma, int c_out, int KS, int NT,
                                                                   const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo,
-                                                                  const float* __restrict__ bias, float* __restrict__ out) {
+                                                                  const float* __restrict__ bias, const int* __restrict__ order,
+                                                                  float* __restrict__ out) {
   constexpr int VEC = C >= 64 ? 4 : 2;          // feature channels per lane and load
   constexpr int G = C / (16 * VEC);             // loads (column-tile groups) per neighbour step
   constexpr int K = 15 * C;                     // contraction depth of phase 2
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   unsigned short* A_lo = A_hi + kFusedRows * RS;
   float4* relw_all = reinterpret_cast<float4*>(A_lo + kFusedRows * RS);  // [WAVES][2][64] (rel.xyz, neighbour index bits), two slots per wave
   int* cnt_s = reinterpret_cast<int*>(relw_all + WAVES * 128);           // [32] neighbours with a positive feature sum
+  int* row_s = cnt_s + kFusedRows;                                       // [32] the tile's query rows (visiting order applied)
   float* part = reinterpret_cast<float*>(fsm);                           // [WAVES][16][64] K partials (reuses the A tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,9 +80,25 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   const int kk_per = (nkk + KPARTS - 1) / KPARTS;
   const int kk0 = kpart * kk_per, kk1 = min(nkk, kk0 + kk_per);
 
+  // Tile t holds the query rows order[32 t .. 32 t + 31] (the grid order of the pyramid: spatial neighbours, which share most of
+  // their neighbour rows) or rows 32 t .. when no order is given; outputs land in their own rows either way, and a row's result never
+  // depends on its tile mates.  Blocks take CONTIGUOUS tile ranges, XCD by XCD (block b runs on XCD b % 8): the blocks resident on one
+  // XCD work through one stretch of the order, so the neighbour rows they share are hits in that XCD's L2.
+  // The rows of a tile are fetched one tile AHEAD (lane i < PPW: the wave's i-th point), so the order lookup never adds a dependent
+  // round trip to the neighbour-index -> position -> feature chain below.  Rows past M are computed on a clamped index, never stored.
+  auto load_rows = [&](int64_t tile) -> int {
+    const int64_t t = min(tile * kFusedRows + wave * PPW + min(lane, PPW - 1), M - 1);
+    return order ? order[t] : (int)t;
+  };
   const int64_t tiles = (M + kFusedRows - 1) / kFusedRows;
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  const int lblock = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);  // gridDim.x % 8 == 0 (host)
+  const int64_t per_block = (tiles + gridDim.x - 1) / gridDim.x;
+  const int64_t tile_end = min(tiles, (int64_t)(lblock + 1) * per_block);
+  int rows_cur = (int64_t)lblock * per_block < tile_end ? load_rows((int64_t)lblock * per_block) : 0;
+  for (int64_t tile = (int64_t)lblock * per_block; tile < tile_end; ++tile) {
     const int64_t m0 = tile * kFusedRows;
+    const int rows_nxt = tile + 1 < tile_end ? load_rows(tile + 1) : 0;  // in flight under this tile's work
+    if (lane < PPW) row_s[wave * PPW + lane] = rows_cur;                 // read by the epilogue, three barriers later
     // ------------------------------------------------------------------ phase 1: g = w . f per point, software-pipelined over the wave's points
     // Three dependent global round trips lead to a point's first MFMA (neighbour index -> support position -> feature row); done
     // one point after the other they cost ~2 us each and the kernel was latency-bound at 3.7x its matrix-pipe time.  Pipeline:
@@ -89,11 +107,11 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
     // iteration i runs A2(i+1), A1(i+2), B1(i+1) BEFORE B2(i): the loads of the next point are in flight under this point's MFMAs.
     // Rows past M are computed on a clamped index and never stored.
     auto stage_a1 = [&](int i) -> int64_t {  // -> the lane's neighbour index of the wave's i-th point (lanes >= H: pad)
-      const int64_t m = min(m0 + wave * PPW + i, M - 1);
+      const int64_t m = __builtin_amdgcn_readlane(rows_cur, i);
       return lane < H ? nb[m * H + lane] : Ns;
     };
     auto stage_a2 = [&](int i, int64_t j) {
-      const int64_t m = min(m0 + wave * PPW + i, M - 1);
+      const int64_t m = __builtin_amdgcn_readlane(rows_cur, i);
       float4 rv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
       bool counted = false;
       if (j < Ns) {
@@ -219,8 +237,8 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
     // ------------------------------------------------------------------ epilogue: sum the K partials, / count + bias, whole rows out
     for (int e = tid; e < kFusedRows * c_out; e += 64 * WAVES) {
       const int row = e / c_out, col = e - row * c_out;
-      const int64_t m = m0 + row;
-      if (m >= M) continue;
+      if (m0 + row >= M) continue;
+      const int64_t m = row_s[row];
       const int t = col >> 5, cc = col & 31;
       // element (row, cc) of a 32 x 32 accumulator: lane = cc + 32 ((row >> 2) & 1), register = (row & 3) + 4 (row >> 3)
       const int src = ((row & 3) + 4 * (row >> 3)) * 64 + cc + 32 * ((row >> 2) & 1);
@@ -228,7 +246,8 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
       for (int p = 0; p < KPARTS; ++p) v += part[(p * CT + t) * 16 * 64 + src];
       out[m * c_out + col] = v / (float)max(cnt_s[row], 1) + (bias ? bias[col] : 0.f);
     }
-    __syncthreads();  // partials and counts are consumed before the next tile overwrites them
+    __syncthreads();  // partials, counts and rows are consumed before the next tile overwrites them
+    rows_cur = rows_nxt;
   }
 }
 
@@ -244,7 +263,7 @@ __global__ __launch_bounds__(256) void kpconv_c1_fused_kernel(const float* __res
                                                               const float* __restrict__ sp, const int64_t* __restrict__ nb,
                                                               const float* __restrict__ kp, int64_t M, int64_t Ns, int H, float sigma,
                                                               const float* __restrict__ W, const float* __restrict__ bias, int c_out,
-                                                              float* __restrict__ out) {
+                                                              const int* __restrict__ order, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char c1sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int recs = kC1Points * H;                                   // <= 256
@@ -255,15 +274,27 @@ __global__ __launch_bounds__(256) void kpconv_c1_fused_kernel(const float* __res
   const int p16 = lane >> 4, k16 = lane & 15;
   const bool is_kp = k16 < 15;
   const float kx = is_kp ? kp[3 * k16] : 0.f, ky = is_kp ? kp[3 * k16 + 1] : 0.f, kz = is_kp ? kp[3 * k16 + 2] : 0.f;
+  // groups of 4 consecutive points of the visiting order (see kpconv_fused_kernel); blocks take contiguous ranges, XCD by XCD
+  auto load_rows = [&](int64_t grp) -> int {  // lane p < 4: the row of the group's p-th point, fetched one group ahead
+    const int64_t t = min(grp * kC1Points + min(lane, kC1Points - 1), M - 1);
+    return order ? order[t] : (int)t;
+  };
   const int64_t groups = (M + kC1Points - 1) / kC1Points;
-  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
+  const int lblock = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);  // gridDim.x % 8 == 0 (host)
+  const int64_t per_block = (groups + gridDim.x - 1) / gridDim.x;
+  const int64_t grp_end = min(groups, (int64_t)(lblock + 1) * per_block);
+  int rows_cur = (int64_t)lblock * per_block + wave < grp_end ? load_rows((int64_t)lblock * per_block + wave) : 0;
+  for (int64_t grp = (int64_t)lblock * per_block + wave; grp < grp_end; grp += 4) {
     const int64_t m0 = grp * kC1Points;
+    const int rows_nxt = grp + 4 < grp_end ? load_rows(grp + 4) : 0;
+    const int row4[kC1Points] = {__builtin_amdgcn_readlane(rows_cur, 0), __builtin_amdgcn_readlane(rows_cur, 1),
+                                 __builtin_amdgcn_readlane(rows_cur, 2), __builtin_amdgcn_readlane(rows_cur, 3)};
     // (1) neighbour records; an absent neighbour (pad index, or a point past M) is marked by an infinite x offset
     for (int e = lane; e < recs; e += 64) {
       const int p = e / H, h = e - p * H;
-      const int64_t m = m0 + p;
       float4 r = make_float4(__int_as_float(0x7f800000), 0.f, 0.f, 0.f);
-      if (m < M) {
+      if (m0 + p < M) {
+        const int64_t m = p == 0 ? row4[0] : (p == 1 ? row4[1] : (p == 2 ? row4[2] : row4[3]));
         const int64_t j = nb[m * H + h];
         if (j < Ns) {
           r.x = sp[3 * j] - qp[3 * m], r.y = sp[3 * j + 1] - qp[3 * m + 1], r.z = sp[3 * j + 2] - qp[3 * m + 2];
@@ -302,8 +333,8 @@ __global__ __launch_bounds__(256) void kpconv_c1_fused_kernel(const float* __res
       const float b = bias ? bias[c] : 0.f;
 #pragma unroll
       for (int p = 0; p < kC1Points; ++p) {
-        const int64_t m = m0 + p;
-        if (m >= M) break;
+        if (m0 + p >= M) break;
+        const int64_t m = row4[p];
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < 15; ++k) v = fmaf(g_s[p * 16 + k], wk[k], v);
@@ -311,6 +342,7 @@ __global__ __launch_bounds__(256) void kpconv_c1_fused_kernel(const float* __res
       }
     }
     __builtin_amdgcn_wave_barrier();
+    rows_cur = rows_nxt;
   }
 }
 
@@ -331,25 +363,25 @@ int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h) {
 
 int geotr_kpconv_c1_fused(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
                           const float* kernel_points, int64_t m, int64_t ns, int64_t h, int64_t c_out, int64_t num_kernel_points, float sigma,
-                          const float* weights, const float* bias, float* out, void* stream_) {
-  GEOTR_CHECK_ARG(m >= 0 && ns >= 0 && h >= 1 && h <= 64 && c_out >= 1, "kpconv_c1_fused: bad sizes (h <= 64)");
+                          const float* weights, const float* bias, const int32_t* order, float* out, void* stream_) {
+  GEOTR_CHECK_ARG(m >= 0 && m < (1ll << 31) && ns >= 0 && h >= 1 && h <= 64 && c_out >= 1, "kpconv_c1_fused: bad sizes (h <= 64)");
   GEOTR_CHECK_ARG(num_kernel_points == 15, "kpconv_c1_fused: only 15 kernel points are supported (got %lld)", (long long)num_kernel_points);
   if (m == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(s_feats && q_points && s_points && neighbors && kernel_points && weights && out, "kpconv_c1_fused: null pointer");
   const size_t lds = 4 * (256 + 16 + 4) * sizeof(float4);
   const int64_t groups = (m + kC1Points - 1) / kC1Points;
-  const unsigned grid = (unsigned)std::min<int64_t>((groups + 3) / 4, 256 * 16);
+  const unsigned grid = (unsigned)((std::min<int64_t>((groups + 3) / 4, 256 * 16) + 7) / 8 * 8);  // a multiple of 8: one share per XCD
   kpconv_c1_fused_kernel<<<dim3(grid), dim3(256), lds, (hipStream_t)stream_>>>(s_feats, q_points, s_points, neighbors, kernel_points, m, ns, (int)h,
-                                                                             sigma, weights, bias, (int)c_out, out);
+                                                                             sigma, weights, bias, (int)c_out, order, out);
   GEOTR_CHECK_LAUNCH("kpconv_c1_fused");
   return GEOTR_OK;
 }
 
 int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
                        const float* kernel_points, const uint8_t* pos_flag, int64_t m, int64_t ns, int64_t h, int64_t c_in, int64_t c_out,
-                       int64_t num_kernel_points, float sigma, const void* packed, const float* bias, int bf16_operands, float* out,
-                       void* stream_) {
-  GEOTR_CHECK_ARG(m >= 0 && ns >= 0, "kpconv_fused: bad sizes");
+                       int64_t num_kernel_points, float sigma, const void* packed, const float* bias, int bf16_operands,
+                       const int32_t* order, float* out, void* stream_) {
+  GEOTR_CHECK_ARG(m >= 0 && m < (1ll << 31) && ns >= 0, "kpconv_fused: bad sizes");
   GEOTR_CHECK_ARG(num_kernel_points == 15, "kpconv_fused: only 15 kernel points are supported (got %lld)", (long long)num_kernel_points);
   GEOTR_CHECK_ARG(geotr_kpconv_fused_supported(c_in, c_out, h), "kpconv_fused: unsupported shape (c_in %lld, c_out %lld, h %lld)",
                   (long long)c_in, (long long)c_out, (long long)h);
@@ -364,9 +396,10 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
   const unsigned short* blo = bhi + np_pad * kp_pad;
   const int KS = (int)(kp_pad / 16), NT = (int)(np_pad / 32);
   const int waves = 8;
-  const size_t lds = (size_t)2 * kFusedRows * (kdim + 8) * 2 + (size_t)waves * 128 * 16 + 32 * 4;
+  const size_t lds = (size_t)2 * kFusedRows * (kdim + 8) * 2 + (size_t)waves * 128 * 16 + 2 * kFusedRows * 4;
   const int64_t tiles = (m + kFusedRows - 1) / kFusedRows;
-  const unsigned grid = (unsigned)std::min<int64_t>(tiles, 256 * (c_in == 32 ? 8 : 4));  // persistent: a few tiles per resident workgroup
+  // persistent: a few tiles per resident workgroup; a multiple of 8 blocks, one share of the tile range per XCD
+  const unsigned grid = (unsigned)((std::min<int64_t>(tiles, 256 * (c_in == 32 ? 8 : 4)) + 7) / 8 * 8);
 #define GEOTR_KPF(CC, WW, TT)                                                                                                      \
   do {                                                                                                                             \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<CC, WW, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -374,7 +407,7 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
       return fail(GEOTR_E_LAUNCH, "kpconv_fused: cannot reserve %zu B of LDS", lds);                                               \
     kpconv_fused_kernel<CC, WW, TT><<<dim3(grid), dim3(64 * WW), lds, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points,  \
                                                                                pos_flag, m, ns, (int)h, sigma, (int)c_out, KS, NT, bhi, \
-                                                                               blo, bias, out);                                    \
+                                                                               blo, bias, order, out);                             \
   } while (0)
   if (c_in == 32) {  // 8 waves in both widths: two resident workgroups at c_in = 32 give 4 waves per SIMD, the LDS tile allows no more
     if (bf16_operands) GEOTR_KPF(32, 8, 1);

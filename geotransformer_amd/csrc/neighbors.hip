@@ -726,6 +726,30 @@ int geotr_radius_grid_build(const float* s_points, const int64_t* s_len, int64_t
   return GEOTR_OK;
 }
 
+// Cell order of the support rows as a row list: order[t] = the row (0 .. ns-1 over the stacked clouds) of the t-th point in grid
+// order (cloud by cloud, cells x-fastest).  The gather kernels of the backbone visit their query rows in this order so that a tile's
+// points are spatial neighbours and share most of their neighbour rows in L1 / L2 (the reference's row order is the hash-map order of
+// grid_subsampling.cpp, i.e. spatially scattered).  The order inside a cell depends on the scatter's atomics: it is a visiting order
+// only and never changes a result.
+__global__ void rg_order_kernel(const float4* __restrict__ sorted, const CloudGrid* __restrict__ hdr, int batch, int64_t ns,
+                                int* __restrict__ order) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ns) return;
+  int b = 0;
+  while (b < batch - 1 && t >= hdr[b].s_start + hdr[b].s_len) ++b;
+  order[t] = (int)(hdr[b].s_start + (int64_t)__float_as_int(sorted[t].w));
+}
+
+int geotr_radius_grid_order(const void* grid_ws, int64_t ns, int64_t batch, int32_t* order, void* stream_) {
+  GEOTR_CHECK_ARG(grid_ws && (order || ns == 0), "radius_grid_order: null pointer");
+  GEOTR_CHECK_ARG(batch >= 1 && batch <= kMaxBatch && ns >= 0 && ns < (1ll << 31), "radius_grid_order: bad sizes");
+  if (ns == 0) return GEOTR_OK;
+  GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns, batch);
+  rg_order_kernel<<<dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>(L.sorted, L.hdr, (int)batch, ns, order);
+  GEOTR_CHECK_LAUNCH("radius_grid_order");
+  return GEOTR_OK;
+}
+
 static int radius_query_common(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
                                int64_t batch, int64_t nq, int64_t ns, float radius, int64_t width, int64_t cap,
                                int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_) {

@@ -76,6 +76,14 @@ class RadiusGrid:
                                                self.radius, _lib.ptr(self.ws), self.ws.numel(), _lib.stream_ptr()),
                    'geotr_radius_grid_build')
 
+    def order(self):
+        """(ns,) int32: the support rows in grid order (consecutive entries are spatial neighbours) -- the visiting order the
+        gather kernels take (kernels.kpconv_fused / kpconv_c1_fused / maxpool `order=`); a permutation of 0 .. ns-1."""
+        out = torch.empty(self.ns, dtype=torch.int32, device=self.s_points.device)
+        _lib.check(_lib.load().geotr_radius_grid_order(_lib.ptr(self.ws), self.ns, self.batch, _lib.ptr(out), _lib.stream_ptr()),
+                   'geotr_radius_grid_order')
+        return out
+
     def count(self, q_points, q_lengths):
         """Per-query neighbour counts (int32, device) and their max (int32 device scalar)."""
         lib = _lib.load()

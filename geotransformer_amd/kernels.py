@@ -142,8 +142,17 @@ def kpconv_fused_supported(c_in, c_out, h):
     return bool(KPCONV_FUSED and GEMM_PACKED and _lib.load().geotr_kpconv_fused_supported(int(c_in), int(c_out), int(h)))
 
 
-def kpconv_fused(s_feats, q_points, s_points, neighbor_indices, kernel_points, sigma, packed, c_out, bias=None):
-    """Whole KPConv layer in one kernel (csrc/kpconv_fused.hip): -> (M, c_out).  `packed` = gemm_pack of the (15 C_in, c_out) weights."""
+def _order(order, m):
+    """Visiting order of m query rows for the gather kernels: an int32 permutation of 0 .. m-1 (None = row order)."""
+    if order is None:
+        return None
+    assert order.dtype == torch.int32 and order.is_cuda and order.is_contiguous() and order.numel() == m
+    return order
+
+
+def kpconv_fused(s_feats, q_points, s_points, neighbor_indices, kernel_points, sigma, packed, c_out, bias=None, order=None):
+    """Whole KPConv layer in one kernel (csrc/kpconv_fused.hip): -> (M, c_out).  `packed` = gemm_pack of the (15 C_in, c_out) weights.
+    `order`: visiting order of the query rows (ext.RadiusGrid.order(); results do not depend on it)."""
     lib = _lib.load()
     s_feats, q_points, s_points = _f32c(s_feats), _f32c(q_points), _f32c(s_points)
     nb = neighbor_indices if neighbor_indices.is_contiguous() else neighbor_indices.contiguous()
@@ -154,11 +163,12 @@ def kpconv_fused(s_feats, q_points, s_points, neighbor_indices, kernel_points, s
     out = torch.empty((M, c_out), dtype=torch.float32, device=s_feats.device)
     _lib.check(lib.geotr_kpconv_fused(_lib.ptr(s_feats), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(nb), _lib.ptr(_f32c(kernel_points)),
                                       _lib.ptr(flag), M, Ns, H, C, int(c_out), kernel_points.shape[0], float(sigma), _lib.ptr(packed),
-                                      _lib.ptr(bias), int(GEMM_PACKED == 'bf16'), _lib.ptr(out), _lib.stream_ptr()), 'geotr_kpconv_fused')
+                                      _lib.ptr(bias), int(GEMM_PACKED == 'bf16'), _lib.ptr(_order(order, M)), _lib.ptr(out), _lib.stream_ptr()),
+               'geotr_kpconv_fused')
     return out
 
 
-def kpconv_c1_fused(s_feats, q_points, s_points, neighbor_indices, kernel_points, sigma, weights, bias=None):
+def kpconv_c1_fused(s_feats, q_points, s_points, neighbor_indices, kernel_points, sigma, weights, bias=None, order=None):
     """First layer (C_in = 1) in one exact-fp32 kernel: weights (15, 1, c_out) -> (M, c_out)."""
     lib = _lib.load()
     s_feats, q_points, s_points, weights = _f32c(s_feats), _f32c(q_points), _f32c(s_points), _f32c(weights.detach())
@@ -169,7 +179,7 @@ def kpconv_c1_fused(s_feats, q_points, s_points, neighbor_indices, kernel_points
     out = torch.empty((M, c_out), dtype=torch.float32, device=s_feats.device)
     _lib.check(lib.geotr_kpconv_c1_fused(_lib.ptr(s_feats), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(nb), _lib.ptr(_f32c(kernel_points)),
                                          M, s_feats.shape[0], H, c_out, kernel_points.shape[0], float(sigma), _lib.ptr(weights), _lib.ptr(bias),
-                                         _lib.ptr(out), _lib.stream_ptr()), 'geotr_kpconv_c1_fused')
+                                         _lib.ptr(_order(order, M)), _lib.ptr(out), _lib.stream_ptr()), 'geotr_kpconv_c1_fused')
     return out
 
 
@@ -191,14 +201,14 @@ def kpconv_gather(s_feats, q_points, s_points, neighbor_indices, kernel_points, 
     return weighted, nnum
 
 
-def maxpool(x, neighbor_indices):
+def maxpool(x, neighbor_indices, order=None):
     lib = _lib.load()
     x = _f32c(x)
     nb = neighbor_indices if neighbor_indices.is_contiguous() else neighbor_indices.contiguous()
     M, H = nb.shape
     out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
-    _lib.check(lib.geotr_maxpool(_lib.ptr(x), _lib.ptr(nb), M, x.shape[0], H, x.shape[1], _lib.ptr(out), _lib.stream_ptr()),
-               'geotr_maxpool')
+    _lib.check(lib.geotr_maxpool_ordered(_lib.ptr(x), _lib.ptr(nb), M, x.shape[0], H, x.shape[1], _lib.ptr(_order(order, M)), _lib.ptr(out),
+                                         _lib.stream_ptr()), 'geotr_maxpool_ordered')
     return out
 
 

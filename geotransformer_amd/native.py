@@ -53,12 +53,12 @@ class Pyramid(ctypes.Structure):
                 ('neighbors', P_F32 * MAX_STAGES), ('neighbors_w', I64 * MAX_STAGES),
                 ('subsampling', P_F32 * MAX_STAGES), ('subsampling_w', I64 * MAX_STAGES),
                 ('upsampling', P_F32 * MAX_STAGES), ('upsampling_w', I64 * MAX_STAGES),
-                ('cloud_n', (I64 * (2 * MAX_PAIRS)) * MAX_STAGES)]
+                ('cloud_n', (I64 * (2 * MAX_PAIRS)) * MAX_STAGES), ('order', P_F32 * MAX_STAGES)]
 
 
 class PyramidBuffers(ctypes.Structure):
     _fields_ = [('points', P_F32 * MAX_STAGES), ('lengths', P_F32 * MAX_STAGES), ('neighbors', P_F32 * MAX_STAGES),
-                ('subsampling', P_F32 * MAX_STAGES), ('upsampling', P_F32 * MAX_STAGES)]
+                ('subsampling', P_F32 * MAX_STAGES), ('upsampling', P_F32 * MAX_STAGES), ('order', P_F32 * MAX_STAGES)]
 
 
 class AttnLayer(ctypes.Structure):
@@ -279,7 +279,11 @@ class NativeModel:
         S = len(data_dict['points'])
         p.num_stages = S
         p.num_pairs = len(lengths_host[0]) // 2
+        order = data_dict.get('_order')  # grid order of each stage's rows (build_pyramid); absent for a reference-built dict
         for i in range(S):
+            if order is not None:
+                assert order[i].dtype == torch.int32 and order[i].is_contiguous() and order[i].numel() == data_dict['points'][i].shape[0]
+                p.order[i] = order[i].data_ptr()
             pts, nb = data_dict['points'][i], data_dict['neighbors'][i]
             assert pts.is_contiguous() and nb.is_contiguous()
             p.points[i], p.n[i] = pts.data_ptr(), pts.shape[0]
@@ -499,9 +503,11 @@ def build_pyramid(points, lengths, num_stages, voxel_size, radius, neighbor_limi
     nb = [torch.empty((n0, neighbor_limits[i]), dtype=torch.int64, device=dev) for i in range(S)]
     sub = [torch.empty((n0, neighbor_limits[i]), dtype=torch.int64, device=dev) for i in range(S - 1)]
     up = [torch.empty((n0, neighbor_limits[i + 1]), dtype=torch.int64, device=dev) for i in range(S - 1)]
+    order = [torch.empty(n0, dtype=torch.int32, device=dev) for _ in range(S)]
     buf = PyramidBuffers()
     for i in range(S):
         buf.points[i], buf.lengths[i], buf.neighbors[i] = pts[i].data_ptr(), lens[i].data_ptr(), nb[i].data_ptr()
+        buf.order[i] = order[i].data_ptr()
         if i < S - 1:
             buf.subsampling[i], buf.upsampling[i] = sub[i].data_ptr(), up[i].data_ptr()
     host = (ctypes.c_int64 * (S * B))()
@@ -525,4 +531,5 @@ def build_pyramid(points, lengths, num_stages, voxel_size, radius, neighbor_limi
         'upsampling': [up[i][: n[i]] for i in range(S - 1)],
         'lengths_host': lengths_host,
         '_overflow': overflow,
+        '_order': [order[i][: n[i]] for i in range(S)],  # visiting order of the gather kernels (grid order of each stage)
     }

@@ -72,6 +72,10 @@ int geotr_grid_subsample(const float* points, const int64_t* len, int64_t batch,
  *                             and that row is unspecified: re-run with a larger capacity.
  * ---------------------------------------------------------------------------------------------- */
 size_t geotr_radius_grid_workspace_bytes(int64_t ns, int64_t batch);
+/* order[t] (ns int32) = the support row of the t-th point in grid order (cloud by cloud, cells x-fastest): a visiting order in which
+ * consecutive rows are spatial neighbours -- the `order` argument of the gather kernels below (K1 / K2).  No reference counterpart:
+ * the reference's row order (grid_subsampling.cpp's hash-map order) is kept for every table and result. */
+int geotr_radius_grid_order(const void* grid_ws, int64_t ns, int64_t batch, int32_t* order, void* stream);
 int geotr_radius_grid_build(const float* s_points, const int64_t* s_len, int64_t batch, int64_t ns, float radius,
                             void* grid_ws, size_t grid_ws_bytes, void* stream);
 int geotr_radius_count(const void* grid_ws, int64_t ns, const float* q_points, const int64_t* q_len, int64_t batch,
@@ -170,17 +174,20 @@ int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* packed, floa
  * and the neighbour contraction on the fp32 matrix pipe into an LDS tile, the kernel-point contraction on the bf16 matrix pipe against
  * `packed` = geotr_gemm_pack(weights viewed (15 c_in, c_out), b_is_kn = 1), epilogue / max(count, 1) + bias (kpconv/kpconv.py:79-121).
  * pos_flag (ns) as for geotr_kpconv_gather (required).  Shapes: geotr_kpconv_fused_supported(c_in, c_out, h) -- c_in in {32, 64},
- * c_out a multiple of 32 (<= 128 / 256), h <= 40; other layers use the two-kernel path.  bf16_operands as geotr_gemm_packed_splitk. */
+ * c_out a multiple of 32 (<= 128 / 256), h <= 40; other layers use the two-kernel path.  bf16_operands as geotr_gemm_packed_splitk.
+ * order (m int32, may be NULL = row order): the sequence in which the query rows are visited, 32 per workgroup tile -- pass the grid
+ * order of the query stage (geotr_radius_grid_order / geotr_pyramid_buffers.order) so that a tile's rows share their neighbour rows in
+ * L1 / L2 and each XCD works through one stretch of space.  Results land in their own rows and do not depend on the order. */
 int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h);
 /* The first layer (c_in = 1: s_feats is (ns,)), whole layer in one kernel, exact fp32: weights (15, 1, c_out) row-major as the
  * reference's parameter, h <= 64.  Bitwise the two-kernel path's result (the same fmaf chains over h and over k). */
 int geotr_kpconv_c1_fused(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
                           const float* kernel_points, int64_t m, int64_t ns, int64_t h, int64_t c_out, int64_t num_kernel_points, float sigma,
-                          const float* weights, const float* bias, float* out, void* stream);
+                          const float* weights, const float* bias, const int32_t* order, float* out, void* stream);
 int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
                        const float* kernel_points, const uint8_t* pos_flag, int64_t m, int64_t ns, int64_t h, int64_t c_in, int64_t c_out,
-                       int64_t num_kernel_points, float sigma, const void* packed, const float* bias, int bf16_operands, float* out,
-                       void* stream);
+                       int64_t num_kernel_points, float sigma, const void* packed, const float* bias, int bf16_operands,
+                       const int32_t* order, float* out, void* stream);
 int geotr_l2_normalize(const float* x, int64_t n, int64_t c, float* out, void* stream);
 int geotr_row_positive(const float* x, int64_t n, int64_t c, uint8_t* flag, void* stream);
 int geotr_kpconv_gather(const float* s_feats, const float* q_points, const float* s_points, const int64_t* neighbors,
@@ -189,6 +196,9 @@ int geotr_kpconv_gather(const float* s_feats, const float* q_points, const float
                         void* stream);
 int geotr_maxpool(const float* x, const int64_t* neighbors, int64_t m, int64_t ns, int64_t h, int64_t c, float* out,
                   void* stream);
+/* the same with a visiting order of the query rows (as geotr_kpconv_fused; NULL = row order) */
+int geotr_maxpool_ordered(const float* x, const int64_t* neighbors, int64_t m, int64_t ns, int64_t h, int64_t c, const int32_t* order,
+                          float* out, void* stream);
 int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int64_t* up_idx, int64_t ld_idx,
                           const float* skip, int64_t c2, int64_t m, float* out, void* stream);
 size_t geotr_group_norm_workspace_bytes(int64_t n, int64_t c);
@@ -390,6 +400,7 @@ typedef struct geotr_pyramid {                                       /* output o
   const int64_t* subsampling[GEOTR_MAX_STAGES]; int64_t subsampling_w[GEOTR_MAX_STAGES];
   const int64_t* upsampling[GEOTR_MAX_STAGES];  int64_t upsampling_w[GEOTR_MAX_STAGES];
   int64_t cloud_n[GEOTR_MAX_STAGES][2 * GEOTR_MAX_PAIRS]; /* points per cloud per stage (lengths[i][:]) */
+  const int32_t* order[GEOTR_MAX_STAGES];      /* optional (NULL): grid order of each stage's rows, the visiting order of the gather kernels */
 } geotr_pyramid;
 typedef struct geotr_attn_layer {                                    /* RPETransformerLayer / TransformerLayer */
   int32_t is_self, pad_;
@@ -474,6 +485,7 @@ typedef struct geotr_pyramid_buffers {
   int64_t* neighbors[GEOTR_MAX_STAGES];     /* (n0, limits[i]) */
   int64_t* subsampling[GEOTR_MAX_STAGES];   /* (n0, limits[i]),   i < S-1: queries stage i+1, supports stage i */
   int64_t* upsampling[GEOTR_MAX_STAGES];    /* (n0, limits[i+1]), i < S-1: queries stage i,   supports stage i+1 */
+  int32_t* order[GEOTR_MAX_STAGES];         /* (n0) optional (NULL): receives geotr_radius_grid_order of the stage's grid */
 } geotr_pyramid_buffers;
 size_t geotr_pyramid_workspace_bytes(int64_t n0, int64_t batch, int64_t num_stages);
 int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t batch, int64_t n0, int64_t num_stages, float voxel_size,

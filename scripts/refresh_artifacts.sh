@@ -27,9 +27,19 @@ try:
 except Exception as e: print('$name FAILED', e)" | tee -a $OUT/ab_runs.txt; }
 EXTRA="" ab default X=1
 EXTRA="" ab two_kernel_kpconv GEOTR_KPCONV_FUSED=0
+EXTRA="" ab two_kernel_first_layer GEOTR_KPCONV_C1_FUSED=0
 EXTRA="--gse mfma" ab gse_mfma_kernel X=1
 EXTRA="" ab no_split_k GEOTR_SPLITK=0
+EXTRA="" ab row_order_gathers GEOTR_SPATIAL_ORDER=0
+EXTRA="--stack 8" ab stack8 X=1
 EXTRA="--lanes 1" ab one_lane X=1
 EXTRA="--lanes 2" ab two_lanes X=1
 EXTRA="--lanes 6" ab six_lanes X=1
+EXTRA="" ab default_again X=1
+# the other BASELINE configurations, each with its own parity block and CPU baseline
+timeout 500 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 4 --no-fp32-mode > $OUT/bench_kitti.json 2> $OUT/bench_kitti.err; echo "kitti rc=$?"
+timeout 400 python $ROOT/bench.py --config lomatch --precision bf16 --no-fp32-mode > $OUT/bench_lomatch_bf16.json 2> $OUT/bench_lomatch_bf16.err; echo "lomatch bf16 rc=$?"
+timeout 300 python $ROOT/bench.py --config modelnet --no-fp32-mode > $OUT/bench_modelnet.json 2> $OUT/bench_modelnet.err; echo "modelnet rc=$?"
+python $ROOT/scripts/other_configs_summary.py $OUT/other_configs.md modelnet=$OUT/bench_modelnet.json kitti=$OUT/bench_kitti.json lomatch_bf16=$OUT/bench_lomatch_bf16.json
+head -12 $OUT/other_configs.md
 ls -la $OUT | head -40

@@ -195,3 +195,59 @@ def test_backbone_matches_reference_golden(name):
         assert got.shape == want.shape
         assert _mse(got.cpu(), want) <= 1e-6, key  # north_star: feature MSE <= 1e-4
         assert torch.allclose(got.cpu(), want, atol=2e-3, rtol=2e-3), (key, float((got.cpu() - want).abs().max()))
+
+
+def test_visiting_order_never_changes_a_gather_kernels_result():
+    """The gather kernels take a visiting order of their query rows (the pyramid passes each stage's grid order so that a tile's
+    rows are spatial neighbours); any permutation must give bit-identical outputs in the rows' own places: fused KPConv
+    (C_in = 32 / 64), the first-layer kernel, the strided max-pool."""
+    from geotransformer_amd import ext, kernels
+    g = np.load('tests/golden/neighbors_3dmatch_small_s2.npz')
+    fine = torch.from_numpy(g['points1'])
+    nb_self = torch.from_numpy(g['neighbors1'].astype(np.int64))
+    reps = 1 + 1500 // fine.shape[0]
+    n1 = fine.shape[0]
+    pts = torch.cat([fine + 10.0 * r for r in range(reps)]).cuda()
+    nb = torch.cat([torch.where(nb_self < n1, nb_self + r * n1, torch.full_like(nb_self, n1 * reps)) for r in range(reps)])[:, :36]
+    nb = nb[: nb.shape[0] - 5].contiguous().cuda()  # M not a multiple of the tile
+    M = nb.shape[0]
+    q = pts[:M].contiguous()
+    gen = torch.Generator().manual_seed(5)
+    lengths = torch.tensor([M], dtype=torch.int64).cuda()
+    orders = [torch.randperm(M, generator=gen).to(torch.int32).cuda(), ext.RadiusGrid(q, lengths, 0.1).order()]
+    assert sorted(orders[1].tolist()) == list(range(M))  # the grid order is a permutation of the rows
+    kp = torch.randn(15, 3, generator=gen).mul(0.05).cuda()
+    for C, CO in ((32, 64), (64, 64)):
+        feats = torch.randn(pts.shape[0], C, generator=gen)
+        feats[::7] = -feats[::7].abs()
+        feats = feats.cuda()
+        w = torch.randn(15 * C, CO, generator=gen).cuda()
+        packed = kernels.gemm_pack(w, b_is_kn=True)
+        bias = torch.randn(CO, generator=gen).cuda()
+        base = kernels.kpconv_fused(feats, q, pts, nb, kp, 0.1, packed, CO, bias)
+        for order in orders:
+            assert torch.equal(kernels.kpconv_fused(feats, q, pts, nb, kp, 0.1, packed, CO, bias, order=order), base)
+        pooled = kernels.maxpool(feats, nb)
+        for order in orders:
+            assert torch.equal(kernels.maxpool(feats, nb, order=order), pooled)
+    ones = torch.ones(pts.shape[0], 1).cuda()
+    ones[::5] = -1.0
+    w1 = torch.randn(15, 1, 64, generator=gen).cuda()
+    base = kernels.kpconv_c1_fused(ones, q, pts, nb, kp, 0.1, w1)
+    for order in orders:
+        assert torch.equal(kernels.kpconv_c1_fused(ones, q, pts, nb, kp, 0.1, w1, order=order), base)
+
+
+def test_grid_order_lists_spatial_neighbours_next_to_each_other():
+    """geotr_radius_grid_order over a stack of two clouds: a permutation, cloud by cloud, and consecutive rows are much closer in space
+    than consecutive rows of the (hash-map ordered) cloud itself."""
+    from geotransformer_amd import ext
+    g = np.load('tests/golden/neighbors_3dmatch_small_s2.npz')
+    a = torch.from_numpy(g['points1'])
+    pts = torch.cat([a, a + 5.0]).cuda()
+    lengths = torch.tensor([a.shape[0], a.shape[0]], dtype=torch.int64).cuda()
+    order = ext.RadiusGrid(pts, lengths, 0.1).order().long()
+    assert sorted(order.tolist()) == list(range(pts.shape[0]))
+    assert bool((order[: a.shape[0]] < a.shape[0]).all()) and bool((order[a.shape[0]:] >= a.shape[0]).all())
+    hop = lambda p: float((p[1:] - p[:-1]).norm(dim=1).median())
+    assert hop(pts[order][: a.shape[0]]) < 0.5 * hop(pts[: a.shape[0]])
