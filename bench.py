@@ -175,7 +175,8 @@ def roofline_blocks(events, cfg, args, pipe, out, kernels):
     if len(order) > 1:
         main['other'] = fam[order[1]]
     recorded = sum(fam[f]['launches'] for f in fam)
-    main['events'] = f'{recorded} launches bracketed (first {recorded} of the timed region; pool capacity bounds the count)'
+    main['events'] = (f'{recorded} launches bracketed: every {args.profile_stride}th launch of these kernel families over the timed region '
+                      f'(pool capacity {args.profile_events})')
     return main
 
 
@@ -351,6 +352,9 @@ def main():
                     help='geometric structure embedding: by table lookup (default) or on the fused sinusoid -> MFMA kernel (A/B runs)')
     ap.add_argument('--profile-events', type=int, default=2048,
                     help='launches of the two heaviest kernel families bracketed by HIP events inside the timed region (0 = none)')
+    ap.add_argument('--profile-stride', type=int, default=8,
+                    help='bracket every Nth eligible launch: a timed event pair keeps its launch from overlapping its stream neighbours, '
+                         'so the sample is spread over the whole region instead of covering every launch of its start')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the exact-fp32 mode line')
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32', 'bf16'],
                     help="matrix-pipe arithmetic: bf16x3 = split-bf16, fp32-grade (default, the headline mode); fp32 = exact fp32 MFMA; "
@@ -398,6 +402,7 @@ def main():
     runner = ConcurrentRegistration(pipe, lanes=args.lanes, stack=args.stack)
 
     last = {}
+    arrivals = []  # host time at which each pair's result was handed back (stderr diagnostics only: throughput over the timed region)
 
     def pair_of(i, j):
         return (i * args.batch + j) % len(pairs)
@@ -411,9 +416,15 @@ def main():
             if record is not None:
                 results[record, j] = out['estimated_transform']
             last[j] = (pair_of(i, j), out)  # kept for the parity block: the output of the timed run itself
+            arrivals.append(time.perf_counter())
 
         runner.submit(batch, sink)
 
+    # the event pool is created BEFORE the warm-up: creating and recording 2 x 2048 events takes ~0.1 s of GPU idle time, and an idle gap
+    # right before the timed region costs its first stacks (profiles/r02_ab_runs.md: in some first runs on a fresh box the first quarter of the 1.3 s region ran at
+    # half its rate, the other three quarters at the usual one)
+    from geotransformer_amd.native import KernelProfiler
+    prof = KernelProfiler(args.profile_events, stride=args.profile_stride)  # HIP events around the GSE / packed-GEMM / fused KPConv launches
     note(f'rank {rank}: model + {len(pairs)} pairs ready; warm-up')
     for i in range(args.warmup):
         step(i)
@@ -422,10 +433,9 @@ def main():
     out = last[0][1]
     info['superpoints'] = [int(out['ref_points_c'].shape[0]), int(out['src_points_c'].shape[0])]
 
-    from geotransformer_amd.native import KernelProfiler
-    prof = KernelProfiler(args.profile_events)  # HIP events around the GSE / packed-GEMM launches, recorded on the launch streams
     gd.barrier()
     torch.cuda.synchronize()
+    arrivals.clear()
     with prof:
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -438,6 +448,16 @@ def main():
     elapsed = gd.max_over_ranks(elapsed, device)
     events = prof.results()
     note(f'rank {rank}: timed region done ({args.steps} steps in {elapsed:.2f} s)')
+    from geotransformer_amd import pipeline as _pl
+    if _pl.HOST_TIMES:  # GEOTR_HOST_TIMING=1: where the lane threads spend their host time, per stack (all steps incl. warm-up)
+        ht = np.array(_pl.HOST_TIMES[-(args.steps * args.batch // args.stack):], dtype=np.float64)
+        note(f'rank {rank}: host ms per stack of {int(ht[:, 0].mean())} pairs over {len(ht)} stacks: pyramid call {1e3 * ht[:, 1].mean():.2f}, '
+             f'forward launches {1e3 * ht[:, 2].mean():.2f}, final read (waits for the GPU) {1e3 * ht[:, 3].mean():.2f}; '
+             f'wall per stack per lane {1e3 * elapsed * args.lanes / len(ht):.2f}')
+    if arrivals:  # pairs handed back per quarter of the timed region: a slow start (clock ramp, first-touch) shows up as a low first figure
+        edges = [t0 + elapsed * q / 4 for q in range(1, 5)]
+        quarters = [sum(1 for a in arrivals if (edges[q - 1] if q else t0) <= a < edges[q]) for q in range(4)]
+        note(f'rank {rank}: results handed back per quarter of the timed region: {quarters} (of {len(arrivals)})')
 
     # exact-fp32 matrix arithmetic on the same workload (a few steps; a mode line next to the headline, not the headline)
     fp32_mode = None

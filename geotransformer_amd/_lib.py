@@ -88,6 +88,7 @@ SIGNATURES = {
     'geotr_pyramid_build': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_profile_gse': (c_int, [c_ptr, c_ptr, c_ptr, c_i64]),
     'geotr_profile_gse_count': (c_i64, []),
+    'geotr_profile_stride': (c_int, [c_i64]),
     'geotr_gse_table_bytes': (c_size, [c_i64, c_i64]),
     'geotr_gse_table_build': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_gse_knn_clouds': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),

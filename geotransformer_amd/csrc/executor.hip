@@ -23,6 +23,8 @@ static void** g_prof_stop = nullptr;
 static int64_t* g_prof_size = nullptr;
 static int g_prof_cap = 0;
 static std::atomic<int> g_prof_used{0};
+static std::atomic<int> g_prof_seq{0};  // eligible launches seen since arming
+static int g_prof_stride = 1;           // every g_prof_stride-th eligible launch is bracketed (geotr_profile_stride)
 
 struct Ctx {
   char* base;
@@ -66,7 +68,7 @@ struct ProfScope {
   int slot = -1;
   hipStream_t stream;
   explicit ProfScope(hipStream_t st) : stream(st) {
-    if (g_prof_cap > 0) {
+    if (g_prof_cap > 0 && g_prof_seq.fetch_add(1) % g_prof_stride == 0) {
       slot = g_prof_used.fetch_add(1);
       if (slot >= g_prof_cap) slot = -1;
     }
@@ -720,7 +722,14 @@ int geotr_profile_gse(void** start_events, void** stop_events, int64_t* sizes, i
   g_prof_stop = stop_events;
   g_prof_size = sizes;
   g_prof_used.store(0);
+  g_prof_seq.store(0);
   g_prof_cap = (int)capacity;
+  return GEOTR_OK;
+}
+
+int geotr_profile_stride(int64_t stride) {
+  GEOTR_CHECK_ARG(stride >= 1 && stride < (1 << 20), "profile_stride: stride must be >= 1");
+  g_prof_stride = (int)stride;
   return GEOTR_OK;
 }
 

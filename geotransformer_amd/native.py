@@ -452,9 +452,12 @@ class KernelProfiler:
     GEMM_TAG = 1 << 62
     KPCONV_TAG = 1 << 61
 
-    def __init__(self, capacity):
+    def __init__(self, capacity, stride=1):
+        """`stride`: bracket every stride-th eligible launch only -- a timed event pair keeps its launch from overlapping its
+        neighbours in the stream, so a sample spread over the whole region disturbs it far less than every launch of its start."""
         _bind()
         self.capacity = capacity
+        self.stride = max(1, int(stride))
         self.start = [torch.cuda.Event(enable_timing=True) for _ in range(capacity)]
         self.stop = [torch.cuda.Event(enable_timing=True) for _ in range(capacity)]
         for e in self.start + self.stop:
@@ -465,12 +468,14 @@ class KernelProfiler:
         self._sizes = (ctypes.c_int64 * capacity)()
 
     def __enter__(self):
+        _lib.check(_lib.load().geotr_profile_stride(self.stride), 'geotr_profile_stride')
         _lib.check(_lib.load().geotr_profile_gse(self._start, self._stop, self._sizes, self.capacity), 'geotr_profile_gse')
         return self
 
     def __exit__(self, *exc):
         self.used = int(_lib.load().geotr_profile_gse_count())
         _lib.load().geotr_profile_gse(None, None, None, 0)
+        _lib.load().geotr_profile_stride(1)
 
     def results(self):
         """Every recorded launch; call after torch.cuda.synchronize()."""

@@ -4,13 +4,19 @@ This is the unit bench.py times ("a pair"): 3-4 grid subsa
 (geotransformer/utils/data.py:13-77) followed by GeoTransformer.forward (experiments/*/model.py:69-212), all on
 device-resident inputs.
 """
+import os
 import queue
 import threading
+import time
 
 import torch
 
 from .model import create_model
 from .utils.data import precompute_data_stack_mode
+
+
+# GEOTR_HOST_TIMING=1 (measurement aid): register_batch appends (pairs, pyramid s, forward-launch s, final-read s) of host time per stack
+HOST_TIMES = [] if os.environ.get('GEOTR_HOST_TIMING') == '1' else None
 
 
 def _check_cloud(points):
@@ -97,13 +103,19 @@ class RegistrationPipeline:
             _check_cloud(c)
         points = torch.cat(clouds, dim=0)
         lengths = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64, device=points.device)
+        t0 = time.perf_counter()
         data = build_pyramid(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.neighbor_limits)
         data['features'] = torch.ones((points.shape[0], 1), dtype=torch.float32, device=points.device)
         data['batch_size'] = len(pairs)
         if self.model._native is None:
             self.model._native = NativeModel(self.model)
+        t1 = time.perf_counter()
+        raw = self.model._native.forward_batch(data)
+        t2 = time.perf_counter()
         # the pyramid's overflow flag rides on the one host read of the counts and raises when set
-        outs = NativeModel.finalize_stack(self.model._native.forward_batch(data), overflow=data['_overflow'])
+        outs = NativeModel.finalize_stack(raw, overflow=data['_overflow'])
+        if HOST_TIMES is not None:  # GEOTR_HOST_TIMING=1: host seconds inside (pyramid incl. its stage-size reads, forward launches, final read)
+            HOST_TIMES.append((len(pairs), t1 - t0, t2 - t1, time.perf_counter() - t2))
         return (outs, data) if return_pyramid else outs
 
 

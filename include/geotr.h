@@ -445,9 +445,13 @@ typedef struct geotr_outputs {                                       /* caller-a
 size_t geotr_model_workspace_bytes(const geotr_model* net, const geotr_pyramid* pyr);
 /* Measurement hook: arm (capacity > 0) / disarm (capacity = 0) a pool of caller-created hipEvent_t handles; every GSE
  * embedding launch issued by geotr_model_forward is then bracketed by hipEventRecord(start[i]) / (stop[i]) on the launch
- * stream and sizes[i] = number of superpoints.  geotr_profile_gse_count() = slots used so far. */
+ * stream and sizes[i] = number of superpoints.  geotr_profile_gse_count() = slots used so far.
+ * geotr_profile_stride(s): bracket every s-th eligible launch only (default 1).  A timed event pair keeps its launch from overlapping
+ * its neighbours in the stream and costs host time: bracketing EVERY launch of the first stacks lowered the first quarter of a
+ * 20-step bench region by 20-45 % (profiles/r02_ab_runs.md); a stride spreads the sample over the whole region at 1/s of that cost. */
 int geotr_profile_gse(void** start_events, void** stop_events, int64_t* sizes, int64_t capacity);
 int64_t geotr_profile_gse_count(void);
+int geotr_profile_stride(int64_t stride);
 int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const float* features /* (n[0], in_dim) */,
                         const geotr_outputs* out, void* ws, size_t ws_bytes, void* stream);
 

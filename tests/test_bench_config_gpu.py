@@ -1,7 +1,7 @@
 """GPU: parity ON THE BENCHMARKED WORKLOAD and on the reference's own real-data fixture.
 
 (1) bench.py's exact configuration -- BASELINE configs[1]: 8 distinct synthetic 3DMatch pairs of 20 000 + 20 000 points at the
-    reference's full widths (4-stage KPConv-FPN, d = 256, 256 patches of 64 points), 8 pairs stacked per launch sequence, 4 lanes
+    reference's full widths (4-stage KPConv-FPN, d = 256, 256 patches of 64 points), 16 pairs stacked per launch sequence, 4 lanes
     -- every pair compared with the CPU oracle run on that pair alone (oracle/parity.py states the tolerances), the stacked
     pyramid cut back into per-pair tables that must be byte-identical to the oracle's, and every repetition of a pair on another
     lane / in another stack slot bit-identical to the first.
@@ -25,6 +25,9 @@ def _pipeline(exp='3dmatch', **kw):
     return cfg, RegistrationPipeline(cfg, device='cuda:0', **kw)
 
 
+STACK = 16  # bench.py LAUNCH_SHAPE['3dmatch'] = (4 lanes, 16 pairs stacked per launch sequence)
+
+
 def test_bench_workload_stacked_lanes_match_oracle():
     from geotransformer_amd.pipeline import ConcurrentRegistration, RegistrationPipeline
     from geotransformer_amd.synthetic import make_pair
@@ -34,20 +37,20 @@ def test_bench_workload_stacked_lanes_match_oracle():
     pairs = [(torch.from_numpy(it['ref_points']).cuda(), torch.from_numpy(it['src_points']).cuda()) for it in items]
     sd = {k: v.detach().cpu() for k, v in pipe.model.state_dict().items()}
 
-    # the bench's execution shape: 32 pairs per step, 4 lanes, stacks of 8; pairs rotated so that each one meets every stack slot
-    runner = ConcurrentRegistration(pipe, lanes=4, stack=8)
-    order = [(j + j // 8) % 8 for j in range(32)]
+    # the bench's execution shape: 64 pairs per step, 4 lanes, stacks of 16; pairs rotated so that each one meets 8 of the stack slots
+    runner = ConcurrentRegistration(pipe, lanes=4, stack=STACK)
+    order = [(j + j // STACK) % 8 for j in range(4 * STACK)]
     got = {}
     for step in range(2):
         runner.submit([pairs[q] for q in order], lambda j, out, step=step: got.__setitem__((step, j), out))
     runner.drain()
     torch.cuda.synchronize()
     runner.close()
-    assert len(got) == 64
+    assert len(got) == 2 * 4 * STACK
     keys = ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f', 'ref_node_corr_indices', 'src_node_corr_indices',
             'matching_scores', 'corr_scores', 'estimated_transform')
     first = {}
-    for j in range(32):
+    for j in range(4 * STACK):
         # the same stack on whatever lane picked it up: bit-identical (nothing in the path depends on the stream or on timing)
         for k in keys:
             assert torch.equal(got[(0, j)][k], got[(1, j)][k]), f'slot {j}: {k} differs between two runs of the same stack'
@@ -61,13 +64,15 @@ def test_bench_workload_stacked_lanes_match_oracle():
             assert d <= 2e-5, f'pair {q}: {k} differs by {d} between stack slots'
 
     # the stacked pyramid, cut back into per-pair tables
-    outs, stacked = pipe.register_batch(pairs, return_pyramid=True)
+    outs, stacked = pipe.register_batch([pairs[q] for q in order[:STACK]], return_pyramid=True)  # stack 0 of the runner
+    for j in range(STACK):
+        for k in keys:
+            assert torch.equal(outs[j][k], got[(0, j)][k]), (j, k)
     reports = []
-    for q, item in enumerate(items):
+    for q, item in enumerate(items):  # slot q of stack 0 holds pair q (and slot q + 8 again)
         pyr, want = parity.oracle_pair(cfg, sd, item)
         assert parity.pyramid_identical(RegistrationPipeline.pair_pyramid(stacked, q), pyr), f'pair {q}: stacked pyramid differs'
-        for k in keys:  # stack 0 of the runner is exactly this stack
-            assert torch.equal(outs[q][k], first[q][k]), (q, k)
+        assert parity.pyramid_identical(RegistrationPipeline.pair_pyramid(stacked, q + 8), pyr), f'pair {q}: stacked pyramid differs (slot {q + 8})'
         rep = parity.compare_pair(first[q], want)
         reports.append(rep)
         print(f'pair {q}:', rep)
