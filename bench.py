@@ -355,6 +355,7 @@ def main():
     ap.add_argument('--profile-stride', type=int, default=8,
                     help='bracket every Nth eligible launch: a timed event pair keeps its launch from overlapping its stream neighbours, '
                          'so the sample is spread over the whole region instead of covering every launch of its start')
+    ap.add_argument('--no-numa-bind', action='store_true', help="do not bind the process to the GPU's NUMA node (A/B runs)")
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the exact-fp32 mode line')
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32', 'bf16'],
                     help="matrix-pipe arithmetic: bf16x3 = split-bf16, fp32-grade (default, the headline mode); fp32 = exact fp32 MFMA; "
@@ -384,6 +385,8 @@ def main():
     backend = tdist.get_backend() if tdist.is_initialized() else 'none (single process)'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    torch.zeros(1, device=device)  # the runtime's threads exist from here on
+    numa_note, all_cpus = gd.bind_to_device_numa(local) if not args.no_numa_bind else ('NUMA binding off (--no-numa-bind)', os.sched_getaffinity(0))
 
     exp, shape, overrides, _, baseline_index = WORKLOADS[args.config]
     cfg = make_cfg(exp, overrides)
@@ -425,6 +428,7 @@ def main():
     # half its rate, the other three quarters at the usual one)
     from geotransformer_amd.native import KernelProfiler
     prof = KernelProfiler(args.profile_events, stride=args.profile_stride)  # HIP events around the GSE / packed-GEMM / fused KPConv launches
+    note(f'rank {rank}: {numa_note}')
     note(f'rank {rank}: model + {len(pairs)} pairs ready; warm-up')
     for i in range(args.warmup):
         step(i)
@@ -512,6 +516,7 @@ def main():
                                    f'P={cfg.coarse_matching.num_correspondences}, K={cfg.model.num_points_in_patch}, '
                                    f'pyramid + full forward per pair',
                        'pairs_per_step_per_gpu': args.batch, 'lanes_per_gpu': args.lanes, 'pairs_stacked_per_launch_sequence': args.stack,
+                       'host_binding': numa_note,
                        'parallelism': f'pairs sharded over {world} rank(s), one process per GPU, no data-path collective',
                        'collective_backend': 'rccl' if backend == 'nccl' else backend,
                        'weights': 'random init, seed 7351', 'matrix_precision': args.precision, 'gse': args.gse,
@@ -521,6 +526,7 @@ def main():
         if fp32_mode is not None:
             line['exact_fp32_mode'] = fp32_mode
         if world == 1 and not args.no_cpu_baseline:
+            os.sched_setaffinity(0, all_cpus)  # the CPU legs (child processes) may use every core the box allows
             note('CPU baseline (oracle on the host cores)')
             base, pyr0, want0 = cpu_baseline(cfg, items, pipe.model)
             note('parity of the timed run vs the oracle')

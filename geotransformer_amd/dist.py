@@ -99,3 +99,46 @@ def shutdown():
         if dist.get_world_size() > 1:
             dist.barrier()
         dist.destroy_process_group()
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_device_numa(device_index):
+    """One process per GPU, on the GPU's own NUMA node: restrict every thread of this process (and the threads it creates later: the
+    lanes, the HIP runtime's helpers) to the CPUs local to the device's PCIe root (`/sys/bus/pci/devices/<bdf>/local_cpulist`).
+
+    On the dual-socket MI355X hosts four GPUs hang off each socket (PCIe roots on NUMA node 0 / 1); a process the scheduler places on the
+    other socket pays the inter-socket hop on every doorbell write, kernel-argument copy and completion-signal read.  Binding removes
+    that variable from the launch path (some first runs on shared hosts launched at a third of the usual rate -- 9.1 ms of launches per
+    stack instead of 2.6, profiles/r02_ab_runs.md -- though seven alternating bound / unbound runs on a quiet box read the same).  Returns a short description of what was
+    done (for logs); does nothing when the topology is not exposed.  Undo with `os.sched_setaffinity(0, previous)` (returned set)."""
+    previous = os.sched_getaffinity(0)
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
+        base = f'/sys/bus/pci/devices/{bdf}'
+        with open(f'{base}/numa_node') as f:
+            node = int(f.read().strip())
+        with open(f'{base}/local_cpulist') as f:
+            local = _parse_cpulist(f.read())
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError) as exc:  # no device / no sysfs topology
+        return f'NUMA binding skipped ({type(exc).__name__}: {exc})', previous
+    cpus = local & previous
+    if node < 0 or not cpus or cpus == previous:
+        return f'NUMA binding not needed (device {bdf}: node {node}, {len(local)} local CPUs, {len(previous)} allowed)', previous
+    bound = 0
+    for tid in os.listdir('/proc/self/task'):  # threads that exist already (runtime helpers) as well as this one
+        try:
+            os.sched_setaffinity(int(tid), cpus)
+            bound += 1
+        except OSError:
+            pass
+    return f'{bound} threads bound to NUMA node {node} of device {bdf} ({len(cpus)} of {len(previous)} CPUs)', previous

@@ -90,7 +90,7 @@ class RegistrationPipeline:
         }
 
     @torch.no_grad()
-    def register_batch(self, pairs, return_pyramid=False):
+    def register_batch(self, pairs, return_pyramid=False, pyramid_stream=None):
         """Several independent pairs through ONE launch sequence: the clouds are stacked (ref_0, src_0, ref_1, ...), the
         pyramid and the KPConv-FPN run once over the stack (GroupNorm statistics stay per pair), the heads run pair by
         pair.  `pairs` = [(ref_points, src_points), ...] (at most 16); returns one output dict per pair.  Per-pair results
@@ -104,7 +104,16 @@ class RegistrationPipeline:
         points = torch.cat(clouds, dim=0)
         lengths = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64, device=points.device)
         t0 = time.perf_counter()
-        data = build_pyramid(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.neighbor_limits)
+        if pyramid_stream is None:
+            data = build_pyramid(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.neighbor_limits)
+        else:
+            # the pyramid's chain of small dependent kernels on a high-priority queue of the lane (ConcurrentRegistration): they do not
+            # queue behind the other lanes' long kernels.  Its tensors stay alive until this call's final read of the lane's stream.
+            current = torch.cuda.current_stream(points.device)
+            pyramid_stream.wait_stream(current)
+            with torch.cuda.stream(pyramid_stream):
+                data = build_pyramid(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.neighbor_limits)
+            current.wait_stream(pyramid_stream)
         data['features'] = torch.ones((points.shape[0], 1), dtype=torch.float32, device=points.device)
         data['batch_size'] = len(pairs)
         if self.model._native is None:
@@ -137,6 +146,9 @@ class ConcurrentRegistration:
         self.stack = max(1, min(16, int(stack)))
         self.device = pipeline.device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
+        # GEOTR_PYRAMID_PRIORITY=1 (experiment): a second, high-priority queue per lane for the pyramid's small dependent kernels
+        self.pyramid_streams = ([torch.cuda.Stream(device=self.device, priority=-1) for _ in range(self.lanes)]
+                                if os.environ.get('GEOTR_PYRAMID_PRIORITY') == '1' else [None] * self.lanes)
         self._queue = queue.SimpleQueue()
         self._pending = 0
         self._cv = threading.Condition()
@@ -163,7 +175,8 @@ class ConcurrentRegistration:
                         index, ref, src, sink, _ = job[0]
                         sink(index, self.pipeline(ref, src))
                     else:
-                        outs = self.pipeline.register_batch([(ref, src) for _, ref, src, _, _ in job])
+                        outs = self.pipeline.register_batch([(ref, src) for _, ref, src, _, _ in job],
+                                                            pyramid_stream=self.pyramid_streams[lane])
                         for (index, _, _, sink, _), out in zip(job, outs):
                             sink(index, out)
                 except BaseException as exc:  # surfaced by drain()

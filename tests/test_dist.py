@@ -57,3 +57,13 @@ def test_single_process_fast_path():
     gd.barrier()
     assert gd.max_over_ranks(3.5, 'cpu') == 3.5
     gd.shutdown()  # no group: nothing to do
+
+
+def test_numa_binding_helper_parses_cpu_lists_and_skips_without_a_device():
+    from geotransformer_amd import dist as gd
+    assert gd._parse_cpulist('0-3,8,10-11\n') == {0, 1, 2, 3, 8, 10, 11}
+    assert gd._parse_cpulist('') == set()
+    before = os.sched_getaffinity(0)
+    note, previous = gd.bind_to_device_numa(0)  # no HIP device here: nothing may change
+    assert previous == before and os.sched_getaffinity(0) == before
+    assert 'skipped' in note or 'not needed' in note
