@@ -77,6 +77,8 @@ SIGNATURES = {
                                          c_ptr, c_size, c_ptr]),
     'geotr_group_norm_segmented': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geotr_group_norm_flags_supported': (c_int, [c_i64]),
+    'geotr_group_norm_shortcut': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_i64, c_ptr, c_ptr, c_f32, c_int, c_ptr, c_ptr,
+                                          c_i64, c_ptr, c_ptr]),
     'geotr_group_norm_segmented_flags': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_i64, c_ptr,
                                                  c_ptr, c_ptr]),
     'geotr_l2_normalize': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),

@@ -233,8 +233,26 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
     if (c.live()) c.check(geotr_maxpool_ordered(s_feats, nb, m, ns, h, in_ch, c.order[q_stage], pooled, c.stream));
     sc = pooled;
   }
+  static const bool fuse_shortcut_norm = [] {
+    const char* e = std::getenv("GEOTR_GN_SHORTCUT_FUSED");  // A/B switch for measurements: 0 = normalise the shortcut in its own pass
+    return !(e && e[0] == '0');
+  }();
   if (b.has_shortcut) {
     float* t = linear(c, b.shortcut, sc, b.shortcut.in, m, 0);
+    if (fuse_shortcut_norm && b.shortcut_norm.groups > 0 && b.unary2_norm.groups > 0 && b.shortcut.out == b.unary2.out) {
+      // leaky_relu(GN(unary2(x)) + GN(shortcut Linear)): the shortcut's affine rides in the apply pass of the main branch (bit-identical);
+      // its normalised (m, out) tensor -- 328 MB per 16-pair stack at stage 0 -- is neither written nor re-read
+      float* z = linear(c, b.unary2, y, b.unary2.in, m, 0);
+      float* out = c.alloc<float>((size_t)m * b.unary2.out);
+      const size_t mk = c.mark();
+      double* ws = reinterpret_cast<double*>(c.alloc<char>(geotr_group_norm_workspace_bytes(m, b.unary2.out)));
+      if (c.live())
+        c.check(geotr_group_norm_shortcut(z, t, m, b.unary2.out, b.unary2_norm.groups, b.unary2_norm.gamma, b.unary2_norm.beta, b.unary2_norm.eps,
+                                          b.shortcut_norm.groups, b.shortcut_norm.gamma, b.shortcut_norm.beta, b.shortcut_norm.eps, 2, out,
+                                          c.seg_rows[q_stage], c.nseg, ws, c.stream));
+      c.release(mk);
+      return out;
+    }
     sc = norm(c, b.shortcut_norm, t, m, b.shortcut.out, nullptr, 0, q_stage);
   }
   float* z = linear(c, b.unary2, y, b.unary2.in, m, 0);

@@ -353,18 +353,26 @@ __global__ __launch_bounds__(256) void gn_group_kernel(const float* __restrict__
 // over the tensor: the C / 4 lanes that hold a row are an aligned group of one wave, reduced with shuffles.
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gn_apply2_kernel(const float* __restrict__ x, int64_t total, int C, const float* __restrict__ ab_all,
-                                                        GnSegs sg, const float* __restrict__ residual, int act, float* __restrict__ out,
-                                                        unsigned char* __restrict__ flag) {
+                                                        GnSegs sg, const float* __restrict__ residual, const float* __restrict__ res_ab_all,
+                                                        int act, float* __restrict__ out, unsigned char* __restrict__ flag) {
   const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (VEC4 ? 4 : 1);
   if (e >= total) return;  // total is a multiple of C, so a row's lane group leaves together
-  const float* ab = ab_all + (int64_t)(sg.nseg > 1 ? gn_seg_of_row(sg, e / C) : 0) * 2 * C;
+  const int64_t seg_off = (int64_t)(sg.nseg > 1 ? gn_seg_of_row(sg, e / C) : 0) * 2 * C;
+  const float* ab = ab_all + seg_off;
+  // res_ab_all (optional): the residual is the RAW input of another GroupNorm whose affine is applied here, value by value exactly as
+  // that norm's own apply pass would have (multiply, then add: two roundings) -- its normalised tensor is never written
+  const float* rab = res_ab_all ? res_ab_all + seg_off : nullptr;
   if (VEC4) {
     const int c = (int)(e % C);
     const float4 v = *reinterpret_cast<const float4*>(x + e);
     float r[4] = {v.x * ab[c] + ab[C + c], v.y * ab[c + 1] + ab[C + c + 1], v.z * ab[c + 2] + ab[C + c + 2],
                   v.w * ab[c + 3] + ab[C + c + 3]};
     if (residual) {
-      const float4 q = *reinterpret_cast<const float4*>(residual + e);
+      float4 q = *reinterpret_cast<const float4*>(residual + e);
+      if (rab) {
+        q.x = q.x * rab[c] + rab[C + c], q.y = q.y * rab[c + 1] + rab[C + c + 1];
+        q.z = q.z * rab[c + 2] + rab[C + c + 2], q.w = q.w * rab[c + 3] + rab[C + c + 3];
+      }
       r[0] += q.x; r[1] += q.y; r[2] += q.z; r[3] += q.w;
     }
 #pragma unroll
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(256) void gn_apply2_kernel(const float* __restrict_
   } else {
     const int c = (int)(e % C);
     float v = x[e] * ab[c] + ab[C + c];
-    if (residual) v += residual[e];
+    if (residual) v += rab ? residual[e] * rab[c] + rab[C + c] : residual[e];
     if (act == 2) v = v > 0.f ? v : 0.1f * v;
     if (act == 1) v = fmaxf(v, 0.f);
     out[e] = v;
@@ -589,7 +597,7 @@ int geotr_upsample_concat(const float* coarse, int64_t nc, int64_t c1, const int
 
 size_t geotr_group_norm_workspace_bytes(int64_t n, int64_t c) {
   const size_t nb = (size_t)((n + kGnRows - 1) / kGnRows) + GEOTR_MAX_PAIRS;  // every segment may end in a partial block
-  return sizeof(double) * 2 * (size_t)c + sizeof(float) * 2 * (size_t)c * (nb + GEOTR_MAX_PAIRS);
+  return sizeof(double) * 2 * (size_t)c + sizeof(float) * 2 * (size_t)c * (nb + 2 * GEOTR_MAX_PAIRS);  // partials + ab + shortcut ab
 }
 
 int geotr_group_norm_flags_supported(int64_t c) { return c % 4 == 0 && c / 4 <= 64 && ((c / 4) & (c / 4 - 1)) == 0; }
@@ -600,13 +608,24 @@ int geotr_group_norm_segmented(const float* x, int64_t n, int64_t c, int64_t gro
   return geotr_group_norm_segmented_flags(x, n, c, groups, gamma, beta, eps, residual, act, out, seg_rows_host, nseg, stats_ws, nullptr, stream_);
 }
 
-int geotr_group_norm_segmented_flags(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
-                                     const float* residual, int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws,
-                                     uint8_t* row_positive, void* stream_) {
+// statistics of one tensor: partials -> per (segment, channel) scale / shift in `ab` (nseg x 2c floats)
+static void gn_statistics(const float* x, const GnSegs& sg, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                          float* partial, float* ab, hipStream_t stream) {
+  const unsigned nb = (unsigned)sg.blk0[sg.nseg];
+  const int per = c < 256 ? (int)(256 / c) : 0;
+  gn_partial_kernel<<<dim3(nb), dim3(256), sizeof(float) * 2 * (size_t)c * per, stream>>>(x, sg, (int)c, partial);
+  gn_group_kernel<<<dim3((unsigned)groups, (unsigned)sg.nseg), dim3(256), 0, stream>>>(partial, sg, (int)c, (int)groups, gamma, beta, eps, ab);
+}
+
+// shared body: out = act(GN(x) + R) with R = residual, or GN'(residual) when res_gamma is given (its own statistics, never materialised)
+static int group_norm_impl(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                           const float* residual, int64_t res_groups, const float* res_gamma, const float* res_beta, float res_eps, int act,
+                           float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws, uint8_t* row_positive, void* stream_) {
   GEOTR_CHECK_ARG(!row_positive || geotr_group_norm_flags_supported(c), "group_norm: row flags need c / 4 a power of two <= 64 (c = %lld)",
                   (long long)c);
   GEOTR_CHECK_ARG(n >= 0 && c >= 1 && groups >= 1 && c % groups == 0, "group_norm: %lld channels / %lld groups",
                   (long long)c, (long long)groups);
+  GEOTR_CHECK_ARG(!res_gamma || (residual && res_beta && res_groups >= 1 && c % res_groups == 0), "group_norm: bad shortcut norm");
   GEOTR_CHECK_ARG(nseg >= 1 && nseg <= GEOTR_MAX_PAIRS && seg_rows_host, "group_norm: 1..%d row segments", GEOTR_MAX_PAIRS);
   if (n == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(x && gamma && beta && out && stats_ws, "group_norm: null pointer");
@@ -626,21 +645,39 @@ int geotr_group_norm_segmented_flags(const float* x, int64_t n, int64_t c, int64
   sg.blk0[nseg] = blk;
   GEOTR_CHECK_ARG(row == n, "group_norm: segments cover %lld rows, expected %lld", (long long)row, (long long)n);
   hipStream_t stream = (hipStream_t)stream_;
-  const unsigned nb = (unsigned)blk;
+  // workspace: [2c doubles (legacy)] [partials: blk x 2c] [ab: MAX_PAIRS x 2c] [shortcut ab: MAX_PAIRS x 2c]
   float* partial = reinterpret_cast<float*>(stats_ws + 2 * c);
-  const int per = c < 256 ? (int)(256 / c) : 0;
-  gn_partial_kernel<<<dim3(nb), dim3(256), sizeof(float) * 2 * (size_t)c * per, stream>>>(x, sg, (int)c, partial);
-  float* ab = partial + (size_t)nb * 2 * c;
-  gn_group_kernel<<<dim3((unsigned)groups, (unsigned)nseg), dim3(256), 0, stream>>>(partial, sg, (int)c, (int)groups, gamma, beta, eps, ab);
+  float* ab = partial + (size_t)blk * 2 * c;
+  float* res_ab = nullptr;
+  if (res_gamma) {  // the shortcut's statistics first; the partial records are free again once its finalize kernel has run (stream order)
+    res_ab = ab + (size_t)GEOTR_MAX_PAIRS * 2 * c;
+    gn_statistics(residual, sg, c, res_groups, res_gamma, res_beta, res_eps, partial, res_ab, stream);
+  }
+  gn_statistics(x, sg, c, groups, gamma, beta, eps, partial, ab, stream);
   const int64_t total = n * c;
   if (c % 4 == 0)
-    gn_apply2_kernel<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, act, out,
-                                                                                                row_positive);
+    gn_apply2_kernel<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, res_ab, act,
+                                                                                                out, row_positive);
   else
-    gn_apply2_kernel<false><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, act, out,
-                                                                                             nullptr);
+    gn_apply2_kernel<false><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, res_ab, act,
+                                                                                             out, nullptr);
   GEOTR_CHECK_LAUNCH("group_norm");
   return GEOTR_OK;
+}
+
+int geotr_group_norm_segmented_flags(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                                     const float* residual, int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws,
+                                     uint8_t* row_positive, void* stream_) {
+  return group_norm_impl(x, n, c, groups, gamma, beta, eps, residual, 0, nullptr, nullptr, 0.f, act, out, seg_rows_host, nseg, stats_ws,
+                         row_positive, stream_);
+}
+
+int geotr_group_norm_shortcut(const float* x, const float* shortcut, int64_t n, int64_t c, int64_t groups, const float* gamma,
+                              const float* beta, float eps, int64_t sc_groups, const float* sc_gamma, const float* sc_beta, float sc_eps,
+                              int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws, void* stream_) {
+  GEOTR_CHECK_ARG(shortcut && sc_gamma && sc_beta, "group_norm_shortcut: null pointer");
+  return group_norm_impl(x, n, c, groups, gamma, beta, eps, shortcut, sc_groups, sc_gamma, sc_beta, sc_eps, act, out, seg_rows_host, nseg,
+                         stats_ws, nullptr, stream_);
 }
 
 int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,

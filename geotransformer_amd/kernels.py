@@ -245,6 +245,24 @@ def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, act=None):
     return out
 
 
+def group_norm_shortcut(x, shortcut, groups, weight, bias, sc_groups, sc_weight, sc_bias, eps=1e-5, sc_eps=1e-5, act=None, seg_rows=None):
+    """act(GN(x) + GN(shortcut)) with the shortcut's normalised tensor never materialised (geotr_group_norm_shortcut); bit-identical to
+    group_norm(x, ..., residual=group_norm(shortcut, ...)).  `seg_rows`: rows per stacked pair (statistics stay inside a segment)."""
+    import ctypes
+    lib = _lib.load()
+    x, shortcut = _f32c(x), _f32c(shortcut)
+    N, C = x.shape
+    assert shortcut.shape == x.shape
+    segs = [N] if seg_rows is None else [int(r) for r in seg_rows]
+    out = torch.empty_like(x)
+    stats = _lib.workspace(lib.geotr_group_norm_workspace_bytes(N, C), x.device)
+    _lib.check(lib.geotr_group_norm_shortcut(_lib.ptr(x), _lib.ptr(shortcut), N, C, groups, _lib.ptr(weight), _lib.ptr(bias), float(eps),
+                                             sc_groups, _lib.ptr(sc_weight), _lib.ptr(sc_bias), float(sc_eps), ACT[act], _lib.ptr(out),
+                                             (ctypes.c_int64 * len(segs))(*segs), len(segs), _lib.ptr(stats), _lib.stream_ptr()),
+               'geotr_group_norm_shortcut')
+    return out
+
+
 def layer_norm(x, weight, bias, eps=1e-5, residual=None):
     lib = _lib.load()
     shape = x.shape

@@ -214,6 +214,14 @@ int geotr_group_norm_segmented(const float* x, int64_t n, int64_t c, int64_t gro
  * features (kpconv/kpconv.py:113-115; geotr_row_positive as a separate pass).  Requires geotr_group_norm_flags_supported(c)
  * (c / 4 a power of two <= 64); row_positive may be NULL. */
 int geotr_group_norm_flags_supported(int64_t c);
+/* Tail of a ResidualBlock whose shortcut has its own Linear + GroupNorm (kpconv/modules.py:204-224):
+ *   out = act(GN(x; gamma, beta) + GN(shortcut; sc_gamma, sc_beta))
+ * with `shortcut` the RAW output of the shortcut Linear: its statistics are computed here and its affine is applied value by value
+ * inside the apply pass of x (the same multiply-then-add its own apply pass would perform: bit-identical to two geotr_group_norm
+ * calls), so the normalised shortcut tensor is never written or re-read.  Segments and workspace as geotr_group_norm_segmented. */
+int geotr_group_norm_shortcut(const float* x, const float* shortcut, int64_t n, int64_t c, int64_t groups, const float* gamma,
+                              const float* beta, float eps, int64_t sc_groups, const float* sc_gamma, const float* sc_beta, float sc_eps,
+                              int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws, void* stream);
 int geotr_group_norm_segmented_flags(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
                                      const float* residual, int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws,
                                      uint8_t* row_positive, void* stream);

@@ -4,6 +4,7 @@ import ctypes
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -169,3 +170,33 @@ def test_group_norm_row_flags_and_row_positive(C):
     sep = kernels.row_positive(out)
     assert torch.equal(sep.bool()[clear], (sums > 0)[clear])
     assert float((sep.bool() != flags.bool()).float().mean()) <= 1e-3  # another summation order: only rows with |sum| ~ 0 may differ
+
+
+@pytest.mark.parametrize('C,segs', [(128, [9000, 777, 2048]), (256, [300, 301]), (1024, [517]), (6, [40, 33])])
+def test_group_norm_shortcut_is_bitwise_two_group_norms(C, segs):
+    """geotr_group_norm_shortcut -- act(GN(x) + GN'(shortcut)) with the shortcut's affine applied inside the apply pass of x, its
+    normalised tensor never written -- equals the two-pass form bit for bit (segments of both statistics-block sizes, a width that is
+    not a multiple of 4), and the torch formula within fp32 tolerance."""
+    from geotransformer_amd import _lib, kernels
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(C)
+    n = sum(segs)
+    groups = 32 if C >= 32 else 3
+    x, t = (torch.randn(n, C, generator=g) * 2 + 0.3).cuda(), (torch.randn(n, C, generator=g) * 0.7 - 0.1).cuda()
+    w1, b1, w2, b2 = [torch.randn(C, generator=g).cuda() for _ in range(4)]
+    arr = (ctypes.c_int64 * len(segs))(*segs)
+    ws = _lib.workspace(lib.geotr_group_norm_workspace_bytes(n, C), x.device)
+    sc, two = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(lib.geotr_group_norm_segmented(_lib.ptr(t), n, C, groups, _lib.ptr(w2), _lib.ptr(b2), 1e-5, None, 0, _lib.ptr(sc), arr, len(segs),
+                                              _lib.ptr(ws), _lib.stream_ptr()), 'gn shortcut')
+    _lib.check(lib.geotr_group_norm_segmented(_lib.ptr(x), n, C, groups, _lib.ptr(w1), _lib.ptr(b1), 1e-5, _lib.ptr(sc), 2, _lib.ptr(two), arr,
+                                              len(segs), _lib.ptr(ws), _lib.stream_ptr()), 'gn main')
+    fused = kernels.group_norm_shortcut(x, t, groups, w1, b1, groups, w2, b2, act='leaky', seg_rows=segs)
+    assert torch.equal(fused, two)
+    want, r0 = [], 0
+    for rows in segs:  # per segment: statistics over all its rows (modules.py:47-50)
+        def gn(v, w, b):
+            return F.group_norm(v.t().unsqueeze(0), groups, w, b, 1e-5).squeeze(0).t()
+        want.append(F.leaky_relu(gn(x[r0:r0 + rows], w1, b1) + gn(t[r0:r0 + rows], w2, b2), 0.1))
+        r0 += rows
+    assert torch.allclose(fused, torch.cat(want), atol=2e-4, rtol=2e-4)
