@@ -17,6 +17,8 @@ c_ptr = ctypes.c_void_p
 c_size = ctypes.c_size_t
 c_int = ctypes.c_int
 
+ABI_VERSION = 3  # geotr_abi_version() of the library this package's ctypes mirrors (native.py, kernels.py) were written against
+
 # name -> (restype, argtypes); must list every symbol include/geotr.h declares (tests check this)
 SIGNATURES = {
     'geotr_last_error': (ctypes.c_char_p, []),
@@ -119,6 +121,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if lib.geotr_abi_version() != ABI_VERSION:  # descriptor structs are mirrored field by field (native.py): a stale build would misread them
+            raise RuntimeError(f'{LIB_PATH} has ABI version {lib.geotr_abi_version()}, this package needs {ABI_VERSION}: rebuild it '
+                               f'(`python -c "import __graft_entry__ as g; g.build()"`)')
         _lib = lib
     return _lib
 

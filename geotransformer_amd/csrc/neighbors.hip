@@ -689,7 +689,9 @@ using namespace geotr;
 extern "C" {
 
 const char* geotr_last_error(void) { return error_buffer(); }
-int geotr_abi_version(void) { return 2; }  // 2: geotr_transformer carries the GSE lookup tables
+// 2: geotr_transformer carries the GSE lookup tables; 3: geotr_pyramid / geotr_pyramid_buffers carry the visiting order, the fused
+// KPConv entry points take it
+int geotr_abi_version(void) { return 3; }
 
 size_t geotr_radius_grid_workspace_bytes(int64_t ns, int64_t batch) {
   return grid_layout(nullptr, ns, batch).bytes;

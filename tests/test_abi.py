@@ -33,7 +33,7 @@ def test_python_binding_covers_header():
     from geotransformer_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.geotr_abi_version() >= 1
+    assert lib.geotr_abi_version() == _lib.ABI_VERSION
 
 
 def test_argument_validation_without_gpu():
