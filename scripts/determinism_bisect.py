@@ -1,4 +1,4 @@
-"""GPU debug (round 2, call C): (1) where does the HIP grid subsample differ from the oracle on the reference's demo pair;
+"""Determinism / first-difference bisect tool (round 2; used for profiles/r02_concurrency_hazard.md): (1) where does the HIP grid subsample differ from the oracle on the reference's demo pair;
 (2) is the stacked path run-to-run deterministic, and if not, which output first and under which switch."""
 import os
 import sys

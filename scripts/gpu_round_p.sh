@@ -25,5 +25,5 @@ EXTRA="--lanes 1" ab lanes1_unfused_nosplitk GEOTR_KPCONV_FUSED=0 GEOTR_SPLITK=0
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode > $OUT/bench_under_rocprof.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_l1 -o bench -- python $ROOT/bench.py --steps 6 --warmup 2 --lanes 1 --no-cpu-baseline --no-fp32-mode > $OUT/bench_l1_under_rocprof.json 2>/dev/null
 cd $ROOT
-bad=0; for i in 1 2 3 4 5 6 7 8; do n=$(GEOTR_POISON_WS=1 LABEL=m GSE=table python scripts/debug_c.py bisect 1 2>&1 | grep -c "DIFFERENCES"); bad=$((bad + n)); done; echo "concurrency determinism (4 lanes x 4 rotated stacks, poisoned workspaces): $bad of 8 runs nondeterministic" | tee $OUT/determinism.txt
+bad=0; for i in 1 2 3 4 5 6 7 8; do n=$(GEOTR_POISON_WS=1 LABEL=m GSE=table python scripts/determinism_bisect.py bisect 1 2>&1 | grep -c "DIFFERENCES"); bad=$((bad + n)); done; echo "concurrency determinism (4 lanes x 4 rotated stacks, poisoned workspaces): $bad of 8 runs nondeterministic" | tee $OUT/determinism.txt
 ls $OUT | head -40
