@@ -375,6 +375,9 @@ def main():
     from geotransformer_amd.pipeline import ConcurrentRegistration, RegistrationPipeline
     from geotransformer_amd.synthetic import CONFIGS
 
+    # before the device context exists: spin in stream waits only while every waiting thread of every local rank can have its own CPU
+    local_ranks = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
+    sync_note = gd.choose_host_waits(local_ranks * (args.lanes + 1), os.environ.get('GEOTR_BLOCKING_SYNC'))
     _lib.require_gpu()
     _lib.load()
     kernels.set_precision(args.precision, gse=args.gse)
@@ -428,7 +431,7 @@ def main():
     # half its rate, the other three quarters at the usual one)
     from geotransformer_amd.native import KernelProfiler
     prof = KernelProfiler(args.profile_events, stride=args.profile_stride)  # HIP events around the GSE / packed-GEMM / fused KPConv launches
-    note(f'rank {rank}: {numa_note}')
+    note(f'rank {rank}: {numa_note}; host waits: {sync_note}')
     note(f'rank {rank}: model + {len(pairs)} pairs ready; warm-up')
     for i in range(args.warmup):
         step(i)
@@ -516,7 +519,7 @@ def main():
                                    f'P={cfg.coarse_matching.num_correspondences}, K={cfg.model.num_points_in_patch}, '
                                    f'pyramid + full forward per pair',
                        'pairs_per_step_per_gpu': args.batch, 'lanes_per_gpu': args.lanes, 'pairs_stacked_per_launch_sequence': args.stack,
-                       'host_binding': numa_note,
+                       'host_binding': numa_note, 'host_waits': sync_note,
                        'parallelism': f'pairs sharded over {world} rank(s), one process per GPU, no data-path collective',
                        'collective_backend': 'rccl' if backend == 'nccl' else backend,
                        'weights': 'random init, seed 7351', 'matrix_precision': args.precision, 'gse': args.gse,

@@ -142,3 +142,50 @@ def bind_to_device_numa(device_index):
         except OSError:
             pass
     return f'{bound} threads bound to NUMA node {node} of device {bdf} ({len(cpus)} of {len(previous)} CPUs)', previous
+
+
+def set_blocking_sync():
+    """Ask the HIP runtime to BLOCK (interrupt wait) instead of spinning in stream / event synchronisation.  Must run before the process
+    creates its device context (first CUDA call of torch); returns a short description.  A registration process keeps 4 lane threads
+    waiting on their streams most of the time: spinning, each burns a whole CPU (3.7 CPUs busy per process measured,
+    scripts/host_cpu_usage.py) -- harmless alone, but eight ranks on a CPU-quota'd host would starve each other's launch threads."""
+    import ctypes
+    try:
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+        hip = ctypes.CDLL(path if os.path.exists(path) else 'libamdhip64.so')
+        rc = hip.hipSetDeviceFlags(ctypes.c_uint(0x4))  # hipDeviceScheduleBlockingSync
+        return f'hipSetDeviceFlags(hipDeviceScheduleBlockingSync) -> {rc}'
+    except OSError as exc:
+        return f'blocking sync not set ({exc})'
+
+
+def cpu_budget(cgroup_root='/sys/fs/cgroup'):
+    """CPUs this process may keep busy: the affinity mask, capped by the cgroup CPU quota (v2 `cpu.max`, v1 `cpu/cpu.cfs_quota_us`)."""
+    budget = float(len(os.sched_getaffinity(0)))
+    try:
+        with open(os.path.join(cgroup_root, 'cpu.max')) as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            budget = min(budget, int(quota) / int(period))
+    except (OSError, ValueError):
+        try:
+            with open(os.path.join(cgroup_root, 'cpu', 'cpu.cfs_quota_us')) as f:
+                quota = int(f.read())
+            with open(os.path.join(cgroup_root, 'cpu', 'cpu.cfs_period_us')) as f:
+                period = int(f.read())
+            if quota > 0:
+                budget = min(budget, quota / period)
+        except (OSError, ValueError):
+            pass
+    return budget
+
+
+def choose_host_waits(waiting_threads, override=None):
+    """Spin (the runtime's default: lowest wake-up latency, +4 % at one rank) while every waiting thread of every local rank can have a
+    CPU of its own, block otherwise.  `waiting_threads` = local ranks x (lanes + 1).  `override`: '1' / '0' forces blocking / spinning
+    (GEOTR_BLOCKING_SYNC).  Must run before the device context exists.  Returns a description for the logs."""
+    budget = cpu_budget()
+    block = override == '1' or (override != '0' and waiting_threads > budget)
+    if not block:
+        return f'spin ({waiting_threads} waiting threads, CPU budget {budget:g})'
+    return f'{set_blocking_sync()} ({waiting_threads} waiting threads, CPU budget {budget:g})'

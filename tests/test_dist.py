@@ -67,3 +67,25 @@ def test_numa_binding_helper_parses_cpu_lists_and_skips_without_a_device():
     note, previous = gd.bind_to_device_numa(0)  # no HIP device here: nothing may change
     assert previous == before and os.sched_getaffinity(0) == before
     assert 'skipped' in note or 'not needed' in note
+
+
+def test_cpu_budget_reads_the_cgroup_quota_and_waits_are_chosen_from_it(tmp_path, monkeypatch):
+    from geotransformer_amd import dist as gd
+    cores = len(os.sched_getaffinity(0))
+    (tmp_path / 'cpu.max').write_text('1600000 100000\n')
+    assert gd.cpu_budget(str(tmp_path)) == min(cores, 16.0)
+    (tmp_path / 'cpu.max').write_text('max 100000\n')
+    assert gd.cpu_budget(str(tmp_path)) == cores
+    v1 = tmp_path / 'v1'
+    (v1 / 'cpu').mkdir(parents=True)
+    (v1 / 'cpu' / 'cpu.cfs_quota_us').write_text('250000\n')
+    (v1 / 'cpu' / 'cpu.cfs_period_us').write_text('100000\n')
+    assert gd.cpu_budget(str(v1)) == min(cores, 2.5)
+    assert gd.cpu_budget(str(tmp_path / 'absent')) == cores
+    monkeypatch.setattr(gd, 'cpu_budget', lambda: 16.0)
+    called = []
+    monkeypatch.setattr(gd, 'set_blocking_sync', lambda: called.append(1) or 'blocking set')
+    assert gd.choose_host_waits(5).startswith('spin') and not called       # one rank, 4 lanes: every waiter has a CPU
+    assert gd.choose_host_waits(40).startswith('blocking set') and called  # eight ranks on a 16-CPU quota
+    assert gd.choose_host_waits(40, override='0').startswith('spin')
+    assert gd.choose_host_waits(5, override='1').startswith('blocking set')
