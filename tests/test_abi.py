@@ -45,6 +45,28 @@ def test_argument_validation_without_gpu():
     assert b'null pointer' in lib.geotr_last_error()
     assert lib.geotr_radius_grid_workspace_bytes(1000, 2) > 0
     assert lib.geotr_grid_subsample_workspace_bytes(1000, 2) > 0
+    # the entry points added in round 2 validate before they launch, too
+    one = ctypes.c_void_p(16)  # a non-null address that is never dereferenced: every call below is rejected on its arguments
+    assert lib.geotr_radius_grid_order(None, 10, 1, None, None) == -1 and b'radius_grid_order' in lib.geotr_last_error()
+    assert lib.geotr_radius_grid_order(one, 10, 1000, one, None) == -1
+    assert lib.geotr_kpconv_c1_fused(one, one, one, one, one, 8, 8, 65, 64, 15, 0.1, one, None, None, one, None) == -1
+    assert b'h <= 64' in lib.geotr_last_error()
+    assert lib.geotr_kpconv_c1_fused(one, one, one, one, one, 8, 8, 38, 64, 14, 0.1, one, None, None, one, None) == -1
+    assert b'15 kernel points' in lib.geotr_last_error()
+    assert lib.geotr_kpconv_fused_supported(32, 64, 38) == 1 and lib.geotr_kpconv_fused_supported(128, 128, 38) == 0
+    assert lib.geotr_kpconv_fused_supported(64, 96, 38) == 0 and lib.geotr_kpconv_fused_supported(64, 64, 41) == 0
+    assert lib.geotr_kpconv_fused(one, one, one, one, one, one, 8, 8, 38, 128, 128, 15, 0.1, one, None, 0, None, one, None) == -1
+    assert b'unsupported shape' in lib.geotr_last_error()
+    assert lib.geotr_maxpool_ordered(None, None, 4, 4, 3, 8, None, None, None) == -1 and b'maxpool' in lib.geotr_last_error()
+    segs = (ctypes.c_int64 * 2)(5, 4)
+    assert lib.geotr_group_norm_shortcut(one, None, 9, 8, 2, one, one, 1e-5, 2, one, one, 1e-5, 0, one, segs, 2, one, None) == -1
+    assert lib.geotr_group_norm_shortcut(one, one, 9, 8, 3, one, one, 1e-5, 2, one, one, 1e-5, 0, one, segs, 2, one, None) == -1
+    assert b'channels' in lib.geotr_last_error()  # 8 channels / 3 groups
+    assert lib.geotr_group_norm_shortcut(one, one, 10, 8, 2, one, one, 1e-5, 2, one, one, 1e-5, 0, one, segs, 2, one, None) == -1
+    assert b'segments cover' in lib.geotr_last_error()
+    assert lib.geotr_group_norm_flags_supported(128) == 1 and lib.geotr_group_norm_flags_supported(6) == 0
+    assert lib.geotr_profile_stride(0) == -1 and lib.geotr_profile_stride(8) == 0 and lib.geotr_profile_stride(1) == 0
+    assert lib.geotr_group_norm_workspace_bytes(1000, 64) >= 4 * 2 * 64 * (1000 // 32 + 2 * 16)
 
 
 def test_product_never_imports_oracle():
