@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of the whole hot path over one batch of `--batch` independent synthetic 3DMatch-shape pairs
-(default 32 per GPU; `--lanes` persistent host threads with a HIP stream each pull stacks of `--stack` pairs from one queue,
+(default 64 per GPU; `--lanes` persistent host threads with a HIP stream each pull stacks of `--stack` pairs from one queue,
 and a stack goes through ONE launch sequence; BASELINE configs[1]: ~20k + 20k points, 4-stage KPConv-FPN, d = 256): the
 collate-equivalent pyramid (3 grid subsamples + 10 radius searches) plus the full GeoTransformer forward through
 `estimated_transform`.  Inputs (raw xyz) are resident in HBM when the timed region starts; weights are random-init
@@ -16,13 +16,16 @@ broadcast once from rank 0 over RCCL and the per-pair transforms are all-gathere
 GPU) and fails if the node has fewer than N devices or a rank does not come up.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  parity       : pair 0 of the LAST timed step (one of the 8 stacked pairs of a lane's launch sequence) compared with the CPU
+  parity       : pair 0 of the LAST timed step (one of the 16 stacked pairs of a lane's launch sequence) compared with the CPU
                  oracle run on that pair alone: feature MSE, coarse-set overlap, matching scores, transform (oracle/parity.py
                  states the tolerances) + the stacked pyramid of that lane's stack cut back to the pair, byte-compared.
-  roofline     : dominant kernel (fused GSE embedding).  `achieved` = ALGORITHMIC FLOPs per launch (2 n^2 (1+k) D^2) over the
-                 HIP-event average launch duration measured live in the timed region, vs the 2.5 PFLOP/s dense bf16 peak of the
-                 pipe it runs on; `executed_*` = the 3 bf16 MFMA products the split-bf16 path issues per algorithmic product;
-                 `isolated` = the same kernel with the GPU otherwise idle.  `--precision fp32`: vs the 157.3 TFLOP/s fp32 peak.
+  roofline     : the kernel family with the largest summed launch time among the bracketed ones (packed GEMMs, GSE embedding, fused
+                 KPConv; `other` = the runner-up), from HIP events recorded by the executor on the launch streams around every
+                 `--profile-stride`-th launch of the timed region.  Packed GEMMs: BOTH roofs are computed from the recorded shapes --
+                 ALGORITHMIC bytes (A read + C written + packed weight) and ALGORITHMIC 2 m n k FLOP over the summed durations --
+                 and `bound` / `achieved` / `peak` / `frac` are those of the roof the family is closer to (HBM in this workload: the
+                 tall layers have k = 32 .. 64); `executed_*` counts the 3 bf16 MFMA products of the split-bf16 path; `isolated` =
+                 the heaviest shapes re-run with the GPU otherwise idle; `traffic` = HBM bytes per launch from the committed PMC passes.
   cpu_baseline : the CPU oracle (reference C++ neighbour cores from oracle/_ref when present, else the restatement,
                  + the torch-fp32 restatement of the model) timed on this box's host cores per SURVEY.md 8(d): 1 warm-up +
                  3 timed pairs, median; collate on one thread (as the reference), forward on all cores and on 16 threads
@@ -64,6 +67,50 @@ def time_alone(fn, reps=10):
     return sum(a.elapsed_time(b) for a, b in evs[2:]) / reps / 1e3
 
 
+def gemm_bytes(m, n, k):
+    """Algorithmic HBM bytes of one packed GEMM launch: the fp32 activation read once, the fp32 result written once, the packed weight
+    (hi + lo bf16 planes = 4 B per element) read once."""
+    return 4.0 * (m * k + m * n + n * k)
+
+
+def gemm_family_block(gemm, gemm_mode, lanes_note):
+    """Roofline block of the packed-GEMM family from [(seconds, (m, n, k))] event records (pure arithmetic: unit-tested on CPU).
+    Both roofs are stated; `bound` / `achieved` / `peak` / `frac` are those of the roof the family sits closer to.  In this workload
+    that is HBM: the tall stage-0/1 layers have k = 32 .. 64 (arithmetic intensity ~20 FLOP/B against the ~300 FLOP/B ridge), alone
+    they move 3.4 TB/s.  Returns (block, the six heaviest shapes)."""
+    sec = sum(s for s, _ in gemm)
+    flops = sum(2.0 * m * n * kk for _, (m, n, kk) in gemm)
+    nbytes = sum(gemm_bytes(m, n, kk) for _, (m, n, kk) in gemm)
+    peak = FP32_MATRIX_PEAK_TFLOPS if gemm_mode is False else BF16_MATRIX_PEAK_TFLOPS
+    ex = 3.0 if gemm_mode is True else 1.0
+    shapes = {}
+    for s_, w in gemm:
+        d = shapes.setdefault(w, [0, 0.0])
+        d[0] += 1
+        d[1] += s_
+    top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:6]
+    mfma_frac = ex * flops / sec / 1e12 / peak
+    hbm_frac = nbytes / sec / 1e12 / HBM_PEAK_TBS
+    blk = {'kernel': 'gemm_packed_kernel<WM,WN,TERMS> (+ split-K reduce) -- every packed Linear / KPConv contraction of the stack'}
+    if hbm_frac >= mfma_frac:
+        blk.update(bound='hbm', achieved=round(nbytes / sec / 1e9, 1), peak=HBM_PEAK_TBS * 1e3, unit='GB/s', frac=round(hbm_frac, 4))
+    else:
+        blk.update(bound='mfma', achieved=round(flops / sec / 1e12, 2), peak=peak, unit='TFLOP/s', frac=round(flops / sec / 1e12 / peak, 4))
+    blk.update({
+        'algorithmic_bytes_per_launch': round(nbytes / len(gemm)), 'hbm_gbps': round(nbytes / sec / 1e9, 1), 'hbm_frac': round(hbm_frac, 4),
+        'algorithmic_tflops': round(flops / sec / 1e12, 2), 'mfma_frac_algorithmic': round(flops / sec / 1e12 / peak, 4),
+        'executed_tflops': round(ex * flops / sec / 1e12, 2), 'executed_frac': round(mfma_frac, 4),
+        'launches': len(gemm), 'avg_launch_us': round(1e6 * sec / len(gemm), 1), 'total_ms': round(1e3 * sec, 2),
+        'top_shapes_in_flight': [{'m_n_k': list(w), 'launches': c, 'avg_us': round(1e6 * t / c, 1),
+                                  'tflops': round(2.0 * w[0] * w[1] * w[2] * c / t / 1e12, 1),
+                                  'hbm_gbps': round(gemm_bytes(*w) * c / t / 1e9, 1)} for w, (c, t) in top],
+        'note': 'both roofs over the recorded launches: hbm_* = ALGORITHMIC bytes (A read + C written + packed weight, once each) / summed '
+                'duration against the 8 TB/s HBM peak; *_tflops = ALGORITHMIC 2 m n k FLOP / summed duration, executed_* counts the 3 bf16 MFMA '
+                'products per algorithmic product of the split-bf16 path, against the dense bf16 MFMA peak; bound = the roof the family is '
+                'closer to; ' + lanes_note})
+    return blk, top
+
+
 def roofline_blocks(events, cfg, args, pipe, out, kernels):
     """Live roofline of the two heaviest kernel families from the executor's HIP events (recorded on the launch streams inside the
     timed region).  Returns the block of the family with the larger summed launch time (`roofline`), the other one under
@@ -99,26 +146,9 @@ def roofline_blocks(events, cfg, args, pipe, out, kernels):
                    'executed_tflops': round(ex * flops / sec / 1e12, 2), 'note': 'achieved = algorithmic 2 n^2 (1+k) D^2 FLOP / launch time; ' + lanes_note}
         blk.update(launches=len(gse), avg_launch_us=round(1e6 * sec / len(gse), 1), total_ms=round(1e3 * sec, 2))
         fam['gse'] = blk
+    top = []
     if gemm:
-        sec = sum(s for s, _ in gemm)
-        flops = sum(2.0 * m * n * kk for _, (m, n, kk) in gemm)
-        peak = FP32_MATRIX_PEAK_TFLOPS if gemm_mode is False else BF16_MATRIX_PEAK_TFLOPS
-        ex = 3.0 if gemm_mode is True else 1.0
-        shapes = {}
-        for s_, w in gemm:
-            d = shapes.setdefault(w, [0, 0.0])
-            d[0] += 1
-            d[1] += s_
-        top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:6]
-        blk = {'bound': 'mfma', 'kernel': 'gemm_packed_kernel<WM,WN,TERMS> (+ split-K reduce) -- every packed Linear / KPConv contraction of the stack',
-               'achieved': round(flops / sec / 1e12, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(flops / sec / 1e12 / peak, 4),
-               'executed_tflops': round(ex * flops / sec / 1e12, 2), 'executed_frac': round(ex * flops / sec / 1e12 / peak, 4),
-               'launches': len(gemm), 'avg_launch_us': round(1e6 * sec / len(gemm), 1), 'total_ms': round(1e3 * sec, 2),
-               'top_shapes_in_flight': [{'m_n_k': list(w), 'launches': c, 'avg_us': round(1e6 * t / c, 1),
-                                         'tflops': round(2.0 * w[0] * w[1] * w[2] * c / t / 1e12, 1)} for w, (c, t) in top],
-               'note': 'achieved = ALGORITHMIC 2 m n k FLOP summed over the recorded launches / their summed duration; executed_* counts the 3 bf16 '
-                       'MFMA products per algorithmic product of the split-bf16 path; ' + lanes_note}
-        fam['gemm'] = blk
+        fam['gemm'], top = gemm_family_block(gemm, gemm_mode, lanes_note)
     kpc = [(sec, work) for sec, kind, work in events if kind == 'kpconv']
     if kpc:
         sec = sum(s_ for s_, _ in kpc)
@@ -168,7 +198,8 @@ def roofline_blocks(events, cfg, args, pipe, out, kernels):
             y = torch.empty((m, n), dtype=torch.float32, device=a.device)
             t_iso = time_alone(lambda: kernels.gemm_packed(a, packed, n, out=y))
             iso.append({'m_n_k': [m, n, kk], 'avg_us': round(1e6 * t_iso, 1), 'tflops': round(2.0 * m * n * kk / t_iso / 1e12, 1),
-                        'frac': round(2.0 * m * n * kk / t_iso / 1e12 / fam['gemm']['peak'], 4)})
+                        'mfma_frac_algorithmic': round(2.0 * m * n * kk / t_iso / 1e12 / (FP32_MATRIX_PEAK_TFLOPS if gemm_mode is False else BF16_MATRIX_PEAK_TFLOPS), 4),
+                        'hbm_gbps': round(gemm_bytes(m, n, kk) / t_iso / 1e9, 1), 'hbm_frac': round(gemm_bytes(m, n, kk) / t_iso / 1e12 / HBM_PEAK_TBS, 4)})
         fam['gemm']['isolated'] = {'shapes': iso, 'note': 'the heaviest shapes re-run alone (random operands, bias-free epilogue), GPU otherwise idle'}
     order = sorted(fam, key=lambda f: -fam[f]['total_ms'])
     main = fam[order[0]]

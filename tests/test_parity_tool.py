@@ -93,3 +93,25 @@ def test_pyramid_tables_may_differ_in_width_only():
     wrong = wide.copy()
     wrong[0, 3] = 2
     assert not parity.pyramid_identical({**want, 'neighbors': [wrong]}, want)
+
+
+def test_bench_gemm_roofline_block_states_both_roofs():
+    """bench.py's packed-GEMM family block from event records (pure arithmetic): tall k = 64 layers sit on the HBM roof, deep-K ones on
+    the MFMA roof; every figure follows from the records."""
+    import bench
+    tall = [(1.0e-3, (640000, 128, 64))] * 3 + [(0.4e-3, (180000, 256, 64))] * 2
+    blk, top = bench.gemm_family_block(tall, True, 'note')
+    nbytes = 3 * bench.gemm_bytes(640000, 128, 64) + 2 * bench.gemm_bytes(180000, 256, 64)
+    assert blk['bound'] == 'hbm' and blk['unit'] == 'GB/s' and blk['peak'] == 8000.0
+    assert abs(blk['achieved'] - nbytes / 3.8e-3 / 1e9) < 0.1 and abs(blk['frac'] - blk['achieved'] / blk['peak']) < 1e-3
+    assert blk['launches'] == 5 and blk['algorithmic_bytes_per_launch'] == round(nbytes / 5)
+    assert top[0][0] == (640000, 128, 64) and blk['top_shapes_in_flight'][0]['launches'] == 3
+    assert abs(blk['executed_tflops'] - 3 * blk['algorithmic_tflops']) < 0.05
+    deep = [(50e-6, (4096, 512, 8192))] * 4
+    blk, _ = bench.gemm_family_block(deep, True, 'note')
+    assert blk['bound'] == 'mfma' and blk['unit'] == 'TFLOP/s' and blk['peak'] == 2500.0
+    assert abs(blk['achieved'] - 2.0 * 4096 * 512 * 8192 / 50e-6 / 1e12) < 0.01
+    blk, _ = bench.gemm_family_block(deep, False, 'note')  # exact-fp32 mode: one product per product, the fp32 matrix peak
+    assert blk['peak'] == 157.3 and blk['executed_tflops'] == blk['algorithmic_tflops']
+    import json
+    json.dumps(blk)
