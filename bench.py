@@ -408,7 +408,7 @@ def main():
 
     # before the device context exists: spin in stream waits only while every waiting thread of every local rank can have its own CPU
     local_ranks = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
-    sync_note = gd.choose_host_waits(local_ranks * (args.lanes + 1), os.environ.get('GEOTR_BLOCKING_SYNC'))
+    sync_note = gd.choose_host_waits(local_ranks * (args.lanes + 1), os.environ.get('GEOTR_BLOCKING_SYNC'), int(os.environ.get('LOCAL_RANK', '0')))
     _lib.require_gpu()
     _lib.load()
     kernels.set_precision(args.precision, gse=args.gse)

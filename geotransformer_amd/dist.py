@@ -144,7 +144,7 @@ def bind_to_device_numa(device_index):
     return f'{bound} threads bound to NUMA node {node} of device {bdf} ({len(cpus)} of {len(previous)} CPUs)', previous
 
 
-def set_blocking_sync():
+def set_blocking_sync(device_index=None):
     """Ask the HIP runtime to BLOCK (interrupt wait) instead of spinning in stream / event synchronisation.  Must run before the process
     creates its device context (first CUDA call of torch); returns a short description.  A registration process keeps 4 lane threads
     waiting on their streams most of the time: spinning, each burns a whole CPU (3.7 CPUs busy per process measured,
@@ -153,6 +153,8 @@ def set_blocking_sync():
     try:
         path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
         hip = ctypes.CDLL(path if os.path.exists(path) else 'libamdhip64.so')
+        if device_index is not None:  # the flags belong to the CURRENT device: select this rank's first (an invalid index is ignored)
+            hip.hipSetDevice(ctypes.c_int(int(device_index)))
         rc = hip.hipSetDeviceFlags(ctypes.c_uint(0x4))  # hipDeviceScheduleBlockingSync
         return f'hipSetDeviceFlags(hipDeviceScheduleBlockingSync) -> {rc}'
     except OSError as exc:
@@ -180,7 +182,7 @@ def cpu_budget(cgroup_root='/sys/fs/cgroup'):
     return budget
 
 
-def choose_host_waits(waiting_threads, override=None):
+def choose_host_waits(waiting_threads, override=None, device_index=None):
     """Spin (the runtime's default: lowest wake-up latency, +4 % at one rank) while every waiting thread of every local rank can have a
     CPU of its own, block otherwise.  `waiting_threads` = local ranks x (lanes + 1).  `override`: '1' / '0' forces blocking / spinning
     (GEOTR_BLOCKING_SYNC).  Must run before the device context exists.  Returns a description for the logs."""
@@ -188,4 +190,4 @@ def choose_host_waits(waiting_threads, override=None):
     block = override == '1' or (override != '0' and waiting_threads > budget)
     if not block:
         return f'spin ({waiting_threads} waiting threads, CPU budget {budget:g})'
-    return f'{set_blocking_sync()} ({waiting_threads} waiting threads, CPU budget {budget:g})'
+    return f'{set_blocking_sync(device_index)} ({waiting_threads} waiting threads, CPU budget {budget:g})'

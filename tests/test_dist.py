@@ -84,8 +84,8 @@ def test_cpu_budget_reads_the_cgroup_quota_and_waits_are_chosen_from_it(tmp_path
     assert gd.cpu_budget(str(tmp_path / 'absent')) == cores
     monkeypatch.setattr(gd, 'cpu_budget', lambda: 16.0)
     called = []
-    monkeypatch.setattr(gd, 'set_blocking_sync', lambda: called.append(1) or 'blocking set')
+    monkeypatch.setattr(gd, 'set_blocking_sync', lambda device_index=None: called.append(device_index) or 'blocking set')
     assert gd.choose_host_waits(5).startswith('spin') and not called       # one rank, 4 lanes: every waiter has a CPU
     assert gd.choose_host_waits(40).startswith('blocking set') and called  # eight ranks on a 16-CPU quota
     assert gd.choose_host_waits(40, override='0').startswith('spin')
-    assert gd.choose_host_waits(5, override='1').startswith('blocking set')
+    assert gd.choose_host_waits(5, override='1', device_index=3).startswith('blocking set') and called[-1] == 3
