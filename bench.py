@@ -531,7 +531,8 @@ def main():
         if roof is not None:
             name = 'gse_embed' if roof['kernel'].startswith('gse') else 'gemm_packed'
             roof['traffic'] = pmc_traffic_bytes(name)
-            roof['traffic_unit'] = 'HBM bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; latest profiles/r*_pmc_hbm_traffic.md)'
+            roof['traffic_unit'] = ('HBM bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; latest profiles/r*_pmc_hbm_traffic.md; '
+                                    'collected with --lanes 1 --stack 8: a launch there covers 8 stacked pairs, half the rows of a 16-pair launch)')
         line = {
             'metric': {'3dmatch': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)',
                        'kitti': 'registration pairs/sec (120k-pt synthetic KITTI-shape pair)',
