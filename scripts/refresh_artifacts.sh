@@ -30,6 +30,8 @@ EXTRA="" ab two_kernel_kpconv GEOTR_KPCONV_FUSED=0
 EXTRA="" ab two_kernel_first_layer GEOTR_KPCONV_C1_FUSED=0
 EXTRA="--gse mfma" ab gse_mfma_kernel X=1
 EXTRA="" ab no_split_k GEOTR_SPLITK=0
+EXTRA="" ab two_pass_shortcut_norm GEOTR_GN_SHORTCUT_FUSED=0
+EXTRA="" ab blocking_host_waits GEOTR_BLOCKING_SYNC=1
 EXTRA="" ab row_order_gathers GEOTR_SPATIAL_ORDER=0
 EXTRA="--stack 8" ab stack8 X=1
 EXTRA="--lanes 1" ab one_lane X=1
