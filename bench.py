@@ -269,6 +269,9 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ocfg = mo.config_from_reference(cfg)
     nproc = os.cpu_count() or 1
+    from geotransformer_amd.dist import cpu_budget
+    budget = max(1, int(cpu_budget()))  # CPUs this container may keep busy: the affinity mask capped by the cgroup quota
+    avail = min(nproc, budget)
 
     def collate_with(which, item):
         pts = np.concatenate([item['ref_points'], item['src_points']])
@@ -291,7 +294,7 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
     # distances, which is the product's default; the reference cores order such ties by kd-tree traversal -- same
     # sets, and the timing above is theirs
     _, pyr0, data0 = collate_with(on.restated(), sample[0]) if lib is not on.restated() else collated[0]
-    torch.set_num_threads(min(nproc, 16))
+    torch.set_num_threads(min(avail, 16))
     out0 = mo.forward(sd, ocfg, data0)  # the parity reference for items[0] (in-process, 16 threads)
 
     legs = {}
@@ -315,10 +318,10 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
                 last = json.loads(lines[-1]) if lines else {'median_s': None, 'times_s': []}
                 return last['median_s'], last['times_s'], True
 
-        few = min(nproc, 16)
+        few = min(avail, 16)
         legs[few] = leg(few, 1, 3, 60.0)
-        if nproc > few:
-            legs[nproc] = leg(nproc, 1, 3, 45.0)
+        if avail > few:  # "nproc threads" of SURVEY 8(d) = what the container may actually run: threads beyond the quota only throttle each other
+            legs[avail] = leg(avail, 1, 3, 45.0)
         if few > 1:
             legs[1] = leg(1, 0, 1, 75.0)
 
@@ -327,7 +330,7 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
 
     candidates = [(med(k), k) for k in legs if (k != 1 or len(legs) == 1) and med(k) is not None]
     t_forward, threads = min(candidates) if candidates else (None, None)
-    workers = min(8, nproc)  # the reference overlaps collate in 8 DataLoader workers (experiments/*/config.py:49)
+    workers = min(8, avail)  # the reference overlaps collate in 8 DataLoader workers (experiments/*/config.py:49)
 
     def describe(key):
         m, times, timed_out = legs[key]
@@ -339,9 +342,10 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
         'value': None if t_forward is None else 1.0 / (t_collate + t_forward), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
         'sample': f'1 warm-up + 3 timed pairs of the same workload (pairs of this run), medians: collate {t_collate:.2f} s '
                   f'(1 thread, {kind_nb}) + forward {describe(threads) if threads else "n/a"} (torch fp32 restatement, {threads} threads, '
-                  f'the best of the thread counts tried); host has {nproc} logical cores',
-        'nproc': nproc, 'collate_s': round(t_collate, 3), 'forward_s': None if t_forward is None else round(t_forward, 3),
-        f'forward_{few}_threads': describe(few), 'forward_all_cores': describe(nproc),
+                  f'the best of the thread counts tried); host has {nproc} logical cores, CPU budget of the container {budget}',
+        'nproc': nproc, 'cpu_budget': budget, 'collate_s': round(t_collate, 3), 'forward_s': None if t_forward is None else round(t_forward, 3),
+        f'forward_{few}_threads': describe(few),
+        'forward_all_cores': describe(avail) if avail > few else f'= the {few}-thread figure: all this container may keep busy ({nproc} logical cores, CPU budget {budget})',
         'forward_one_thread': describe(1) if 1 in legs else describe(few),
         'one_thread_pairs_per_s': None if med(1) is None else round(1.0 / (t_collate + med(1)), 4),
         'pipelined_bound_pairs_per_s': None if t_forward is None else round(1.0 / max(t_collate / workers, t_forward), 4),
