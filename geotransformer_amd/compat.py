@@ -5,7 +5,7 @@ The reference's experiment scripts import `geotransformer.modules.*`, `geotransf
 `install()` -- or with `compat/` on PYTHONPATH, whose `geotransformer/__init__.py` calls it -- every `geotransformer.X.Y` import
 resolves to THE SAME module object as `geotransformer_amd.X.Y`, so those scripts run unchanged on the HIP hot path.  A name the
 replacement does not provide (the training engine, open3d visualisation, losses: outside the hot-path scope) raises the usual
-ModuleNotFoundError naming the missing `geotransformer_amd` module.
+ModuleNotFoundError for `geotransformer.<name>`; `importlib.util.find_spec` on it returns None.
 """
 import importlib
 import importlib.abc
@@ -21,10 +21,16 @@ class _AliasLoader(importlib.abc.Loader):
         self.module = module
 
     def create_module(self, spec):
-        return self.module  # the already-imported geotransformer_amd module object itself
+        # the already-imported geotransformer_amd module object itself; importlib then stamps the ALIAS spec onto it
+        # (module.__spec__ / __loader__ / __package__), so its own import-system identity is saved here ...
+        self.saved = {k: getattr(self.module, k) for k in ('__spec__', '__loader__', '__package__') if hasattr(self.module, k)}
+        return self.module
 
     def exec_module(self, module):
-        pass
+        # ... and restored here: geotransformer_amd.X.__spec__.name stays 'geotransformer_amd.X' (importlib.reload, pickling of
+        # classes by module name and find_spec on the real name keep working)
+        for k, v in self.saved.items():
+            setattr(module, k, v)
 
 
 class _AliasFinder(importlib.abc.MetaPathFinder):
@@ -32,7 +38,12 @@ class _AliasFinder(importlib.abc.MetaPathFinder):
         if fullname != ALIAS and not fullname.startswith(ALIAS + '.'):
             return None
         real = TARGET + fullname[len(ALIAS):]
-        module = importlib.import_module(real)  # ModuleNotFoundError names what is missing
+        try:
+            module = importlib.import_module(real)
+        except ModuleNotFoundError as exc:
+            if exc.name == real:   # the replacement has no such module: "not found" for finders / find_spec probes (-> None);
+                return None        # a plain `import` then raises ModuleNotFoundError for the alias name as usual
+            raise                  # a missing dependency INSIDE an existing module is a real error
         spec = importlib.machinery.ModuleSpec(fullname, _AliasLoader(module), is_package=hasattr(module, '__path__'))
         spec.submodule_search_locations = getattr(module, '__path__', None)
         return spec

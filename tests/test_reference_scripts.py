@@ -4,8 +4,8 @@ SURVEY.md section 2 #14 / section 8b boundary 2.  For each of the three experime
 must construct on the replacement modules, and under the reference's seeds its state_dict must be the reference model's:
 same keys, same shapes, same bytes (so released checkpoints load with strict=True and seeded runs start from identical
 weights).  Absent third-party imports of those scripts (easydict, IPython) are stubbed exactly as oracle/ref_harness.py does.
-The forward of that model needs a GPU and the reference tree at once, which no box of this setup has; the same modules'
-forwards are covered module by module in tests/test_*_gpu.py (use_native=False path of geotransformer_amd/model.py)."""
+The FORWARD of those scripts runs on the GPU box from byte-for-byte snapshots (tests/golden/reference_scripts.npz ->
+tests/test_reference_forward_gpu.py); here the snapshots are checked against the live tree."""
 import json
 import os
 import subprocess
@@ -98,3 +98,42 @@ def test_reference_model_py_constructs_on_the_replacement(exp, tmp_path):
     if '3dmatch' in exp:  # and it is the state_dict the demo golden was produced with
         from util import load_demo_golden
         assert got['sha256'] == str(load_demo_golden()['sd/sha256'])
+
+
+def test_reference_scripts_fixture_is_the_live_tree():
+    """tests/golden/reference_scripts.npz (what tests/test_reference_forward_gpu.py executes on the GPU box) holds the reference's
+    scripts byte for byte."""
+    import hashlib
+
+    import numpy as np
+    if not os.path.isdir(os.path.join(REF, 'experiments')):
+        pytest.skip('/root/reference not present (GPU box): the build container runs this')
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_scripts.npz'))
+    for short in ('3dmatch', 'kitti', 'modelnet'):
+        exp_dir = os.path.join(REF, 'experiments', str(g[f'{short}/dirname']))
+        for name in ('config.py', 'backbone.py', 'model.py'):
+            with open(os.path.join(exp_dir, name), 'rb') as f:
+                blob = f.read()
+            assert g[f'{short}/{name}'].tobytes() == blob, (short, name)
+            assert str(g[f'{short}/{name}/sha256']) == hashlib.sha256(blob).hexdigest()
+
+
+def test_alias_package_keeps_module_identity_and_probes_return_none():
+    """aliasing must not overwrite geotransformer_amd.X.__spec__, and find_spec on a name the replacement lacks is None."""
+    code = r'''
+import importlib.util
+import geotransformer, geotransformer.utils.common as a, geotransformer_amd.utils.common as b
+assert a is b and b.__spec__.name == 'geotransformer_amd.utils.common' and b.__package__ == 'geotransformer_amd.utils'
+assert importlib.util.find_spec('geotransformer.engine') is None
+try:
+    import geotransformer.engine
+    raise SystemExit('imported a module that does not exist')
+except ModuleNotFoundError as exc:
+    assert 'geotransformer.engine' in str(exc)
+from geotransformer.modules.kpconv import ConvBlock
+assert ConvBlock.__module__ == 'geotransformer_amd.modules.kpconv.modules'
+print('ALIAS-OK')
+'''
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', PYTHONPATH=os.path.join(ROOT, 'compat'))
+    res = subprocess.run([sys.executable, '-c', code], env=env, cwd='/tmp', capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and 'ALIAS-OK' in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
