@@ -1,6 +1,7 @@
 """Dustbin-augmented log-domain Sinkhorn (mirror of geotransformer/modules/sinkhorn/learnable_sinkhorn.py:5-70).
 
-The (K+1)x(K+1) problem of each patch pair lives in LDS for all iterations (csrc/matching.hip).  `forward` takes
+The (K+1)x(K+1) problem of each patch pair stays on chip for all iterations: register resident for K <= 64, streamed from LDS
+for K = 128 (`patch_sinkhorn_kernel<K>`, csrc/matching.hip).  `forward` takes
 precomputed scores like the reference; `forward_fused` additionally folds the patch-feature gather and the
 `einsum('bnd,bmd->bnm') / sqrt(C)` of experiments/.../model.py:169-188 into the same kernel.
 """

@@ -6,12 +6,20 @@ Tolerances (BASELINE.json north_star: neighbour indices bit-exact, feature MSE <
   pyramid tables            byte-identical
   features (4 tensors)      MSE <= 1e-6 (two orders inside the north-star bound)
   coarse correspondences    a global top-k over nearly flat scores under random weights: reported as set overlap (>= 0.95); when
-                            the selected SET is identical the patches are aligned pair by pair (equal scores may swap ranks) and
-                            everything downstream is compared one to one
-  matching scores           |d| <= 5e-3 on every patch holding the same point set (>= 75% of them; points re-aligned one to one
-                            when equal-to-rounding distances list them in another order)
-  transform                 |d| <= 5e-3 per entry when the patch and point order is identical throughout (else reported only: equally
-                            supported hypotheses are ranked by position); rotation / translation error always reported
+                            the selected SET is identical the patches are aligned pair by pair, and every rank that differs must
+                            be explained by oracle scores that are equal to rounding (relative 1e-4; measured gap reported) -- else the pair fails
+  superpoint patches        the K nearest points of a superpoint, by the reference's expanded distance |x|^2 - 2xy + |y|^2 (a BLAS
+                            product in the reference): equal-to-rounding distances may list the same points in another order
+                            (aligned point by point), and may move a point across the K-th-nearest boundary or to an equidistant
+                            neighbouring superpoint -- every patch whose point SET differs is examined and must be explained by
+                            such a distance tie (|d - d'| <= 2e-5 m^2 at scene-scale coordinates); an unexplained patch fails the
+                            pair (round 2 tolerated 25 % of them: ADVICE r2)
+  matching scores           |d| <= 5e-3 on every aligned patch
+  transform                 asserted for EVERY pair whose patches all align: the oracle's local-to-global registration
+                            (oracle/model_oracle.py) is re-run on the oracle's own matching scores listed in the HIP side's patch
+                            and point order (hypotheses with equal inlier counts are ranked by position, so the pose is a function
+                            of that order), and |d| <= 5e-3 per entry is required against it; the plain difference to the
+                            oracle's pose in its own order, rotation / translation errors are reported as well
 """
 import numpy as np
 import torch
@@ -32,7 +40,9 @@ def oracle_pair(cfg, state_dict, item, lib=None):
     pyr = on.precompute_pyramid(lib, pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, list(cfg.neighbor_limits))
     data = {k: [torch.from_numpy(np.ascontiguousarray(a)) for a in v] for k, v in pyr.items()}
     data['features'] = torch.ones((pts.shape[0], 1))
-    want = mo.forward(state_dict, mo.config_from_reference(cfg), data)
+    ocfg = mo.config_from_reference(cfg)
+    want = mo.forward(state_dict, ocfg, data)
+    want['_fine_cfg'] = ocfg['fine']  # compare_pair re-runs the oracle's registration head in the HIP side's patch order
     return pyr, want
 
 
@@ -83,9 +93,43 @@ def _same_points(g, w):
     return take
 
 
-def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND):
+DIST_TIE_ATOL = 2e-5   # m^2: rounding of |x|^2 - 2xy + |y|^2 in fp32 at |x| of a few metres
+SCORE_TIE_RTOL = 1e-4  # fp32 feature rounding (MSE ~4e-13 on unit vectors) through exp(2xy - 2) and the dual normalisation
+
+
+def _explain_patch(g_pts, g_mask, w_pts, w_mask, node, nodes):
+    """A patch whose point SET differs between the two sides: every point held by one side only must sit at a distance tie --
+    with the K-th nearest point of the patch (it falls on the other side of the truncation) or with a second superpoint (it is
+    assigned to the neighbour).  Returns (explained, number of points differing)."""
+    gs = {tuple(r) for r in g_pts[g_mask].tolist()}
+    ws = {tuple(r) for r in w_pts[w_mask].tolist()}
+    diff = (gs ^ ws)
+    if not diff:
+        return True, 0
+    both = np.asarray(sorted(gs | ws), dtype=np.float64)
+    d_all = ((both - node[None].astype(np.float64)) ** 2).sum(1)
+    k = min(int(g_mask.sum()), int(w_mask.sum()))
+    d_k = np.sort(d_all)[k - 1] if k >= 1 else 0.0
+    nodes64 = nodes.astype(np.float64)
+    for pt in diff:
+        pt = np.asarray(pt, dtype=np.float64)
+        d = float(((pt - node.astype(np.float64)) ** 2).sum())
+        d_nodes = np.sort(((nodes64 - pt[None]) ** 2).sum(1))
+        boundary_tie = abs(d - d_k) <= DIST_TIE_ATOL
+        assignment_tie = len(d_nodes) > 1 and abs(d_nodes[1] - d_nodes[0]) <= DIST_TIE_ATOL and abs(d - d_nodes[0]) <= DIST_TIE_ATOL
+        if not (boundary_tie or assignment_tie):
+            return False, len(diff)
+    return True, len(diff)
+
+
+def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, score_tie_rtol=SCORE_TIE_RTOL):
     """Returns a JSON-able report; report['ok'] is the verdict under the tolerances in this file's header.
-    `feature_mse_bound`: the default is for the fp32-grade modes; plain-bf16 operands are held to the north-star bound (1e-4)."""
+    `feature_mse_bound`: the default is for the fp32-grade modes; plain-bf16 operands are held to the north-star bound (1e-4).
+    `score_tie_rtol`: how close two oracle coarse scores must be for a rank swap to count as a tie (plain-bf16 features carry 2^-9
+    relative error, which exp(2xy - 2) turns into percents: bench.py / the bf16 tests pass 5e-2 there).
+    `fine_cfg`: the oracle's registration-head settings (default: want['_fine_cfg'], put there by oracle_pair); with them the pose
+    is asserted for every pair whose patches align."""
+    fine_cfg = fine_cfg or want.get('_fine_cfg')
     rep = {'feature_mse_bound': feature_mse_bound}
     ok = True
     for k in ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f'):
@@ -102,6 +146,7 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND):
     rep['coarse_identical'] = bool(gi.shape == wi.shape and torch.equal(gi, wi))
     ok &= gi.shape == wi.shape and rep['coarse_set_overlap'] >= 0.95
     rep['matching_scores_max_err'] = rep['transform_max_abs_diff'] = rep['rre_deg_vs_oracle'] = rep['rte_m_vs_oracle'] = None
+    rep['transform_compared'] = False
     rep['correspondences'] = [int(got['corr_scores'].shape[0]), int(want['corr_scores'].shape[0])]
     rep['coarse_same_set'] = bool(gi.shape == wi.shape and gs == ws and len(gs) == gi.shape[0])
     if rep['coarse_same_set']:
@@ -109,19 +154,45 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND):
         # oracle with the patch of the same (ref, src) pair here, then compare patch by patch
         where = {pair: i for i, pair in enumerate(map(tuple, gi.tolist()))}
         perm = torch.tensor([where[pair] for pair in map(tuple, wi.tolist())], dtype=torch.long)
+        if not rep['coarse_identical'] and 'node_corr_scores' in want:
+            # rank p of the oracle sits at rank perm[p] here: legitimate only between scores that are equal to rounding
+            sc = want['node_corr_scores'].double()
+            moved = (perm != torch.arange(len(perm))).nonzero().flatten()
+            gap = ((sc[moved] - sc[perm[moved]]).abs() / sc[moved].abs().clamp_min(1e-30)).max() if len(moved) else torch.tensor(0.0)
+            rep['coarse_rank_swaps'] = int(len(moved))
+            rep['coarse_rank_swaps_max_rel_score_gap'] = float(gap)
+            ok &= float(gap) <= score_tie_rtol
         g_ref, g_src = got['ref_node_corr_knn_points'].cpu()[perm].numpy(), got['src_node_corr_knn_points'].cpu()[perm].numpy()
+        g_rm, g_sm = got['ref_node_corr_knn_masks'].cpu()[perm].numpy(), got['src_node_corr_knn_masks'].cpu()[perm].numpy()
         w_ref, w_src = want['ref_node_corr_knn_points'].numpy(), want['src_node_corr_knn_points'].numpy()
+        w_rm, w_sm = want['ref_node_corr_knn_masks'].numpy(), want['src_node_corr_knn_masks'].numpy()
         gm_all, wm_all = got['matching_scores'].cpu()[perm].numpy(), want['matching_scores'].numpy()
         same_order = same_set = 0
         masks_equal, worst = True, 0.0
+        unexplained, tie_patches, tie_points = [], 0, 0
+        canon = np.array(wm_all, copy=True)  # the oracle's scores, to be listed in THIS side's point order patch by patch
         for p in range(len(perm)):
             # the K nearest points of a superpoint: squared distances that agree to rounding (|x|^2 + |y|^2 - 2xy at scene-scale
             # coordinates) may list the same points in another order; align the patch point by point before comparing scores
             tr, ts = _same_points(g_ref[p], w_ref[p]), _same_points(g_src[p], w_src[p])
             if tr is None or ts is None:
+                expl = True
+                for side, gp, gmk, wp, wmk, col in (('ref', g_ref[p], g_rm[p], w_ref[p], w_rm[p], 0), ('src', g_src[p], g_sm[p], w_src[p], w_sm[p], 1)):
+                    if f'{side}_points_c' in got:
+                        nodes = got[f'{side}_points_c'].detach().cpu().numpy()
+                        e, npts = _explain_patch(gp, gmk, wp, wmk, nodes[int(wi[p, col])], nodes)
+                    else:
+                        e, npts = False, -1
+                    expl &= e
+                    tie_points += max(npts, 0)
+                tie_patches += int(expl)
+                if not expl:
+                    unexplained.append(int(p))
                 continue
             same_set += 1
             same_order += int(np.array_equal(g_ref[p], w_ref[p]) and np.array_equal(g_src[p], w_src[p]))
+            if not (np.array_equal(g_rm[p][tr], w_rm[p]) and np.array_equal(g_sm[p][ts], w_sm[p])):
+                masks_equal = False
             if gm_all.shape[1] == len(tr) + 1:  # the slack row / column of the optimal-transport scores stays last
                 tr, ts = np.append(tr, len(tr)), np.append(ts, len(ts))
             gm, wm = gm_all[p][tr][:, ts], wm_all[p]
@@ -130,18 +201,38 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND):
                 masks_equal = False
             elif live.any():
                 worst = max(worst, float(np.abs(gm[live] - wm[live]).max()))
+            inv_r, inv_s = np.empty_like(tr), np.empty_like(ts)
+            inv_r[tr], inv_s[ts] = np.arange(len(tr)), np.arange(len(ts))
+            canon[p] = wm[inv_r][:, inv_s]
         n_patch = max(len(perm), 1)
         rep['patches_with_identical_point_set'] = same_set / n_patch
         rep['patches_in_identical_point_order'] = same_order / n_patch
+        rep['patches_differing_by_distance_ties'] = tie_patches
+        rep['points_moved_by_distance_ties'] = tie_points
+        rep['patches_unexplained'] = unexplained[:16]
         rep['matching_scores_max_err'] = worst if masks_equal and same_set else None
-        ok &= masks_equal and worst <= SCORE_ATOL and rep['patches_with_identical_point_set'] >= 0.75
+        ok &= masks_equal and worst <= SCORE_ATOL and not unexplained
         T, Tw = got['estimated_transform'].cpu().numpy(), want['estimated_transform'].numpy()
-        rep['transform_max_abs_diff'] = float(np.abs(T - Tw).max())
+        rep['transform_max_abs_diff_vs_oracle_order'] = float(np.abs(T - Tw).max())
         rep['rre_deg_vs_oracle'], rep['rte_m_vs_oracle'] = rotation_translation_error(T, Tw)
         # The pose is the best-supported hypothesis refined on the correspondence set; hypotheses with EQUAL inlier counts (common
         # under random weights, whose transforms are not registrations) are ranked by position, i.e. by the order of patches and of
-        # the points inside a patch.  It is therefore required to agree when that order is identical throughout, reported otherwise.
-        rep['transform_compared'] = bool(rep['coarse_identical'] and rep['patches_in_identical_point_order'] == 1.0)
+        # the points inside a patch.  So the oracle's head is re-run on the oracle's scores listed in THIS side's order and the pose
+        # must agree with that; without the head's settings only an identical order is comparable.
+        if same_set == len(perm) and masks_equal and fine_cfg is not None:
+            from . import model_oracle as mo
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(len(perm))
+            scores = torch.from_numpy(canon)[inv]   # oracle scores: this side's patch order, this side's point order
+            if scores.shape[1] == got['ref_node_corr_knn_points'].shape[1] + 1:
+                scores = scores[:, :-1, :-1]
+            _, _, _, Tc = mo.local_global_registration(got['ref_node_corr_knn_points'].cpu(), got['src_node_corr_knn_points'].cpu(),
+                                                       got['ref_node_corr_knn_masks'].cpu(), got['src_node_corr_knn_masks'].cpu(), scores, fine_cfg)
+            rep['transform_max_abs_diff'] = float(np.abs(T - Tc.numpy()).max())
+            rep['transform_compared'] = True
+        elif rep['coarse_identical'] and rep['patches_in_identical_point_order'] == 1.0:
+            rep['transform_max_abs_diff'] = rep['transform_max_abs_diff_vs_oracle_order']
+            rep['transform_compared'] = True
         if rep['transform_compared']:
             ok &= rep['transform_max_abs_diff'] <= TRANSFORM_ATOL
     ok &= bool(torch.isfinite(got['estimated_transform']).all())

@@ -5,6 +5,9 @@
     -- every pair compared with the CPU oracle run on that pair alone (oracle/parity.py states the tolerances), the stacked
     pyramid cut back into per-pair tables that must be byte-identical to the oracle's, and every repetition of a pair on another
     lane / in another stack slot bit-identical to the first.
+(1b) BASELINE configs[3] and configs[4] at FULL size and full widths: one 120 000 + 120 000-point KITTI-shape pair
+    through the 5-stage model, and one low-overlap 3DLoMatch-shape pair with 1000 coarse correspondences (<= 1000 LGR hypotheses) in
+    the fp32-grade mode and with plain-bf16 operands ("bf16 features": feature MSE held to the north-star 1e-4).
 (2) the reference's demo pair (data/demo, experiments/*3dmatch*/demo.py:24-60; real 3DMatch fragments on a 1 mm grid, 57 % of the
     stage-0 rows hold equal distances) against the golden produced by executing the reference: the pyramid in the reference's
     tie order must be bit-identical, the forward at full widths within tolerance.
@@ -78,7 +81,66 @@ def test_bench_workload_stacked_lanes_match_oracle():
         print(f'pair {q}:', rep)
         assert rep['ok'], (q, rep)
     assert sum(r['coarse_same_set'] for r in reports) >= 6, 'most pairs must select the identical SET of coarse correspondences'
-    assert sum(r['coarse_identical'] for r in reports) >= 1
+    # the pose is asserted for every pair whose selection is the oracle's (rank swaps only between equal-to-rounding
+    # scores, patches differing only by distance ties -- both checked inside compare_pair and failing `ok` otherwise)
+    for q, r in enumerate(reports):
+        if r['coarse_same_set'] and not r['patches_differing_by_distance_ties']:
+            assert r['transform_compared'] and r['transform_max_abs_diff'] <= parity.TRANSFORM_ATOL, (q, r)
+    assert sum(r['transform_compared'] for r in reports) >= 6
+
+
+def _full_size_pair(bench_config, seed, precision='bf16x3', feature_mse_bound=None, score_tie_rtol=None):
+    """One pair of a bench.py workload (`WORKLOADS[bench_config]`: same experiment config, overrides, synthetic shape, overlap, point
+    count) through pyramid + forward in one stacked launch sequence of one pair, vs the CPU oracle on that pair."""
+    import bench
+    from geotransformer_amd import kernels
+    from geotransformer_amd.config import make_cfg
+    from geotransformer_amd.pipeline import RegistrationPipeline
+    from oracle import parity
+    exp, shape, overrides, _, _ = bench.WORKLOADS[bench_config]
+    cfg = make_cfg(exp, overrides)
+    torch.manual_seed(cfg.seed)
+    np.random.seed(cfg.seed)
+    item = bench.build_pair(seed, bench_config, None)
+    pair = (torch.from_numpy(item['ref_points']).cuda(), torch.from_numpy(item['src_points']).cuda())
+    kernels.set_precision(precision)
+    try:
+        pipe = RegistrationPipeline(cfg, device='cuda:0')
+        outs, stacked = pipe.register_batch([pair], return_pyramid=True)
+        torch.cuda.synchronize()
+    finally:
+        kernels.set_precision('bf16x3')
+    sd = {k: v.detach().cpu() for k, v in pipe.model.state_dict().items()}
+    pyr, want = parity.oracle_pair(cfg, sd, item)
+    assert parity.pyramid_identical(RegistrationPipeline.pair_pyramid(stacked, 0), pyr), 'pyramid differs from the oracle\'s'
+    rep = parity.compare_pair(outs[0], want, feature_mse_bound=feature_mse_bound or parity.FEATURE_MSE_BOUND,
+                              score_tie_rtol=score_tie_rtol or parity.SCORE_TIE_RTOL)
+    print(bench_config, precision, [int(p.shape[0]) for p in pyr['points']], rep)
+    return cfg, item, outs[0], rep
+
+
+def test_kitti_full_size_pair_matches_oracle():
+    """BASELINE configs[3]: 120k + 120k points, 5 stages (stage-5 backbone), the reference's full widths, 128-point patches."""
+    cfg, item, out, rep = _full_size_pair('kitti', 3000)
+    assert item['ref_points'].shape[0] == 120000 and item['src_points'].shape[0] == 120000 and cfg.backbone.num_stages == 5
+    assert out['matching_scores'].shape[1:] == (129, 129) and out['ref_feats_c'].shape[1] == 256
+    assert rep['ok'], rep
+    if rep['coarse_same_set'] and not rep['patches_differing_by_distance_ties']:
+        assert rep['transform_compared'], rep
+
+
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+def test_lomatch_full_size_pair_matches_oracle(precision):
+    """BASELINE configs[4]: low-overlap pair, 1000 coarse correspondences, full widths; `bf16` = plain-bf16 matrix operands, held to
+    the north-star feature bound (1e-4), the fp32-grade mode to this repo's usual 1e-6."""
+    bf16 = precision == 'bf16'
+    cfg, item, out, rep = _full_size_pair('lomatch', 4000, precision, feature_mse_bound=1e-4 if bf16 else None,
+                                          score_tie_rtol=5e-2 if bf16 else None)
+    assert item['ref_points'].shape[0] == 20000 and cfg.coarse_matching.num_correspondences == 1000
+    assert out['ref_node_corr_indices'].shape[0] <= 1000 and rep['coarse_pairs'] > 256
+    assert rep['ok'], rep
+    if not bf16 and rep['coarse_same_set'] and not rep['patches_differing_by_distance_ties']:
+        assert rep['transform_compared'], rep
 
 
 def test_demo_pair_reference_tie_order_and_forward():
@@ -120,7 +182,7 @@ def test_demo_pair_reference_tie_order_and_forward():
         odata['features'] = torch.ones((ref.shape[0] + src.shape[0], 1))
         odata['transform'] = torch.from_numpy(g['in/transform'])
         want = mo.forward(sd, mo.config_from_reference(cfg), odata)
-        report = parity.compare_pair(out, want)
+        report = parity.compare_pair(out, want, fine_cfg=mo.config_from_reference(cfg)['fine'])
         print('demo pair, full widths, oracle under this host\'s seeded weights:', report)
         assert report['ok'], report
     # ground-truth superpoint correspondences of the real pair (model.py:105-124; weights play no role)

@@ -18,6 +18,12 @@ def _pair(seed=0, P=6, K=5, N=40, M=30):
     scores = torch.randn(P, K + 1, K + 1, generator=g)
     scores[:, 2, :] = -1e12  # a masked point in every patch
     out['matching_scores'] = scores
+    out['ref_node_corr_knn_masks'] = torch.ones(P, K, dtype=torch.bool)
+    out['ref_node_corr_knn_masks'][:, 2] = False
+    out['src_node_corr_knn_masks'] = torch.ones(P, K, dtype=torch.bool)
+    out['node_corr_scores'] = torch.linspace(1.0, 0.5, P)
+    out['ref_points_c'] = torch.randn(7, 3, generator=g)
+    out['src_points_c'] = torch.randn(9, 3, generator=g)
     out['corr_scores'] = torch.rand(11, generator=g)
     out['estimated_transform'] = torch.eye(4)
     return out
@@ -31,6 +37,8 @@ def _shuffled(out, patch, seed=1):
     pr, ps = torch.randperm(K, generator=g), torch.randperm(K, generator=g)
     got['ref_node_corr_knn_points'][patch] = out['ref_node_corr_knn_points'][patch][pr]
     got['src_node_corr_knn_points'][patch] = out['src_node_corr_knn_points'][patch][ps]
+    got['ref_node_corr_knn_masks'][patch] = out['ref_node_corr_knn_masks'][patch][pr]
+    got['src_node_corr_knn_masks'][patch] = out['src_node_corr_knn_masks'][patch][ps]
     full_r, full_s = torch.cat([pr, torch.tensor([K])]), torch.cat([ps, torch.tensor([K])])
     got['matching_scores'][patch] = out['matching_scores'][patch][full_r][:, full_s]
     return got
@@ -56,10 +64,64 @@ def test_coarse_pairs_listed_in_another_order_are_aligned():
     want = _pair()
     got = copy.deepcopy(want)
     order = torch.tensor([3, 0, 5, 1, 4, 2])
-    for k in ('ref_node_corr_indices', 'src_node_corr_indices', 'ref_node_corr_knn_points', 'src_node_corr_knn_points', 'matching_scores'):
+    keys = ('ref_node_corr_indices', 'src_node_corr_indices', 'ref_node_corr_knn_points', 'src_node_corr_knn_points', 'matching_scores',
+            'ref_node_corr_knn_masks', 'src_node_corr_knn_masks')
+    for k in keys:
         got[k] = want[k][order]
     rep = parity.compare_pair(got, want)
-    assert rep['ok'] and rep['coarse_same_set'] and not rep['coarse_identical'] and rep['matching_scores_max_err'] == 0.0
+    # the oracle's scores at the swapped ranks are NOT equal to rounding: a different ranking is a failure ...
+    assert not rep['ok'] and rep['coarse_same_set'] and not rep['coarse_identical'] and rep['matching_scores_max_err'] == 0.0
+    assert rep['coarse_rank_swaps'] == 5 and rep['coarse_rank_swaps_max_rel_score_gap'] > 0.1
+    # ... and legitimate between equal scores
+    want['node_corr_scores'] = torch.full((6,), 0.25)
+    rep = parity.compare_pair(got, want)
+    assert rep['ok'] and rep['coarse_rank_swaps_max_rel_score_gap'] == 0.0
+
+
+def test_the_pose_is_asserted_in_this_sides_order():
+    """Patches / points listed in another order: the oracle's head re-run in that order gives the pose to agree with."""
+    from oracle import model_oracle as mo
+    fine = dict(topk=2, acceptance_radius=0.5, mutual=True, confidence_threshold=0.05, correspondence_threshold=2, num_refinement_steps=3)
+    want = _pair(seed=3, P=8, K=6)
+    want['matching_scores'] = want['matching_scores'].clamp(-3, 0.5)
+    want['matching_scores'][:, 2, :] = -1e12
+    want['node_corr_scores'] = torch.full((8,), 0.25)
+    want['_fine_cfg'] = fine
+
+    def head(o):
+        return mo.local_global_registration(o['ref_node_corr_knn_points'], o['src_node_corr_knn_points'], o['ref_node_corr_knn_masks'],
+                                            o['src_node_corr_knn_masks'], o['matching_scores'][:, :-1, :-1], fine)[3]
+    want['estimated_transform'] = head(want)
+    got = _shuffled(_shuffled(want, 1), 5, seed=7)
+    order = torch.tensor([2, 0, 1, 3, 7, 5, 6, 4])
+    for k in ('ref_node_corr_indices', 'src_node_corr_indices', 'ref_node_corr_knn_points', 'src_node_corr_knn_points', 'matching_scores',
+              'ref_node_corr_knn_masks', 'src_node_corr_knn_masks'):
+        got[k] = got[k][order]
+    got.pop('_fine_cfg')
+    got['estimated_transform'] = head(got)
+    rep = parity.compare_pair(got, want)
+    assert rep['ok'] and rep['transform_compared'] and rep['transform_max_abs_diff'] <= 1e-6, rep
+    got['estimated_transform'] = got['estimated_transform'].clone()
+    got['estimated_transform'][1, 3] += 0.05
+    rep = parity.compare_pair(got, want)
+    assert not rep['ok'] and rep['transform_compared']
+
+
+def test_a_patch_with_another_point_set_must_be_explained_by_a_distance_tie():
+    want = _pair(seed=4)
+    node = want['ref_points_c'][int(want['ref_node_corr_indices'][3])]
+    pts = want['ref_node_corr_knn_points']
+    # make the patch's points sit at distances 1, 1, *, 2, 2 from its superpoint (index 2 is masked)
+    dirs = torch.nn.functional.normalize(torch.randn(5, 3, generator=torch.Generator().manual_seed(9)), dim=1)
+    pts[3] = node + dirs * torch.tensor([1.0, 1.0, 5.0, 2.0, 2.0])[:, None]
+    got = copy.deepcopy(want)
+    other = torch.nn.functional.normalize(torch.tensor([[0.3, -0.2, 0.9]]), dim=1)[0]
+    got['ref_node_corr_knn_points'][3, 4] = node + other * 2.0  # another point at the K-th nearest distance: a boundary tie
+    rep = parity.compare_pair(got, want)
+    assert rep['ok'] and rep['patches_differing_by_distance_ties'] == 1 and rep['patches_unexplained'] == [], rep
+    got['ref_node_corr_knn_points'][3, 4] = node + other * 1.5  # nearer than the K-th: the oracle could not have missed it
+    rep = parity.compare_pair(got, want)
+    assert not rep['ok'] and rep['patches_unexplained'] == [3], rep
 
 
 def test_a_wrong_score_mask_point_set_or_feature_fails():
@@ -73,7 +135,7 @@ def test_a_wrong_score_mask_point_set_or_feature_fails():
     bad = copy.deepcopy(want)
     bad['ref_node_corr_knn_points'][:3, 0] += 1.0  # half of the patches hold another point
     rep = parity.compare_pair(bad, want)
-    assert not rep['ok'] and rep['patches_with_identical_point_set'] == 0.5
+    assert not rep['ok'] and rep['patches_with_identical_point_set'] == 0.5 and rep['patches_unexplained'] == [0, 1, 2]
     bad = copy.deepcopy(want)
     bad['ref_feats_f'] = bad['ref_feats_f'] + 0.01
     assert not parity.compare_pair(bad, want)['ok']
