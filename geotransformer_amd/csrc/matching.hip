@@ -6,6 +6,7 @@
 //                           geotransformer/modules/sinkhorn/learnable_sinkhorn.py:13-66 (100 log-domain iterations with
 //                           the (K+1)x(K+1) matrix resident in LDS)
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -15,9 +16,13 @@ namespace geotr {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __device__ __forceinline__ float sqn3(const float* p) { return (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]; }
-// ops/pairwise_distance.py:23-30: x2 - 2xy + y2, clamped at 0
+// ops/pairwise_distance.py:23-30: x2 - 2xy + y2, clamped at 0.  The reference's xy is a BLAS product over k = 3: an x86 sgemm micro-kernel
+// accumulates it as the FMA chain fma(a2, b2, fma(a1, b1, a0 * b0)) (checked against MKL, AVX512: 100 % of 6 M products bit-equal, 77 %
+// for the FMA-free sum; scripts/host_blas_rounding.py), while x2 / y2 are torch.sum over rounded squares.  With the same chain here the
+// K nearest points of a superpoint come out in the reference CPU path's own ORDER (round 2: 94.9 % of the patches, the rest permuted by
+// last-bit differences of this expansion at scene-scale coordinates).
 __device__ __forceinline__ float sqdist_expanded(const float* a, const float* b) {
-  const float xy = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+  const float xy = fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]));
   return fmaxf((sqn3(a) - 2.f * xy) + sqn3(b), 0.f);
 }
 
@@ -37,21 +42,38 @@ struct P2nClouds {
 // the wrong superpoint (0 of 10 runs affected with these loads, 3 of 10 without on the same box; profiles/r02_concurrency_hazard.md).
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Load flavours of the hazard investigation (GEOTR_P2N_MODE, profiles/r03_concurrency_hazard.md): 0 = agent scope (shipped),
+// 1 = plain, 2 = plain behind an agent-scope acquire fence at kernel entry, 3 = non-temporal (bypasses L1, no scope semantics)
+// (a C++ `volatile` load is NOT plain on this target: it becomes `flat_load ... sc0 sc1`, system scope; hence the asm)
+__device__ __forceinline__ float ld_plain(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int MODE>
+__device__ __forceinline__ float ld_pt(const float* p) {
+  if constexpr (MODE == 0) return ld_agent(p);
+  else if constexpr (MODE == 3) return __builtin_nontemporal_load(p);
+  else return ld_plain(p);
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void p2n_assign_kernel(const float* __restrict__ pts, int64_t N, const float* __restrict__ nodes,
                                                          int M, int64_t* __restrict__ point_to_node,
                                                          unsigned char* __restrict__ node_masks, P2nClouds tb) {
   extern __shared__ float nd[];  // [M][3]
+  if constexpr (MODE == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (tb.count > 0) {
     const int q = blockIdx.y;
     N = tb.f0[q + 1] - tb.f0[q], M = (int)(tb.c0[q + 1] - tb.c0[q]);
     pts += 3 * tb.f0[q], nodes += 3 * tb.c0[q], point_to_node += tb.f0[q], node_masks += tb.c0[q];
     if ((int64_t)blockIdx.x * blockDim.x >= N) return;
   }
-  for (int e = threadIdx.x; e < 3 * M; e += blockDim.x) nd[e] = ld_agent(nodes + e);
+  for (int e = threadIdx.x; e < 3 * M; e += blockDim.x) nd[e] = ld_pt<MODE>(nodes + e);
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float p[3] = {ld_agent(pts + 3 * i), ld_agent(pts + 3 * i + 1), ld_agent(pts + 3 * i + 2)};
+  const float p[3] = {ld_pt<MODE>(pts + 3 * i), ld_pt<MODE>(pts + 3 * i + 1), ld_pt<MODE>(pts + 3 * i + 2)};
   float best = 3.4e38f;
   int bi = 0;
   for (int m = 0; m < M; ++m) {
@@ -63,6 +85,49 @@ __global__ __launch_bounds__(256) void p2n_assign_kernel(const float* __restrict
   }
   point_to_node[i] = bi;
   node_masks[bi] = 1;
+}
+
+// ---- diagnostic (GEOTR_P2N_PROBE=1; not part of the ABI): launched right before p2n_assign with its grid and its access pattern, every
+// word of the two point arrays is read with a PLAIN load first, then at agent scope, then plainly again; a word whose first read differs
+// from the agent-scope read is a stale read, recorded with its address, the three values, the compute unit and a timestamp
+// (geotr_debug_probe_read).  Answers: WHAT does a stale read return, in which granularity, on which units (profiles/r03_concurrency_hazard.md).
+struct ProbeRecord {
+  unsigned long long addr, clock;
+  unsigned plain, agent, plain_again, kind_cloud, elem, hw_id, xcc_id, block;
+};
+constexpr int kProbeCap = 1 << 16;
+static ProbeRecord* g_probe_records = nullptr;  // [kProbeCap], device
+static unsigned* g_probe_counters = nullptr;    // [0] stale words seen, [1] words compared, device
+
+__device__ __forceinline__ void probe_word(const float* p, unsigned kind_cloud, unsigned elem, ProbeRecord* rec, unsigned* counters) {
+  const unsigned a = __float_as_uint(ld_plain(p));
+  const unsigned b = __float_as_uint(ld_agent(p));
+  const unsigned c = __float_as_uint(ld_plain(p));
+  if (a != b) {
+    const unsigned slot = atomicAdd(&counters[0], 1u);
+    if (slot < (unsigned)kProbeCap) {
+      ProbeRecord r;
+      r.addr = (unsigned long long)(uintptr_t)p, r.clock = wall_clock64();
+      r.plain = a, r.agent = b, r.plain_again = c, r.kind_cloud = kind_cloud, r.elem = elem;
+      r.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID, all 32 bits (cu / sh / se ids)
+      r.xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID[3:0]
+      r.block = blockIdx.x;
+      rec[slot] = r;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void p2n_probe_kernel(const float* __restrict__ pts, const float* __restrict__ nodes, P2nClouds tb,
+                                                        ProbeRecord* __restrict__ rec, unsigned* __restrict__ counters) {
+  const int q = blockIdx.y;
+  const int64_t N = tb.f0[q + 1] - tb.f0[q];
+  const int M = (int)(tb.c0[q + 1] - tb.c0[q]);
+  pts += 3 * tb.f0[q], nodes += 3 * tb.c0[q];
+  if ((int64_t)blockIdx.x * blockDim.x >= N) return;
+  for (int e = threadIdx.x; e < 3 * M; e += blockDim.x) probe_word(nodes + e, (unsigned)q, (unsigned)e, rec, counters);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N)
+    for (int c = 0; c < 3; ++c) probe_word(pts + 3 * i + c, 0x10000u | (unsigned)q, (unsigned)(3 * i + c), rec, counters);
+  if (threadIdx.x == 0) atomicAdd(&counters[1], (unsigned)(3 * M + 3 * min((int64_t)256, N - (int64_t)blockIdx.x * 256)));
 }
 
 constexpr int kP2nCap = 4096;  // owned points per node kept in LDS
@@ -816,10 +881,32 @@ int p2n_launch(const float* points, const float* nodes, int clouds, const int64_
   if (zero_async(node_masks, (size_t)c0[clouds], stream) != GEOTR_OK) return GEOTR_E_LAUNCH;
   const size_t lds = sizeof(float) * 3 * (size_t)maxm;
   if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      (hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+       hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+       hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+       hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
     return fail(GEOTR_E_LAUNCH, "point_to_node: cannot reserve LDS");
-  p2n_assign_kernel<<<dim3((unsigned)((maxn + 255) / 256), (unsigned)clouds), dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node,
-                                                                                                    node_masks, tb);
+  static const int mode = [] {  // hazard investigation switch (see ld_pt); the shipped flavour is 0
+    const char* e = std::getenv("GEOTR_P2N_MODE");
+    return e ? std::atoi(e) : 0;
+  }();
+  static const bool probe = [] {
+    const char* e = std::getenv("GEOTR_P2N_PROBE");
+    return e && e[0] == '1';
+  }();
+  const dim3 grid((unsigned)((maxn + 255) / 256), (unsigned)clouds);
+  if (probe) {
+    if (!g_probe_records) {
+      if (hipMalloc(&g_probe_records, sizeof(ProbeRecord) * kProbeCap) != hipSuccess || hipMalloc(&g_probe_counters, 16) != hipSuccess ||
+          hipMemset(g_probe_counters, 0, 16) != hipSuccess)
+        return fail(GEOTR_E_LAUNCH, "point_to_node: probe buffers");
+    }
+    p2n_probe_kernel<<<grid, dim3(256), 0, stream>>>(points, nodes, tb, g_probe_records, g_probe_counters);
+  }
+  if (mode == 1) p2n_assign_kernel<1><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
+  else if (mode == 2) p2n_assign_kernel<2><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
+  else if (mode == 3) p2n_assign_kernel<3><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
+  else p2n_assign_kernel<0><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
   p2n_knn_kernel<<<dim3((unsigned)maxm, (unsigned)clouds), dim3(256), 0, stream>>>(points, 0, nodes, point_to_node, (int)k, knn_indices, knn_masks,
                                                                                  overflow, tb);
   GEOTR_CHECK_LAUNCH("point_to_node");
@@ -968,6 +1055,23 @@ int geotr_node_correspondences(const float* ref_nodes, const float* src_nodes, c
   nc_compact_kernel<<<1, 1024, 0, st>>>(overlap, (int)m, (int)n, corr_indices, corr_overlaps, num_corr);
   GEOTR_CHECK_LAUNCH("geotr_node_correspondences");
   return GEOTR_OK;
+}
+
+// ---- diagnostics of the hazard investigation (not declared in include/geotr.h: not part of the ABI) ----
+// Copies up to `cap` probe records (10 x 4-byte-aligned fields: struct ProbeRecord above, 48 bytes each) to `host`, writes
+// {stale words, words compared} to counters[2], resets the device counters.  Synchronises the device.
+int64_t geotr_debug_probe_read(void* host, int64_t cap, uint32_t* counters) {
+  if (!g_probe_records) {
+    if (counters) counters[0] = counters[1] = 0;
+    return 0;
+  }
+  unsigned c[4] = {0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(c, g_probe_counters, 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const int64_t n = std::min<int64_t>(std::min<int64_t>(c[0], kProbeCap), cap);
+  if (n > 0 && host && hipMemcpy(host, g_probe_records, sizeof(ProbeRecord) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemset(g_probe_counters, 0, 16) != hipSuccess) return -1;
+  if (counters) counters[0] = c[0], counters[1] = c[1];
+  return n;
 }
 
 }  // extern "C"

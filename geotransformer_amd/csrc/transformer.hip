@@ -22,8 +22,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // pairwise squared distance exactly as ops/pairwise_distance.py:23-30 (x2 - 2xy + y2, clamped at 0)
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sq_norm3(const float* p) { return (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]; }
+// xy as the FMA chain an x86 sgemm micro-kernel runs over k = 3 (matching.hip: sqdist_expanded): bit-equal to the reference CPU path's
+// torch.matmul, INCLUDING the rounding noise it leaves on the diagonal (sqrt(|x|^2 - 2 x.x + |x|^2) ~ 1e-3 instead of 0)
 __device__ __forceinline__ float expanded_sqdist(const float* a, const float* b) {
-  const float xy = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+  const float xy = fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]));
   const float d = (sq_norm3(a) - 2.f * xy) + sq_norm3(b);
   return fmaxf(d, 0.f);
 }

@@ -14,6 +14,18 @@ from . import _lib, kernels
 import os
 
 _POISON = os.environ.get('GEOTR_POISON_WS') == '1'  # fill workspaces / output buffers with 0xFF before every forward (debug)
+# GEOTR_ALLOC_LOG=1 (hazard investigation, scripts/hazard_probe.py): (thread, what, first byte, bytes, host time) of every buffer the two
+# native calls are handed, so that a stale word's address can be traced back to the buffers that owned it before
+ALLOC_LOG = [] if os.environ.get('GEOTR_ALLOC_LOG') == '1' else None
+
+
+def _log_buffers(what, tensors):
+    if ALLOC_LOG is None:
+        return
+    import time
+    now, who = time.perf_counter(), threading.current_thread().name
+    for name, t in tensors:
+        ALLOC_LOG.append((who, f'{what}.{name}', t.data_ptr(), t.numel() * t.element_size(), now))
 MAX_STAGES = 5
 MAX_PAIRS = 16  # GEOTR_MAX_PAIRS
 P_F32 = ctypes.c_void_p
@@ -364,6 +376,7 @@ class NativeModel:
         if nbytes == 0:
             raise RuntimeError('geotr_model_workspace_bytes failed: ' + lib.geotr_last_error().decode('utf-8', 'replace'))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _log_buffers('forward', [('ws', ws)] + list(o.items()))
         if _POISON:  # debugging aid: a kernel that reads workspace / output memory it never wrote then shows up as NaNs
             ws.fill_(0xFF)
             for t in o.values():
@@ -519,6 +532,9 @@ def build_pyramid(points, lengths, num_stages, voxel_size, radius, neighbor_limi
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
     nbytes = lib.geotr_pyramid_workspace_bytes(n0, B, S)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _log_buffers('pyramid', [('ws', ws), ('input', points)] + [(f'points{i}', t) for i, t in enumerate(pts[1:], 1)] +
+                 [(f'neighbors{i}', t) for i, t in enumerate(nb)] + [(f'subsampling{i}', t) for i, t in enumerate(sub)] +
+                 [(f'upsampling{i}', t) for i, t in enumerate(up)] + [(f'order{i}', t) for i, t in enumerate(order)])
     if _POISON:
         ws.fill_(0xFF)
     rc = lib.geotr_pyramid_build(points.data_ptr(), lengths.data_ptr(), B, n0, S, float(voxel_size), float(radius), limits,

@@ -138,10 +138,12 @@ class ConcurrentRegistration:
     and makes the caller's stream wait for the lanes.
     """
 
-    def __init__(self, pipeline, lanes=2, stack=1):
+    def __init__(self, pipeline, lanes=2, stack=1, return_pyramid=False):
         """`stack` > 1: a lane takes up to `stack` queued pairs at a time and runs them as one stacked launch sequence
-        (RegistrationPipeline.register_batch)."""
+        (RegistrationPipeline.register_batch).  `return_pyramid` (tests): every output dict of a stack carries the stack's pyramid
+        under '_stack_pyramid' (the stacked tables; RegistrationPipeline.pair_pyramid cuts a pair out)."""
         self.pipeline = pipeline
+        self.return_pyramid = bool(return_pyramid)
         self.lanes = max(1, int(lanes))
         self.stack = max(1, min(16, int(stack)))
         self.device = pipeline.device
@@ -176,7 +178,11 @@ class ConcurrentRegistration:
                         sink(index, self.pipeline(ref, src))
                     else:
                         outs = self.pipeline.register_batch([(ref, src) for _, ref, src, _, _ in job],
-                                                            pyramid_stream=self.pyramid_streams[lane])
+                                                            pyramid_stream=self.pyramid_streams[lane], return_pyramid=self.return_pyramid)
+                        if self.return_pyramid:
+                            outs, data = outs
+                            for out in outs:
+                                out['_stack_pyramid'] = data
                         for (index, _, _, sink, _), out in zip(job, outs):
                             sink(index, out)
                 except BaseException as exc:  # surfaced by drain()
@@ -196,7 +202,12 @@ class ConcurrentRegistration:
                 if len(group) == 1:
                     sink(g, self.pipeline(*group[0]))
                 else:
-                    for j, out in enumerate(self.pipeline.register_batch(group)):
+                    outs = self.pipeline.register_batch(group, return_pyramid=self.return_pyramid)
+                    if self.return_pyramid:
+                        outs, data = outs
+                        for out in outs:
+                            out['_stack_pyramid'] = data
+                    for j, out in enumerate(outs):
                         sink(g + j, out)
             return
         ready = torch.cuda.Event()

@@ -1,0 +1,162 @@
+"""Round 3: what IS the multi-stream stale read of profiles/r02_concurrency_hazard.md?  (writes the evidence for profiles/r03_concurrency_hazard.md)
+
+One process = one experiment (the switches are environment variables read at start-up):
+  GEOTR_P2N_MODE   0 agent-scope loads in p2n_assign (shipped) | 1 plain | 2 plain behind an agent acquire fence at kernel entry | 3 nt
+  GEOTR_P2N_PROBE  1: a probe kernel in front of p2n_assign reads every word of the two point arrays plain / agent / plain and records
+                   the words whose first read differs from the agent-scope read (csrc/matching.hip, geotr_debug_probe_read)
+  GEOTR_ALLOC_LOG  1: every buffer handed to the two native calls is logged (thread, name, address range, time) -> the owners of a
+                   stale word's address over time
+  GEOTR_POISON_WS  1: workspaces / outputs filled with 0xFF before use
+  anything else the runtime reads (GPU_MAX_HW_QUEUES, AMD_SERIALIZE_KERNEL, PYTORCH_NO_HIP_MEMORY_CACHING, ...)
+Workload: `LANES` lanes (default 4), `LANES` rotated stacks of 8 x (20k + 20k) per submission, `REPS` submissions (default 24); every
+output of every stack slot -- pyramid tables included -- is hashed per submission and compared with the majority over submissions.
+
+usage: LABEL=name [env switches] python scripts/hazard_probe.py            (one JSON line on stdout, details on stderr)
+"""
+import ctypes
+import hashlib
+import json
+import os
+import sys
+import time
+from collections import Counter, defaultdict
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def note(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class ProbeRecord(ctypes.Structure):
+    _fields_ = [('addr', ctypes.c_uint64), ('clock', ctypes.c_uint64), ('plain', ctypes.c_uint32), ('agent', ctypes.c_uint32),
+                ('plain_again', ctypes.c_uint32), ('kind_cloud', ctypes.c_uint32), ('elem', ctypes.c_uint32), ('hw_id', ctypes.c_uint32),
+                ('xcc_id', ctypes.c_uint32), ('block', ctypes.c_uint32)]
+
+
+def digest(t):
+    return hashlib.sha1(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
+
+
+def main():
+    from geotransformer_amd import _lib, kernels, native
+    from geotransformer_amd.config import make_cfg
+    from geotransformer_amd.pipeline import ConcurrentRegistration, RegistrationPipeline
+    from geotransformer_amd.synthetic import make_pair
+    label = os.environ.get('LABEL', 'run')
+    lanes, reps, stack = int(os.environ.get('LANES', '4')), int(os.environ.get('REPS', '24')), int(os.environ.get('STACK', '8'))
+    kernels.set_precision('bf16x3')
+    cfg = make_cfg('3dmatch')
+    torch.manual_seed(cfg.seed)
+    np.random.seed(cfg.seed)
+    pipe = RegistrationPipeline(cfg, device='cuda:0')
+    items = [make_pair(i, '3dmatch', n_points=20000) for i in range(8)]
+    pairs = [(torch.from_numpy(it['ref_points']).cuda(), torch.from_numpy(it['src_points']).cuda()) for it in items]
+    runner = ConcurrentRegistration(pipe, lanes=lanes, stack=stack, return_pyramid=True)
+    n = stack * lanes
+    batch = [pairs[(j + j // stack) % 8] for j in range(n)]  # rotated stacks: every lane holds a DIFFERENT stack at any time
+    head_keys = ('ref_node_corr_knn_points', 'src_node_corr_knn_points', 'ref_node_corr_knn_masks', 'src_node_corr_knn_masks',
+                 'matching_scores', 'estimated_transform')
+    feat_keys = ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f', 'ref_node_corr_indices', 'src_node_corr_indices')
+    hashes = defaultdict(dict)   # (slot, key) -> {rep: digest}
+    values = {}                  # float bits -> set of (slot, side, level, element) over rep 0 (for tracing stale values)
+    lib = _lib.load()
+    lib.geotr_debug_probe_read.restype = ctypes.c_int64
+    lib.geotr_debug_probe_read.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_uint32)]
+    probe_on = os.environ.get('GEOTR_P2N_PROBE') == '1'
+    records, stale_total, words_total = [], 0, 0
+    t0 = time.perf_counter()
+    for rep in range(reps):
+        got = {}
+        runner.submit(batch, lambda j, out: got.__setitem__(j, out))
+        runner.drain()
+        torch.cuda.synchronize()
+        for j in range(n):
+            o = got[j]
+            for k in head_keys + feat_keys:
+                hashes[(j, k)][rep] = digest(o[k])
+            if j % stack == 0:  # the stack's pyramid, every table
+                pyr = o['_stack_pyramid']
+                for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
+                    for i, t in enumerate(pyr[key]):
+                        hashes[(j, f'pyramid.{key}{i}')][rep] = digest(t)
+        if probe_on:
+            buf = (ProbeRecord * 65536)()
+            cnt = (ctypes.c_uint32 * 2)()
+            k = lib.geotr_debug_probe_read(buf, 65536, cnt)
+            stale_total += int(cnt[0])
+            words_total += int(cnt[1])
+            for r in buf[:max(k, 0)]:
+                records.append((rep, r.addr, r.clock, r.plain, r.agent, r.plain_again, r.kind_cloud, r.elem, r.hw_id, r.xcc_id, r.block))
+            if rep == 0:
+                for j in range(0, n, stack):
+                    pyr = got[j]['_stack_pyramid']
+                    for level in (1, len(pyr['points']) - 1):
+                        bits = pyr['points'][level].cpu().numpy().view(np.uint32).ravel()
+                        for e, b in enumerate(bits.tolist()):
+                            values.setdefault(b, []).append((j // stack, level, e)) if len(values.get(b, ())) < 4 else None
+        del got
+    dt = time.perf_counter() - t0
+    runner.close()
+
+    # ---- determinism: digest of every (slot, key) per submission vs the majority over submissions ----
+    bad_reps, bad_keys = set(), Counter()
+    for (j, k), per_rep in hashes.items():
+        major, _ = Counter(per_rep.values()).most_common(1)[0]
+        for rep, h in per_rep.items():
+            if h != major:
+                bad_reps.add(rep)
+                bad_keys[k] += 1
+    res = {'label': label, 'lanes': lanes, 'stack': stack, 'submissions': reps, 'submissions_with_any_difference': len(bad_reps),
+           'differing_outputs_by_key': dict(bad_keys), 'seconds': round(dt, 1),
+           'env': {k: os.environ[k] for k in sorted(os.environ) if k.startswith(('GEOTR_', 'GPU_', 'AMD_', 'HSA_', 'PYTORCH_', 'HIP_', 'ROC'))}}
+
+    # ---- the probe's stale words ----
+    if probe_on:
+        res['probe'] = {'words_compared': words_total, 'stale_words': stale_total, 'records': len(records)}
+        if records:
+            kinds = Counter('nodes' if (r[6] >> 16) == 0 else 'points_f' for r in records)
+            lines = Counter((r[0], r[1] // 128) for r in records)
+            per_line = Counter(lines.values())
+            healed = sum(1 for r in records if r[5] == r[4])   # the second plain read returned the fresh value
+            still = sum(1 for r in records if r[5] == r[3])
+            res['probe'].update({
+                'by_array': dict(kinds), 'distinct_128B_lines': len(lines), 'stale_words_per_line_histogram': dict(sorted(per_line.items())),
+                'second_plain_read_fresh': healed, 'second_plain_read_still_stale': still,
+                'by_xcc': dict(sorted(Counter(r[9] for r in records).items())),
+                'distinct_compute_units': len({(r[9], r[8] & 0xffff00) for r in records}),
+                'stale_value_is_poison_0xffffffff': sum(1 for r in records if r[3] == 0xFFFFFFFF),
+                'stale_value_is_zero': sum(1 for r in records if r[3] == 0),
+            })
+            # where do the stale VALUES come from?  (a) the same element of another stack's array, (b) another element, (c) unknown
+            src = Counter()
+            for r in records[:4096]:
+                hits = values.get(r[3], [])
+                fresh = values.get(r[4], [])
+                if not hits:
+                    src['value not in any point array of this workload'] += 1
+                else:
+                    same_elem = [h for h in hits if fresh and h[1] == fresh[0][1] and h[2] == fresh[0][2]]
+                    src['same element of ANOTHER stack\'s array' if same_elem else 'some other element of a point array'] += 1
+            res['probe']['stale_value_origin'] = dict(src)
+            # owners of the stale addresses over time (allocation log)
+            log = native.ALLOC_LOG or []
+            if log:
+                owners = Counter()
+                for r in records[:512]:
+                    hist = [(t, who, what) for who, what, ptr, nbytes, t in log if ptr <= r[1] < ptr + nbytes]
+                    hist.sort()
+                    owners[' -> '.join(f'{what}@{who[-1]}' for _, who, what in hist[-4:])] += 1
+                res['probe']['address_owner_histories_last4'] = dict(owners.most_common(12))
+            for r in records[:24]:
+                note('  stale: rep %d addr %#x %s elem %d plain %#010x agent %#010x plain2 %#010x xcc %d hw %#x block %d' %
+                     (r[0], r[1], 'nodes' if (r[6] >> 16) == 0 else 'pts_f', r[7], r[3], r[4], r[5], r[9], r[8], r[10]))
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()

@@ -41,7 +41,7 @@ def test_bench_workload_stacked_lanes_match_oracle():
     sd = {k: v.detach().cpu() for k, v in pipe.model.state_dict().items()}
 
     # the bench's execution shape: 64 pairs per step, 4 lanes, stacks of 16; pairs rotated so that each one meets 8 of the stack slots
-    runner = ConcurrentRegistration(pipe, lanes=4, stack=STACK)
+    runner = ConcurrentRegistration(pipe, lanes=4, stack=STACK, return_pyramid=True)
     order = [(j + j // STACK) % 8 for j in range(4 * STACK)]
     got = {}
     for step in range(2):
@@ -52,11 +52,19 @@ def test_bench_workload_stacked_lanes_match_oracle():
     assert len(got) == 2 * 4 * STACK
     keys = ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f', 'ref_node_corr_indices', 'src_node_corr_indices',
             'matching_scores', 'corr_scores', 'estimated_transform')
+    more = ('ref_points_c', 'src_points_c', 'ref_points_f', 'src_points_f', 'ref_node_corr_knn_points', 'src_node_corr_knn_points',
+            'ref_node_corr_knn_masks', 'src_node_corr_knn_masks', 'ref_corr_points', 'src_corr_points')
     first = {}
     for j in range(4 * STACK):
-        # the same stack on whatever lane picked it up: bit-identical (nothing in the path depends on the stream or on timing)
-        for k in keys:
+        # the same stack on whatever lane picked it up: bit-identical (nothing in the path depends on the stream or on timing) --
+        # heads, features, superpoint patches, and every table of the stack's pyramid
+        for k in keys + more:
             assert torch.equal(got[(0, j)][k], got[(1, j)][k]), f'slot {j}: {k} differs between two runs of the same stack'
+        if j % STACK == 0:
+            a, b = got[(0, j)]['_stack_pyramid'], got[(1, j)]['_stack_pyramid']
+            for key in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling'):
+                for i, (ta, tb) in enumerate(zip(a[key], b[key])):
+                    assert torch.equal(ta, tb), f'stack {j // STACK}: pyramid {key}[{i}] differs between two runs of the same stack'
         # the same pair in another stack slot: its rows meet other GEMM tiles / GroupNorm partial blocks -> fp32 rounding only
         q = order[j]
         if q not in first:
