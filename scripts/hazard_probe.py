@@ -38,8 +38,17 @@ class ProbeRecord(ctypes.Structure):
                 ('xcc_id', ctypes.c_uint32), ('block', ctypes.c_uint32)]
 
 
+_weights = {}
+
+
 def digest(t):
-    return hashlib.sha1(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
+    """Position-weighted 64-bit checksum computed on the device (the tables of one stack are hundreds of MB)."""
+    t = t.detach().contiguous()
+    flat = (t.view(torch.uint8) if t.element_size() == 1 else t.view(torch.int32)).reshape(-1).to(torch.int64)
+    n = flat.numel()
+    if n not in _weights:
+        _weights[n] = torch.arange(n, device=t.device, dtype=torch.int64) % 1000003 + 1
+    return int((flat * _weights[n]).sum().item())
 
 
 def main():
@@ -70,11 +79,16 @@ def main():
     probe_on = os.environ.get('GEOTR_P2N_PROBE') == '1'
     records, stale_total, words_total = [], 0, 0
     t0 = time.perf_counter()
-    for rep in range(reps):
-        got = {}
-        runner.submit(batch, lambda j, out: got.__setitem__(j, out))
-        runner.drain()
-        torch.cuda.synchronize()
+    depth = int(os.environ.get('DEPTH', '4'))  # submissions queued back to back before anything is drained: the lanes drift apart, so
+    # that a stack's heads run while OTHER stacks are in their pyramid / backbone phases (a drained pipeline starts all lanes in step)
+    for rnd in range(0, reps, depth):
+      allgot = {}
+      for rep in range(rnd, min(reps, rnd + depth)):
+        runner.submit(batch, lambda j, out, rep=rep: allgot.__setitem__((rep, j), out))
+      runner.drain()
+      torch.cuda.synchronize()
+      for rep in range(rnd, min(reps, rnd + depth)):
+        got = {j: allgot[(rep, j)] for j in range(n)}
         for j in range(n):
             o = got[j]
             for k in head_keys + feat_keys:
@@ -84,7 +98,7 @@ def main():
                 for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
                     for i, t in enumerate(pyr[key]):
                         hashes[(j, f'pyramid.{key}{i}')][rep] = digest(t)
-        if probe_on:
+        if probe_on and rep == min(reps, rnd + depth) - 1:
             buf = (ProbeRecord * 65536)()
             cnt = (ctypes.c_uint32 * 2)()
             k = lib.geotr_debug_probe_read(buf, 65536, cnt)
@@ -92,7 +106,7 @@ def main():
             words_total += int(cnt[1])
             for r in buf[:max(k, 0)]:
                 records.append((rep, r.addr, r.clock, r.plain, r.agent, r.plain_again, r.kind_cloud, r.elem, r.hw_id, r.xcc_id, r.block))
-            if rep == 0:
+            if not values:
                 for j in range(0, n, stack):
                     pyr = got[j]['_stack_pyramid']
                     for level in (1, len(pyr['points']) - 1):
@@ -100,6 +114,7 @@ def main():
                         for e, b in enumerate(bits.tolist()):
                             values.setdefault(b, []).append((j // stack, level, e)) if len(values.get(b, ())) < 4 else None
         del got
+      del allgot
     dt = time.perf_counter() - t0
     runner.close()
 

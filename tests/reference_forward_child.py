@@ -172,6 +172,7 @@ if short in GOLDENS:
 
 # ---- (3) a synthetic pair of this experiment's shape through the demo flow: their forward vs the native executor ----
 overrides = dict(SMALL)
+overrides['geotransformer.input_dim'] = 16 * 2 ** {'3dmatch': 4, 'kitti': 5, 'modelnet': 3}[short]  # backbone width at the coarsest stage
 if short == 'modelnet':
     overrides['coarse_matching.num_correspondences'] = 32
 cfg, model, native = build(overrides)
