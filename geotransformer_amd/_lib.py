@@ -17,7 +17,7 @@ c_ptr = ctypes.c_void_p
 c_size = ctypes.c_size_t
 c_int = ctypes.c_int
 
-ABI_VERSION = 3  # geotr_abi_version() of the library this package's ctypes mirrors (native.py, kernels.py) were written against
+ABI_VERSION = 4  # geotr_abi_version() of the library this package's ctypes mirrors (native.py, kernels.py) were written against
 
 # name -> (restype, argtypes); must list every symbol include/geotr.h declares (tests check this)
 SIGNATURES = {
@@ -77,6 +77,12 @@ SIGNATURES = {
     'geotr_gemm_packed_splitk_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
     'geotr_gemm_packed_splitk': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_int,
                                          c_ptr, c_size, c_ptr]),
+    'geotr_gemm_packed_stats_rows_per_record': (c_i64, [c_i64]),
+    'geotr_gemm_packed_stats_floats': (c_size, [c_ptr, c_i64, c_i64]),
+    'geotr_gemm_packed_stats': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_int, c_int, c_ptr, c_i64, c_ptr,
+                                        c_ptr]),
+    'geotr_group_norm_stats': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr,
+                                       c_f32, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     'geotr_group_norm_segmented': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geotr_group_norm_flags_supported': (c_int, [c_i64]),
     'geotr_group_norm_shortcut': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_i64, c_ptr, c_ptr, c_f32, c_int, c_ptr, c_ptr,

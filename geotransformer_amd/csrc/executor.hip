@@ -109,22 +109,58 @@ static float* linear(Ctx& c, const geotr_linear& l, const float* x, int64_t lda,
   return y;
 }
 
+// GroupNorm statistics out of the producing GEMM's epilogue (round 3; geotr_gemm_packed_stats): the records of one Linear output
+struct GnStats {
+  const float* rec = nullptr;  // null: not produced (shape not on the packed path, K-split launch, switch off) -> the norm computes its own
+  int64_t rpr = 0;             // rows per record
+};
+static const bool gn_epilogue_stats = [] {
+  const char* e = std::getenv("GEOTR_GN_EPILOGUE_STATS");  // A/B switch for measurements: 0 = every GroupNorm runs its own statistics pass
+  return !(e && e[0] == '0');
+}();
+// y = x W^T + b for a Linear whose output feeds a GroupNorm over the row segments of `stage`: the statistics records ride in `st`
+static float* linear_gn(Ctx& c, const geotr_linear& l, const float* x, int64_t lda, int64_t m, int stage, GnStats& st) {
+  st = GnStats();
+  // unsplit packed launches only: a launch that is split over K for occupancy keeps its split (the statistics pass of such a narrow
+  // output is small) -- geotr_gemm_packed_splitk_workspace_bytes == 0 says the shape is not split
+  if (!(gn_epilogue_stats && use_packed(l.packed, x, lda, m, l.in) && geotr_gemm_packed_splitk_workspace_bytes(m, l.out, l.in) == 0))
+    return linear(c, l, x, lda, m, 0);
+  float* y = c.alloc<float>((size_t)m * l.out);
+  float* rec = c.alloc<float>(geotr_gemm_packed_stats_floats(c.seg_rows[stage], c.nseg, l.out));
+  if (c.live()) {
+    ProfScope prof(c.stream);
+    c.check(geotr_gemm_packed_stats(x, lda, l.packed, y, l.out, m, l.out, l.in, l.b, nullptr, 0, c.gemm_bf16 ? 1 : 0, c.seg_rows[stage], c.nseg, rec,
+                                    c.stream));
+    if (m < (1 << 24) && l.out < (1 << 12) && l.in < (1 << 14)) prof.done(kProfGemm | (m << 26) | (l.out << 14) | l.in);
+    else prof.done(0);
+  }
+  st.rec = rec;
+  st.rpr = geotr_gemm_packed_stats_rows_per_record(l.out);
+  return y;
+}
+
 // GroupNorm (groups > 0) or LayerNorm (groups == 0) with optional residual / activation; returns a new (n, ch) buffer
 // `stage` selects the pair segments of the row set (GroupNorm only)
 // `row_flags` (GroupNorm only, optional): receives (row sum of the output > 0) per row -- what the KPConv fed by this output
 // needs for its neighbour count -- when the width allows it (geotr_group_norm_flags_supported), else it is left untouched and
 // *row_flags_done stays false
+// `st` (GroupNorm only, optional): x's statistics records from its producing GEMM (linear_gn)
 static float* norm(Ctx& c, const geotr_norm& nm, const float* x, int64_t n, int64_t ch, const float* residual, int act, int stage = 0,
-                   float* y = nullptr, uint8_t* row_flags = nullptr, bool* row_flags_done = nullptr) {
+                   float* y = nullptr, uint8_t* row_flags = nullptr, bool* row_flags_done = nullptr, const GnStats* st = nullptr) {
   if (!y) y = c.alloc<float>((size_t)n * ch);
   if (nm.groups > 0) {
     const size_t m = c.mark();
     double* ws = reinterpret_cast<double*>(c.alloc<char>(geotr_group_norm_workspace_bytes(n, ch)));
     const bool flags = row_flags && geotr_group_norm_flags_supported(ch);
     if (row_flags_done) *row_flags_done = flags;
-    if (c.live())
-      c.check(geotr_group_norm_segmented_flags(x, n, ch, nm.groups, nm.gamma, nm.beta, nm.eps, residual, act, y, c.seg_rows[stage], c.nseg, ws,
-                                               flags ? row_flags : nullptr, c.stream));
+    if (c.live()) {
+      if (st && st->rec)
+        c.check(geotr_group_norm_stats(x, n, ch, nm.groups, nm.gamma, nm.beta, nm.eps, st->rec, st->rpr, residual, nullptr, 0, 0, nullptr, nullptr,
+                                       0.f, act, y, c.seg_rows[stage], c.nseg, ws, flags ? row_flags : nullptr, c.stream));
+      else
+        c.check(geotr_group_norm_segmented_flags(x, n, ch, nm.groups, nm.gamma, nm.beta, nm.eps, residual, act, y, c.seg_rows[stage], c.nseg, ws,
+                                                 flags ? row_flags : nullptr, c.stream));
+    }
     c.release(m);
   } else {
     if (c.live()) c.check(geotr_layer_norm(x, residual, n, ch, nm.gamma, nm.beta, nm.eps, y, c.stream));
@@ -218,10 +254,11 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
   const float* x = s_feats;
   const uint8_t* x_flags = nullptr;
   if (b.has_unary1) {
-    float* t = linear(c, b.unary1, s_feats, b.unary1.in, ns, 0);
+    GnStats st1;
+    float* t = b.unary1_norm.groups > 0 ? linear_gn(c, b.unary1, s_feats, b.unary1.in, ns, s_stage, st1) : linear(c, b.unary1, s_feats, b.unary1.in, ns, 0);
     uint8_t* f = c.alloc<uint8_t>((size_t)ns);
     bool done = false;
-    x = norm(c, b.unary1_norm, t, ns, b.unary1.out, nullptr, 2, s_stage, nullptr, f, &done);
+    x = norm(c, b.unary1_norm, t, ns, b.unary1.out, nullptr, 2, s_stage, nullptr, f, &done, &st1);
     if (done) x_flags = f;  // the KPConv below needs no separate pass over its input
   }
   float* y = kpconv(c, b.conv, x, ns, q_pts, m, s_pts, nb, h, c.order[q_stage], x_flags);
@@ -238,25 +275,28 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
     return !(e && e[0] == '0');
   }();
   if (b.has_shortcut) {
-    float* t = linear(c, b.shortcut, sc, b.shortcut.in, m, 0);
+    GnStats st_sc;
+    float* t = b.shortcut_norm.groups > 0 ? linear_gn(c, b.shortcut, sc, b.shortcut.in, m, q_stage, st_sc) : linear(c, b.shortcut, sc, b.shortcut.in, m, 0);
     if (fuse_shortcut_norm && b.shortcut_norm.groups > 0 && b.unary2_norm.groups > 0 && b.shortcut.out == b.unary2.out) {
       // leaky_relu(GN(unary2(x)) + GN(shortcut Linear)): the shortcut's affine rides in the apply pass of the main branch (bit-identical);
       // its normalised (m, out) tensor -- 328 MB per 16-pair stack at stage 0 -- is neither written nor re-read
-      float* z = linear(c, b.unary2, y, b.unary2.in, m, 0);
+      GnStats st_z;
+      float* z = linear_gn(c, b.unary2, y, b.unary2.in, m, q_stage, st_z);
       float* out = c.alloc<float>((size_t)m * b.unary2.out);
       const size_t mk = c.mark();
       double* ws = reinterpret_cast<double*>(c.alloc<char>(geotr_group_norm_workspace_bytes(m, b.unary2.out)));
       if (c.live())
-        c.check(geotr_group_norm_shortcut(z, t, m, b.unary2.out, b.unary2_norm.groups, b.unary2_norm.gamma, b.unary2_norm.beta, b.unary2_norm.eps,
-                                          b.shortcut_norm.groups, b.shortcut_norm.gamma, b.shortcut_norm.beta, b.shortcut_norm.eps, 2, out,
-                                          c.seg_rows[q_stage], c.nseg, ws, c.stream));
+        c.check(geotr_group_norm_stats(z, m, b.unary2.out, b.unary2_norm.groups, b.unary2_norm.gamma, b.unary2_norm.beta, b.unary2_norm.eps, st_z.rec,
+                                       st_z.rpr, t, st_sc.rec, st_sc.rpr, b.shortcut_norm.groups, b.shortcut_norm.gamma, b.shortcut_norm.beta,
+                                       b.shortcut_norm.eps, 2, out, c.seg_rows[q_stage], c.nseg, ws, nullptr, c.stream));
       c.release(mk);
       return out;
     }
-    sc = norm(c, b.shortcut_norm, t, m, b.shortcut.out, nullptr, 0, q_stage);
+    sc = norm(c, b.shortcut_norm, t, m, b.shortcut.out, nullptr, 0, q_stage, nullptr, nullptr, nullptr, &st_sc);
   }
-  float* z = linear(c, b.unary2, y, b.unary2.in, m, 0);
-  return norm(c, b.unary2_norm, z, m, b.unary2.out, sc, 2, q_stage);  // leaky_relu(unary2(x) + shortcut)
+  GnStats st_z;
+  float* z = b.unary2_norm.groups > 0 ? linear_gn(c, b.unary2, y, b.unary2.in, m, q_stage, st_z) : linear(c, b.unary2, y, b.unary2.in, m, 0);
+  return norm(c, b.unary2_norm, z, m, b.unary2.out, sc, 2, q_stage, nullptr, nullptr, nullptr, &st_z);  // leaky_relu(unary2(x) + shortcut)
 }
 
 struct BackboneOut {
@@ -297,8 +337,9 @@ static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geo
                            c.stream));
       latent = feats_f_out;
     } else {
-      float* t = linear(c, l, cat, tot, p.n[i], 0);
-      latent = norm(c, net.decoder_norm[d], t, p.n[i], l.out, nullptr, 2, i);
+      GnStats st_d;
+      float* t = net.decoder_norm[d].groups > 0 ? linear_gn(c, l, cat, tot, p.n[i], i, st_d) : linear(c, l, cat, tot, p.n[i], 0);
+      latent = norm(c, net.decoder_norm[d], t, p.n[i], l.out, nullptr, 2, i, nullptr, nullptr, nullptr, &st_d);
     }
     lat_ch = l.out;
   }

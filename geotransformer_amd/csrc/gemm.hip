@@ -42,10 +42,14 @@ struct GemmArgs {
 // The MFMA C/D layout (col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) gives each lane one column of 16
 // scattered rows; storing from it directly (two 128-byte pieces per instruction) cost ~6-10 us per launch, so the block is
 // transposed in a wave-private LDS slab ((32*WM) x (32*WN + 4) floats) and written as float4 row segments.
+// `stats_rec` (optional): this wave's GroupNorm record -- per column the sum and the sum of squares of the values it STORES, over its
+// 32 * WM rows in ascending row order per lane, lanes combined by a fixed xor tree: [0, N) sums, [N, 2N) sums of squares (rows past M
+// and columns past N contribute nothing; a wave entirely past M writes zeros).  The record is a function of the tile's rows alone.
 template <int WM, int WN>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float* slab, int lane, int row0, int col0, int M, int N,
                                              float alpha, const float* __restrict__ bias, const int32_t* __restrict__ row_div,
-                                             const float* __restrict__ residual, int64_t ldr, int act, float* __restrict__ C, int64_t ldc) {
+                                             const float* __restrict__ residual, int64_t ldr, int act, float* __restrict__ C, int64_t ldc,
+                                             float* __restrict__ stats_rec = nullptr) {
   constexpr int TW = 32 * WN, TS = TW + 4;
   const int fr = lane & 31, fk = lane >> 5;
 #pragma unroll
@@ -75,6 +79,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
         if (gn + e < N) bv[e] = bias[gn + e];
     }
   }
+  float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
   for (int rr = rl; rr < 32 * WM; rr += RPI) {
     const int gm = row0 + rr;
@@ -111,6 +116,30 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (gn + e < N) cp[e] = x[e];
+    }
+    if (stats_rec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        st_s[e] += x[e];
+        st_q[e] = fmaf(x[e], x[e], st_q[e]);
+      }
+    }
+  }
+  if (stats_rec) {  // (wave-uniform: every lane takes part in the shuffles)
+#pragma unroll
+    for (int o = V4; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        st_s[e] += __shfl_xor(st_s[e], o, 64);
+        st_q[e] += __shfl_xor(st_q[e], o, 64);
+      }
+    if (rl == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gn + e < N) {
+          stats_rec[gn + e] = st_s[e];
+          stats_rec[N + gn + e] = st_q[e];
+        }
     }
   }
 }
@@ -451,6 +480,16 @@ struct PackedArgs {
   // applies the epilogue.  gridDim.z == 1: kt_split = KS / 2, partial unused -- the launch is exactly the unsplit kernel.
   int kt_split;
   float* partial;
+  // round 3: row tiles aligned to row SEGMENTS (the pairs of a stack) and GroupNorm statistics of the output out of the epilogue.
+  // nseg > 0: blockIdx.y counts 128-row tiles segment by segment (seg_tile0 = first tile, seg_row0 = first row of a segment;
+  // entry [nseg] = one past the last): a tile never straddles two segments, a segment's last tile is partly filled.
+  // stats (optional, unsplit launches only): record (tile * WAVES_M + wave row group) = {sum[N], sum of squares[N]} over 32 * WM rows
+  // (epilogue_lds) -- exactly the per-block partial sums gn_partial_kernel (kpconv.hip) would produce for blocks of 32 * WM rows laid
+  // from each segment's first row, so gn_group_kernel finalises them unchanged; a pair's records are the same bits in any stack slot.
+  int nseg;
+  int seg_tile0[GEOTR_MAX_PAIRS + 1];
+  int seg_row0[GEOTR_MAX_PAIRS + 1];
+  float* stats;
 };
 
 __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b_is_kn, int N, int K, int KS, int64_t nvec,
@@ -512,7 +551,14 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   constexpr int B_PER_WAVE = (B_INSTR + 3) / 4;    // issued round-robin by the 4 waves
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * BM, ct0 = blockIdx.x * NT_BLK;
+  const int ct0 = blockIdx.x * NT_BLK;
+  int m0 = blockIdx.y * BM, m_end = g.M;  // this block's first row and the end of its row segment
+  if (g.nseg > 0) {
+    int sgi = 0;
+    while (sgi + 1 < g.nseg && (int)blockIdx.y >= g.seg_tile0[sgi + 1]) ++sgi;
+    m0 = g.seg_row0[sgi] + ((int)blockIdx.y - g.seg_tile0[sgi]) * BM;
+    m_end = g.seg_row0[sgi + 1];
+  }
   const int wrow = (wave / WAVES_N) * 32 * WM, wctl = (wave % WAVES_N) * WN;  // wave's first row / local column tile
   const int fr = lane & 31, fk = lane >> 5;
   const int kt_first = blockIdx.z * g.kt_split;              // this block's K range in 32-deep stages (split-K: gridDim.z slices)
@@ -526,7 +572,7 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   for (int s = 0; s < 4; ++s) {
     const int r = 8 * (4 * wave + s) + (lane >> 3);
     const int c = (lane & 7) ^ (r & 7);
-    const int gm = min(m0 + r, g.M - 1);  // rows past M: any valid row (never stored)
+    const int gm = min(m0 + r, m_end - 1);  // rows past the segment's end: any valid row (never stored)
     a_src[s] = g.A + (int64_t)gm * g.lda + 4 * c + (int64_t)kt_first * 32;
   }
   auto issue = [&](int kt) {
@@ -654,10 +700,10 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   __builtin_amdgcn_s_barrier();
   float* slab = reinterpret_cast<float*>(psm) + wave * (32 * WM * (32 * WN + 4));
   if (gridDim.z == 1)
-    epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), g.M, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act, g.C,
-                         g.ldc);
+    epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act, g.C,
+                         g.ldc, g.stats ? g.stats + ((int64_t)blockIdx.y * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr);
   else  // raw partial sums of this K slice; the epilogue runs in the reduce kernel
-    epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), g.M, g.N, 1.0f, nullptr, nullptr, nullptr, 0, 0,
+    epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, 1.0f, nullptr, nullptr, nullptr, 0, 0,
                          g.partial + (int64_t)blockIdx.z * g.M * g.N, g.N);
 }
 
@@ -773,10 +819,14 @@ static int packed_splits(int64_t M, int64_t N, int64_t K) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, most), 16));
 }
 
+// rows of a statistics record / records per 128-row tile of a packed launch with n_cols output columns (WM = 2 above 64 columns)
+static inline int64_t packed_stats_rpr(int64_t n_cols) { return n_cols > 64 ? 64 : 32; }
+
 template <int TERMS>
 static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                               const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
-                              void* stream_, void* ws = nullptr, size_t ws_bytes = 0) {
+                              void* stream_, void* ws = nullptr, size_t ws_bytes = 0, const int64_t* seg_rows_host = nullptr, int64_t nseg = 0,
+                              float* stats = nullptr) {
   GEOTR_CHECK_ARG(M >= 0 && N >= 1 && K >= 1, "gemm_packed: bad sizes");
   if (M == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(A && packed && C, "gemm_packed: null pointer");
@@ -788,7 +838,23 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   g.C = C; g.bias = bias; g.row_div = row_div; g.residual = residual;
   g.lda = lda; g.ldc = ldc; g.ldr = residual ? ldr : 0;
   g.M = (int)M; g.N = (int)N; g.K = (int)K; g.KS = (int)(kp / 16); g.NT = (int)(np / 32); g.alpha = alpha; g.act = act;
-  int splits = ws ? packed_splits(M, N, K) : 1;
+  g.nseg = 0;
+  g.stats = stats;
+  int64_t tiles = (M + 127) / 128;
+  if (nseg > 0) {  // segment-aligned row tiles
+    GEOTR_CHECK_ARG(seg_rows_host && nseg <= GEOTR_MAX_PAIRS, "gemm_packed: 1..%d row segments", GEOTR_MAX_PAIRS);
+    int64_t row = 0;
+    tiles = 0;
+    for (int64_t q = 0; q < nseg; ++q) {
+      GEOTR_CHECK_ARG(seg_rows_host[q] >= 1, "gemm_packed: empty row segment %lld", (long long)q);
+      g.seg_tile0[q] = (int)tiles, g.seg_row0[q] = (int)row;
+      tiles += (seg_rows_host[q] + 127) / 128, row += seg_rows_host[q];
+    }
+    GEOTR_CHECK_ARG(row == M, "gemm_packed: segments cover %lld rows, expected %lld", (long long)row, (long long)M);
+    for (int64_t q = nseg; q <= GEOTR_MAX_PAIRS; ++q) g.seg_tile0[q] = (int)tiles, g.seg_row0[q] = (int)row;
+    g.nseg = (int)nseg;
+  }
+  int splits = ws && !stats ? packed_splits(M, N, K) : 1;  // statistics come out of the unsplit epilogue only
   if (splits > 1 && ws_bytes < sizeof(float) * (size_t)splits * (size_t)M * (size_t)N) splits = 1;  // never more than the caller's scratch holds
   const int nkt_all = g.KS / 2;
   g.kt_split = (nkt_all + splits - 1) / splits;
@@ -798,8 +864,8 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   GEOTR_CHECK_ARG((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && K % 32 == 0,
                   "gemm_packed: A must be 16-byte aligned with lda %% 4 == 0 and K %% 32 == 0 (use geotr_gemm otherwise)");
   hipStream_t stream = (hipStream_t)stream_;
-  const unsigned gy = (unsigned)((M + 127) / 128);
-  GEOTR_CHECK_ARG(gy <= 65535, "gemm_packed: M too large");
+  const unsigned gy = (unsigned)tiles;
+  GEOTR_CHECK_ARG(tiles <= 65535, "gemm_packed: M too large");
 #define GEOTR_PACKED(WM, WN, BN)                                                                                        \
   do {                                                                                                                  \
     const int lds = std::max(kPStages * (128 * 128 + (BN / 32) * (TERMS == 3 ? 4096 : 2048)), 4 * 32 * WM * (32 * WN + 4) * 4); /* ring | epilogue slabs */ \
@@ -838,6 +904,24 @@ extern "C" int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void*
                                         int bf16_operands, void* ws, size_t ws_bytes, void* stream) {
   if (bf16_operands) return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream, ws, ws_bytes);
   return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream, ws, ws_bytes);
+}
+
+extern "C" int64_t geotr_gemm_packed_stats_rows_per_record(int64_t n_cols) { return packed_stats_rpr(n_cols); }
+
+extern "C" size_t geotr_gemm_packed_stats_floats(const int64_t* seg_rows_host, int64_t nseg, int64_t n_cols) {
+  if (!seg_rows_host || nseg < 1 || n_cols < 1) return 0;
+  int64_t tiles = 0;
+  for (int64_t q = 0; q < nseg; ++q) tiles += (seg_rows_host[q] + 127) / 128;
+  return (size_t)(tiles * (128 / packed_stats_rpr(n_cols)) * 2 * n_cols);
+}
+
+extern "C" int geotr_gemm_packed_stats(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                       const float* bias, const int32_t* row_div, int act, int bf16_operands, const int64_t* seg_rows_host,
+                                       int64_t nseg, float* stats, void* stream) {
+  GEOTR_CHECK_ARG(stats && seg_rows_host && nseg >= 1, "gemm_packed_stats: null pointer / no segments");
+  if (bf16_operands)
+    return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, nullptr, 0, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg, stats);
+  return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, row_div, nullptr, 0, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg, stats);
 }
 
 extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

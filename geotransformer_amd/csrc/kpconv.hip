@@ -617,10 +617,28 @@ static void gn_statistics(const float* x, const GnSegs& sg, int64_t c, int64_t g
   gn_group_kernel<<<dim3((unsigned)groups, (unsigned)sg.nseg), dim3(256), 0, stream>>>(partial, sg, (int)c, (int)groups, gamma, beta, eps, ab);
 }
 
+// The block layout of statistics records a PRODUCER wrote (round 3: the packed GEMM's epilogue, geotr_gemm_packed_stats): records of
+// `rpr` rows laid from each segment's first row, every segment padded to whole 128-row tiles (the surplus records hold zeros).
+static void gn_producer_segs(const GnSegs& rows, const int64_t* seg_rows_host, int64_t rpr, GnSegs& out) {
+  out = rows;
+  int blk = 0;
+  for (int s = 0; s < rows.nseg; ++s) {
+    out.blk0[s] = blk;
+    out.rpb[s] = (int)rpr;
+    blk += (int)((seg_rows_host[s] + 127) / 128 * (128 / rpr));
+  }
+  out.blk0[rows.nseg] = blk;
+}
+
 // shared body: out = act(GN(x) + R) with R = residual, or GN'(residual) when res_gamma is given (its own statistics, never materialised)
+// x_stats / res_stats (optional): the partial records of x / of the residual as their producing GEMM wrote them (rows per record
+// x_rpr / res_rpr); the statistics pass over that tensor is then skipped
 static int group_norm_impl(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
                            const float* residual, int64_t res_groups, const float* res_gamma, const float* res_beta, float res_eps, int act,
-                           float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws, uint8_t* row_positive, void* stream_) {
+                           float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws, uint8_t* row_positive, void* stream_,
+                           const float* x_stats = nullptr, int64_t x_rpr = 0, const float* res_stats = nullptr, int64_t res_rpr = 0) {
+  GEOTR_CHECK_ARG((!x_stats || x_rpr == 32 || x_rpr == 64) && (!res_stats || res_rpr == 32 || res_rpr == 64),
+                  "group_norm: producer statistics come in records of 32 or 64 rows");
   GEOTR_CHECK_ARG(!row_positive || geotr_group_norm_flags_supported(c), "group_norm: row flags need c / 4 a power of two <= 64 (c = %lld)",
                   (long long)c);
   GEOTR_CHECK_ARG(n >= 0 && c >= 1 && groups >= 1 && c % groups == 0, "group_norm: %lld channels / %lld groups",
@@ -649,11 +667,23 @@ static int group_norm_impl(const float* x, int64_t n, int64_t c, int64_t groups,
   float* partial = reinterpret_cast<float*>(stats_ws + 2 * c);
   float* ab = partial + (size_t)blk * 2 * c;
   float* res_ab = nullptr;
+  GnSegs psg;
   if (res_gamma) {  // the shortcut's statistics first; the partial records are free again once its finalize kernel has run (stream order)
     res_ab = ab + (size_t)GEOTR_MAX_PAIRS * 2 * c;
-    gn_statistics(residual, sg, c, res_groups, res_gamma, res_beta, res_eps, partial, res_ab, stream);
+    if (res_stats) {
+      gn_producer_segs(sg, seg_rows_host, res_rpr, psg);
+      gn_group_kernel<<<dim3((unsigned)res_groups, (unsigned)sg.nseg), dim3(256), 0, stream>>>(res_stats, psg, (int)c, (int)res_groups, res_gamma,
+                                                                                               res_beta, res_eps, res_ab);
+    } else {
+      gn_statistics(residual, sg, c, res_groups, res_gamma, res_beta, res_eps, partial, res_ab, stream);
+    }
   }
-  gn_statistics(x, sg, c, groups, gamma, beta, eps, partial, ab, stream);
+  if (x_stats) {
+    gn_producer_segs(sg, seg_rows_host, x_rpr, psg);
+    gn_group_kernel<<<dim3((unsigned)groups, (unsigned)sg.nseg), dim3(256), 0, stream>>>(x_stats, psg, (int)c, (int)groups, gamma, beta, eps, ab);
+  } else {
+    gn_statistics(x, sg, c, groups, gamma, beta, eps, partial, ab, stream);
+  }
   const int64_t total = n * c;
   if (c % 4 == 0)
     gn_apply2_kernel<true><<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream>>>(x, total, (int)c, ab, sg, residual, res_ab, act,
@@ -678,6 +708,15 @@ int geotr_group_norm_shortcut(const float* x, const float* shortcut, int64_t n, 
   GEOTR_CHECK_ARG(shortcut && sc_gamma && sc_beta, "group_norm_shortcut: null pointer");
   return group_norm_impl(x, n, c, groups, gamma, beta, eps, shortcut, sc_groups, sc_gamma, sc_beta, sc_eps, act, out, seg_rows_host, nseg,
                          stats_ws, nullptr, stream_);
+}
+
+int geotr_group_norm_stats(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                           const float* x_stats, int64_t x_rows_per_record, const float* residual, const float* res_stats,
+                           int64_t res_rows_per_record, int64_t res_groups, const float* res_gamma, const float* res_beta, float res_eps, int act,
+                           float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws, uint8_t* row_positive, void* stream_) {
+  GEOTR_CHECK_ARG(!res_stats || res_gamma, "group_norm_stats: residual statistics without a residual norm");
+  return group_norm_impl(x, n, c, groups, gamma, beta, eps, residual, res_gamma ? res_groups : 0, res_gamma, res_beta, res_eps, act, out,
+                         seg_rows_host, nseg, stats_ws, row_positive, stream_, x_stats, x_rows_per_record, res_stats, res_rows_per_record);
 }
 
 int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,

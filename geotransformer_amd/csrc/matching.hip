@@ -43,17 +43,30 @@ struct P2nClouds {
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Load flavours of the hazard investigation (GEOTR_P2N_MODE, profiles/r03_concurrency_hazard.md): 0 = agent scope (shipped),
-// 1 = plain, 2 = plain behind an agent-scope acquire fence at kernel entry, 3 = non-temporal (bypasses L1, no scope semantics)
+// 1 = plain dword loads (asm), 2 = the same behind an agent-scope acquire fence at kernel entry, 3 = non-temporal (bypasses L1, no
+// scope semantics), 4 = plain C++ loads exactly as round 2's failing kernel had them (the compiler merges a point's three words into ONE
+// 12-byte global_load_dwordx3), 5 = superpoints by plain dword loads, points by ONE plain global_load_dwordx3 (asm), 6 = superpoints
+// by plain C++ loads, points by three plain dword loads (asm)
 // (a C++ `volatile` load is NOT plain on this target: it becomes `flat_load ... sc0 sc1`, system scope; hence the asm)
 __device__ __forceinline__ float ld_plain(const float* p) {
   float v;
   asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+struct f3 {
+  float x, y, z;
+};
+using f32x3_t = __attribute__((ext_vector_type(3))) float;
+__device__ __forceinline__ f3 ld_plain_x3(const float* p) {
+  f32x3_t v;
+  asm volatile("global_load_dwordx3 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return f3{v.x, v.y, v.z};
+}
 template <int MODE>
 __device__ __forceinline__ float ld_pt(const float* p) {
   if constexpr (MODE == 0) return ld_agent(p);
   else if constexpr (MODE == 3) return __builtin_nontemporal_load(p);
+  else if constexpr (MODE == 4) return *p;
   else return ld_plain(p);
 }
 
@@ -69,11 +82,18 @@ __global__ __launch_bounds__(256) void p2n_assign_kernel(const float* __restrict
     pts += 3 * tb.f0[q], nodes += 3 * tb.c0[q], point_to_node += tb.f0[q], node_masks += tb.c0[q];
     if ((int64_t)blockIdx.x * blockDim.x >= N) return;
   }
-  for (int e = threadIdx.x; e < 3 * M; e += blockDim.x) nd[e] = ld_pt<MODE>(nodes + e);
+  for (int e = threadIdx.x; e < 3 * M; e += blockDim.x) nd[e] = ld_pt<MODE == 6 ? 4 : (MODE == 5 ? 1 : MODE)>(nodes + e);
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float p[3] = {ld_pt<MODE>(pts + 3 * i), ld_pt<MODE>(pts + 3 * i + 1), ld_pt<MODE>(pts + 3 * i + 2)};
+  float p[3];
+  if constexpr (MODE == 5) {
+    const f3 v = ld_plain_x3(pts + 3 * i);
+    p[0] = v.x, p[1] = v.y, p[2] = v.z;
+  } else {
+    constexpr int PM = MODE == 6 ? 1 : MODE;
+    p[0] = ld_pt<PM>(pts + 3 * i), p[1] = ld_pt<PM>(pts + 3 * i + 1), p[2] = ld_pt<PM>(pts + 3 * i + 2);
+  }
   float best = 3.4e38f;
   int bi = 0;
   for (int m = 0; m < M; ++m) {
@@ -125,13 +145,86 @@ __global__ __launch_bounds__(256) void p2n_probe_kernel(const float* __restrict_
   if ((int64_t)blockIdx.x * blockDim.x >= N) return;
   for (int e = threadIdx.x; e < 3 * M; e += blockDim.x) probe_word(nodes + e, (unsigned)q, (unsigned)e, rec, counters);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N)
+  if (i < N) {
+    // the point's three words by ONE 12-byte plain load (what the compiler makes of plain C++ loads), compared word by word with
+    // agent-scope dword loads: kind 2 = a word of the 12-byte load differs
+    const f3 v = ld_plain_x3(pts + 3 * i);
+    const unsigned got[3] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
+    for (int c = 0; c < 3; ++c) {
+      const unsigned b = __float_as_uint(ld_agent(pts + 3 * i + c));
+      if (got[c] != b) {
+        const unsigned slot = atomicAdd(&counters[0], 1u);
+        if (slot < (unsigned)kProbeCap) {
+          ProbeRecord r;
+          r.addr = (unsigned long long)(uintptr_t)(pts + 3 * i + c), r.clock = wall_clock64();
+          r.plain = got[c], r.agent = b, r.plain_again = __float_as_uint(ld_plain(pts + 3 * i + c));
+          r.kind_cloud = 0x20000u | (unsigned)q, r.elem = (unsigned)(3 * i + c);
+          r.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), r.xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20), r.block = blockIdx.x;
+          rec[slot] = r;
+        }
+      }
+    }
     for (int c = 0; c < 3; ++c) probe_word(pts + 3 * i + c, 0x10000u | (unsigned)q, (unsigned)(3 * i + c), rec, counters);
+  }
   if (threadIdx.x == 0) atomicAdd(&counters[1], (unsigned)(3 * M + 3 * min((int64_t)256, N - (int64_t)blockIdx.x * 256)));
+}
+
+// Whole-array sweep (GEOTR_P2N_PROBE=1): EVERY block reads ALL words of `a` 16 bytes at a time, plainly and at agent scope, so a stale
+// line in any compute unit's L1 at this point of the stream is seen by a block that runs there.  tag: which array at which site.
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+__global__ __launch_bounds__(256) void array_probe_kernel(const float* __restrict__ a, int64_t words, unsigned tag, ProbeRecord* __restrict__ rec,
+                                                          unsigned* __restrict__ counters) {
+  const uintptr_t lo = (reinterpret_cast<uintptr_t>(a) + 15) & ~(uintptr_t)15, hi = reinterpret_cast<uintptr_t>(a + words) & ~(uintptr_t)15;
+  const unsigned* base = reinterpret_cast<const unsigned*>(lo);
+  const int64_t quads = hi > lo ? (int64_t)((hi - lo) / 16) : 0;
+  for (int64_t q = threadIdx.x; q < quads; q += 256) {
+    const unsigned* p = base + 4 * q;
+    u32x4_t x, y;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x), "=&v"(y) : "v"(p) : "memory");
+    const unsigned xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (xs[c] != ys[c]) {
+        const unsigned slot = atomicAdd(&counters[0], 1u);
+        if (slot < (unsigned)kProbeCap) {
+          ProbeRecord r;
+          r.addr = (unsigned long long)(uintptr_t)(p + c), r.clock = wall_clock64();
+          r.plain = xs[c], r.agent = ys[c], r.plain_again = __float_as_uint(ld_plain(reinterpret_cast<const float*>(p + c)));
+          r.kind_cloud = tag << 16, r.elem = (unsigned)(4 * q + c);
+          r.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), r.xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20), r.block = blockIdx.x;
+          rec[slot] = r;
+        }
+      }
+  }
+  if (threadIdx.x == 0) atomicAdd(&counters[1], (unsigned)(quads * 4 >> 8));  // (in units of 256 words: 512 blocks x MBs overflow 32 bits)
+}
+static bool probe_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("GEOTR_P2N_PROBE");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+static int p2n_mode() {  // hazard investigation switch (see ld_pt); the shipped flavour is 0
+  static const int mode = [] {
+    const char* e = std::getenv("GEOTR_P2N_MODE");
+    return e ? std::atoi(e) : 0;
+  }();
+  return mode;
+}
+static int probe_array(const float* a, int64_t words, unsigned tag, hipStream_t stream) {
+  if (!g_probe_records) {
+    if (hipMalloc(&g_probe_records, sizeof(ProbeRecord) * kProbeCap) != hipSuccess || hipMalloc(&g_probe_counters, 16) != hipSuccess ||
+        hipMemset(g_probe_counters, 0, 16) != hipSuccess)
+      return fail(GEOTR_E_LAUNCH, "probe buffers");
+  }
+  array_probe_kernel<<<dim3(512), dim3(256), 0, stream>>>(a, words, tag, g_probe_records, g_probe_counters);
+  return GEOTR_OK;
 }
 
 constexpr int kP2nCap = 4096;  // owned points per node kept in LDS
 
+template <bool AGENT>
 __global__ __launch_bounds__(256) void p2n_knn_kernel(const float* __restrict__ pts, int64_t N, const float* __restrict__ nodes,
                                                       const int64_t* __restrict__ point_to_node, int K,
                                                       int64_t* __restrict__ knn_idx, unsigned char* __restrict__ knn_mask,
@@ -148,10 +241,10 @@ __global__ __launch_bounds__(256) void p2n_knn_kernel(const float* __restrict__ 
   }
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
-  const float nd[3] = {ld_agent(nodes + 3 * node), ld_agent(nodes + 3 * node + 1), ld_agent(nodes + 3 * node + 2)};
+  const float nd[3] = {ld_pt<AGENT ? 0 : 4>(nodes + 3 * node), ld_pt<AGENT ? 0 : 4>(nodes + 3 * node + 1), ld_pt<AGENT ? 0 : 4>(nodes + 3 * node + 2)};
   for (int64_t i = threadIdx.x; i < N; i += blockDim.x) {
     if (point_to_node[i] != node) continue;
-    const float p[3] = {ld_agent(pts + 3 * i), ld_agent(pts + 3 * i + 1), ld_agent(pts + 3 * i + 2)};
+    const float p[3] = {ld_pt<AGENT ? 0 : 4>(pts + 3 * i), ld_pt<AGENT ? 0 : 4>(pts + 3 * i + 1), ld_pt<AGENT ? 0 : 4>(pts + 3 * i + 2)};
     const float d = sqdist_expanded(nd, p);
     const int pos = atomicAdd(&cnt, 1);
     if (pos < kP2nCap) keys[pos] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
@@ -647,6 +740,7 @@ __global__ __launch_bounds__(K == 128 ? 1024 : 512) void patch_sinkhorn_kernel(c
 
 // patches of the selected superpoint pairs (experiments/.../model.py:169-174): row p of the outputs = row corr_idx[p] of
 // the per-node tables; grid (P, 2): blockIdx.y = 0 reference side, 1 source side
+template <bool AGENT>
 __global__ __launch_bounds__(128) void patch_gather_kernel(const int64_t* __restrict__ node_knn_idx0, const unsigned char* __restrict__ node_knn_mask0,
                                                            const float* __restrict__ pts0, int64_t n0, const int64_t* __restrict__ corr0,
                                                            const int64_t* __restrict__ node_knn_idx1, const unsigned char* __restrict__ node_knn_mask1,
@@ -670,9 +764,9 @@ __global__ __launch_bounds__(128) void patch_gather_kernel(const int64_t* __rest
     io[j] = id;
     mo[j] = live ? mtab[node * K + j] : 0;
     const bool real = id < n;  // the pad index selects the zero row appended by model.py:114-115
-    po[3 * j] = real ? ld_agent(pts + 3 * id) : 0.f;
-    po[3 * j + 1] = real ? ld_agent(pts + 3 * id + 1) : 0.f;
-    po[3 * j + 2] = real ? ld_agent(pts + 3 * id + 2) : 0.f;
+    po[3 * j] = real ? ld_pt<AGENT ? 0 : 4>(pts + 3 * id) : 0.f;
+    po[3 * j + 1] = real ? ld_pt<AGENT ? 0 : 4>(pts + 3 * id + 1) : 0.f;
+    po[3 * j + 2] = real ? ld_pt<AGENT ? 0 : 4>(pts + 3 * id + 2) : 0.f;
   }
 }
 
@@ -886,29 +980,28 @@ int p2n_launch(const float* points, const float* nodes, int clouds, const int64_
        hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
        hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
     return fail(GEOTR_E_LAUNCH, "point_to_node: cannot reserve LDS");
-  static const int mode = [] {  // hazard investigation switch (see ld_pt); the shipped flavour is 0
-    const char* e = std::getenv("GEOTR_P2N_MODE");
-    return e ? std::atoi(e) : 0;
-  }();
-  static const bool probe = [] {
-    const char* e = std::getenv("GEOTR_P2N_PROBE");
-    return e && e[0] == '1';
-  }();
+  const int mode = p2n_mode();
+  const bool probe = probe_enabled();
   const dim3 grid((unsigned)((maxn + 255) / 256), (unsigned)clouds);
-  if (probe) {
-    if (!g_probe_records) {
-      if (hipMalloc(&g_probe_records, sizeof(ProbeRecord) * kProbeCap) != hipSuccess || hipMalloc(&g_probe_counters, 16) != hipSuccess ||
-          hipMemset(g_probe_counters, 0, 16) != hipSuccess)
-        return fail(GEOTR_E_LAUNCH, "point_to_node: probe buffers");
-    }
+  if (probe) {  // site 1: in front of p2n_assign -- the access-pattern probe and the whole-array sweeps
+    if (probe_array(points, 3 * f0[clouds], 0x11, stream) != GEOTR_OK || probe_array(nodes, 3 * c0[clouds], 0x12, stream) != GEOTR_OK) return GEOTR_E_LAUNCH;
     p2n_probe_kernel<<<grid, dim3(256), 0, stream>>>(points, nodes, tb, g_probe_records, g_probe_counters);
   }
   if (mode == 1) p2n_assign_kernel<1><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
   else if (mode == 2) p2n_assign_kernel<2><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
   else if (mode == 3) p2n_assign_kernel<3><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
+  else if (mode == 4 || mode == 7) p2n_assign_kernel<4><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
+  else if (mode == 5) p2n_assign_kernel<5><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
+  else if (mode == 6) p2n_assign_kernel<6><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
   else p2n_assign_kernel<0><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
-  p2n_knn_kernel<<<dim3((unsigned)maxm, (unsigned)clouds), dim3(256), 0, stream>>>(points, 0, nodes, point_to_node, (int)k, knn_indices, knn_masks,
-                                                                                 overflow, tb);
+  if (probe && (probe_array(points, 3 * f0[clouds], 0x13, stream) != GEOTR_OK || probe_array(nodes, 3 * c0[clouds], 0x14, stream) != GEOTR_OK))
+    return GEOTR_E_LAUNCH;  // site 2: in front of p2n_knn
+  if (mode == 7)  // 7 = plain C++ loads in ALL three consumers of the point arrays (p2n_assign, p2n_knn, patch_gather): round 2's failing state
+    p2n_knn_kernel<false><<<dim3((unsigned)maxm, (unsigned)clouds), dim3(256), 0, stream>>>(points, 0, nodes, point_to_node, (int)k, knn_indices,
+                                                                                           knn_masks, overflow, tb);
+  else
+    p2n_knn_kernel<true><<<dim3((unsigned)maxm, (unsigned)clouds), dim3(256), 0, stream>>>(points, 0, nodes, point_to_node, (int)k, knn_indices,
+                                                                                          knn_masks, overflow, tb);
   GEOTR_CHECK_LAUNCH("point_to_node");
   return GEOTR_OK;
 }
@@ -969,10 +1062,20 @@ int geotr_patch_gather(const int64_t* ref_node_knn_indices, const uint8_t* ref_n
   GEOTR_CHECK_ARG(ref_node_knn_indices && ref_node_knn_masks && ref_points && ref_corr_indices && src_node_knn_indices &&
                       src_node_knn_masks && src_points && src_corr_indices && ref_knn_indices && ref_knn_masks && ref_knn_points &&
                       src_knn_indices && src_knn_masks && src_knn_points, "patch_gather: null pointer");
-  patch_gather_kernel<<<dim3((unsigned)p, 2), dim3(128), 0, (hipStream_t)stream>>>(
-      ref_node_knn_indices, ref_node_knn_masks, ref_points, nr, ref_corr_indices, src_node_knn_indices, src_node_knn_masks, src_points,
-      ns, src_corr_indices, (int)k, p_count, ref_knn_indices, ref_knn_masks, ref_knn_points, src_knn_indices, src_knn_masks,
-      src_knn_points);
+  if (probe_enabled() && (probe_array(ref_points, 3 * nr, 0x15, (hipStream_t)stream) != GEOTR_OK ||
+                          probe_array(src_points, 3 * ns, 0x15, (hipStream_t)stream) != GEOTR_OK ||
+                          probe_array(reinterpret_cast<const float*>(ref_node_knn_indices), 2 * k * 64, 0x16, (hipStream_t)stream) != GEOTR_OK))
+    return GEOTR_E_LAUNCH;  // site 3: in front of patch_gather (tag 6: the head of the per-superpoint index table, workspace memory)
+  if (p2n_mode() == 7)
+    patch_gather_kernel<false><<<dim3((unsigned)p, 2), dim3(128), 0, (hipStream_t)stream>>>(
+        ref_node_knn_indices, ref_node_knn_masks, ref_points, nr, ref_corr_indices, src_node_knn_indices, src_node_knn_masks, src_points,
+        ns, src_corr_indices, (int)k, p_count, ref_knn_indices, ref_knn_masks, ref_knn_points, src_knn_indices, src_knn_masks,
+        src_knn_points);
+  else
+    patch_gather_kernel<true><<<dim3((unsigned)p, 2), dim3(128), 0, (hipStream_t)stream>>>(
+        ref_node_knn_indices, ref_node_knn_masks, ref_points, nr, ref_corr_indices, src_node_knn_indices, src_node_knn_masks, src_points,
+        ns, src_corr_indices, (int)k, p_count, ref_knn_indices, ref_knn_masks, ref_knn_points, src_knn_indices, src_knn_masks,
+        src_knn_points);
   GEOTR_CHECK_LAUNCH("patch_gather");
   return GEOTR_OK;
 }

@@ -4,6 +4,8 @@ or a failing call raises RuntimeError."""
 import ctypes
 import math
 
+import os
+
 import torch
 
 from . import _lib
@@ -124,6 +126,52 @@ def linear(x, weight, bias=None, act=None, residual=None, packed=False):
     else:
         y = gemm(x2, weight, bias=bias, act=act, residual=res2)
     return y.view(*shape[:-1], weight.shape[0])
+
+
+GN_EPILOGUE_STATS = os.environ.get('GEOTR_GN_EPILOGUE_STATS', '1') != '0'  # same A/B switch as the native executor (csrc/executor.hip)
+
+
+def linear_gn(x, weight, bias=None, seg_rows=None):
+    """A Linear whose output feeds a GroupNorm: (y, stats, rows_per_record).  On the packed path the producing GEMM's epilogue also writes
+    the GroupNorm statistics records of y (geotr_gemm_packed_stats: no statistics pass over y later); otherwise stats is None and the
+    norm computes its own.  Same predicate as the native executor (linear_gn in csrc/executor.hip): unsplit packed launches only."""
+    import ctypes
+    lib = _lib.load()
+    assert x.dim() == 2
+    x2 = x if x.stride(-1) == 1 else x.contiguous()
+    M, K = x2.shape
+    n = weight.shape[0]
+    if not (GN_EPILOGUE_STATS and use_packed(x2) and lib.geotr_gemm_packed_splitk_workspace_bytes(M, n, K) == 0):
+        return linear(x2, weight, bias, packed=True), None, 0
+    segs = [M] if seg_rows is None else [int(r) for r in seg_rows]
+    seg_arr = (ctypes.c_int64 * len(segs))(*segs)
+    y = torch.empty((M, n), dtype=torch.float32, device=x2.device)
+    stats = torch.empty(lib.geotr_gemm_packed_stats_floats(seg_arr, len(segs), n), dtype=torch.float32, device=x2.device)
+    _lib.check(lib.geotr_gemm_packed_stats(_lib.ptr(x2), x2.stride(0), _lib.ptr(gemm_pack(weight)), _lib.ptr(y), y.stride(0), M, n, K,
+                                           _lib.ptr(bias), None, 0, int(GEMM_PACKED == 'bf16'), seg_arr, len(segs), _lib.ptr(stats),
+                                           _lib.stream_ptr()), 'geotr_gemm_packed_stats')
+    return y, stats, int(lib.geotr_gemm_packed_stats_rows_per_record(n))
+
+
+def group_norm_stats(x, groups, weight, bias, eps=1e-5, x_stats=None, x_rpr=0, residual=None, res_stats=None, res_rpr=0, res_norm=None,
+                     act=None, seg_rows=None):
+    """act(GN(x) + R) with the statistics of x (and of a residual carrying its own norm, res_norm = (groups, weight, bias, eps)) taken from
+    the records their producing GEMMs wrote (linear_gn) where given (geotr_group_norm_stats)."""
+    import ctypes
+    lib = _lib.load()
+    x = _f32c(x)
+    N, C = x.shape
+    segs = [N] if seg_rows is None else [int(r) for r in seg_rows]
+    out = torch.empty_like(x)
+    ws = _lib.workspace(lib.geotr_group_norm_workspace_bytes(N, C), x.device)
+    if residual is not None:
+        residual = _f32c(residual)
+    rg, rw, rb, re = res_norm if res_norm is not None else (0, None, None, 0.0)
+    _lib.check(lib.geotr_group_norm_stats(_lib.ptr(x), N, C, groups, _lib.ptr(weight), _lib.ptr(bias), float(eps), _lib.ptr(x_stats), int(x_rpr),
+                                          _lib.ptr(residual), _lib.ptr(res_stats), int(res_rpr), int(rg), _lib.ptr(rw), _lib.ptr(rb), float(re),
+                                          ACT[act], _lib.ptr(out), (ctypes.c_int64 * len(segs))(*segs), len(segs), _lib.ptr(ws), None,
+                                          _lib.stream_ptr()), 'geotr_group_norm_stats')
+    return out
 
 
 def row_positive(feats):

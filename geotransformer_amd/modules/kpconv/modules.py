@@ -19,7 +19,11 @@ class GroupNorm(nn.Module):
         self.num_channels = num_channels
         self.norm = nn.GroupNorm(self.num_groups, self.num_channels)  # holds weight/bias under the reference's names
 
-    def forward(self, x, residual=None, act=None):
+    def forward(self, x, residual=None, act=None, stats=None, rows_per_record=0):
+        """`stats`: the statistics records of x written by its producing GEMM (kernels.linear_gn), else computed here."""
+        if stats is not None:
+            return kernels.group_norm_stats(x, self.num_groups, self.norm.weight, self.norm.bias, self.norm.eps, x_stats=stats,
+                                            x_rpr=rows_per_record, residual=residual, act=act)
         return kernels.group_norm(x, self.num_groups, self.norm.weight, self.norm.bias, self.norm.eps, residual, act)
 
 
@@ -42,10 +46,15 @@ class UnaryBlock(nn.Module):
         self.leaky_relu = nn.LeakyReLU(0.1) if has_relu else None
 
     def forward(self, x, residual=None, act_after_residual=None):
-        x = kernels.linear(x, self.mlp.weight, self.mlp.bias, packed=True)
+        if isinstance(self.norm, GroupNorm) and x.dim() == 2:
+            # the GroupNorm statistics of the Linear's output come out of the GEMM's epilogue where the packed path applies
+            x, stats, rpr = kernels.linear_gn(x, self.mlp.weight, self.mlp.bias)
+            kw = dict(stats=stats, rows_per_record=rpr)
+        else:
+            x, kw = kernels.linear(x, self.mlp.weight, self.mlp.bias, packed=True), {}
         if residual is not None:  # fused tail of ResidualBlock: leaky_relu(norm(x) + shortcut)
-            return self.norm(x, residual=residual, act=act_after_residual)
-        return self.norm(x, act='leaky' if self.leaky_relu is not None else None)
+            return self.norm(x, residual=residual, act=act_after_residual, **kw)
+        return self.norm(x, act='leaky' if self.leaky_relu is not None else None, **kw)
 
 
 class LastUnaryBlock(nn.Module):

@@ -148,6 +148,18 @@ size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K)
 int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                              const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                              int bf16_operands, void* ws, size_t ws_bytes, void* stream);
+/* GroupNorm statistics out of the producing GEMM (round 3; kpconv/modules.py:33-50 normalises what modules.py:68 / :98 just wrote):
+ * the launch tiles the rows SEGMENT by segment (seg_rows_host[nseg] rows each, summing to M; a 128-row tile never straddles two
+ * segments) and every wave's epilogue also writes, per output column, the sum and the sum of squares of the values it stores over its
+ * rows -- records of geotr_gemm_packed_stats_rows_per_record(N) rows laid from each segment's first row, each segment padded to whole
+ * tiles (surplus records are zero), 2 N floats per record: `stats` holds geotr_gemm_packed_stats_floats(seg_rows_host, nseg, N) floats.
+ * geotr_group_norm_stats finalises them, so the statistics pass over C (a full re-read) disappears.  A segment's records are the same
+ * bits whatever it is stacked with.  Never split over K (epilogue: / row_div + bias, act; no residual). */
+int64_t geotr_gemm_packed_stats_rows_per_record(int64_t n_cols);
+size_t geotr_gemm_packed_stats_floats(const int64_t* seg_rows_host, int64_t nseg, int64_t n_cols);
+int geotr_gemm_packed_stats(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                            const float* bias, const int32_t* row_div, int act, int bf16_operands, const int64_t* seg_rows_host,
+                            int64_t nseg, float* stats, void* stream);
 /* The same launch with plain bf16 operands (hi planes of the same packed weight, a_hi*b_hi only, fp32 accumulation; ~2^-8 relative
  * error per product): the "bf16 features" mode of BASELINE configs[4].  Never the default. */
 int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
@@ -225,6 +237,14 @@ int geotr_group_norm_shortcut(const float* x, const float* shortcut, int64_t n, 
 int geotr_group_norm_segmented_flags(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
                                      const float* residual, int act, float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws,
                                      uint8_t* row_positive, void* stream);
+/* GroupNorm whose statistics (of x, and / or of a residual that carries its own norm) were written by the producing GEMM
+ * (geotr_gemm_packed_stats; x_stats / res_stats with their rows per record, NULL = computed here by a pass over the tensor):
+ *   out = act(GN(x) + R),  R = residual (res_gamma NULL), GN'(residual) (res_gamma given), or nothing (residual NULL).
+ * Arguments otherwise as geotr_group_norm_segmented_flags / geotr_group_norm_shortcut. */
+int geotr_group_norm_stats(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta, float eps,
+                           const float* x_stats, int64_t x_rows_per_record, const float* residual, const float* res_stats,
+                           int64_t res_rows_per_record, int64_t res_groups, const float* res_gamma, const float* res_beta, float res_eps, int act,
+                           float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws, uint8_t* row_positive, void* stream);
 int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c, const float* gamma, const float* beta,
                      float eps, float* out, void* stream);
 

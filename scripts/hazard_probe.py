@@ -24,7 +24,7 @@ from collections import Counter, defaultdict
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.environ.get('GEOTR_TREE') or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # GEOTR_TREE: another checkout
 sys.path.insert(0, ROOT)
 
 
@@ -65,7 +65,12 @@ def main():
     pipe = RegistrationPipeline(cfg, device='cuda:0')
     items = [make_pair(i, '3dmatch', n_points=20000) for i in range(8)]
     pairs = [(torch.from_numpy(it['ref_points']).cuda(), torch.from_numpy(it['src_points']).cuda()) for it in items]
-    runner = ConcurrentRegistration(pipe, lanes=lanes, stack=stack, return_pyramid=True)
+    try:
+        runner = ConcurrentRegistration(pipe, lanes=lanes, stack=stack, return_pyramid=True)
+        have_pyramid = True
+    except TypeError:  # a checkout from before round 3
+        runner = ConcurrentRegistration(pipe, lanes=lanes, stack=stack)
+        have_pyramid = False
     n = stack * lanes
     batch = [pairs[(j + j // stack) % 8] for j in range(n)]  # rotated stacks: every lane holds a DIFFERENT stack at any time
     head_keys = ('ref_node_corr_knn_points', 'src_node_corr_knn_points', 'ref_node_corr_knn_masks', 'src_node_corr_knn_masks',
@@ -81,7 +86,15 @@ def main():
     t0 = time.perf_counter()
     depth = int(os.environ.get('DEPTH', '4'))  # submissions queued back to back before anything is drained: the lanes drift apart, so
     # that a stack's heads run while OTHER stacks are in their pyramid / backbone phases (a drained pipeline starts all lanes in step)
+    fresh = os.environ.get('FRESH_PIPELINE') == '1'  # a new model + new lanes (threads, streams) for every round, as round 2's bisect tool did
     for rnd in range(0, reps, depth):
+      if fresh and rnd:
+        runner.close()
+        torch.manual_seed(cfg.seed)
+        np.random.seed(cfg.seed)
+        pipe = RegistrationPipeline(cfg, device='cuda:0')
+        runner = (ConcurrentRegistration(pipe, lanes=lanes, stack=stack, return_pyramid=True) if have_pyramid else
+                  ConcurrentRegistration(pipe, lanes=lanes, stack=stack))
       allgot = {}
       for rep in range(rnd, min(reps, rnd + depth)):
         runner.submit(batch, lambda j, out, rep=rep: allgot.__setitem__((rep, j), out))
@@ -93,7 +106,7 @@ def main():
             o = got[j]
             for k in head_keys + feat_keys:
                 hashes[(j, k)][rep] = digest(o[k])
-            if j % stack == 0:  # the stack's pyramid, every table
+            if j % stack == 0 and have_pyramid:  # the stack's pyramid, every table
                 pyr = o['_stack_pyramid']
                 for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
                     for i, t in enumerate(pyr[key]):
@@ -107,12 +120,12 @@ def main():
             for r in buf[:max(k, 0)]:
                 records.append((rep, r.addr, r.clock, r.plain, r.agent, r.plain_again, r.kind_cloud, r.elem, r.hw_id, r.xcc_id, r.block))
             if not values:
-                for j in range(0, n, stack):
-                    pyr = got[j]['_stack_pyramid']
-                    for level in (1, len(pyr['points']) - 1):
-                        bits = pyr['points'][level].cpu().numpy().view(np.uint32).ravel()
+                for j in range(n):  # every float of the two point arrays of every pair -> (slot, which array, element)
+                    for level, key in ((1, 'ref_points_f'), (1, 'src_points_f'), (3, 'ref_points_c'), (3, 'src_points_c')):
+                        bits = got[j][key].cpu().numpy().view(np.uint32).ravel()
                         for e, b in enumerate(bits.tolist()):
-                            values.setdefault(b, []).append((j // stack, level, e)) if len(values.get(b, ())) < 4 else None
+                            if len(values.setdefault(b, [])) < 4:
+                                values[b].append((j, key, e))
         del got
       del allgot
     dt = time.perf_counter() - t0
@@ -134,7 +147,11 @@ def main():
     if probe_on:
         res['probe'] = {'words_compared': words_total, 'stale_words': stale_total, 'records': len(records)}
         if records:
-            kinds = Counter('nodes' if (r[6] >> 16) == 0 else 'points_f' for r in records)
+            names = {0: 'assign pattern: superpoints', 1: 'assign pattern: points (dword)', 2: 'assign pattern: points (12-byte load)',
+                     0x11: 'sweep before p2n_assign: points', 0x12: 'sweep before p2n_assign: superpoints', 0x13: 'sweep before p2n_knn: points',
+                     0x14: 'sweep before p2n_knn: superpoints', 0x15: 'sweep before patch_gather: points',
+                     0x16: 'sweep before patch_gather: per-superpoint index table (workspace)'}
+            kinds = Counter(names.get(r[6] >> 16, hex(r[6] >> 16)) for r in records)
             lines = Counter((r[0], r[1] // 128) for r in records)
             per_line = Counter(lines.values())
             healed = sum(1 for r in records if r[5] == r[4])   # the second plain read returned the fresh value
@@ -155,11 +172,11 @@ def main():
                 if not hits:
                     src['value not in any point array of this workload'] += 1
                 else:
-                    same_elem = [h for h in hits if fresh and h[1] == fresh[0][1] and h[2] == fresh[0][2]]
-                    src['same element of ANOTHER stack\'s array' if same_elem else 'some other element of a point array'] += 1
+                    same_elem = [h for h in hits if fresh and h[1] == fresh[0][1] and h[2] == fresh[0][2] and h[0] != fresh[0][0]]
+                    src['same element of ANOTHER pair\'s array' if same_elem else 'some other element of a point array'] += 1
             res['probe']['stale_value_origin'] = dict(src)
             # owners of the stale addresses over time (allocation log)
-            log = native.ALLOC_LOG or []
+            log = getattr(native, 'ALLOC_LOG', None) or []
             if log:
                 owners = Counter()
                 for r in records[:512]:
@@ -169,7 +186,7 @@ def main():
                 res['probe']['address_owner_histories_last4'] = dict(owners.most_common(12))
             for r in records[:24]:
                 note('  stale: rep %d addr %#x %s elem %d plain %#010x agent %#010x plain2 %#010x xcc %d hw %#x block %d' %
-                     (r[0], r[1], 'nodes' if (r[6] >> 16) == 0 else 'pts_f', r[7], r[3], r[4], r[5], r[9], r[8], r[10]))
+                     (r[0], r[1], hex(r[6] >> 16), r[7], r[3], r[4], r[5], r[9], r[8], r[10]))
     print(json.dumps(res))
 
 

@@ -200,3 +200,51 @@ def test_group_norm_shortcut_is_bitwise_two_group_norms(C, segs):
         want.append(F.leaky_relu(gn(x[r0:r0 + rows], w1, b1) + gn(t[r0:r0 + rows], w2, b2), 0.1))
         r0 += rows
     assert torch.allclose(fused, torch.cat(want), atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize('N,K,segs', [(128, 32, [5000, 3333, 129, 128, 1, 77]), (32, 64, [2049, 4000]), (64, 64, [1500, 1500, 700]),
+                                      (256, 128, [40000]), (96, 256, [1024, 255, 1300])])
+def test_group_norm_statistics_out_of_the_gemm_epilogue(N, K, segs):
+    """geotr_gemm_packed_stats + geotr_group_norm_stats (round 3): row tiles aligned to the row segments, the GroupNorm statistics
+    of the output written by the GEMM's epilogue.  (a) the output is bitwise the plain packed GEMM's; (b) every record holds the
+    column sums / sums of squares of its rows; (c) GroupNorm from the records agrees with the statistics-pass GroupNorm of each
+    segment to fp32 rounding; (d) a segment alone gives bitwise the records and the normalised rows it gives inside a stack."""
+    from geotransformer_amd import _lib, kernels
+    g = torch.Generator().manual_seed(N * 1000 + K + len(segs))
+    M = sum(segs)
+    a = (torch.randn(M, K, generator=g) * 1.5 + 0.3).cuda()
+    w = torch.randn(N, K, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    gamma, beta = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    groups = 8
+    y, stats, rpr = kernels.linear_gn(a, w, bias, seg_rows=segs)
+    assert stats is not None and rpr == (64 if N > 64 else 32)
+    assert torch.equal(y, kernels.gemm_packed(a, kernels.gemm_pack(w), N, bias=bias))                               # (a)
+    rec = stats.view(-1, 2, N).double().cpu()
+    yd = y.double().cpu()
+    r0, b0 = 0, 0
+    for rows in segs:                                                                                                 # (b)
+        nrec = (rows + 127) // 128 * (128 // rpr)
+        for b in range(nrec):
+            blk = yd[r0 + b * rpr: r0 + min(rows, (b + 1) * rpr)]
+            assert torch.allclose(rec[b0 + b, 0], blk.sum(0), rtol=1e-5, atol=1e-4), (rows, b)
+            assert torch.allclose(rec[b0 + b, 1], (blk * blk).sum(0), rtol=1e-5, atol=1e-4), (rows, b)
+        r0, b0 = r0 + rows, b0 + nrec
+    assert b0 == rec.shape[0]
+    out = kernels.group_norm_stats(y, groups, gamma, beta, x_stats=stats, x_rpr=rpr, act='leaky', seg_rows=segs)
+    r0 = 0
+    for i, rows in enumerate(segs):
+        want = kernels.group_norm(y[r0:r0 + rows].contiguous(), groups, gamma, beta, act='leaky')                    # (c)
+        assert torch.allclose(out[r0:r0 + rows], want, rtol=2e-5, atol=2e-5), i
+        if rows >= kernels.PACKED_MIN_ROWS:                                                                           # (d)
+            ya, sa, _ = kernels.linear_gn(a[r0:r0 + rows].contiguous(), w, bias)
+            alone = kernels.group_norm_stats(ya, groups, gamma, beta, x_stats=sa, x_rpr=rpr, act='leaky')
+            assert torch.equal(ya, y[r0:r0 + rows]) and torch.equal(alone, out[r0:r0 + rows]), i
+        r0 += rows
+    # the residual with its own norm: both statistics from records == the two-pass composition
+    t, st, _ = kernels.linear_gn(a, (w * 0.7 + 0.1).contiguous(), bias, seg_rows=segs)
+    fused = kernels.group_norm_stats(y, groups, gamma, beta, x_stats=stats, x_rpr=rpr, residual=t, res_stats=st, res_rpr=rpr,
+                                     res_norm=(4, beta, gamma, 1e-5), act='leaky', seg_rows=segs)
+    tn = kernels.group_norm_stats(t, 4, beta, gamma, x_stats=st, x_rpr=rpr, seg_rows=segs)
+    two = kernels.group_norm_stats(y, groups, gamma, beta, x_stats=stats, x_rpr=rpr, residual=tn, act='leaky', seg_rows=segs)
+    assert torch.equal(fused, two)
