@@ -96,6 +96,7 @@ SIGNATURES = {
     'geotr_model_forward': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_pyramid_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
     'geotr_pyramid_build': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    'geotr_pyramid_build_async': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_profile_gse': (c_int, [c_ptr, c_ptr, c_ptr, c_i64]),
     'geotr_profile_gse_count': (c_i64, []),
     'geotr_profile_stride': (c_int, [c_i64]),

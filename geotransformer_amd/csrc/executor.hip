@@ -829,13 +829,14 @@ size_t geotr_pyramid_workspace_bytes(int64_t n0, int64_t batch, int64_t num_stag
          (size_t)num_stages * align_up(geotr_radius_grid_workspace_bytes(n0, batch)) + 4096;
 }
 
-int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t batch, int64_t n0, int64_t num_stages, float voxel_size,
-                        float radius, const int64_t* limits_host, const geotr_pyramid_buffers* buf, int64_t* lengths_host,
-                        int32_t* overflow, void* ws, size_t ws_bytes, void* stream_) {
-  GEOTR_CHECK_ARG(points && lengths && limits_host && buf && lengths_host && ws, "pyramid_build: null pointer");
+// The whole pyramid is enqueued without a single host read (round 3): every launch is sized from the row capacity n0, the kernels read
+// the stage sizes from the device-resident lengths (neighbors.hip), and the cell budget of a stage's grid comes from a hint.
+static int pyramid_enqueue(const float* points, const int64_t* lengths, int64_t batch, int64_t n0, int64_t num_stages, float voxel_size,
+                           float radius, const int64_t* limits_host, const geotr_pyramid_buffers* buf, int32_t* overflow, void* ws,
+                           size_t ws_bytes, hipStream_t stream) {
+  GEOTR_CHECK_ARG(points && lengths && limits_host && buf && ws, "pyramid_build: null pointer");
   GEOTR_CHECK_ARG(num_stages >= 1 && num_stages <= GEOTR_MAX_STAGES && batch >= 1 && n0 >= 1, "pyramid_build: bad sizes");
   if (ws_bytes < geotr_pyramid_workspace_bytes(n0, batch, num_stages)) return fail(GEOTR_E_WORKSPACE, "pyramid_build: workspace too small");
-  hipStream_t stream = (hipStream_t)stream_;
   const int S = (int)num_stages;
   char* base = reinterpret_cast<char*>(ws);
   const size_t gs_bytes = align_up(geotr_grid_subsample_workspace_bytes(n0, batch));
@@ -843,34 +844,27 @@ int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t bat
   void* gs_ws = base;
   const float* pts[GEOTR_MAX_STAGES];
   const int64_t* len[GEOTR_MAX_STAGES];
-  int64_t n[GEOTR_MAX_STAGES];
+  int64_t hint[GEOTR_MAX_STAGES];
   pts[0] = points;
   len[0] = lengths;
-  n[0] = n0;
-  if (hipMemcpyAsync(lengths_host, lengths, sizeof(int64_t) * batch, hipMemcpyDeviceToHost, stream) != hipSuccess)
-    return fail(GEOTR_E_LAUNCH, "pyramid_build: memcpy failed");
+  hint[0] = n0;
   float v = voxel_size;
   for (int i = 1; i < S; ++i) {  // data.py:23-28: stage i is the grid subsample of stage i-1 at voxel * 2^i
     v *= 2.0f;
-    int rc = geotr_grid_subsample(pts[i - 1], len[i - 1], batch, n[i - 1], v, buf->points[i], buf->lengths[i], gs_ws, gs_bytes, stream);
+    // (n0 is the capacity of every stage: a subsample never has more points than its input)
+    int rc = geotr_grid_subsample(pts[i - 1], len[i - 1], batch, n0, v, buf->points[i], buf->lengths[i], gs_ws, gs_bytes, stream);
     if (rc != GEOTR_OK) return rc;
-    if (hipMemcpyAsync(lengths_host + (size_t)i * batch, buf->lengths[i], sizeof(int64_t) * batch, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-        hipStreamSynchronize(stream) != hipSuccess)
-      return fail(GEOTR_E_LAUNCH, "pyramid_build: reading the stage sizes failed");
-    int64_t tot = 0;
-    for (int64_t b = 0; b < batch; ++b) tot += lengths_host[(size_t)i * batch + b];
-    GEOTR_CHECK_ARG(tot >= 1, "pyramid_build: stage %d is empty", i);
     pts[i] = buf->points[i];
     len[i] = buf->lengths[i];
-    n[i] = tot;
+    hint[i] = std::max<int64_t>(hint[i - 1] / 3, 1024);  // a voxel twice as large keeps between a quarter and a third of a surface's points
   }
   // one uniform grid per stage serves the three searches against that stage (data.py:31-69)
   float r = radius;
   void* grids[GEOTR_MAX_STAGES];
   for (int i = 0; i < S; ++i) {
     grids[i] = base + gs_bytes + (size_t)i * grid_bytes;
-    int rc = geotr_radius_grid_build(pts[i], len[i], batch, n[i], r, grids[i], grid_bytes, stream);
-    if (rc == GEOTR_OK && buf->order[i]) rc = geotr_radius_grid_order(grids[i], n[i], batch, buf->order[i], stream);
+    int rc = radius_grid_build_hinted(pts[i], len[i], batch, n0, hint[i], r, grids[i], grid_bytes, stream);
+    if (rc == GEOTR_OK && buf->order[i]) rc = radius_grid_order_hinted(grids[i], n0, hint[i], batch, buf->order[i], stream);
     if (rc != GEOTR_OK) return rc;
     r *= 2.0f;
   }
@@ -879,17 +873,52 @@ int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t bat
   // 2.5 + sqrt(3) voxel sizes of its centre (~320), so 512 cannot overflow from stage 1 on; stage 0 (raw input) raises if it does.
   const int64_t kRowCap = 512;
   for (int i = 0; i < S; ++i) {
-    int rc = geotr_radius_query(grids[i], n[i], pts[i], len[i], batch, n[i], r, limits_host[i], kRowCap, buf->neighbors[i], overflow, stream);
+    GEOTR_CHECK_ARG(limits_host[i] >= 1 && limits_host[i] < (1 << 20), "pyramid_build: bad neighbour limit at stage %d", i);
+    int rc = radius_query_hinted(false, grids[i], pts[i], len[i], batch, n0, n0, hint[i], r, limits_host[i], kRowCap, buf->neighbors[i], nullptr,
+                                 nullptr, overflow, stream);
     if (rc != GEOTR_OK) return rc;
     if (i < S - 1) {
-      rc = geotr_radius_query(grids[i], n[i], pts[i + 1], len[i + 1], batch, n[i + 1], r, limits_host[i], kRowCap, buf->subsampling[i], overflow, stream);
+      rc = radius_query_hinted(false, grids[i], pts[i + 1], len[i + 1], batch, n0, n0, hint[i], r, limits_host[i], kRowCap, buf->subsampling[i],
+                               nullptr, nullptr, overflow, stream);
       if (rc != GEOTR_OK) return rc;
-      rc = geotr_radius_query(grids[i + 1], n[i + 1], pts[i], len[i], batch, n[i], 2.0f * r, limits_host[i + 1], kRowCap, buf->upsampling[i], overflow,
-                              stream);
+      rc = radius_query_hinted(false, grids[i + 1], pts[i], len[i], batch, n0, n0, hint[i + 1], 2.0f * r, limits_host[i + 1], kRowCap,
+                               buf->upsampling[i], nullptr, nullptr, overflow, stream);
       if (rc != GEOTR_OK) return rc;
     }
     r *= 2.0f;
   }
+  return GEOTR_OK;
+}
+
+int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t batch, int64_t n0, int64_t num_stages, float voxel_size,
+                        float radius, const int64_t* limits_host, const geotr_pyramid_buffers* buf, int64_t* lengths_host,
+                        int32_t* overflow, void* ws, size_t ws_bytes, void* stream_) {
+  GEOTR_CHECK_ARG(lengths_host, "pyramid_build: null pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int rc = pyramid_enqueue(points, lengths, batch, n0, num_stages, voxel_size, radius, limits_host, buf, overflow, ws, ws_bytes, stream);
+  if (rc != GEOTR_OK) return rc;
+  // the stage sizes, read ONCE after everything is enqueued (round 2 read them stage by stage: num_stages - 1 stream synchronisations)
+  for (int i = 0; i < (int)num_stages; ++i)
+    if (hipMemcpyAsync(lengths_host + (size_t)i * batch, i == 0 ? lengths : buf->lengths[i], sizeof(int64_t) * batch, hipMemcpyDeviceToHost,
+                       stream) != hipSuccess)
+      return fail(GEOTR_E_LAUNCH, "pyramid_build: memcpy failed");
+  if (hipStreamSynchronize(stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "pyramid_build: reading the stage sizes failed");
+  return GEOTR_OK;
+}
+
+// The same without any host synchronisation: `lengths_pinned` must be device-accessible host memory (hipHostMalloc / a pinned torch
+// tensor) of num_stages x batch int64; it holds the stage sizes once the stream has passed this call -- the caller reads it after its
+// next synchronisation of the stream (e.g. together with the previous stack's result counts: ONE host wait per stack).
+int geotr_pyramid_build_async(const float* points, const int64_t* lengths, int64_t batch, int64_t n0, int64_t num_stages, float voxel_size,
+                              float radius, const int64_t* limits_host, const geotr_pyramid_buffers* buf, int64_t* lengths_pinned,
+                              int32_t* overflow, void* ws, size_t ws_bytes, void* stream_) {
+  GEOTR_CHECK_ARG(lengths_pinned, "pyramid_build_async: null pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int rc = pyramid_enqueue(points, lengths, batch, n0, num_stages, voxel_size, radius, limits_host, buf, overflow, ws, ws_bytes, stream);
+  if (rc != GEOTR_OK) return rc;
+  for (int i = 0; i < (int)num_stages; ++i)  // written by a kernel on the stream: an ordinary in-order dispatch, no blit path
+    if (copy_async(lengths_pinned + (size_t)i * batch, i == 0 ? lengths : buf->lengths[i], sizeof(int64_t) * batch, stream) != GEOTR_OK)
+      return GEOTR_E_LAUNCH;
   return GEOTR_OK;
 }
 

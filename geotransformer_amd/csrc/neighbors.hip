@@ -59,11 +59,15 @@ struct GridLayout {
   size_t bytes;
 };
 
-static GridLayout grid_layout(void* ws, int64_t ns, int64_t batch) {
+// `ns` = row CAPACITY of the grid (the stacked support clouds hold at most that many points; the real count is read from the lengths on
+// the device); `ns_hint` (<= ns, 0 = ns) = the expected count, which only sizes the cell budget: too small a hint means coarser cells
+// (more candidates per query), never a wrong result
+static GridLayout grid_layout(void* ws, int64_t ns, int64_t batch, int64_t ns_hint = 0) {
   GridLayout L;
   L.ns = ns;
   L.batch = batch;
-  int64_t budget = std::min<int64_t>(std::max<int64_t>(32 * ns, 1 << 18), 1 << 26);
+  const int64_t expect = ns_hint > 0 ? std::min(ns_hint, ns) : ns;
+  int64_t budget = std::min<int64_t>(std::max<int64_t>(32 * expect, 1 << 18), 1 << 26);
   L.cells_per_cloud = std::max<int64_t>(budget / std::max<int64_t>(batch, 1), 64);
   L.cells = L.cells_per_cloud * std::max<int64_t>(batch, 1);
   L.scan_blocks = (L.cells + kScanTile - 1) / kScanTile;
@@ -145,10 +149,13 @@ __global__ __launch_bounds__(1024) void rg_bbox_kernel(const float* __restrict__
   }
 }
 
-__global__ void rg_count_kernel(const float* __restrict__ s, int64_t ns, int batch, const CloudGrid* __restrict__ hdr,
+// rows actually present (the launch is sized by the capacity): the clouds' headers hold their starts and lengths
+__device__ __forceinline__ int64_t rg_rows(const CloudGrid* hdr, int batch) { return hdr[batch - 1].s_start + hdr[batch - 1].s_len; }
+
+__global__ void rg_count_kernel(const float* __restrict__ s, int batch, const CloudGrid* __restrict__ hdr,
                                 int* __restrict__ cell_cnt, int* __restrict__ cid) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ns) return;
+  if (i >= rg_rows(hdr, batch)) return;
   int b = 0;
   while (b < batch - 1 && i >= hdr[b].s_start + hdr[b].s_len) ++b;
   const CloudGrid g = hdr[b];
@@ -206,11 +213,11 @@ __global__ __launch_bounds__(256) void scan_down_kernel(const int* __restrict__ 
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = sums[gridDim.x];
 }
 
-__global__ void rg_scatter_kernel(const float* __restrict__ s, int64_t ns, int batch, const CloudGrid* __restrict__ hdr,
+__global__ void rg_scatter_kernel(const float* __restrict__ s, int batch, const CloudGrid* __restrict__ hdr,
                                   const int* __restrict__ cid, const int* __restrict__ cell_start,
                                   int* __restrict__ cell_cnt, float4* __restrict__ sorted) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ns) return;
+  if (i >= rg_rows(hdr, batch)) return;
   int b = 0;
   while (b < batch - 1 && i >= hdr[b].s_start + hdr[b].s_len) ++b;
   const int c = cid[i];
@@ -222,91 +229,101 @@ __global__ void rg_scatter_kernel(const float* __restrict__ s, int64_t ns, int b
 // One wave per query.  Candidates = the 3x3x3 cell neighbourhood, visited as 9 x-contiguous runs that
 // are flattened into one index space so all 64 lanes stay busy.  Accepted (d, idx) keys are compacted
 // into an LDS row with ballot + popcount, then ranked (keys are distinct) and written out.
+// The number of queries and the pad index are read on the device (sum of q_len / the support clouds' headers), and the waves walk the
+// queries with a grid stride: the launch is sized from a row CAPACITY, so a pyramid stage whose size only the device knows needs no host
+// read (round 3).
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
                                                        const float4* __restrict__ sorted, const float* __restrict__ q,
-                                                       const int64_t* __restrict__ q_len, int batch, int64_t nq,
-                                                       float r2, int width, int cap, int64_t ns_total,
+                                                       const int64_t* __restrict__ q_len, int batch,
+                                                       float r2, int width, int cap,
                                                        int64_t* __restrict__ out, int* __restrict__ counts,
                                                        int* __restrict__ max_count, int* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t qi = (int64_t)blockIdx.x * 4 + w;
-  if (qi >= nq) return;  // whole wave exits; no block-level barrier is used below
-  int64_t qstart;
-  const int b = cloud_of(q_len, batch, qi, qstart);
-  const CloudGrid g = hdr[b < batch ? b : batch - 1];
-  const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
+  int64_t nq = 0;
+  for (int b = 0; b < batch; ++b) nq += q_len[b];
+  const int64_t ns_total = rg_rows(hdr, batch);
   unsigned long long* keys = lds_keys + (size_t)w * cap;
+  for (int64_t qi = (int64_t)blockIdx.x * 4 + w; qi < nq; qi += (int64_t)gridDim.x * 4) {  // whole waves; no block-level barrier below
+    int64_t qstart;
+    const int b = cloud_of(q_len, batch, qi, qstart);
+    const CloudGrid g = hdr[b < batch ? b : batch - 1];
+    const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
 
-  // --- the 9 runs (lane k < 9 owns run k) ---
-  int seg_start = 0, seg_len = 0;
-  if (lane < 9 && g.s_len > 0) {
-    const int cx = cell_coord(qx, g.mn[0], g.cs), cy = cell_coord(qy, g.mn[1], g.cs) + (lane % 3) - 1,
-              cz = cell_coord(qz, g.mn[2], g.cs) + (lane / 3) - 1;
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
-    if (cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2] && x0 <= x1) {
-      const int row = g.cell_base + g.dim[0] * (cy + g.dim[1] * cz);
-      seg_start = cell_start[row + x0];
-      seg_len = cell_start[row + x1 + 1] - seg_start;
+    // --- the 9 runs (lane k < 9 owns run k) ---
+    int seg_start = 0, seg_len = 0;
+    if (lane < 9 && g.s_len > 0) {
+      const int cx = cell_coord(qx, g.mn[0], g.cs), cy = cell_coord(qy, g.mn[1], g.cs) + (lane % 3) - 1,
+                cz = cell_coord(qz, g.mn[2], g.cs) + (lane / 3) - 1;
+      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+      if (cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2] && x0 <= x1) {
+        const int row = g.cell_base + g.dim[0] * (cy + g.dim[1] * cz);
+        seg_start = cell_start[row + x0];
+        seg_len = cell_start[row + x1 + 1] - seg_start;
+      }
     }
-  }
-  const int inc = wave_inclusive_scan(seg_len);
-  const int total = __shfl(inc, 8, 64);
-  int pre[9], st[9];
+    const int inc = wave_inclusive_scan(seg_len);
+    const int total = __shfl(inc, 8, 64);
+    int pre[9], st[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    pre[k] = __shfl(inc - seg_len, k, 64);
-    st[k] = __shfl(seg_start, k, 64);
-  }
+    for (int k = 0; k < 9; ++k) {
+      pre[k] = __shfl(inc - seg_len, k, 64);
+      st[k] = __shfl(seg_start, k, 64);
+    }
 
-  int base = 0;
-  for (int t0 = 0; t0 < total; t0 += 64) {
-    const int t = t0 + lane;
-    bool accept = false;
-    unsigned long long key = 0;
-    if (t < total) {
-      int k = 0;
+    int base = 0;
+    for (int t0 = 0; t0 < total; t0 += 64) {
+      const int t = t0 + lane;
+      bool accept = false;
+      unsigned long long key = 0;
+      if (t < total) {
+        int k = 0;
 #pragma unroll
-      for (int j = 1; j < 9; ++j) k = (t >= pre[j]) ? j : k;
-      const float4 p = sorted[st[k] + (t - pre[k])];
-      // L2_Simple_Adaptor::evalMetric (nanoflann.hpp:432-440): ((dx*dx) + dy*dy) + dz*dz, no FMA
-      const float dx = __fsub_rn(qx, p.x), dy = __fsub_rn(qy, p.y), dz = __fsub_rn(qz, p.z);
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      accept = d < r2;  // strict (nanoflann.hpp:249-253)
-      key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+        for (int j = 1; j < 9; ++j) k = (t >= pre[j]) ? j : k;
+        const float4 p = sorted[st[k] + (t - pre[k])];
+        // L2_Simple_Adaptor::evalMetric (nanoflann.hpp:432-440): ((dx*dx) + dy*dy) + dz*dz, no FMA
+        const float dx = __fsub_rn(qx, p.x), dy = __fsub_rn(qy, p.y), dz = __fsub_rn(qz, p.z);
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        accept = d < r2;  // strict (nanoflann.hpp:249-253)
+        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+      }
+      const unsigned long long ballot = __ballot(accept);
+      if (!COUNT_ONLY) {
+        const int rank = base + __popcll(ballot & ((1ull << lane) - 1ull));
+        if (accept && rank < cap) keys[rank] = key;
+      }
+      base += __popcll(ballot);
     }
-    const unsigned long long ballot = __ballot(accept);
-    if (!COUNT_ONLY) {
-      const int rank = base + __popcll(ballot & ((1ull << lane) - 1ull));
-      if (accept && rank < cap) keys[rank] = key;
+    int count = base;
+    if (COUNT_ONLY) {
+      if (lane == 0) {
+        counts[qi] = count;
+        atomicMax(max_count, count);
+      }
+      continue;
     }
-    base += __popcll(ballot);
-  }
-  int count = base;
-  if (COUNT_ONLY) {
-    if (lane == 0) {
-      counts[qi] = count;
-      atomicMax(max_count, count);
+    if (count > cap) {
+      if (lane == 0 && overflow) atomicMax(overflow, count);
+      count = cap;
     }
-    return;
+    // make this wave's LDS writes visible to all of its lanes (wave-local; other waves never touch this row)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int64_t* row = out + qi * (int64_t)width;
+    for (int e = lane; e < count; e += 64) {
+      const unsigned long long mine = keys[e];
+      int rank = 0;
+      for (int j = 0; j < count; ++j) rank += keys[j] < mine;  // broadcast LDS reads
+      if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
+    }
+    for (int j = count + lane; j < width; j += 64) row[j] = ns_total;  // pad (radius_neighbors_cpu.cpp:85)
+    // the next query of this wave overwrites the key row: every lane's reads above come first
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  if (count > cap) {
-    if (lane == 0 && overflow) atomicMax(overflow, count);
-    count = cap;
-  }
-  // make this wave's LDS writes visible to all of its lanes (wave-local; other waves never touch this row)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  int64_t* row = out + qi * (int64_t)width;
-  for (int e = lane; e < count; e += 64) {
-    const unsigned long long mine = keys[e];
-    int rank = 0;
-    for (int j = 0; j < count; ++j) rank += keys[j] < mine;  // broadcast LDS reads
-    if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
-  }
-  for (int j = count + lane; j < width; j += 64) row[j] = ns_total;  // pad (radius_neighbors_cpu.cpp:85)
 }
 
 // ================================================================================================
@@ -476,6 +493,9 @@ __global__ __launch_bounds__(1024) void gs_bbox_kernel(const float* __restrict__
   }
 }
 
+// points actually present (launches are sized by the capacity n): the headers written by gs_bbox_kernel hold starts and lengths
+__device__ __forceinline__ int64_t gs_rows(const GsCloud* hdr, int batch) { return hdr[batch - 1].start + hdr[batch - 1].len; }
+
 __device__ __forceinline__ int gs_cloud_of_point(const GsCloud* hdr, int batch, int64_t i) {
   int b = 0;
   while (b < batch - 1 && i >= hdr[b].start + hdr[b].len) ++b;
@@ -483,9 +503,9 @@ __device__ __forceinline__ int gs_cloud_of_point(const GsCloud* hdr, int batch, 
 }
 
 // thread per point: voxel key (:32-35) -> open-addressing insert; first index & count per voxel
-__global__ void gs_insert_kernel(const float* __restrict__ pts, int64_t n, int batch, float voxel, GsLayout L) {
+__global__ void gs_insert_kernel(const float* __restrict__ pts, int batch, float voxel, GsLayout L) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= gs_rows(L.hdr, batch)) return;
   const int b = gs_cloud_of_point(L.hdr, batch, i);
   const GsCloud g = L.hdr[b];
   const float* p = pts + 3 * i;
@@ -550,9 +570,9 @@ __global__ __launch_bounds__(1024) void gs_rank_kernel(int batch, GsLayout L) {
   if (threadIdx.x == 0) L.hdr[b].m = m;
 }
 
-__global__ void gs_fill_kernel(int64_t n, int batch, GsLayout L) {
+__global__ void gs_fill_kernel(int batch, GsLayout L) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= gs_rows(L.hdr, batch)) return;
   const int b = gs_cloud_of_point(L.hdr, batch, i);
   const int64_t start = L.hdr[b].start;
   const int slot = L.slot_of_point[i];
@@ -563,9 +583,9 @@ __global__ void gs_fill_kernel(int64_t n, int batch, GsLayout L) {
 
 // thread per voxel: members in ascending input order -> sequential fp32 sums (grid_subsampling_cpu.h:17-20),
 // barycentre = sum * (float)(1.0 / count)  (grid_subsampling_cpu.cpp:46)
-__global__ void gs_bary_kernel(const float* __restrict__ pts, int64_t n, int batch, GsLayout L) {
+__global__ void gs_bary_kernel(const float* __restrict__ pts, int batch, GsLayout L) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
+  if (t >= gs_rows(L.hdr, batch)) return;
   const int b = gs_cloud_of_point(L.hdr, batch, t);
   const GsCloud g = L.hdr[b];
   const int r = (int)(t - g.start);
@@ -698,15 +718,18 @@ size_t geotr_radius_grid_workspace_bytes(int64_t ns, int64_t batch) {
   return grid_layout(nullptr, ns, batch).bytes;
 }
 
-int geotr_radius_grid_build(const float* s_points, const int64_t* s_len, int64_t batch, int64_t ns, float radius,
-                            void* grid_ws, size_t grid_ws_bytes, void* stream_) {
+}  // extern "C"
+namespace geotr {
+// ns = row capacity (>= the sum of s_len), ns_hint = expected rows (cell budget only; 0 = ns).  The real count is read on the device.
+int radius_grid_build_hinted(const float* s_points, const int64_t* s_len, int64_t batch, int64_t ns, int64_t ns_hint, float radius,
+                             void* grid_ws, size_t grid_ws_bytes, void* stream_) {
   GEOTR_CHECK_ARG(s_len && grid_ws && (s_points || ns == 0), "radius_grid_build: null pointer");
   GEOTR_CHECK_ARG(batch >= 1 && batch <= kMaxBatch, "radius_grid_build: batch %lld outside [1, %d]", (long long)batch,
                   kMaxBatch);
   GEOTR_CHECK_ARG(ns >= 0 && ns < (1ll << 31), "radius_grid_build: ns %lld out of range", (long long)ns);
   GEOTR_CHECK_ARG(radius > 0.f, "radius_grid_build: radius must be positive");
   hipStream_t stream = (hipStream_t)stream_;
-  GridLayout L = grid_layout(grid_ws, ns, batch);
+  GridLayout L = grid_layout(grid_ws, ns, batch, ns_hint);
   if (grid_ws_bytes < L.bytes)
     return fail(GEOTR_E_WORKSPACE, "radius_grid_build: workspace %zu < required %zu", grid_ws_bytes, L.bytes);
   if (zero_async(L.cell_cnt, sizeof(int) * (size_t)L.cells, stream) != GEOTR_OK) return GEOTR_E_LAUNCH;
@@ -714,7 +737,7 @@ int geotr_radius_grid_build(const float* s_points, const int64_t* s_len, int64_t
                                                                     (int)L.cells_per_cloud, L.hdr);
   if (ns > 0) {
     const unsigned nb = (unsigned)((ns + 255) / 256);
-    rg_count_kernel<<<dim3(nb), dim3(256), 0, stream>>>(s_points, ns, (int)batch, L.hdr, L.cell_cnt, L.cid);
+    rg_count_kernel<<<dim3(nb), dim3(256), 0, stream>>>(s_points, (int)batch, L.hdr, L.cell_cnt, L.cid);
   }
   scan_reduce_kernel<<<dim3((unsigned)L.scan_blocks), dim3(256), 0, stream>>>(L.cell_cnt, L.cells, L.block_sums);
   scan_sums_kernel<<<dim3(1), dim3(1024), 0, stream>>>(L.block_sums, L.scan_blocks);
@@ -722,11 +745,17 @@ int geotr_radius_grid_build(const float* s_points, const int64_t* s_len, int64_t
                                                                             L.cell_start);
   if (ns > 0) {
     const unsigned nb = (unsigned)((ns + 255) / 256);
-    rg_scatter_kernel<<<dim3(nb), dim3(256), 0, stream>>>(s_points, ns, (int)batch, L.hdr, L.cid, L.cell_start,
+    rg_scatter_kernel<<<dim3(nb), dim3(256), 0, stream>>>(s_points, (int)batch, L.hdr, L.cid, L.cell_start,
                                                           L.cell_cnt, L.sorted);
   }
   GEOTR_CHECK_LAUNCH("radius_grid_build");
   return GEOTR_OK;
+}
+}  // namespace geotr
+extern "C" {
+int geotr_radius_grid_build(const float* s_points, const int64_t* s_len, int64_t batch, int64_t ns, float radius,
+                            void* grid_ws, size_t grid_ws_bytes, void* stream_) {
+  return radius_grid_build_hinted(s_points, s_len, batch, ns, 0, radius, grid_ws, grid_ws_bytes, stream_);
 }
 
 // Cell order of the support rows as a row list: order[t] = the row (0 .. ns-1 over the stacked clouds) of the t-th point in grid
@@ -734,36 +763,41 @@ int geotr_radius_grid_build(const float* s_points, const int64_t* s_len, int64_t
 // points are spatial neighbours and share most of their neighbour rows in L1 / L2 (the reference's row order is the hash-map order of
 // grid_subsampling.cpp, i.e. spatially scattered).  The order inside a cell depends on the scatter's atomics: it is a visiting order
 // only and never changes a result.
-__global__ void rg_order_kernel(const float4* __restrict__ sorted, const CloudGrid* __restrict__ hdr, int batch, int64_t ns,
+__global__ void rg_order_kernel(const float4* __restrict__ sorted, const CloudGrid* __restrict__ hdr, int batch,
                                 int* __restrict__ order) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ns) return;
+  if (t >= rg_rows(hdr, batch)) return;
   int b = 0;
   while (b < batch - 1 && t >= hdr[b].s_start + hdr[b].s_len) ++b;
   order[t] = (int)(hdr[b].s_start + (int64_t)__float_as_int(sorted[t].w));
 }
 
-int geotr_radius_grid_order(const void* grid_ws, int64_t ns, int64_t batch, int32_t* order, void* stream_) {
+}  // extern "C"
+namespace geotr {
+int radius_grid_order_hinted(const void* grid_ws, int64_t ns, int64_t ns_hint, int64_t batch, int32_t* order, void* stream_) {
   GEOTR_CHECK_ARG(grid_ws && (order || ns == 0), "radius_grid_order: null pointer");
   GEOTR_CHECK_ARG(batch >= 1 && batch <= kMaxBatch && ns >= 0 && ns < (1ll << 31), "radius_grid_order: bad sizes");
   if (ns == 0) return GEOTR_OK;
-  GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns, batch);
-  rg_order_kernel<<<dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>(L.sorted, L.hdr, (int)batch, ns, order);
+  GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns, batch, ns_hint);
+  rg_order_kernel<<<dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>(L.sorted, L.hdr, (int)batch, order);
   GEOTR_CHECK_LAUNCH("radius_grid_order");
   return GEOTR_OK;
 }
 
-static int radius_query_common(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
-                               int64_t batch, int64_t nq, int64_t ns, float radius, int64_t width, int64_t cap,
-                               int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_) {
+// nq = capacity of the query rows (>= the sum of q_len; the real count is read on the device): at most kQueryBlocks blocks walk
+// the queries with a grid stride, so a launch sized from a capacity far above the real count costs nothing
+constexpr int64_t kQueryBlocks = 256 * 16;
+int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
+                        int64_t batch, int64_t nq, int64_t ns, int64_t ns_hint, float radius, int64_t width, int64_t cap,
+                        int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns, batch);
+  GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns, batch, ns_hint);
   if (nq == 0) return GEOTR_OK;
   const float r2 = radius * radius;  // fp32 product, as radius_neighbors_cpu.cpp:12
-  const unsigned nb = (unsigned)((nq + 3) / 4);
+  const unsigned nb = (unsigned)std::min<int64_t>((nq + 3) / 4, kQueryBlocks);
   if (count_only) {
-    rg_query_kernel<true><<<dim3(nb), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
-                                                             r2, 0, 0, ns, nullptr, counts, max_count, nullptr);
+    rg_query_kernel<true><<<dim3(nb), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch,
+                                                             r2, 0, 0, nullptr, counts, max_count, nullptr);
   } else {
     const size_t lds = (size_t)cap * 4 * sizeof(unsigned long long);
     if (lds > 64 * 1024) {
@@ -772,11 +806,21 @@ static int radius_query_common(bool count_only, const void* grid_ws, const float
       if (e != hipSuccess) return fail(GEOTR_E_LAUNCH, "radius_query: cannot reserve %zu B of LDS", lds);
     }
     rg_query_kernel<false><<<dim3(nb), dim3(256), lds, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch,
-                                                                nq, r2, (int)width, (int)cap, ns, out, nullptr,
+                                                                r2, (int)width, (int)cap, out, nullptr,
                                                                 nullptr, overflow);
   }
   GEOTR_CHECK_LAUNCH("radius_query");
   return GEOTR_OK;
+}
+}  // namespace geotr
+extern "C" {
+int geotr_radius_grid_order(const void* grid_ws, int64_t ns, int64_t batch, int32_t* order, void* stream_) {
+  return radius_grid_order_hinted(grid_ws, ns, 0, batch, order, stream_);
+}
+static int radius_query_common(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
+                               int64_t batch, int64_t nq, int64_t ns, float radius, int64_t width, int64_t cap,
+                               int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_) {
+  return radius_query_hinted(count_only, grid_ws, q, q_len, batch, nq, ns, 0, radius, width, cap, out, counts, max_count, overflow, stream_);
 }
 
 int geotr_radius_count(const void* grid_ws, int64_t ns, const float* q_points, const int64_t* q_len, int64_t batch,
@@ -822,11 +866,13 @@ int geotr_grid_subsample(const float* points, const int64_t* len, int64_t batch,
   const unsigned nb = (unsigned)std::max<int64_t>((n + 255) / 256, 1);
   gs_init_kernel<<<dim3(std::min(nb * 2, 4096u)), dim3(256), 0, stream>>>(L, n);
   gs_bbox_kernel<<<dim3((unsigned)batch), dim3(1024), 0, stream>>>(points, len, (int)batch, voxel, inv_voxel, L.hdr);
-  if (n > 0) gs_insert_kernel<<<dim3(nb), dim3(256), 0, stream>>>(points, n, (int)batch, voxel, L);
+  // `n` is a CAPACITY from here on (round 3): the kernels read the real point count from the lengths on the device, so a caller that
+  // only knows an upper bound (the pyramid: a stage's size is data dependent) needs no host read; n = sum(len) is the exact call
+  if (n > 0) gs_insert_kernel<<<dim3(nb), dim3(256), 0, stream>>>(points, (int)batch, voxel, L);
   gs_rank_kernel<<<dim3((unsigned)batch), dim3(1024), 0, stream>>>((int)batch, L);
   if (n > 0) {
-    gs_fill_kernel<<<dim3(nb), dim3(256), 0, stream>>>(n, (int)batch, L);
-    gs_bary_kernel<<<dim3(nb), dim3(256), 0, stream>>>(points, n, (int)batch, L);
+    gs_fill_kernel<<<dim3(nb), dim3(256), 0, stream>>>((int)batch, L);
+    gs_bary_kernel<<<dim3(nb), dim3(256), 0, stream>>>(points, (int)batch, L);
   }
   gs_replay_kernel<<<dim3((unsigned)batch), dim3(1024), 0, stream>>>((int)batch, L, sch, s_points, s_len);
   GEOTR_CHECK_LAUNCH("grid_subsample");

@@ -434,6 +434,22 @@ class NativeModel:
         return [NativeModel.finalize(o, counts=counts[o['_counts_stack'][2]]) for o in outs]
 
     @staticmethod
+    def counts_to_host_async(outs, overflow):
+        """The data-dependent counts of a forward_batch call (and the pyramid's overflow flag) on their way to pinned host memory: an
+        asynchronous copy on the current stream; `.tolist()` the result once the stream has been synchronised past this point."""
+        num_node, num_corr, _ = outs[0]['_counts_stack']
+        dev = torch.cat([num_node, num_corr, overflow.view(1, 1).expand(num_node.shape[0], 1)], dim=1)  # (B, 3) int32
+        host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+        host.copy_(dev, non_blocking=True)
+        return host
+
+    @staticmethod
+    def finalize_stack_counts(outs, counts):
+        """finalize_stack with the counts already on the host (counts_to_host_async(...).tolist())."""
+        NativeModel.raise_on_overflow(counts[0][2])
+        return [NativeModel.finalize(o, counts=counts[o['_counts_stack'][2]]) for o in outs]
+
+    @staticmethod
     def finalize(out, counts=None, overflow=None):
         """Trim the variable-length outputs to their true sizes (the one host<-device read of a pair); the pyramid's
         overflow flag, when given, is read together with the counts and raises when set."""
@@ -507,15 +523,38 @@ class KernelProfiler:
 GseProfiler = KernelProfiler  # former name
 
 
-@torch.no_grad()
-def build_pyramid(points, lengths, num_stages, voxel_size, radius, neighbor_limits):
-    """precompute_data_stack_mode in one native call (fixed-width neighbour tables).  Device tensors in; returns the
-    reference's dict (lists of device tensors) plus 'lengths_host' (python ints)."""
-    lib = _lib.load()
-    assert points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()
+class PyramidPlan:
+    """A pyramid whose kernels are enqueued but whose stage sizes are still on their way to the host (build_pyramid_async).
+    `finish()` turns it into the reference's dict once the stream has passed the enqueue point (the caller synchronises: an event
+    recorded after build_pyramid_async, or any later synchronisation of that stream)."""
+
+    def __init__(self, pts, lens, nb, sub, up, order, overflow, host, B, S, ws):
+        self.pts, self.lens, self.nb, self.sub, self.up, self.order = pts, lens, nb, sub, up, order
+        self.overflow, self.host, self.B, self.S, self.ws = overflow, host, B, S, ws
+
+    def finish(self):
+        B, S = self.B, self.S
+        flat = self.host.tolist()  # pinned host memory, written by a kernel of the stream (complete: the caller synchronised)
+        lengths_host = [[int(flat[i * B + b]) for b in range(B)] for i in range(S)]
+        n = [sum(l) for l in lengths_host]
+        if min(n) < 1:
+            raise RuntimeError(f'pyramid: an empty stage (sizes {n}) -- finish() called before the stream was synchronised?')
+        self.ws = None
+        return {
+            'points': [self.pts[i][: n[i]] for i in range(S)],
+            'lengths': self.lens,
+            'neighbors': [self.nb[i][: n[i]] for i in range(S)],
+            'subsampling': [self.sub[i][: n[i + 1]] for i in range(S - 1)],
+            'upsampling': [self.up[i][: n[i]] for i in range(S - 1)],
+            'lengths_host': lengths_host,
+            '_overflow': self.overflow,
+            '_order': [self.order[i][: n[i]] for i in range(S)],  # visiting order of the gather kernels (grid order of each stage)
+        }
+
+
+def _pyramid_buffers(points, lengths, S, neighbor_limits):
     dev = points.device
-    n0, B, S = points.shape[0], lengths.shape[0], int(num_stages)
-    limits = (ctypes.c_int64 * S)(*[int(x) for x in neighbor_limits])
+    n0, B = points.shape[0], lengths.shape[0]
     pts = [points] + [torch.empty((n0, 3), dtype=torch.float32, device=dev) for _ in range(S - 1)]
     lens = [lengths] + [torch.empty(B, dtype=torch.int64, device=dev) for _ in range(S - 1)]
     nb = [torch.empty((n0, neighbor_limits[i]), dtype=torch.int64, device=dev) for i in range(S)]
@@ -528,6 +567,46 @@ def build_pyramid(points, lengths, num_stages, voxel_size, radius, neighbor_limi
         buf.order[i] = order[i].data_ptr()
         if i < S - 1:
             buf.subsampling[i], buf.upsampling[i] = sub[i].data_ptr(), up[i].data_ptr()
+    return pts, lens, nb, sub, up, order, buf
+
+
+@torch.no_grad()
+def build_pyramid_async(points, lengths, num_stages, voxel_size, radius, neighbor_limits):
+    """The pyramid of `build_pyramid` enqueued on the current stream WITHOUT any host synchronisation (geotr_pyramid_build_async: every
+    launch is sized from the row capacity, the stage sizes stay on the device and travel to pinned host memory by a kernel of the
+    stream).  Returns a PyramidPlan; call `.finish()` after the stream has been synchronised past this point."""
+    lib = _lib.load()
+    assert points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()
+    dev = points.device
+    n0, B, S = points.shape[0], lengths.shape[0], int(num_stages)
+    limits = (ctypes.c_int64 * S)(*[int(x) for x in neighbor_limits])
+    pts, lens, nb, sub, up, order, buf = _pyramid_buffers(points, lengths, S, neighbor_limits)
+    host = torch.zeros(S * B, dtype=torch.int64).pin_memory()
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    nbytes = lib.geotr_pyramid_workspace_bytes(n0, B, S)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _log_buffers('pyramid', [('ws', ws), ('input', points)] + [(f'points{i}', t) for i, t in enumerate(pts[1:], 1)])
+    if _POISON:
+        ws.fill_(0xFF)
+    rc = lib.geotr_pyramid_build_async(points.data_ptr(), lengths.data_ptr(), B, n0, S, float(voxel_size), float(radius), limits,
+                                       ctypes.byref(buf), host.data_ptr(), overflow.data_ptr(), ws.data_ptr(), nbytes,
+                                       torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, 'geotr_pyramid_build_async')
+    ws.record_stream(torch.cuda.current_stream())
+    return PyramidPlan(pts, lens, nb, sub, up, order, overflow, host, B, S, ws)
+
+
+@torch.no_grad()
+def build_pyramid(points, lengths, num_stages, voxel_size, radius, neighbor_limits):
+    """precompute_data_stack_mode in one native call (fixed-width neighbour tables).  Device tensors in; returns the
+    reference's dict (lists of device tensors) plus 'lengths_host' (python ints).  One host read at the end (the stage sizes);
+    `build_pyramid_async` is the variant without any."""
+    lib = _lib.load()
+    assert points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()
+    dev = points.device
+    n0, B, S = points.shape[0], lengths.shape[0], int(num_stages)
+    limits = (ctypes.c_int64 * S)(*[int(x) for x in neighbor_limits])
+    pts, lens, nb, sub, up, order, buf = _pyramid_buffers(points, lengths, S, neighbor_limits)
     host = (ctypes.c_int64 * (S * B))()
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
     nbytes = lib.geotr_pyramid_workspace_bytes(n0, B, S)
@@ -542,15 +621,6 @@ def build_pyramid(points, lengths, num_stages, voxel_size, radius, neighbor_limi
                                  torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, 'geotr_pyramid_build')
     ws.record_stream(torch.cuda.current_stream())
-    lengths_host = [[int(host[i * B + b]) for b in range(B)] for i in range(S)]
-    n = [sum(l) for l in lengths_host]
-    return {
-        'points': [pts[i][: n[i]] for i in range(S)],
-        'lengths': lens,
-        'neighbors': [nb[i][: n[i]] for i in range(S)],
-        'subsampling': [sub[i][: n[i + 1]] for i in range(S - 1)],
-        'upsampling': [up[i][: n[i]] for i in range(S - 1)],
-        'lengths_host': lengths_host,
-        '_overflow': overflow,
-        '_order': [order[i][: n[i]] for i in range(S)],  # visiting order of the gather kernels (grid order of each stage)
-    }
+    plan = PyramidPlan(pts, lens, nb, sub, up, order, overflow, None, B, S, None)
+    plan.host = torch.tensor(list(host), dtype=torch.int64)
+    return plan.finish()

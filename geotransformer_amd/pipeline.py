@@ -144,6 +144,11 @@ class ConcurrentRegistration:
         under '_stack_pyramid' (the stacked tables; RegistrationPipeline.pair_pyramid cuts a pair out)."""
         self.pipeline = pipeline
         self.return_pyramid = bool(return_pyramid)
+        # Pipelined lanes (round 3, default; GEOTR_PIPELINED=0 restores the synchronous lane loop for A/B runs): a lane enqueues the NEXT
+        # stack's pyramid -- which needs no host read any more (native.build_pyramid_async) -- behind the forward it has just launched,
+        # and waits on the host ONCE per stack: for that pyramid's stage sizes, which arrive together with the previous stack's result
+        # counts.  Only stacked jobs (stack > 1) are pipelined.
+        self.pipelined = os.environ.get('GEOTR_PIPELINED', '1') != '0' and int(stack) > 1
         self.lanes = max(1, int(lanes))
         self.stack = max(1, min(16, int(stack)))
         self.device = pipeline.device
@@ -156,13 +161,133 @@ class ConcurrentRegistration:
         self._cv = threading.Condition()
         self._error = None
         self._threads = []
-        if self.lanes > 1:
+        if self.lanes > 1 or self.pipelined:
             for lane in range(self.lanes):
                 t = threading.Thread(target=self._lane_main, args=(lane,), daemon=True, name=f'geotr-lane-{lane}')
                 t.start()
                 self._threads.append(t)
 
+    # ---- pipelined lane loop -----------------------------------------------------------------------------------------------------
+    _EMPTY = object()
+
+    def _job_done(self, job, exc=None):
+        with self._cv:
+            if exc is not None:
+                self._error = self._error or exc
+            self._pending -= len(job)
+            if self._pending == 0:
+                self._cv.notify_all()
+
+    def _begin(self, job, stream):
+        """Enqueue the pyramid of a stacked job on the lane's stream -- no host synchronisation -- and record the event its sizes wait on."""
+        from .native import build_pyramid_async
+        b = self.pipeline.cfg.backbone
+        for _, _, _, _, ready in job:
+            stream.wait_event(ready)  # inputs produced on the submitter's stream
+        clouds = [c for _, ref, src, _, _ in job for c in (ref, src)]
+        for c in clouds:
+            _check_cloud(c)
+        points = torch.cat(clouds, dim=0)
+        # (a torch.tensor(..., device=...) from a Python list is a pageable host-to-device copy: it would block the host until the
+        # stream has drained, i.e. until the previous stack's forward is done -- pinned + non_blocking keeps the host running ahead)
+        lengths = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64).pin_memory().to(points.device, non_blocking=True)
+        plan = build_pyramid_async(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.pipeline.neighbor_limits)
+        event = torch.cuda.Event()
+        event.record(stream)
+        return job, plan, points, event
+
+    def _launch(self, begun):
+        """The stage sizes are on the host (the caller waited for the event): launch the forward and start the counts on their way."""
+        from .native import NativeModel
+        job, plan, points, _ = begun
+        model = self.pipeline.model
+        data = plan.finish()
+        data['features'] = torch.ones((points.shape[0], 1), dtype=torch.float32, device=points.device)
+        data['batch_size'] = len(job)
+        if model._native is None:
+            model._native = NativeModel(model)
+        raw = model._native.forward_batch(data)
+        counts = NativeModel.counts_to_host_async(raw, data['_overflow'])
+        return job, raw, data, counts
+
+    def _deliver(self, flying):
+        """The counts are on the host (the stream was synchronised past their copy): trim the outputs and hand them to the sinks."""
+        from .native import NativeModel
+        job, raw, data, counts = flying
+        outs = NativeModel.finalize_stack_counts(raw, counts.tolist())
+        for (index, _, _, sink, _), out in zip(job, outs):
+            if self.return_pyramid:
+                out['_stack_pyramid'] = data
+            sink(index, out)
+
+    def _lane_main_pipelined(self, lane):
+        torch.cuda.set_device(self.device)
+        stream = self.streams[lane]
+        with torch.cuda.stream(stream), torch.no_grad():
+            begun = None   # (job, plan, points, event): pyramid enqueued, its sizes not yet on the host
+            flying = None  # (job, raw, data, counts): forward launched, its counts not yet on the host
+
+            def land():  # nothing else to overlap with: wait for the stack in flight and deliver it
+                nonlocal flying
+                if flying is not None:
+                    job = flying[0]
+                    try:
+                        stream.synchronize()
+                        self._deliver(flying)
+                        self._job_done(job)
+                    except BaseException as exc:
+                        self._job_done(job, exc)
+                    flying = None
+
+            while True:
+                if begun is None:
+                    try:
+                        job = self._queue.get() if flying is None else self._queue.get_nowait()
+                    except queue.Empty:
+                        land()
+                        continue
+                    if job is None:
+                        land()
+                        return
+                    if len(job) == 1:  # a single pair: the one-pair entry point, synchronously
+                        land()
+                        index, ref, src, sink, ready = job[0]
+                        try:
+                            stream.wait_event(ready)
+                            sink(index, self.pipeline(ref, src))
+                            self._job_done(job)
+                        except BaseException as exc:
+                            self._job_done(job, exc)
+                        continue
+                    try:
+                        begun = self._begin(job, stream)
+                    except BaseException as exc:
+                        self._job_done(job, exc)
+                        continue
+                job = begun[0]
+                try:
+                    begun[3].synchronize()  # THE host wait of this stack: its pyramid's sizes + the previous stack's counts
+                except BaseException as exc:
+                    self._job_done(job, exc)
+                    begun = None
+                    continue
+                if flying is not None:
+                    prev = flying[0]
+                    try:
+                        self._deliver(flying)
+                        self._job_done(prev)
+                    except BaseException as exc:
+                        self._job_done(prev, exc)
+                    flying = None
+                try:
+                    flying = self._launch(begun)
+                except BaseException as exc:
+                    self._job_done(job, exc)
+                begun = None
+
     def _lane_main(self, lane):
+        if self.pipelined:
+            return self._lane_main_pipelined(lane)
         torch.cuda.set_device(self.device)
         stream = self.streams[lane]
         with torch.cuda.stream(stream):
@@ -196,7 +321,7 @@ class ConcurrentRegistration:
 
     def submit(self, pairs, sink):
         """Queue every (ref, src) of `pairs`; `sink(i, output_dict)` is called on the lane's stream per pair."""
-        if self.lanes == 1:
+        if self.lanes == 1 and not self.pipelined:
             for g in range(0, len(pairs), self.stack):
                 group = pairs[g:g + self.stack]
                 if len(group) == 1:
@@ -219,7 +344,7 @@ class ConcurrentRegistration:
 
     def drain(self):
         """Wait until all submitted pairs are enqueued on their lanes; the current stream then waits for the lanes."""
-        if self.lanes == 1:
+        if self.lanes == 1 and not self.pipelined:
             return
         with self._cv:
             while self._pending:

@@ -507,9 +507,15 @@ int geotr_index_select(const void* data, const int64_t* index, int64_t outer, in
  * Native pyramid: precompute_data_stack_mode (geotransformer/utils/data.py:13-77) as one host call: (S-1) grid
  * subsamples, one radius grid per stage, 3S-2 radius searches with fixed widths `limits[i]` (pad = support count).
  * Stage buffers have capacity n0 rows (a stage never has more points than the input); the true row counts are returned
- * in lengths_host (num_stages x batch).  The call synchronises `stream` once per subsampled stage to read those counts.
+ * in lengths_host (num_stages x batch).  Round 3: every launch is sized from the capacity n0 and the kernels read the stage sizes
+ * from the device-resident lengths, so NOTHING is read back while the sequence is enqueued: geotr_pyramid_build synchronises `stream`
+ * once, at the end, to hand the sizes to lengths_host (any host memory); geotr_pyramid_build_async does not synchronise at all --
+ * lengths_pinned must be device-accessible host memory (hipHostMalloc / a pinned tensor), written by a kernel of the stream and valid
+ * once the caller has synchronised the stream past the call (e.g. together with the previous stack's result counts).
  * *overflow (device int32, zeroed by the caller) receives the largest neighbour count if a ball exceeds the row capacity
- * (256): the tables are then incomplete and the caller must fall back to geotr_radius_count + geotr_radius_query.
+ * (512): the tables are then incomplete and the caller must fall back to geotr_radius_count + geotr_radius_query.
+ * geotr_grid_subsample / geotr_radius_grid_build / geotr_radius_query accept, in the same spirit, a row CAPACITY for n / ns / nq
+ * (>= the sum of the device lengths, which is what the kernels use).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct geotr_pyramid_buffers {
   float* points[GEOTR_MAX_STAGES];          /* stage 0 may alias the input */
@@ -523,6 +529,9 @@ size_t geotr_pyramid_workspace_bytes(int64_t n0, int64_t batch, int64_t num_stag
 int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t batch, int64_t n0, int64_t num_stages, float voxel_size,
                         float radius, const int64_t* limits_host, const geotr_pyramid_buffers* buf, int64_t* lengths_host,
                         int32_t* overflow, void* ws, size_t ws_bytes, void* stream);
+int geotr_pyramid_build_async(const float* points, const int64_t* lengths, int64_t batch, int64_t n0, int64_t num_stages, float voxel_size,
+                              float radius, const int64_t* limits_host, const geotr_pyramid_buffers* buf, int64_t* lengths_pinned,
+                              int32_t* overflow, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }
