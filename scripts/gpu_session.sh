@@ -1,11 +1,12 @@
 set -u
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3g; mkdir -p $O
-rocm-smi --showuniqueid --showfwinfo 2>/dev/null | grep -i "unique\|MEC\|SMC\|CP " | head -8 > $O/box.txt; cat $O/box.txt
-# same box: the round-2 tree with its ORIGINAL matching.hip (plain loads) vs the same tree with this round's matching.hip (plain loads) vs HEAD
-( cd .ab_old/r2orig && LABEL=orig timeout 300 python scripts/debug_c.py bisect 12 2>&1 | grep -v "^ " | tail -13 ) | tee $O/old_orig_debug_c.txt
-( cd .ab_old/r2fix && GEOTR_P2N_MODE=7 LABEL=newmatching timeout 300 python scripts/debug_c.py bisect 12 2>&1 | grep -v "^ " | tail -13 ) | tee $O/old_newmatching_debug_c.txt
-timeout 600 python -m pytest tests/test_gemm_gpu.py -m gpu -q -x -p no:cacheprovider --timeout 600 2>&1 | tail -15
-timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 --deselect tests/test_gemm_gpu.py > $O/gputests.log 2>&1; echo "pytest rc=$?"; tail -25 $O/gputests.log
+O=gpurun_out/r3h; mkdir -p $O
+timeout 900 python -m pytest tests/test_pipeline_gpu.py tests/test_neighbors_gpu.py tests/test_datasets_gpu.py -m gpu -q -x -p no:cacheprovider --timeout 600 2>&1 | tail -25
+timeout 900 python -m pytest tests/test_bench_config_gpu.py -m gpu -q -x -p no:cacheprovider --timeout 900 -k "bench_workload or kitti" 2>&1 | tail -25
 cd /tmp && export TMPDIR=/tmp
-for v in 1 0 1 0; do GEOTR_GN_EPILOGUE_STATS=$v timeout 300 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-mode 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('gn_epilogue_stats=$v', d['value'], d['ms_per_step'])"; done | tee $GRAFT_REPO_ROOT/$O/ab_gn_stats.txt
+b() { name=$1; shift; env "$@" timeout 300 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-mode ${EXTRA:-} 2>$GRAFT_REPO_ROOT/$O/bench_$name.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$name', d['value'], d['ms_per_step'])" || tail -5 $GRAFT_REPO_ROOT/$O/bench_$name.err; }
+( EXTRA="" b pipelined X=1; EXTRA="" b sync_lanes GEOTR_PIPELINED=0; EXTRA="--lanes 1" b pipelined_l1 X=1; EXTRA="--lanes 1" b sync_l1 GEOTR_PIPELINED=0
+  EXTRA="--lanes 2" b pipelined_l2 X=1; EXTRA="--lanes 3" b pipelined_l3 X=1; EXTRA="--lanes 6" b pipelined_l6 X=1; EXTRA="" b pipelined_again X=1 ) | tee $GRAFT_REPO_ROOT/$O/ab_pipelined.txt
+cd $GRAFT_REPO_ROOT
+for t in r2orig r2A r2B; do ( cd .ab_old/$t && GEOTR_P2N_MODE=7 TRUTH=1 DISSECT=1 LABEL=$t timeout 400 python scripts/debug_c.py bisect 12 > $GRAFT_REPO_ROOT/$O/hz_$t.txt 2>&1; echo "$t: $(grep -c DIFFERENCES $GRAFT_REPO_ROOT/$O/hz_$t.txt) of 12 runs differ" ); done
+grep -A12 "dissect" $O/hz_r2orig.txt | head -60

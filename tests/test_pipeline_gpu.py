@@ -78,3 +78,66 @@ def test_stacked_pairs_match_single_pair_runs():
     one = pipe.register_batch(pairs[:1])[0]
     for k in ('ref_feats_c', 'matching_scores', 'estimated_transform', 'ref_node_corr_indices'):
         assert torch.equal(one[k], want[0][k]), k
+
+
+@pytest.mark.parametrize('lanes', [1, 3])
+def test_pipelined_lanes_match_the_synchronous_stack_call(lanes, monkeypatch):
+    """Round 3: a lane enqueues the next stack's pyramid -- no host read (build_pyramid_async) -- behind the forward it has just launched
+    and waits on the host once per stack.  Outputs, pyramid tables included, must be bitwise those of the synchronous
+    register_batch call on the same stack; a bad input in the middle of the queue surfaces in drain() and leaves the lanes usable."""
+    from geotransformer_amd import native
+    from geotransformer_amd.config import make_cfg
+    from geotransformer_amd.pipeline import ConcurrentRegistration, RegistrationPipeline
+    from geotransformer_amd.synthetic import make_pair
+    cfg = make_cfg('3dmatch', {'backbone.init_dim': 16, 'backbone.group_norm': 4, 'backbone.output_dim': 64,
+                               'geotransformer.input_dim': 256, 'geotransformer.hidden_dim': 64, 'geotransformer.output_dim': 64})
+    torch.manual_seed(cfg.seed)
+    pipe = RegistrationPipeline(cfg, device='cuda:0')
+    items = [make_pair(70 + i, '3dmatch', n_points=2500 + 400 * i) for i in range(6)]
+    pairs = [(torch.from_numpy(it['ref_points']).cuda(), torch.from_numpy(it['src_points']).cuda()) for it in items]
+    stacks = [pairs[0:3], pairs[3:6], pairs[1:4], pairs[2:5], pairs[0:3]]  # 5 stacks of 3 pairs
+    want = [pipe.register_batch(st, return_pyramid=True) for st in stacks]
+    # the asynchronous pyramid alone: same tables as the synchronous call
+    b = cfg.backbone
+    pts = torch.cat([c for pr in stacks[1] for c in pr])
+    lens = torch.tensor([c.shape[0] for pr in stacks[1] for c in pr], dtype=torch.int64, device='cuda')
+    plan = native.build_pyramid_async(pts, lens, b.num_stages, b.init_voxel_size, b.init_radius, pipe.neighbor_limits)
+    torch.cuda.current_stream().synchronize()
+    data = plan.finish()
+    assert data['lengths_host'] == want[1][1]['lengths_host']
+    for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
+        for ta, tb in zip(data[key], want[1][1][key]):
+            assert torch.equal(ta, tb), key
+    torch.cuda.synchronize()
+    runner = ConcurrentRegistration(pipe, lanes=lanes, stack=3, return_pyramid=True)
+    assert runner.pipelined
+    got = {}
+    flat = [pr for st in stacks for pr in st]
+    for rep in range(2):  # two submissions without a join in between: 10 stacks queued
+        runner.submit(flat, lambda i, out, rep=rep: got.__setitem__((rep, i), out))
+    runner.drain()
+    torch.cuda.synchronize()
+    assert len(got) == 2 * len(flat)
+    keys = ('estimated_transform', 'ref_node_corr_indices', 'src_node_corr_indices', 'matching_scores', 'ref_feats_c', 'src_feats_f',
+            'ref_corr_points', 'corr_scores', 'ref_node_corr_knn_points', 'src_points_c')
+    for (rep, i), out in got.items():
+        outs, pyr = want[i // 3]
+        for k in keys:
+            assert out[k].shape == outs[i % 3][k].shape and torch.equal(out[k], outs[i % 3][k]), (rep, i, k)
+        for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
+            for ta, tb in zip(out['_stack_pyramid'][key], pyr[key]):
+                assert torch.equal(ta, tb), (rep, i, key)
+    # an error inside the queue: reported by drain(), the other stacks complete, the runner stays usable
+    bad = (torch.zeros((10, 2), device='cuda'), pairs[0][1])
+    got.clear()
+    runner.submit(stacks[0] + [bad, pairs[1], pairs[2]] + stacks[2], lambda i, out: got.__setitem__(i, out))
+    with pytest.raises(ValueError):
+        runner.drain()
+    torch.cuda.synchronize()
+    assert sorted(got) == [0, 1, 2, 6, 7, 8]
+    got.clear()
+    runner.run_batch(stacks[3], lambda i, out: got.__setitem__(i, out))
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(got[i]['estimated_transform'], want[3][0][i]['estimated_transform'])
+    runner.close()
