@@ -354,13 +354,13 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
     return rec, pyr0, out0
 
 
-def relaunch_under_torchrun(n):
+def relaunch_under_torchrun(n, need_devices=True):
     """`bench.py --gpus N` from a plain shell: become N ranks (one process per GPU, RCCL) -- the analogue of the reference's
     launcher convention (geotransformer/engine/base_trainer.py:63-78 reads the same environment)."""
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if need_devices and have < n:
         sys.exit(f'bench.py: --gpus {n} but this node exposes {have} HIP device(s)')
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
@@ -369,6 +369,46 @@ def relaunch_under_torchrun(n):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def dry_run(args):
+    """`--dry-run`: the N-rank run WITHOUT devices -- the launcher path, every rank's bring-up decisions (host waits against the CPU budget,
+    NUMA set of its device), the round-robin sharding, the three collectives of the timed region (over gloo) and the JSON line, with
+    stand-in results.  tests/test_dist_launch.py runs it with 8 ranks on the CPU box; nothing here is measured."""
+    from geotransformer_amd import dist as gd
+    import torch.distributed as tdist
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_ranks = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
+    waits = gd.choose_host_waits(local_ranks * (args.lanes + 1), os.environ.get('GEOTR_BLOCKING_SYNC'), local_rank, apply=False)
+    rank, world, local = gd.init_from_env(backend='gloo')
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: every rank must come up (one process per GPU)')
+    # the device's PCIe address comes from the HIP properties on a GPU box; the rehearsal takes it from GEOTR_DRYRUN_BDFS (comma list)
+    bdfs = os.environ.get('GEOTR_DRYRUN_BDFS', '').split(',')
+    numa, _ = gd.bind_to_device_numa(local, bdf=bdfs[local] if local < len(bdfs) and bdfs[local] else '0000:00:00.0',
+                                     sysfs_root=os.environ.get('GEOTR_DRYRUN_SYSFS', '/sys/bus/pci/devices'), apply=False)
+    total = args.batch * world                      # pairs of one global step
+    mine = gd.shard_indices(total, rank, world)     # this rank's pairs
+    results = torch.zeros((args.steps, len(mine), 4, 4))
+    for slot, item in enumerate(mine):
+        results[:, slot] = torch.eye(4) * float(item + 1)  # stand-in for the pair's estimated transform
+    gd.barrier()
+    t0 = time.perf_counter()
+    gathered = gd.gather_results(results)
+    gd.barrier()
+    elapsed = gd.max_over_ranks(time.perf_counter() - t0 + 1e-3 * (rank + 1), 'cpu')
+    notes = [None] * world
+    if world > 1:
+        tdist.all_gather_object(notes, {'rank': rank, 'local': local, 'host_waits': waits, 'numa': numa, 'shard': mine})
+    else:
+        notes = [{'rank': rank, 'local': local, 'host_waits': waits, 'numa': numa, 'shard': mine}]
+    if rank == 0:
+        seen = sorted(int(round(float(gathered[r, 0, s, 0, 0]))) - 1 for r in range(world) for s in range(gathered.shape[2]))
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': args.steps, 'pairs_per_step_per_gpu': args.batch,
+                          'lanes_per_gpu': args.lanes, 'pairs_per_step': total, 'every_pair_exactly_once': seen == list(range(total)),
+                          'max_over_ranks_s': round(elapsed, 4), 'collective_backend': 'gloo (rehearsal; nccl = RCCL on the GPU node)',
+                          'ranks': notes}), flush=True)
+    gd.shutdown()
 
 
 def main():
@@ -392,6 +432,8 @@ def main():
                          'so the sample is spread over the whole region instead of covering every launch of its start')
     ap.add_argument('--no-numa-bind', action='store_true', help="do not bind the process to the GPU's NUMA node (A/B runs)")
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the exact-fp32 mode line')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='no devices: rehearse the N-rank launcher path, rank bring-up decisions, sharding and collectives over gloo (CPU test)')
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32', 'bf16'],
                     help="matrix-pipe arithmetic: bf16x3 = split-bf16, fp32-grade (default, the headline mode); fp32 = exact fp32 MFMA; "
                          "bf16 = plain bf16 operands (BASELINE configs[4] 'bf16 features'; not the headline metric)")
@@ -402,7 +444,9 @@ def main():
     args.batch = args.batch or args.lanes * args.stack
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        relaunch_under_torchrun(args.gpus)
+        relaunch_under_torchrun(args.gpus, need_devices=not args.dry_run)
+    if args.dry_run:
+        return dry_run(args)
 
     from geotransformer_amd import _lib, kernels
     from geotransformer_amd import dist as gd

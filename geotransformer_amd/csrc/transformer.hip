@@ -633,12 +633,18 @@ __global__ __launch_bounds__(256) void gse_embed_table_kernel(const float* __res
   while (slow) {  // exact direct evaluation (rare)
     const int e = __builtin_ctzll(slow);
     slow &= slow - 1;
+    // the pair's indices, fetched by EVERY lane before the inactive ones leave (a shuffle after the early-out read lanes that
+    // had already left when D = 32 -- ds_bpermute returns 0 for them, i.e. the embedding of x = 0 -- and indexed vals[] dynamically)
+    float xs[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) xs[s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vals[s]), e));
     if (lane >= ACTIVE) continue;
     float d[V], m[V];
 #pragma unroll
     for (int c = 0; c < V; ++c) d[c] = 0.f, m[c] = -3.4e38f;
+#pragma unroll
     for (int s = 0; s < S; ++s) {
-      const float x = __shfl(vals[s], e, 64);
+      const float x = xs[s];
       float a[V];
 #pragma unroll
       for (int c = 0; c < V; ++c) a[c] = 0.f;

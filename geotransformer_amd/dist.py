@@ -111,7 +111,17 @@ def _parse_cpulist(text):
     return cpus
 
 
-def bind_to_device_numa(device_index):
+def device_numa_cpus(bdf, sysfs_root='/sys/bus/pci/devices'):
+    """(NUMA node, CPUs local to the PCIe root) of the device at `bdf`, from sysfs.  Raises OSError / ValueError when not exposed."""
+    base = os.path.join(sysfs_root, bdf)
+    with open(os.path.join(base, 'numa_node')) as f:
+        node = int(f.read().strip())
+    with open(os.path.join(base, 'local_cpulist')) as f:
+        local = _parse_cpulist(f.read())
+    return node, local
+
+
+def bind_to_device_numa(device_index, bdf=None, sysfs_root='/sys/bus/pci/devices', apply=True):
     """One process per GPU, on the GPU's own NUMA node: restrict every thread of this process (and the threads it creates later: the
     lanes, the HIP runtime's helpers) to the CPUs local to the device's PCIe root (`/sys/bus/pci/devices/<bdf>/local_cpulist`).
 
@@ -122,18 +132,17 @@ def bind_to_device_numa(device_index):
     done (for logs); does nothing when the topology is not exposed.  Undo with `os.sched_setaffinity(0, previous)` (returned set)."""
     previous = os.sched_getaffinity(0)
     try:
-        p = torch.cuda.get_device_properties(device_index)
-        bdf = f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
-        base = f'/sys/bus/pci/devices/{bdf}'
-        with open(f'{base}/numa_node') as f:
-            node = int(f.read().strip())
-        with open(f'{base}/local_cpulist') as f:
-            local = _parse_cpulist(f.read())
+        if bdf is None:  # (`bdf` / `sysfs_root` / `apply=False`: the dry run of bench.py and its CPU test, which have no device)
+            p = torch.cuda.get_device_properties(device_index)
+            bdf = f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
+        node, local = device_numa_cpus(bdf, sysfs_root)
     except (OSError, ValueError, AttributeError, RuntimeError, AssertionError) as exc:  # no device / no sysfs topology
         return f'NUMA binding skipped ({type(exc).__name__}: {exc})', previous
     cpus = local & previous
     if node < 0 or not cpus or cpus == previous:
         return f'NUMA binding not needed (device {bdf}: node {node}, {len(local)} local CPUs, {len(previous)} allowed)', previous
+    if not apply:
+        return f'would bind to NUMA node {node} of device {bdf} ({len(cpus)} of {len(previous)} CPUs)', previous
     bound = 0
     for tid in os.listdir('/proc/self/task'):  # threads that exist already (runtime helpers) as well as this one
         try:
@@ -161,8 +170,10 @@ def set_blocking_sync(device_index=None):
         return f'blocking sync not set ({exc})'
 
 
-def cpu_budget(cgroup_root='/sys/fs/cgroup'):
-    """CPUs this process may keep busy: the affinity mask, capped by the cgroup CPU quota (v2 `cpu.max`, v1 `cpu/cpu.cfs_quota_us`)."""
+def cpu_budget(cgroup_root=None):
+    """CPUs this process may keep busy: the affinity mask, capped by the cgroup CPU quota (v2 `cpu.max`, v1 `cpu/cpu.cfs_quota_us`).
+    GEOTR_CGROUP_ROOT overrides the cgroup mount (the dry-run test fakes a 16-CPU quota with it)."""
+    cgroup_root = cgroup_root or os.environ.get('GEOTR_CGROUP_ROOT', '/sys/fs/cgroup')
     budget = float(len(os.sched_getaffinity(0)))
     try:
         with open(os.path.join(cgroup_root, 'cpu.max')) as f:
@@ -182,7 +193,7 @@ def cpu_budget(cgroup_root='/sys/fs/cgroup'):
     return budget
 
 
-def choose_host_waits(waiting_threads, override=None, device_index=None):
+def choose_host_waits(waiting_threads, override=None, device_index=None, apply=True):
     """Spin (the runtime's default: lowest wake-up latency, +4 % at one rank) while every waiting thread of every local rank can have a
     CPU of its own, block otherwise.  `waiting_threads` = local ranks x (lanes + 1).  `override`: '1' / '0' forces blocking / spinning
     (GEOTR_BLOCKING_SYNC).  Must run before the device context exists.  Returns a description for the logs."""
@@ -190,4 +201,6 @@ def choose_host_waits(waiting_threads, override=None, device_index=None):
     block = override == '1' or (override != '0' and waiting_threads > budget)
     if not block:
         return f'spin ({waiting_threads} waiting threads, CPU budget {budget:g})'
+    if not apply:  # decision only (bench.py --dry-run: no device to configure)
+        return f'block ({waiting_threads} waiting threads, CPU budget {budget:g})'
     return f'{set_blocking_sync(device_index)} ({waiting_threads} waiting threads, CPU budget {budget:g})'

@@ -70,6 +70,26 @@ def test_gse_table_is_the_projection_of_the_sinusoid():
     assert err <= 2e-5 and err <= 3e-6 * scale  # fp32 rounding of 256-term sums dominates; the Taylor remainder is ~1e-6 here
 
 
+@pytest.mark.parametrize('D', [32, 128])
+def test_gse_table_direct_path_at_other_widths(D):
+    """at D = 32 only half of a wave's lanes hold channels; the direct path (indices beyond the table) must fetch the pair's
+    indices before those lanes leave.  A cloud wider than the distance table vs the oracle."""
+    from geotransformer_amd import kernels
+    from oracle import model_oracle as mo
+    sd = _gse_weights(D, 3)
+    cfg = dict(hidden_dim=D, sigma_d=0.2, sigma_a=15, angle_k=3, reduction_a='max')
+    div_term = torch.exp(torch.arange(0, D, 2).float() * (-np.log(10000.0) / D)).cuda()
+    w = [sd[k].cuda() for k in ('e.proj_d.weight', 'e.proj_d.bias', 'e.proj_a.weight', 'e.proj_a.bias')]
+    pts = _random_superpoints(70, 9, extent=20.0)
+    want = mo.gse(sd, 'e.', pts.unsqueeze(0), cfg)[0]
+    knn = kernels.gse_knn(pts.cuda(), 3)
+    got = kernels.gse_embed(pts.cuda(), knn, div_term, *w, 0.2, 15, precision=5).cpu()
+    off = ~torch.eye(70, dtype=torch.bool)
+    err = (got - want).abs()
+    assert float(err[off].max()) <= 3e-4 + 3e-4 * float(want.abs().max()), float(err[off].max())
+    assert int((torch.cdist(pts, pts) / 0.2 > kernels.GSE_TABLE_SPAN).sum()) > 1000  # the direct path really ran
+
+
 def test_gse_table_direct_path_beyond_the_table_and_ragged_clouds():
     """(a) a cloud wider than the distance table (d / sigma_d > 64): the in-kernel direct evaluation must agree with the oracle;
     (b) geotr_gse_knn_clouds / geotr_gse_embed_table over several clouds in one ragged launch == per-cloud calls, bit for bit."""
