@@ -149,6 +149,11 @@ class ConcurrentRegistration:
         # and waits on the host ONCE per stack: for that pyramid's stage sizes, which arrive together with the previous stack's result
         # counts.  Only stacked jobs (stack > 1) are pipelined.
         self.pipelined = os.environ.get('GEOTR_PIPELINED', '1') != '0' and int(stack) > 1
+        # GEOTR_PYRAMID_GRAPH=1 (opt-in, pipelined lanes only): each lane replays ONE captured hipGraph per stack for the pyramid's ~60
+        # dependent launches (native.PyramidGraph) instead of issuing them one by one
+        self.pyramid_graphs = self.pipelined and os.environ.get('GEOTR_PYRAMID_GRAPH') == '1'
+        self._graphs = {}
+        self._graph_lock = threading.Lock()
         self.lanes = max(1, int(lanes))
         self.stack = max(1, min(16, int(stack)))
         self.device = pipeline.device
@@ -187,6 +192,20 @@ class ConcurrentRegistration:
         clouds = [c for _, ref, src, _, _ in job for c in (ref, src)]
         for c in clouds:
             _check_cloud(c)
+        if self.pyramid_graphs:
+            from .native import PyramidGraph
+            key = threading.get_ident()
+            graph = self._graphs.get(key)
+            if graph is None or not graph.fits(clouds):
+                total = sum(c.shape[0] for c in clouds)
+                with self._graph_lock:  # one capture at a time; a larger stack than the graph was captured for replaces it
+                    graph = PyramidGraph(max(total, graph.capacity if graph is not None and graph.B == len(clouds) else 0), len(clouds),
+                                         b.num_stages, b.init_voxel_size, b.init_radius, self.pipeline.neighbor_limits, self.device)
+                self._graphs[key] = graph
+            plan = graph.launch(clouds)
+            event = torch.cuda.Event()
+            event.record(stream)
+            return job, plan, plan.pts[0], event
         points = torch.cat(clouds, dim=0)
         # (a torch.tensor(..., device=...) from a Python list is a pageable host-to-device copy: it would block the host until the
         # stream has drained, i.e. until the previous stack's forward is done -- pinned + non_blocking keeps the host running ahead)
@@ -202,6 +221,15 @@ class ConcurrentRegistration:
         job, plan, points, _ = begun
         model = self.pipeline.model
         data = plan.finish()
+        if self.pyramid_graphs:
+            # the graph's buffers are overwritten by this lane's next stack: what outlives the forward -- the point arrays the output
+            # dicts are views of (and, for the tests' return_pyramid, every table) -- is copied out; the forward reads the copies
+            S, fine = len(data['points']), model.backbone.fine_stage
+            keep = range(S) if self.return_pyramid else (0, fine, S - 1)
+            data['points'] = [t.clone() if i in keep else t for i, t in enumerate(data['points'])]
+            if self.return_pyramid:
+                for key in ('neighbors', 'subsampling', 'upsampling', 'lengths'):
+                    data[key] = [t.clone() for t in data[key]]
         data['features'] = torch.ones((points.shape[0], 1), dtype=torch.float32, device=points.device)
         data['batch_size'] = len(job)
         if model._native is None:

@@ -25,9 +25,9 @@ def table(stats_csv, bench_json, top=32):
 def main():
     out, s4, b4, s1, b1 = sys.argv[1:6]
     with open(out, 'w') as f:
-        f.write('# Round 2: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode` '
-                '(and the same with `--lanes 1 --steps 6 --warmup 2`)\n\nFull tables: `profiles/r02_rocprofv3_kernel_stats.csv`, '
-                '`profiles/r02_rocprofv3_kernel_stats_one_lane.csv` (rocprofv3 stats output, unedited).\n\n'
+        f.write('# `rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode` '
+                '(and the same with `--lanes 1 --steps 6 --warmup 2`)\n\nFull tables: the `rNN_rocprofv3_kernel_stats*.csv` files next to this one '
+                '(rocprofv3 stats output, unedited).\n\n'
                 '## the default configuration\n\n' + table(s4, b4) +
                 '\n## one lane (`--lanes 1`): launch durations without contention from other lanes\n\n' + table(s1, b1))
 
