@@ -64,12 +64,12 @@ int sinkhorn_launch(int batch, const float* const* ref_feats, const int64_t* nr,
                     void* stream);
 
 // radius grids whose row counts only the device knows (neighbors.hip; the pyramid builds every stage without a host read): ns / nq are
-// row CAPACITIES, ns_hint the expected support rows (sizes the cell budget only)
+// row CAPACITIES, ns_hint / nq_hint the expected support / query rows (cell budget and grid size only: never a wrong result)
 int radius_grid_build_hinted(const float* s_points, const int64_t* s_len, int64_t batch, int64_t ns, int64_t ns_hint, float radius,
                              void* grid_ws, size_t grid_ws_bytes, void* stream);
 int radius_grid_order_hinted(const void* grid_ws, int64_t ns, int64_t ns_hint, int64_t batch, int32_t* order, void* stream);
-int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len, int64_t batch, int64_t nq, int64_t ns,
-                        int64_t ns_hint, float radius, int64_t width, int64_t cap, int64_t* out, int32_t* counts, int32_t* max_count,
+int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len, int64_t batch, int64_t nq, int64_t nq_hint,
+                        int64_t ns, int64_t ns_hint, float radius, int64_t width, int64_t cap, int64_t* out, int32_t* counts, int32_t* max_count,
                         int32_t* overflow, void* stream);
 
 int p2n_launch(const float* points, const float* nodes, int clouds, const int64_t* f0, const int64_t* c0, int64_t k, int64_t* point_to_node,

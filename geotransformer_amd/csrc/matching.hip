@@ -36,17 +36,19 @@ struct P2nClouds {
   int64_t f0[2 * GEOTR_MAX_PAIRS + 1], c0[2 * GEOTR_MAX_PAIRS + 1];
 };
 
-// Loads of the pyramid's point arrays in the matching heads go through agent scope (sc1: served by L2, never by a CU's L1).
-// Measured necessity, not style: with several streams in flight (stacks of DIFFERENT pairs on 3-4 lanes) plain loads here
-// occasionally returned the coordinates a previous stack had left at the same address -- a handful of points per cloud then joined
-// the wrong superpoint (0 of 10 runs affected with these loads, 3 of 10 without on the same box; profiles/r02_concurrency_hazard.md).
+// Round 2 shipped agent-scope (sc1) loads of the pyramid's point arrays here as the fix of a multi-stream "stale read".  Round 3 found
+// the cause elsewhere (profiles/r03_concurrency_hazard.md): memory and caches were never wrong (plain and agent-scope reads agreed on
+// 2.7e9 words under the failing workload); the one build of p2n_assign that misassigned points was the SLP-vectorised one (packed fp32
+// code consuming ds_read2_b32 results through v_pk_mov_b32), and the sc1 loads had merely changed what the vectoriser produced.  The
+// heads are now built without SLP vectorisation (Makefile, pinned by tests/test_isa_checks.py), the distance is the reference CPU
+// path's FMA chain, and the loads are plain again; the flavours below remain as switches of the investigation tool.
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Load flavours of the hazard investigation (GEOTR_P2N_MODE, profiles/r03_concurrency_hazard.md): 0 = agent scope (shipped),
+// Load flavours of the hazard investigation (GEOTR_P2N_MODE, profiles/r03_concurrency_hazard.md; default 7): 0 = agent scope (round 2),
 // 1 = plain dword loads (asm), 2 = the same behind an agent-scope acquire fence at kernel entry, 3 = non-temporal (bypasses L1, no
 // scope semantics), 4 = plain C++ loads exactly as round 2's failing kernel had them (the compiler merges a point's three words into ONE
 // 12-byte global_load_dwordx3), 5 = superpoints by plain dword loads, points by ONE plain global_load_dwordx3 (asm), 6 = superpoints
-// by plain C++ loads, points by three plain dword loads (asm)
+// by plain C++ loads, points by three plain dword loads (asm), 7 (shipped) = plain C++ loads in all three consumers of the point arrays
 // (a C++ `volatile` load is NOT plain on this target: it becomes `flat_load ... sc0 sc1`, system scope; hence the asm)
 __device__ __forceinline__ float ld_plain(const float* p) {
   float v;
@@ -205,10 +207,10 @@ static bool probe_enabled() {
   }();
   return on;
 }
-static int p2n_mode() {  // hazard investigation switch (see ld_pt); the shipped flavour is 0
+static int p2n_mode() {  // hazard investigation switch (see ld_pt); the shipped flavour is 7: plain loads everywhere
   static const int mode = [] {
     const char* e = std::getenv("GEOTR_P2N_MODE");
-    return e ? std::atoi(e) : 0;
+    return e ? std::atoi(e) : 7;
   }();
   return mode;
 }
@@ -996,7 +998,7 @@ int p2n_launch(const float* points, const float* nodes, int clouds, const int64_
   else p2n_assign_kernel<0><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
   if (probe && (probe_array(points, 3 * f0[clouds], 0x13, stream) != GEOTR_OK || probe_array(nodes, 3 * c0[clouds], 0x14, stream) != GEOTR_OK))
     return GEOTR_E_LAUNCH;  // site 2: in front of p2n_knn
-  if (mode == 7)  // 7 = plain C++ loads in ALL three consumers of the point arrays (p2n_assign, p2n_knn, patch_gather): round 2's failing state
+  if (mode == 7)  // 7 = plain C++ loads in ALL three consumers of the point arrays (p2n_assign, p2n_knn, patch_gather)
     p2n_knn_kernel<false><<<dim3((unsigned)maxm, (unsigned)clouds), dim3(256), 0, stream>>>(points, 0, nodes, point_to_node, (int)k, knn_indices,
                                                                                            knn_masks, overflow, tb);
   else

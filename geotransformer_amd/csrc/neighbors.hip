@@ -229,26 +229,26 @@ __global__ void rg_scatter_kernel(const float* __restrict__ s, int batch, const 
 // One wave per query.  Candidates = the 3x3x3 cell neighbourhood, visited as 9 x-contiguous runs that
 // are flattened into one index space so all 64 lanes stay busy.  Accepted (d, idx) keys are compacted
 // into an LDS row with ballot + popcount, then ranked (keys are distinct) and written out.
-// The number of queries and the pad index are read on the device (sum of q_len / the support clouds' headers), and the waves walk the
-// queries with a grid stride: the launch is sized from a row CAPACITY, so a pyramid stage whose size only the device knows needs no host
-// read (round 3).
+// The number of queries and the pad index are read on the device (the lengths / the support clouds' headers): a pyramid stage whose size
+// only the device knows needs no host read (round 3).  nq_cap = row capacity of the query array.
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
                                                        const float4* __restrict__ sorted, const float* __restrict__ q,
-                                                       const int64_t* __restrict__ q_len, int batch,
+                                                       const int64_t* __restrict__ q_len, int batch, int64_t nq_cap,
                                                        float r2, int width, int cap,
                                                        int64_t* __restrict__ out, int* __restrict__ counts,
                                                        int* __restrict__ max_count, int* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int64_t nq = 0;
-  for (int b = 0; b < batch; ++b) nq += q_len[b];
   const int64_t ns_total = rg_rows(hdr, batch);
   unsigned long long* keys = lds_keys + (size_t)w * cap;
-  for (int64_t qi = (int64_t)blockIdx.x * 4 + w; qi < nq; qi += (int64_t)gridDim.x * 4) {  // whole waves; no block-level barrier below
+  // The grid is sized from the EXPECTED number of queries (one query per wave, as before); the stride loop only runs a second time when
+  // the real count exceeds the expectation, and stops at the first index past the last cloud (whole waves; no block-level barrier below)
+  for (int64_t qi = (int64_t)blockIdx.x * 4 + w; qi < nq_cap; qi += (int64_t)gridDim.x * 4) {
     int64_t qstart;
     const int b = cloud_of(q_len, batch, qi, qstart);
-    const CloudGrid g = hdr[b < batch ? b : batch - 1];
+    if (b >= batch) break;  // past the last query
+    const CloudGrid g = hdr[b];
     const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
 
     // --- the 9 runs (lane k < 9 owns run k) ---
@@ -784,19 +784,20 @@ int radius_grid_order_hinted(const void* grid_ws, int64_t ns, int64_t ns_hint, i
   return GEOTR_OK;
 }
 
-// nq = capacity of the query rows (>= the sum of q_len; the real count is read on the device): at most kQueryBlocks blocks walk
-// the queries with a grid stride, so a launch sized from a capacity far above the real count costs nothing
-constexpr int64_t kQueryBlocks = 256 * 16;
+// nq = capacity of the query rows (>= the sum of q_len; the real count is read on the device), nq_hint = expected count (0 = nq): the
+// grid holds one wave per EXPECTED query -- a first version with a fixed grid of 4096 blocks walking ~40 queries per wave measured 24 %
+// slower (211 vs 170 us per launch, profiles/r03_ab_runs.md) -- and the waves stride on if there are more
 int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
-                        int64_t batch, int64_t nq, int64_t ns, int64_t ns_hint, float radius, int64_t width, int64_t cap,
+                        int64_t batch, int64_t nq, int64_t nq_hint, int64_t ns, int64_t ns_hint, float radius, int64_t width, int64_t cap,
                         int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns, batch, ns_hint);
   if (nq == 0) return GEOTR_OK;
   const float r2 = radius * radius;  // fp32 product, as radius_neighbors_cpu.cpp:12
-  const unsigned nb = (unsigned)std::min<int64_t>((nq + 3) / 4, kQueryBlocks);
+  const int64_t expect = nq_hint > 0 ? std::min(nq_hint, nq) : nq;
+  const unsigned nb = (unsigned)((expect + 3) / 4);
   if (count_only) {
-    rg_query_kernel<true><<<dim3(nb), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch,
+    rg_query_kernel<true><<<dim3(nb), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
                                                              r2, 0, 0, nullptr, counts, max_count, nullptr);
   } else {
     const size_t lds = (size_t)cap * 4 * sizeof(unsigned long long);
@@ -805,7 +806,7 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(GEOTR_E_LAUNCH, "radius_query: cannot reserve %zu B of LDS", lds);
     }
-    rg_query_kernel<false><<<dim3(nb), dim3(256), lds, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch,
+    rg_query_kernel<false><<<dim3(nb), dim3(256), lds, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
                                                                 r2, (int)width, (int)cap, out, nullptr,
                                                                 nullptr, overflow);
   }
@@ -820,7 +821,7 @@ int geotr_radius_grid_order(const void* grid_ws, int64_t ns, int64_t batch, int3
 static int radius_query_common(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
                                int64_t batch, int64_t nq, int64_t ns, float radius, int64_t width, int64_t cap,
                                int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_) {
-  return radius_query_hinted(count_only, grid_ws, q, q_len, batch, nq, ns, 0, radius, width, cap, out, counts, max_count, overflow, stream_);
+  return radius_query_hinted(count_only, grid_ws, q, q_len, batch, nq, 0, ns, 0, radius, width, cap, out, counts, max_count, overflow, stream_);
 }
 
 int geotr_radius_count(const void* grid_ws, int64_t ns, const float* q_points, const int64_t* q_len, int64_t batch,

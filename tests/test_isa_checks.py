@@ -43,3 +43,29 @@ def test_no_instruction_touches_an_in_flight_lds_fragment(tmp_path, source, pref
     assert len(lines) >= min_kernels, chk.stdout[-2000:]
     # the check must have seen the asm reads at all (guards against the markers / mnemonics changing under it)
     assert all(int(ln.split(': ')[1].split()[0]) > 0 for ln in lines), chk.stdout[-2000:]
+
+
+def test_matching_heads_are_compiled_without_packed_fp32_shuffles(tmp_path):
+    """profiles/r03_concurrency_hazard.md: the one build of p2n_assign that misassigned points under multi-stream load was the
+    SLP-vectorised one (ds_read2_b32 results consumed through v_pk_mov_b32 / op_sel'd v_pk_mul_f32).  matching.hip is therefore
+    compiled with -fno-slp-vectorize; this pins the shipped ISA of the kernels that take discrete decisions: no v_pk_mov_b32 anywhere
+    in the file, no packed fp32 arithmetic at all in the three consumers of the pyramid's point arrays."""
+    if not os.path.exists(HIPCC):
+        pytest.skip('hipcc not available')
+    mk = open(os.path.join(CSRC, 'Makefile')).read()
+    assert 'FLAGS_matching := -fno-slp-vectorize' in mk and '$(FLAGS_$*)' in mk
+    asm = str(tmp_path / 'matching.s')
+    cmd = [HIPCC] + _flags() + ['-fno-slp-vectorize', '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only', os.path.join(CSRC, 'matching.hip'),
+                                '-o', asm]
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+    assert res.returncode == 0, res.stderr[-2000:]
+    name, packed = None, {}
+    for line in open(asm):
+        if line.startswith('_Z') and line.rstrip().endswith(':'):
+            name = line.strip()[:-1]
+        elif name and 'v_pk_' in line and not line.lstrip().startswith(';'):
+            packed.setdefault(name, []).append(line.split()[0])
+    assert not any(op == 'v_pk_mov_b32' for ops in packed.values() for op in ops), {k: v for k, v in packed.items() if 'v_pk_mov_b32' in v}
+    for kernel in ('p2n_assign_kernel', 'p2n_knn_kernel', 'patch_gather_kernel'):
+        hits = {k: v for k, v in packed.items() if kernel in k and any(op.startswith(('v_pk_mul_f32', 'v_pk_add_f32', 'v_pk_fma_f32')) for op in v)}
+        assert not hits, hits
