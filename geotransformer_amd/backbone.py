@@ -39,6 +39,12 @@ class KPConvFPN(nn.Module):
             else:
                 setattr(self, name, UnaryBlock(below + skip, skip, group_norm))
 
+    def decoder_latent_channels(self, i):
+        """Width of the latent entering the decoder at list index i (= the skip index): the coarsest encoder output for the first
+        decoder, the previous decoder's output afterwards."""
+        d = self.encoder1_1.out_channels
+        return d * 2 ** (i + 2) if i == self.num_stages - 2 else getattr(self, f'decoder{i + 2}').out_channels
+
     def forward(self, feats, data_dict):
         pts, nb = data_dict['points'], data_dict['neighbors']
         sub, up = data_dict['subsampling'], data_dict['upsampling']
@@ -54,8 +60,17 @@ class KPConvFPN(nn.Module):
         feats_list = [enc[-1]]
         latent = enc[-1]
         for i in range(self.num_stages - 2, self.fine_stage - 1, -1):
-            latent = kernels.upsample_concat(latent, up[i], enc[i])  # nearest_upsample + torch.cat fused
-            latent = getattr(self, f'decoder{i + 1}')(latent)
+            dec = getattr(self, f'decoder{i + 1}')
+            # Linear(cat(up(latent), skip)) = up(latent W_latent^T) + skip W_skip^T + b: no concatenated operand (kernels.decoder_linear,
+            # the native executor's form); shapes off the packed path concatenate as the reference does (backbone.py:71-78)
+            fused = kernels.decoder_linear(latent, up[i], enc[i], dec.mlp.weight, dec.mlp.bias, want_stats=hasattr(dec, 'norm'))
+            if fused is None:
+                latent = dec(kernels.upsample_concat(latent, up[i], enc[i]))  # nearest_upsample + torch.cat fused
+            elif hasattr(dec, 'norm'):
+                y, stats, rpr = fused
+                latent = (dec.norm(y, act='leaky', stats=stats, rows_per_record=rpr) if stats is not None else dec.norm(y, act='leaky'))
+            else:
+                latent = fused[0]
             feats_list.append(latent)
         feats_list.reverse()
         return feats_list

@@ -323,13 +323,48 @@ static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geo
   const float* latent = enc[S - 1];
   int64_t lat_ch = enc_ch[S - 1];
   int d = 0;
+  static const bool decoder_split = [] {
+    const char* e = std::getenv("GEOTR_DECODER_SPLIT");  // A/B switch for measurements: 0 = concatenate, then one Linear (the reference's form)
+    return !(e && e[0] == '0');
+  }();
   for (int i = S - 2; i >= net.fine_stage; --i, ++d) {
     const int64_t tot = lat_ch + enc_ch[i];
+    const geotr_linear& l = net.decoder[d];
+    const bool last = i == net.fine_stage;  // LastUnaryBlock: straight into the caller's buffer, no norm
+    const bool gn = !last && net.decoder_norm[d].groups > 0;
+    // Linear(cat(up(latent), skip)) = up(latent W_latent^T) + skip W_skip^T + b  (round 3): the coarse-level product is gathered into the
+    // fine-level GEMM's epilogue, so the (rows, latent + skip channels) concatenation -- 553 MB per 16-pair stack at the fine level of the
+    // 3DMatch model, written once and read once -- never exists, and the fine-level contraction is over the skip channels only.
+    // Both products must be on the packed path (>= GEOTR_PACKED_MIN_ROWS rows each), else the reference's form below.
+    if (decoder_split && net.decoder_packed_latent[d] && net.decoder_packed_skip[d] && l.in == tot &&
+        use_packed(net.decoder_packed_latent[d], latent, lat_ch, p.n[i + 1], lat_ch) &&
+        use_packed(net.decoder_packed_skip[d], enc[i], enc_ch[i], p.n[i], enc_ch[i])) {
+      float* coarse = c.alloc<float>((size_t)p.n[i + 1] * l.out);
+      c.check(packed_gemm(c, latent, lat_ch, net.decoder_packed_latent[d], coarse, l.out, p.n[i + 1], l.out, lat_ch, nullptr, nullptr, nullptr, 0,
+                          1.0f, 0, c.stream));
+      float* t = last ? feats_f_out : c.alloc<float>((size_t)p.n[i] * l.out);
+      GnStats st_d;
+      float* rec = nullptr;
+      if (gn && gn_epilogue_stats) {
+        rec = c.alloc<float>(geotr_gemm_packed_stats_floats(c.seg_rows[i], c.nseg, l.out));
+        st_d.rec = rec, st_d.rpr = geotr_gemm_packed_stats_rows_per_record(l.out);
+      }
+      if (c.live()) {
+        ProfScope prof(c.stream);
+        c.check(geotr_gemm_packed_gather(enc[i], enc_ch[i], net.decoder_packed_skip[d], t, l.out, p.n[i], l.out, enc_ch[i], l.b, 0,
+                                         c.gemm_bf16 ? 1 : 0, coarse, l.out, p.n[i + 1], p.upsampling[i], p.upsampling_w[i], c.seg_rows[i], c.nseg, rec,
+                                         c.stream));
+        if (p.n[i] < (1 << 24) && l.out < (1 << 12) && enc_ch[i] < (1 << 14)) prof.done(kProfGemm | (p.n[i] << 26) | (l.out << 14) | enc_ch[i]);
+        else prof.done(0);
+      }
+      latent = last ? t : norm(c, net.decoder_norm[d], t, p.n[i], l.out, nullptr, 2, i, nullptr, nullptr, nullptr, &st_d);
+      lat_ch = l.out;
+      continue;
+    }
     float* cat = c.alloc<float>((size_t)p.n[i] * tot);
     if (c.live())
       c.check(geotr_upsample_concat(latent, p.n[i + 1], lat_ch, p.upsampling[i], p.upsampling_w[i], enc[i], enc_ch[i], p.n[i], cat, c.stream));
-    const geotr_linear& l = net.decoder[d];
-    if (i == net.fine_stage) {  // LastUnaryBlock: straight into the caller's buffer
+    if (last) {  // LastUnaryBlock: straight into the caller's buffer
       if (use_packed(l.packed, cat, tot, p.n[i], l.in))
         c.check(packed_gemm(c, cat, tot, l.packed, feats_f_out, l.out, p.n[i], l.out, l.in, l.b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
       else if (c.live())

@@ -42,6 +42,16 @@ struct GemmArgs {
 // The MFMA C/D layout (col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) gives each lane one column of 16
 // scattered rows; storing from it directly (two 128-byte pieces per instruction) cost ~6-10 us per launch, so the block is
 // transposed in a wave-private LDS slab ((32*WM) x (32*WN + 4) floats) and written as float4 row segments.
+// Gathered residual (optional): C[row, :] += src[index[row * ld_index] * ld + :] when that index is < rows, else nothing -- the
+// "nearest upsample" of a coarse-level product added to a fine-level one (decoder of the KPConv-FPN: Linear(cat(up(latent), skip)) =
+// up(latent W1^T) + skip W2^T, so the concatenated operand never exists).
+struct GatherRes {
+  const float* src;
+  const int64_t* index;
+  int64_t ld, ld_index;
+  int rows;
+};
+
 // `stats_rec` (optional): this wave's GroupNorm record -- per column the sum and the sum of squares of the values it STORES, over its
 // 32 * WM rows in ascending row order per lane, lanes combined by a fixed xor tree: [0, N) sums, [N, 2N) sums of squares (rows past M
 // and columns past N contribute nothing; a wave entirely past M writes zeros).  The record is a function of the tile's rows alone.
@@ -49,7 +59,7 @@ template <int WM, int WN>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float* slab, int lane, int row0, int col0, int M, int N,
                                              float alpha, const float* __restrict__ bias, const int32_t* __restrict__ row_div,
                                              const float* __restrict__ residual, int64_t ldr, int act, float* __restrict__ C, int64_t ldc,
-                                             float* __restrict__ stats_rec = nullptr) {
+                                             float* __restrict__ stats_rec = nullptr, const GatherRes gr = GatherRes{nullptr, nullptr, 0, 0, 0}) {
   constexpr int TW = 32 * WN, TS = TW + 4;
   const int fr = lane & 31, fk = lane >> 5;
 #pragma unroll
@@ -102,6 +112,20 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (gn + e < N) x[e] += rp[e];
+      }
+    }
+    if (gr.src) {
+      const int64_t j = gr.index[(int64_t)gm * gr.ld_index];
+      if (j < gr.rows) {
+        const float* rp = gr.src + j * gr.ld + gn;
+        if (gn + 3 < N && (gr.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(gr.src) & 15) == 0) {
+          const float4 q = *reinterpret_cast<const float4*>(rp);
+          x[0] += q.x, x[1] += q.y, x[2] += q.z, x[3] += q.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gn + e < N) x[e] += rp[e];
+        }
       }
     }
 #pragma unroll
@@ -490,6 +514,7 @@ struct PackedArgs {
   int seg_tile0[GEOTR_MAX_PAIRS + 1];
   int seg_row0[GEOTR_MAX_PAIRS + 1];
   float* stats;
+  GatherRes gres;  // gathered residual (src == nullptr: none); unsplit launches only
 };
 
 __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b_is_kn, int N, int K, int KS, int64_t nvec,
@@ -701,7 +726,7 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   float* slab = reinterpret_cast<float*>(psm) + wave * (32 * WM * (32 * WN + 4));
   if (gridDim.z == 1)
     epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act, g.C,
-                         g.ldc, g.stats ? g.stats + ((int64_t)blockIdx.y * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr);
+                         g.ldc, g.stats ? g.stats + ((int64_t)blockIdx.y * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr, g.gres);
   else  // raw partial sums of this K slice; the epilogue runs in the reduce kernel
     epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, 1.0f, nullptr, nullptr, nullptr, 0, 0,
                          g.partial + (int64_t)blockIdx.z * g.M * g.N, g.N);
@@ -826,7 +851,7 @@ template <int TERMS>
 static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                               const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                               void* stream_, void* ws = nullptr, size_t ws_bytes = 0, const int64_t* seg_rows_host = nullptr, int64_t nseg = 0,
-                              float* stats = nullptr) {
+                              float* stats = nullptr, const GatherRes* gres = nullptr) {
   GEOTR_CHECK_ARG(M >= 0 && N >= 1 && K >= 1, "gemm_packed: bad sizes");
   if (M == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(A && packed && C, "gemm_packed: null pointer");
@@ -840,6 +865,7 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   g.M = (int)M; g.N = (int)N; g.K = (int)K; g.KS = (int)(kp / 16); g.NT = (int)(np / 32); g.alpha = alpha; g.act = act;
   g.nseg = 0;
   g.stats = stats;
+  g.gres = gres ? *gres : GatherRes{nullptr, nullptr, 0, 0, 0};
   int64_t tiles = (M + 127) / 128;
   if (nseg > 0) {  // segment-aligned row tiles
     GEOTR_CHECK_ARG(seg_rows_host && nseg <= GEOTR_MAX_PAIRS, "gemm_packed: 1..%d row segments", GEOTR_MAX_PAIRS);
@@ -854,7 +880,7 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
     for (int64_t q = nseg; q <= GEOTR_MAX_PAIRS; ++q) g.seg_tile0[q] = (int)tiles, g.seg_row0[q] = (int)row;
     g.nseg = (int)nseg;
   }
-  int splits = ws && !stats ? packed_splits(M, N, K) : 1;  // statistics come out of the unsplit epilogue only
+  int splits = ws && !stats && !g.gres.src ? packed_splits(M, N, K) : 1;  // statistics / the gathered residual live in the unsplit epilogue
   if (splits > 1 && ws_bytes < sizeof(float) * (size_t)splits * (size_t)M * (size_t)N) splits = 1;  // never more than the caller's scratch holds
   const int nkt_all = g.KS / 2;
   g.kt_split = (nkt_all + splits - 1) / splits;
@@ -922,6 +948,21 @@ extern "C" int geotr_gemm_packed_stats(const float* A, int64_t lda, const void* 
   if (bf16_operands)
     return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, nullptr, 0, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg, stats);
   return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, row_div, nullptr, 0, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg, stats);
+}
+
+extern "C" int geotr_gemm_packed_gather(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                        const float* bias, int act, int bf16_operands, const float* gathered, int64_t ld_gathered,
+                                        int64_t gathered_rows, const int64_t* index, int64_t ld_index, const int64_t* seg_rows_host, int64_t nseg,
+                                        float* stats, void* stream) {
+  GEOTR_CHECK_ARG(gathered && index && ld_index >= 1 && ld_gathered >= N && gathered_rows >= 0 && gathered_rows < (1ll << 31),
+                  "gemm_packed_gather: bad gathered operand");
+  GEOTR_CHECK_ARG((stats == nullptr) || (seg_rows_host && nseg >= 1), "gemm_packed_gather: statistics need the row segments");
+  const GatherRes gr{gathered, index, ld_gathered, ld_index, (int)gathered_rows};
+  const int64_t* segs = stats ? seg_rows_host : nullptr;
+  const int64_t ns = stats ? nseg : 0;
+  if (bf16_operands)
+    return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 1.0f, act, stream, nullptr, 0, segs, ns, stats, &gr);
+  return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 1.0f, act, stream, nullptr, 0, segs, ns, stats, &gr);
 }
 
 extern "C" int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

@@ -244,9 +244,20 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
   unsigned long long* keys = lds_keys + (size_t)w * cap;
   // The grid is sized from the EXPECTED number of queries (one query per wave, as before); the stride loop only runs a second time when
   // the real count exceeds the expectation, and stops at the first index past the last cloud (whole waves; no block-level barrier below)
+  // Which cloud does query qi belong to?  The lane-parallel form: lane c holds the end row of query cloud c (one 8-byte load per lane + a
+  // wave scan, ONCE per wave), and the cloud of a query is the number of clouds that end at or before it -- one ballot.  The serial
+  // walk over the lengths it replaces cost a dependent scalar load per cloud (~16 on average for a 16-pair stack, up to 32: a third of
+  // a query's ~8 000 cycles -- rocprofv3 SQ counters, profiles/r03_rg_query_counters.md -- and an empty wave paid all 32).
+  int cloud_end = 0x7fffffff;
+  if (batch <= 64) cloud_end = wave_inclusive_scan(lane < batch ? (int)q_len[lane] : 0);
   for (int64_t qi = (int64_t)blockIdx.x * 4 + w; qi < nq_cap; qi += (int64_t)gridDim.x * 4) {
-    int64_t qstart;
-    const int b = cloud_of(q_len, batch, qi, qstart);
+    int b;
+    if (batch <= 64) {
+      b = __popcll(__ballot(lane < batch && qi >= (int64_t)cloud_end));
+    } else {
+      int64_t qstart;
+      b = cloud_of(q_len, batch, qi, qstart);
+    }
     if (b >= batch) break;  // past the last query
     const CloudGrid g = hdr[b];
     const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];

@@ -174,6 +174,61 @@ def group_norm_stats(x, groups, weight, bias, eps=1e-5, x_stats=None, x_rpr=0, r
     return out
 
 
+DECODER_SPLIT = os.environ.get('GEOTR_DECODER_SPLIT', '1') != '0'  # same A/B switch as the native executor
+
+
+def decoder_packs(weight, latent_ch):
+    """The decoder weight W (out, latent_ch + skip_ch) packed in its two column slices [W_latent | W_skip] (gemm_pack of strided views)."""
+    w = weight.detach()
+    key = (weight._version, weight.data_ptr(), int(latent_ch))
+    hit = getattr(weight, '_geotr_split_packed', None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    lib = _lib.load()
+    out = []
+    for view in (w[:, :latent_ch], w[:, latent_ch:]):
+        n, k = view.shape
+        packed = torch.empty(lib.geotr_gemm_pack_bytes(n, k), dtype=torch.uint8, device=w.device)
+        _lib.check(lib.geotr_gemm_pack(view.data_ptr(), view.stride(0), 0, n, k, _lib.ptr(packed), _lib.stream_ptr()), 'geotr_gemm_pack')
+        out.append(packed)
+    try:
+        weight._geotr_split_packed = (key, tuple(out))
+    except AttributeError:
+        pass
+    return tuple(out)
+
+
+def decoder_linear(latent, upsample_indices, skip, weight, bias=None, want_stats=False, seg_rows=None):
+    """Linear(cat(nearest_upsample(latent), skip)) of a KPConv-FPN decoder (experiments/*/backbone.py:71-78) without the concatenation:
+    up(latent W_latent^T) + skip W_skip^T + b -- the coarse-level product is gathered into the fine-level GEMM's epilogue
+    (geotr_gemm_packed_gather).  Returns (y, stats, rows_per_record) like linear_gn (stats only with want_stats), or None when the
+    shapes are not on the packed path (the caller then concatenates, as the native executor does under the same predicate)."""
+    import ctypes
+    lib = _lib.load()
+    latent, skip = _f32c(latent), _f32c(skip)
+    lat_ch, skip_ch = latent.shape[1], skip.shape[1]
+    if not (DECODER_SPLIT and GEMM_PACKED and weight.shape[1] == lat_ch + skip_ch and use_packed(latent) and use_packed(skip)):
+        return None
+    p_lat, p_skip = decoder_packs(weight, lat_ch)
+    n_out = weight.shape[0]
+    coarse = gemm_packed(latent, p_lat, n_out)
+    up = upsample_indices if upsample_indices.is_contiguous() else upsample_indices.contiguous()
+    M = skip.shape[0]
+    assert up.dtype == torch.int64 and up.shape[0] == M
+    y = torch.empty((M, n_out), dtype=torch.float32, device=skip.device)
+    segs = [M] if seg_rows is None else [int(r) for r in seg_rows]
+    seg_arr = (ctypes.c_int64 * len(segs))(*segs)
+    stats, rpr = None, 0
+    if want_stats and GN_EPILOGUE_STATS:
+        stats = torch.empty(lib.geotr_gemm_packed_stats_floats(seg_arr, len(segs), n_out), dtype=torch.float32, device=skip.device)
+        rpr = int(lib.geotr_gemm_packed_stats_rows_per_record(n_out))
+    _lib.check(lib.geotr_gemm_packed_gather(_lib.ptr(skip), skip.stride(0), _lib.ptr(p_skip), _lib.ptr(y), y.stride(0), M, n_out, skip_ch,
+                                            _lib.ptr(bias), 0, int(GEMM_PACKED == 'bf16'), _lib.ptr(coarse), coarse.stride(0), coarse.shape[0],
+                                            _lib.ptr(up), up.stride(0), seg_arr, len(segs), _lib.ptr(stats), _lib.stream_ptr()),
+               'geotr_gemm_packed_gather')
+    return y, stats, rpr
+
+
 def row_positive(feats):
     lib = _lib.load()
     feats = _f32c(feats)

@@ -56,7 +56,8 @@ class Block(ctypes.Structure):
 class Backbone(ctypes.Structure):
     _fields_ = [('num_stages', I32), ('fine_stage', I32), ('num_blocks', I32), ('num_decoders', I32),
                 ('blocks', Block * (2 + 3 * (MAX_STAGES - 1))), ('decoder', Linear * MAX_STAGES),
-                ('decoder_norm', Norm * MAX_STAGES)]
+                ('decoder_norm', Norm * MAX_STAGES), ('decoder_packed_latent', ctypes.c_void_p * MAX_STAGES),
+                ('decoder_packed_skip', ctypes.c_void_p * MAX_STAGES)]
 
 
 class Pyramid(ctypes.Structure):
@@ -186,7 +187,7 @@ class NativeModel:
         the embedding's div_term), by (data_ptr, version)."""
         from . import kernels
         m = self.model
-        return (kernels.GEMM_PACKED, kernels.GSE_PRECISION) + tuple(
+        return (kernels.GEMM_PACKED, kernels.GSE_PRECISION, kernels.DECODER_SPLIT) + tuple(
             (t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
 
     def _build(self):
@@ -207,6 +208,10 @@ class NativeModel:
             dec = getattr(net, f'decoder{i + 1}')
             bb.decoder[n_dec] = _linear(dec.mlp, self._keep)
             bb.decoder_norm[n_dec] = _norm(getattr(dec, 'norm', None))
+            if kernels.GEMM_PACKED and kernels.DECODER_SPLIT:  # W = [W_latent | W_skip] packed slice by slice (kernels.decoder_linear)
+                lat, skp = kernels.decoder_packs(dec.mlp.weight, net.decoder_latent_channels(i))
+                self._keep += [lat, skp]
+                bb.decoder_packed_latent[n_dec], bb.decoder_packed_skip[n_dec] = lat.data_ptr(), skp.data_ptr()
             n_dec += 1
         bb.num_decoders = n_dec
         t, tr = d.transformer, m.transformer

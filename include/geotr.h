@@ -160,6 +160,13 @@ size_t geotr_gemm_packed_stats_floats(const int64_t* seg_rows_host, int64_t nseg
 int geotr_gemm_packed_stats(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                             const float* bias, const int32_t* row_div, int act, int bf16_operands, const int64_t* seg_rows_host,
                             int64_t nseg, float* stats, void* stream);
+/* C = act(A W^T + bias + G), G[row, :] = gathered[index[row * ld_index], :] where that index is < gathered_rows, else 0 (the pad row of a
+ * nearest-upsample table, kpconv/functional.py:6-22): the fine-level half of a decoder layer with the coarse-level half gathered into
+ * the epilogue.  Optional GroupNorm statistics as geotr_gemm_packed_stats (stats NULL: plain row tiling, segments ignored). */
+int geotr_gemm_packed_gather(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                             const float* bias, int act, int bf16_operands, const float* gathered, int64_t ld_gathered,
+                             int64_t gathered_rows, const int64_t* index, int64_t ld_index, const int64_t* seg_rows_host, int64_t nseg,
+                             float* stats, void* stream);
 /* The same launch with plain bf16 operands (hi planes of the same packed weight, a_hi*b_hi only, fp32 accumulation; ~2^-8 relative
  * error per product): the "bf16 features" mode of BASELINE configs[4].  Never the default. */
 int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
@@ -420,6 +427,12 @@ typedef struct geotr_backbone {                                      /* KPConvFP
   geotr_block blocks[2 + 3 * (GEOTR_MAX_STAGES - 1)];               /* encoder1_1, encoder1_2, then (_1,_2,_3) per stage */
   geotr_linear decoder[GEOTR_MAX_STAGES];                            /* coarsest first; the last one is the LastUnaryBlock */
   geotr_norm decoder_norm[GEOTR_MAX_STAGES];
+  /* optional (round 3): the decoder weight packed in two column slices, W = [W_latent | W_skip] (geotr_gemm_pack on w and on
+   * w + latent_ch with ldb = in).  Linear(cat(up(latent), skip)) is then evaluated as up(latent W_latent^T) + skip W_skip^T + b: one
+   * coarse-level product, one fine-level product with the coarse one gathered into its epilogue (geotr_gemm_packed_gather) -- the
+   * (rows, latent_ch + skip_ch) concatenation of backbone.py:71-78 is never written or read. */
+  const void* decoder_packed_latent[GEOTR_MAX_STAGES];
+  const void* decoder_packed_skip[GEOTR_MAX_STAGES];
 } geotr_backbone;
 typedef struct geotr_pyramid {                                       /* output of precompute_data_stack_mode, utils/data.py:13-77 */
   int32_t num_stages, num_pairs;               /* num_pairs >= 1 pairs stacked as ref_0, src_0, ref_1, src_1, ... */

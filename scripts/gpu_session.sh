@@ -1,19 +1,12 @@
 set -u
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/r3i; mkdir -p $O
-( cd .ab_old/r2C && GEOTR_P2N_MODE=7 LABEL=r2C_noslp timeout 300 python scripts/debug_c.py bisect 12 2>&1 | grep -v "^ " > $O/hz_r2C.txt; echo "r2C (no SLP vectorisation): $(grep -c DIFFERENCES $O/hz_r2C.txt) of 12 runs differ" )
-( cd .ab_old/r2orig && GEOTR_P2N_MODE=7 LABEL=r2orig timeout 300 python scripts/debug_c.py bisect 12 2>&1 | grep -v "^ " > $O/hz_r2orig.txt; echo "r2orig: $(grep -c DIFFERENCES $O/hz_r2orig.txt) of 12 runs differ" )
+O=$GRAFT_REPO_ROOT/gpurun_out/r3j; mkdir -p $O
+timeout 1700 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 > $O/gputests.log 2>&1; echo "pytest rc=$?"; tail -30 $O/gputests.log
 cd /tmp && export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $B --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode > $O/bench_under_rocprof.json 2>/dev/null
+b() { name=$1; shift; env "$@" timeout 300 python $B --no-cpu-baseline --no-fp32-mode ${EXTRA:-} 2>$O/bench_$name.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$name', d['value'], d['ms_per_step'])" || tail -5 $O/bench_$name.err; }
+( EXTRA="" b default X=1; EXTRA="" b pyramid_graph GEOTR_PYRAMID_GRAPH=1; EXTRA="" b default_again X=1; EXTRA="" b pyramid_graph_again GEOTR_PYRAMID_GRAPH=1; EXTRA="--lanes 1" b l1_graph GEOTR_PYRAMID_GRAPH=1; EXTRA="--lanes 1" b l1 X=1 ) | tee $O/ab_graph.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_l1 -o bench -- python $B --steps 6 --warmup 2 --lanes 1 --no-cpu-baseline --no-fp32-mode > $O/bench_l1_under_rocprof.json 2>/dev/null
-find $O/stats $O/stats_l1 -name "*kernel_stats.csv" | head; 
-python $GRAFT_REPO_ROOT/scripts/kernel_trace_summary.py $O/kernel_trace.md $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/bench_under_rocprof.json $(find $O/stats_l1 -name "*kernel_stats.csv" | head -1) $O/bench_l1_under_rocprof.json && head -45 $O/kernel_trace.md
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- python $B --steps 2 --warmup 1 --lanes 1 --stack 8 --batch 8 --no-cpu-baseline --no-fp32-mode > /dev/null 2>&1
-done
-python $GRAFT_REPO_ROOT/scripts/pmc_summary.py $O $O/pmc_hbm_traffic.md $O/pmc_hbm_traffic.json "python bench.py --steps 2 --warmup 1 --lanes 1 --stack 8 --batch 8" 2>&1 | tail -3
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq1 -o pmc -- python $B --steps 2 --warmup 1 --lanes 1 --stack 8 --batch 8 --no-cpu-baseline --no-fp32-mode > /dev/null 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/pmc_sq2 -o pmc -- python $B --steps 2 --warmup 1 --lanes 1 --stack 8 --batch 8 --no-cpu-baseline --no-fp32-mode > /dev/null 2>&1
-python $GRAFT_REPO_ROOT/scripts/sq_counters_summary.py $(find $O/pmc_sq1 $O/pmc_sq2 -name "*counter_collection.csv") rg_query $O/sq_rg_query.md; cat $O/sq_rg_query.md
-ls $O; du -sh $O
+grep -E "rg_query|gemm_packed_kernel<2, 2, 3>|gs_|scan_" $(find $O/stats_l1 -name "*kernel_stats.csv" | head -1) | cut -c1-160 | head -12
+timeout 500 python $B --config kitti --steps 5 --warmup 1 --pairs 4 --no-fp32-mode > $O/bench_kitti.json 2> $O/bench_kitti.err; echo "kitti rc=$?"; head -c 300 $O/bench_kitti.json; echo
+timeout 400 python $B --config lomatch --precision bf16 --no-fp32-mode > $O/bench_lomatch_bf16.json 2> $O/bench_lomatch_bf16.err; echo "lomatch bf16 rc=$?"; head -c 300 $O/bench_lomatch_bf16.json; echo

@@ -248,3 +248,37 @@ def test_group_norm_statistics_out_of_the_gemm_epilogue(N, K, segs):
     tn = kernels.group_norm_stats(t, 4, beta, gamma, x_stats=st, x_rpr=rpr, seg_rows=segs)
     two = kernels.group_norm_stats(y, groups, gamma, beta, x_stats=stats, x_rpr=rpr, residual=tn, act='leaky', seg_rows=segs)
     assert torch.equal(fused, two)
+
+
+@pytest.mark.parametrize('lat_ch,skip_ch,n_out,nc,m,segs', [(512, 256, 256, 3000, 9000, [4000, 5000]), (1024, 512, 512, 1100, 4200, None),
+                                                            (256, 128, 96, 2048, 2048, [1024, 1024])])
+def test_decoder_linear_without_the_concatenation(lat_ch, skip_ch, n_out, nc, m, segs):
+    """Linear(cat(nearest_upsample(latent), skip)) = up(latent W_latent^T) + skip W_skip^T + b (geotr_gemm_packed_gather): vs the
+    concatenated form in fp64, pad indices (== number of coarse rows) contribute nothing, GroupNorm statistics of the sum."""
+    from geotransformer_amd import kernels
+    g = torch.Generator().manual_seed(lat_ch + m)
+    latent = torch.randn(nc, lat_ch, generator=g).cuda()
+    skip = torch.randn(m, skip_ch, generator=g).cuda()
+    w = (torch.randn(n_out, lat_ch + skip_ch, generator=g) * 0.05).cuda()
+    bias = torch.randn(n_out, generator=g).cuda()
+    up = torch.randint(0, nc, (m, 5), generator=g)
+    up[::17, 0] = nc  # pad rows of the upsampling table
+    up = up.cuda()
+    y, stats, rpr = kernels.decoder_linear(latent, up, skip, w, bias, want_stats=True, seg_rows=segs)
+    padded = torch.cat([latent, torch.zeros_like(latent[:1])]).double()
+    cat = torch.cat([padded[up[:, 0]], skip.double()], dim=1)
+    want = cat @ w.double().t() + bias.double()
+    assert float((y.double() - want).abs().max()) <= 3e-5 * float(want.abs().max())
+    # the concatenated route through the same packed kernels agrees to fp32 rounding of the two partial sums
+    ref = kernels.linear(kernels.upsample_concat(latent, up, skip), w, bias, packed=True)
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    rec = stats.view(-1, 2, n_out).double().sum(0).cpu() if segs is None else None
+    if rec is not None:
+        assert torch.allclose(rec[0], y.double().sum(0).cpu(), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(rec[1], (y.double() ** 2).sum(0).cpu(), rtol=1e-5, atol=1e-3)
+    gamma, beta = torch.ones(n_out).cuda(), torch.zeros(n_out).cuda()
+    out = kernels.group_norm_stats(y, 8, gamma, beta, x_stats=stats, x_rpr=rpr, act='leaky', seg_rows=segs)
+    r0 = 0
+    for rows in (segs or [m]):
+        assert torch.allclose(out[r0:r0 + rows], kernels.group_norm(y[r0:r0 + rows].contiguous(), 8, gamma, beta, act='leaky'), rtol=2e-5, atol=2e-5)
+        r0 += rows
