@@ -185,7 +185,6 @@ class NativeModel:
     def _version_key(self):
         """Everything whose raw device pointer is baked into the descriptor: parameters AND buffers (KPConv.kernel_points,
         the embedding's div_term), by (data_ptr, version)."""
-        from . import kernels
         m = self.model
         return (kernels.GEMM_PACKED, kernels.GSE_PRECISION, kernels.DECODER_SPLIT) + tuple(
             (t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
@@ -218,7 +217,6 @@ class NativeModel:
         layers = tr.transformer.layers
         t.num_layers, t.num_heads = len(layers), layers[0].attention.attention.num_heads
         t.angle_k, t.sigma_d, t.sigma_a = tr.embedding.angle_k, float(tr.embedding.sigma_d), float(tr.embedding.sigma_a)
-        from . import kernels
         t.gse_precision = int(kernels.GSE_PRECISION)
         if t.gse_precision == 5:  # lookup tables of proj_d / proj_a, built once per weight set (kept alive with the descriptor)
             tab_d, tab_a = tr.embedding.tables()

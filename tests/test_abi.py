@@ -149,3 +149,31 @@ def test_documents_reference_existing_files():
         assert cited or doc == 'README.md'
         missing += [(doc, path) for path in cited if not os.path.exists(os.path.join(ROOT, path))]
     assert not missing, missing
+
+
+def test_native_descriptor_builds_without_a_gpu(monkeypatch):
+    """NativeModel._build walks the module tree into the C descriptor (native.py): run it on CPU tensors with the three GPU-only
+    helpers stubbed, for every experiment -- a Python-level slip in it (round 3 had one) must not need a GPU session to surface."""
+    import torch
+    from geotransformer_amd import kernels, native
+    from geotransformer_amd.config import make_cfg
+    from geotransformer_amd.model import create_model
+    monkeypatch.setattr(kernels, 'gemm_pack', lambda w, **kw: torch.zeros(16, dtype=torch.uint8))
+    monkeypatch.setattr(kernels, 'decoder_packs', lambda w, c: (torch.zeros(16, dtype=torch.uint8), torch.zeros(16, dtype=torch.uint8)))
+    small = {'backbone.init_dim': 16, 'backbone.group_norm': 4, 'backbone.output_dim': 32, 'geotransformer.hidden_dim': 32,
+             'geotransformer.output_dim': 32}
+    for exp, in_dim, stages in (('3dmatch', 256, 4), ('kitti', 512, 5), ('modelnet', 128, 3)):
+        model = create_model(make_cfg(exp, dict(small, **{'geotransformer.input_dim': in_dim})))
+        monkeypatch.setattr(model.transformer.embedding, 'tables', lambda: (torch.zeros(4, 4, 32), torch.zeros(4, 4, 32)), raising=False)
+        desc, keep = native.NativeModel(model)._build()
+        bb = desc.backbone
+        assert bb.num_stages == stages and bb.num_blocks == 2 + 3 * (stages - 1) and bb.num_decoders == stages - 1 - model.backbone.fine_stage
+        for d in range(bb.num_decoders):
+            assert bb.decoder_packed_latent[d] and bb.decoder_packed_skip[d] and bb.decoder[d].packed
+        assert desc.transformer.num_layers == 6 and desc.num_points_in_patch == model.num_points_in_patch
+        # the split point of every decoder weight: latent channels + skip channels = the Linear's input width
+        net = model.backbone
+        for i in range(stages - 2, net.fine_stage - 1, -1):
+            dec = getattr(net, f'decoder{i + 1}')
+            skip = getattr(net, f'encoder{i + 1}_{3 if i > 0 else 2}').out_channels
+            assert net.decoder_latent_channels(i) + skip == dec.mlp.weight.shape[1], (exp, i)
