@@ -151,13 +151,23 @@ __global__ __launch_bounds__(1024) void rg_bbox_kernel(const float* __restrict__
 
 // rows actually present (the launch is sized by the capacity): the clouds' headers hold their starts and lengths
 __device__ __forceinline__ int64_t rg_rows(const CloudGrid* hdr, int batch) { return hdr[batch - 1].s_start + hdr[batch - 1].s_len; }
+// cloud of stacked support row i: the last cloud that starts at or before it (an empty cloud shares its start with its successor, which
+// wins) -- a binary search over the monotone starts, 5 dependent loads for 32 clouds where the former walk took 16 on average (round 3)
+__device__ __forceinline__ int rg_cloud_of_row(const CloudGrid* hdr, int batch, int64_t i) {
+  int lo = 0, hi = batch - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (hdr[mid].s_start <= i) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
 
 __global__ void rg_count_kernel(const float* __restrict__ s, int batch, const CloudGrid* __restrict__ hdr,
                                 int* __restrict__ cell_cnt, int* __restrict__ cid) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rg_rows(hdr, batch)) return;
-  int b = 0;
-  while (b < batch - 1 && i >= hdr[b].s_start + hdr[b].s_len) ++b;
+  const int b = rg_cloud_of_row(hdr, batch, i);
   const CloudGrid g = hdr[b];
   const float* p = s + 3 * i;
   const int cx = cell_coord(p[0], g.mn[0], g.cs), cy = cell_coord(p[1], g.mn[1], g.cs),
@@ -218,8 +228,7 @@ __global__ void rg_scatter_kernel(const float* __restrict__ s, int batch, const 
                                   int* __restrict__ cell_cnt, float4* __restrict__ sorted) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rg_rows(hdr, batch)) return;
-  int b = 0;
-  while (b < batch - 1 && i >= hdr[b].s_start + hdr[b].s_len) ++b;
+  const int b = rg_cloud_of_row(hdr, batch, i);
   const int c = cid[i];
   const int pos = cell_start[c] + atomicSub(&cell_cnt[c], 1) - 1;
   const float* p = s + 3 * i;
@@ -508,9 +517,13 @@ __global__ __launch_bounds__(1024) void gs_bbox_kernel(const float* __restrict__
 __device__ __forceinline__ int64_t gs_rows(const GsCloud* hdr, int batch) { return hdr[batch - 1].start + hdr[batch - 1].len; }
 
 __device__ __forceinline__ int gs_cloud_of_point(const GsCloud* hdr, int batch, int64_t i) {
-  int b = 0;
-  while (b < batch - 1 && i >= hdr[b].start + hdr[b].len) ++b;
-  return b;
+  int lo = 0, hi = batch - 1;  // binary search over the monotone starts (see rg_cloud_of_row)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (hdr[mid].start <= i) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
 }
 
 // thread per point: voxel key (:32-35) -> open-addressing insert; first index & count per voxel
@@ -778,8 +791,7 @@ __global__ void rg_order_kernel(const float4* __restrict__ sorted, const CloudGr
                                 int* __restrict__ order) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rg_rows(hdr, batch)) return;
-  int b = 0;
-  while (b < batch - 1 && t >= hdr[b].s_start + hdr[b].s_len) ++b;
+  const int b = rg_cloud_of_row(hdr, batch, t);
   order[t] = (int)(hdr[b].s_start + (int64_t)__float_as_int(sorted[t].w));
 }
 
