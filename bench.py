@@ -296,6 +296,7 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
     _, pyr0, data0 = collate_with(on.restated(), sample[0]) if lib is not on.restated() else collated[0]
     torch.set_num_threads(min(avail, 16))
     out0 = mo.forward(sd, ocfg, data0)  # the parity reference for items[0] (in-process, 16 threads)
+    out0['_fine_cfg'] = ocfg['fine']    # oracle/parity.py re-runs the oracle's registration head in the HIP side's patch order
 
     legs = {}
     with tempfile.TemporaryDirectory() as tmp:

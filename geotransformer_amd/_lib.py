@@ -81,6 +81,9 @@ SIGNATURES = {
     'geotr_gemm_packed_stats_floats': (c_size, [c_ptr, c_i64, c_i64]),
     'geotr_gemm_packed_stats': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_int, c_int, c_ptr, c_i64, c_ptr,
                                         c_ptr]),
+    'geotr_gemm_packed_tail': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
+                                       c_i64, c_ptr]),
+    'geotr_group_norm_finalize': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr, c_ptr]),
     'geotr_gemm_packed_gather': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_int, c_int, c_ptr, c_i64, c_i64, c_ptr, c_i64,
                                          c_ptr, c_i64, c_ptr, c_ptr]),
     'geotr_group_norm_stats': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr,

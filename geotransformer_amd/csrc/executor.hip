@@ -274,6 +274,62 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
     const char* e = std::getenv("GEOTR_GN_SHORTCUT_FUSED");  // A/B switch for measurements: 0 = normalise the shortcut in its own pass
     return !(e && e[0] == '0');
   }();
+  static const bool tail_fused = [] {
+    const char* e = std::getenv("GEOTR_TAIL_FUSED");  // A/B switch for measurements: 0 = the tail's products are written, then normalised
+    return !(e && e[0] == '0');
+  }();
+  // ---- the block's tail  leaky(GN(unary2(y)) + shortcut)  WITHOUT an apply pass (round 3) -------------------------------------------
+  // unary2(y) and the shortcut Linear are small-K products (K = C/4 and C_in): writing them, re-reading them for the normalisation and
+  // writing the block output costs 5 passes over (m, C_out); here each product is launched twice -- once for its GroupNorm statistics
+  // only (nothing stored), once more with the finalised per-column scale / shift applied in its epilogue -- so only the block output
+  // (and, with a shortcut Linear, one normalised partial) is ever written: 2-3 passes.  Value for value the arithmetic of the apply
+  // kernel (multiply, add, add, LeakyReLU), so the result is bit-identical to the path below.  Needs both products on the unsplit
+  // packed path and GroupNorms on both (every reference config).
+  auto tail_ok = [&](const geotr_linear& l, const geotr_norm& nm, const float* a, int64_t lda) {
+    return nm.groups > 0 && use_packed(l.packed, a, lda, m, l.in) && geotr_gemm_packed_splitk_workspace_bytes(m, l.out, l.in) == 0;
+  };
+  if (tail_fused && gn_epilogue_stats && tail_ok(b.unary2, b.unary2_norm, y, b.unary2.in) &&
+      (!b.has_shortcut || (fuse_shortcut_norm && b.shortcut.out == b.unary2.out && tail_ok(b.shortcut, b.shortcut_norm, sc, b.shortcut.in)))) {
+    const int64_t C = b.unary2.out;
+    const int bf16 = c.gemm_bf16 ? 1 : 0;
+    float* out = c.alloc<float>((size_t)m * C);
+    const size_t mk = c.mark();
+    const size_t rec_floats = geotr_gemm_packed_stats_floats(c.seg_rows[q_stage], c.nseg, C);
+    const int64_t rpr = geotr_gemm_packed_stats_rows_per_record(C);
+    float* rec = c.alloc<float>(rec_floats);
+    float* ab_z = c.alloc<float>((size_t)c.nseg * 2 * C);
+    float* ab_t = b.has_shortcut ? c.alloc<float>((size_t)c.nseg * 2 * C) : nullptr;
+    float* part = b.has_shortcut ? c.alloc<float>((size_t)m * C) : nullptr;
+    if (c.live()) {
+      // statistics of z = unary2(y), then of t = shortcut(sc): the records are free again once their finalize kernel has run
+      c.check(geotr_gemm_packed_tail(y, b.unary2.in, b.unary2.packed, nullptr, C, m, C, b.unary2.in, b.unary2.b, 0, bf16, c.seg_rows[q_stage], c.nseg,
+                                     rec, nullptr, nullptr, 0, c.stream));
+      c.check(geotr_group_norm_finalize(rec, rpr, m, C, b.unary2_norm.groups, b.unary2_norm.gamma, b.unary2_norm.beta, b.unary2_norm.eps,
+                                        c.seg_rows[q_stage], c.nseg, ab_z, c.stream));
+      if (b.has_shortcut) {
+        c.check(geotr_gemm_packed_tail(sc, b.shortcut.in, b.shortcut.packed, nullptr, C, m, C, b.shortcut.in, b.shortcut.b, 0, bf16,
+                                       c.seg_rows[q_stage], c.nseg, rec, nullptr, nullptr, 0, c.stream));
+        c.check(geotr_group_norm_finalize(rec, rpr, m, C, b.shortcut_norm.groups, b.shortcut_norm.gamma, b.shortcut_norm.beta, b.shortcut_norm.eps,
+                                          c.seg_rows[q_stage], c.nseg, ab_t, c.stream));
+        // part = GN(z);  out = leaky(GN(t) + part)
+        c.check(geotr_gemm_packed_tail(y, b.unary2.in, b.unary2.packed, part, C, m, C, b.unary2.in, b.unary2.b, 0, bf16, c.seg_rows[q_stage], c.nseg,
+                                       nullptr, ab_z, nullptr, 0, c.stream));
+        ProfScope prof(c.stream);
+        c.check(geotr_gemm_packed_tail(sc, b.shortcut.in, b.shortcut.packed, out, C, m, C, b.shortcut.in, b.shortcut.b, 2, bf16, c.seg_rows[q_stage],
+                                       c.nseg, nullptr, ab_t, part, C, c.stream));
+        if (m < (1 << 24) && C < (1 << 12) && b.shortcut.in < (1 << 14)) prof.done(kProfGemm | (m << 26) | (C << 14) | b.shortcut.in);
+        else prof.done(0);
+      } else {  // identity shortcut (the block input, or its max-pool): out = leaky(GN(z) + sc)
+        ProfScope prof(c.stream);
+        c.check(geotr_gemm_packed_tail(y, b.unary2.in, b.unary2.packed, out, C, m, C, b.unary2.in, b.unary2.b, 2, bf16, c.seg_rows[q_stage], c.nseg,
+                                       nullptr, ab_z, sc, C, c.stream));
+        if (m < (1 << 24) && C < (1 << 12) && b.unary2.in < (1 << 14)) prof.done(kProfGemm | (m << 26) | (C << 14) | b.unary2.in);
+        else prof.done(0);
+      }
+    }
+    c.release(mk);
+    return out;
+  }
   if (b.has_shortcut) {
     GnStats st_sc;
     float* t = b.shortcut_norm.groups > 0 ? linear_gn(c, b.shortcut, sc, b.shortcut.in, m, q_stage, st_sc) : linear(c, b.shortcut, sc, b.shortcut.in, m, 0);

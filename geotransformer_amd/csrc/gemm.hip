@@ -52,6 +52,10 @@ struct GatherRes {
   int rows;
 };
 
+// `col_affine` (optional): per-column scale [0, N) and shift [N, 2N) of the tile's row segment, applied right after the bias as a multiply
+// and an add (two roundings: exactly what gn_apply2_kernel does to the stored value) -- the GroupNorm of this product applied in the
+// epilogue of a launch that RE-computes it once the statistics are known (the ResidualBlock tail, executor.hip).  C == nullptr: nothing
+// is stored (the statistics-only launch of that scheme).
 // `stats_rec` (optional): this wave's GroupNorm record -- per column the sum and the sum of squares of the values it STORES, over its
 // 32 * WM rows in ascending row order per lane, lanes combined by a fixed xor tree: [0, N) sums, [N, 2N) sums of squares (rows past M
 // and columns past N contribute nothing; a wave entirely past M writes zeros).  The record is a function of the tile's rows alone.
@@ -59,7 +63,8 @@ template <int WM, int WN>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float* slab, int lane, int row0, int col0, int M, int N,
                                              float alpha, const float* __restrict__ bias, const int32_t* __restrict__ row_div,
                                              const float* __restrict__ residual, int64_t ldr, int act, float* __restrict__ C, int64_t ldc,
-                                             float* __restrict__ stats_rec = nullptr, const GatherRes gr = GatherRes{nullptr, nullptr, 0, 0, 0}) {
+                                             float* __restrict__ stats_rec = nullptr, const GatherRes gr = GatherRes{nullptr, nullptr, 0, 0, 0},
+                                             const float* __restrict__ col_affine = nullptr) {
   constexpr int TW = 32 * WN, TS = TW + 4;
   const int fr = lane & 31, fk = lane >> 5;
 #pragma unroll
@@ -78,6 +83,12 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
                       (!residual || ((reinterpret_cast<uintptr_t>(residual) & 15) == 0 && ldr % 4 == 0)) &&
                       (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
   const bool full = vec_ok && gn + 3 < N;
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col_affine) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (gn + e < N) sc[e] = col_affine[gn + e], sh[e] = col_affine[N + gn + e];
+  }
   float bv[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
     if (full) {
@@ -103,6 +114,10 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] += bv[e];
+    if (col_affine) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = x[e] * sc[e] + sh[e];
+    }
     if (residual) {
       const float* rp = residual + (int64_t)gm * ldr + gn;
       if (full) {
@@ -133,13 +148,15 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
       if (act == 1) x[e] = fmaxf(x[e], 0.f);
       if (act == 2) x[e] = x[e] > 0.f ? x[e] : 0.1f * x[e];
     }
-    float* cp = C + (int64_t)gm * ldc + gn;
-    if (full) {
-      *reinterpret_cast<float4*>(cp) = make_float4(x[0], x[1], x[2], x[3]);
-    } else {
+    if (C) {
+      float* cp = C + (int64_t)gm * ldc + gn;
+      if (full) {
+        *reinterpret_cast<float4*>(cp) = make_float4(x[0], x[1], x[2], x[3]);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (gn + e < N) cp[e] = x[e];
+        for (int e = 0; e < 4; ++e)
+          if (gn + e < N) cp[e] = x[e];
+      }
     }
     if (stats_rec) {
 #pragma unroll
@@ -515,6 +532,7 @@ struct PackedArgs {
   int seg_row0[GEOTR_MAX_PAIRS + 1];
   float* stats;
   GatherRes gres;  // gathered residual (src == nullptr: none); unsplit launches only
+  const float* seg_affine;  // optional [nseg][2][N]: scale / shift per (row segment, column), applied after the bias (epilogue_lds)
 };
 
 __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b_is_kn, int N, int K, int KS, int64_t nvec,
@@ -578,8 +596,8 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ct0 = blockIdx.x * NT_BLK;
   int m0 = blockIdx.y * BM, m_end = g.M;  // this block's first row and the end of its row segment
+  int sgi = 0;
   if (g.nseg > 0) {
-    int sgi = 0;
     while (sgi + 1 < g.nseg && (int)blockIdx.y >= g.seg_tile0[sgi + 1]) ++sgi;
     m0 = g.seg_row0[sgi] + ((int)blockIdx.y - g.seg_tile0[sgi]) * BM;
     m_end = g.seg_row0[sgi + 1];
@@ -726,7 +744,8 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   float* slab = reinterpret_cast<float*>(psm) + wave * (32 * WM * (32 * WN + 4));
   if (gridDim.z == 1)
     epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act, g.C,
-                         g.ldc, g.stats ? g.stats + ((int64_t)blockIdx.y * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr, g.gres);
+                         g.ldc, g.stats ? g.stats + ((int64_t)blockIdx.y * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr, g.gres,
+                         g.seg_affine ? g.seg_affine + (int64_t)sgi * 2 * g.N : nullptr);
   else  // raw partial sums of this K slice; the epilogue runs in the reduce kernel
     epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, 1.0f, nullptr, nullptr, nullptr, 0, 0,
                          g.partial + (int64_t)blockIdx.z * g.M * g.N, g.N);
@@ -851,10 +870,10 @@ template <int TERMS>
 static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                               const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                               void* stream_, void* ws = nullptr, size_t ws_bytes = 0, const int64_t* seg_rows_host = nullptr, int64_t nseg = 0,
-                              float* stats = nullptr, const GatherRes* gres = nullptr) {
+                              float* stats = nullptr, const GatherRes* gres = nullptr, const float* seg_affine = nullptr) {
   GEOTR_CHECK_ARG(M >= 0 && N >= 1 && K >= 1, "gemm_packed: bad sizes");
   if (M == 0) return GEOTR_OK;
-  GEOTR_CHECK_ARG(A && packed && C, "gemm_packed: null pointer");
+  GEOTR_CHECK_ARG(A && packed && (C || stats), "gemm_packed: null pointer");
   GEOTR_CHECK_ARG(M < (1ll << 31) && N < (1ll << 24) && K < (1ll << 24), "gemm_packed: size out of range");
   GEOTR_CHECK_ARG(act >= 0 && act <= 2, "gemm_packed: unknown activation %d", act);
   const int64_t np = pack_pad32(N), kp = pack_pad32(K);
@@ -866,6 +885,7 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   g.nseg = 0;
   g.stats = stats;
   g.gres = gres ? *gres : GatherRes{nullptr, nullptr, 0, 0, 0};
+  g.seg_affine = seg_affine;
   int64_t tiles = (M + 127) / 128;
   if (nseg > 0) {  // segment-aligned row tiles
     GEOTR_CHECK_ARG(seg_rows_host && nseg <= GEOTR_MAX_PAIRS, "gemm_packed: 1..%d row segments", GEOTR_MAX_PAIRS);
@@ -880,7 +900,7 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
     for (int64_t q = nseg; q <= GEOTR_MAX_PAIRS; ++q) g.seg_tile0[q] = (int)tiles, g.seg_row0[q] = (int)row;
     g.nseg = (int)nseg;
   }
-  int splits = ws && !stats && !g.gres.src ? packed_splits(M, N, K) : 1;  // statistics / the gathered residual live in the unsplit epilogue
+  int splits = ws && !stats && !g.gres.src && !seg_affine ? packed_splits(M, N, K) : 1;  // statistics / gathered residual / affine: unsplit epilogue
   if (splits > 1 && ws_bytes < sizeof(float) * (size_t)splits * (size_t)M * (size_t)N) splits = 1;  // never more than the caller's scratch holds
   const int nkt_all = g.KS / 2;
   g.kt_split = (nkt_all + splits - 1) / splits;
@@ -948,6 +968,19 @@ extern "C" int geotr_gemm_packed_stats(const float* A, int64_t lda, const void* 
   if (bf16_operands)
     return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, nullptr, 0, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg, stats);
   return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, row_div, nullptr, 0, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg, stats);
+}
+
+extern "C" int geotr_gemm_packed_tail(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                      const float* bias, int act, int bf16_operands, const int64_t* seg_rows_host, int64_t nseg, float* stats,
+                                      const float* seg_affine, const float* residual, int64_t ldr, void* stream) {
+  GEOTR_CHECK_ARG(seg_rows_host && nseg >= 1, "gemm_packed_tail: the row segments are required");
+  GEOTR_CHECK_ARG((C != nullptr) || (stats != nullptr && !seg_affine && !residual), "gemm_packed_tail: no output requested");
+  GEOTR_CHECK_ARG(!seg_affine || (reinterpret_cast<uintptr_t>(seg_affine) & 3) == 0, "gemm_packed_tail: unaligned affine table");
+  if (bf16_operands)
+    return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, residual, ldr, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg,
+                                 stats, nullptr, seg_affine);
+  return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, residual, ldr, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg,
+                               stats, nullptr, seg_affine);
 }
 
 extern "C" int geotr_gemm_packed_gather(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

@@ -719,6 +719,31 @@ int geotr_group_norm_stats(const float* x, int64_t n, int64_t c, int64_t groups,
                          seg_rows_host, nseg, stats_ws, row_positive, stream_, x_stats, x_rows_per_record, res_stats, res_rows_per_record);
 }
 
+// The finalize step alone: statistics records of a producer (geotr_gemm_packed_stats / _tail) -> per (segment, channel) scale and shift,
+// seg_affine[s][0][c] = rstd * gamma[c], seg_affine[s][1][c] = beta[c] - mean * rstd * gamma[c]  (nseg x 2c floats), which a later GEMM
+// launch applies in its epilogue (geotr_gemm_packed_tail) -- the apply pass over the tensor disappears.
+int geotr_group_norm_finalize(const float* stats, int64_t rows_per_record, int64_t n, int64_t c, int64_t groups, const float* gamma,
+                              const float* beta, float eps, const int64_t* seg_rows_host, int64_t nseg, float* seg_affine, void* stream_) {
+  GEOTR_CHECK_ARG(stats && gamma && beta && seg_affine && seg_rows_host, "group_norm_finalize: null pointer");
+  GEOTR_CHECK_ARG(n >= 1 && c >= 1 && groups >= 1 && c % groups == 0 && nseg >= 1 && nseg <= GEOTR_MAX_PAIRS, "group_norm_finalize: bad sizes");
+  GEOTR_CHECK_ARG(rows_per_record == 32 || rows_per_record == 64, "group_norm_finalize: producer statistics come in records of 32 or 64 rows");
+  GnSegs sg, psg;
+  sg.nseg = (int)nseg;
+  int64_t row = 0;
+  for (int s = 0; s < (int)nseg; ++s) {
+    GEOTR_CHECK_ARG(seg_rows_host[s] >= 1, "group_norm_finalize: empty row segment %d", s);
+    sg.row0[s] = row, sg.blk0[s] = 0, sg.rpb[s] = (int)rows_per_record;
+    row += seg_rows_host[s];
+  }
+  sg.row0[nseg] = row;
+  GEOTR_CHECK_ARG(row == n, "group_norm_finalize: segments cover %lld rows, expected %lld", (long long)row, (long long)n);
+  gn_producer_segs(sg, seg_rows_host, rows_per_record, psg);
+  gn_group_kernel<<<dim3((unsigned)groups, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream_>>>(stats, psg, (int)c, (int)groups, gamma, beta, eps,
+                                                                                                seg_affine);
+  GEOTR_CHECK_LAUNCH("group_norm_finalize");
+  return GEOTR_OK;
+}
+
 int geotr_group_norm(const float* x, int64_t n, int64_t c, int64_t groups, const float* gamma, const float* beta,
                      float eps, const float* residual, int act, float* out, double* stats_ws, void* stream_) {
   if (n == 0) return GEOTR_OK;

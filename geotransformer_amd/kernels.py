@@ -174,6 +174,49 @@ def group_norm_stats(x, groups, weight, bias, eps=1e-5, x_stats=None, x_rpr=0, r
     return out
 
 
+def residual_tail(y, weight, bias, norm, shortcut, sc_weight=None, sc_bias=None, sc_norm=None, seg_rows=None):
+    """leaky(GN(y W^T + b) + S) with S = shortcut, or GN'(shortcut W_s^T + b_s) when the shortcut has its own Linear + norm -- the tail of
+    a ResidualBlock (kpconv/modules.py:204-224) WITHOUT an apply pass: every product is launched once for its statistics only and once
+    more with its GroupNorm applied in the epilogue (geotr_gemm_packed_tail, geotr_group_norm_finalize), as the native executor does.
+    norm / sc_norm = (groups, gamma, beta, eps).  Bit-identical to linear_gn + group_norm_stats.  Packed-path shapes only."""
+    import ctypes
+    lib = _lib.load()
+    y, shortcut = _f32c(y), _f32c(shortcut)
+    M, K = y.shape
+    C = weight.shape[0]
+    assert use_packed(y) and lib.geotr_gemm_packed_splitk_workspace_bytes(M, C, K) == 0
+    segs = [M] if seg_rows is None else [int(r) for r in seg_rows]
+    seg_arr = (ctypes.c_int64 * len(segs))(*segs)
+    bf16 = int(GEMM_PACKED == 'bf16')
+    rec = torch.empty(lib.geotr_gemm_packed_stats_floats(seg_arr, len(segs), C), dtype=torch.float32, device=y.device)
+    rpr = int(lib.geotr_gemm_packed_stats_rows_per_record(C))
+    out = torch.empty((M, C), dtype=torch.float32, device=y.device)
+
+    def stats_of(a, w, b, nm):
+        _lib.check(lib.geotr_gemm_packed_tail(_lib.ptr(a), a.stride(0), _lib.ptr(gemm_pack(w)), None, C, M, C, a.shape[1], _lib.ptr(b), 0, bf16,
+                                              seg_arr, len(segs), _lib.ptr(rec), None, None, 0, _lib.stream_ptr()), 'geotr_gemm_packed_tail')
+        ab = torch.empty((len(segs), 2, C), dtype=torch.float32, device=y.device)
+        _lib.check(lib.geotr_group_norm_finalize(_lib.ptr(rec), rpr, M, C, int(nm[0]), _lib.ptr(nm[1]), _lib.ptr(nm[2]), float(nm[3]), seg_arr,
+                                                 len(segs), _lib.ptr(ab), _lib.stream_ptr()), 'geotr_group_norm_finalize')
+        return ab
+
+    def apply(a, w, b, ab, dst, residual, act):
+        _lib.check(lib.geotr_gemm_packed_tail(_lib.ptr(a), a.stride(0), _lib.ptr(gemm_pack(w)), _lib.ptr(dst), C, M, C, a.shape[1], _lib.ptr(b),
+                                              ACT[act], bf16, seg_arr, len(segs), None, _lib.ptr(ab), _lib.ptr(residual),
+                                              residual.stride(0) if residual is not None else 0, _lib.stream_ptr()), 'geotr_gemm_packed_tail')
+
+    ab_z = stats_of(y, weight, bias, norm)
+    if sc_weight is None:
+        apply(y, weight, bias, ab_z, out, shortcut, 'leaky')
+    else:
+        assert use_packed(shortcut) and lib.geotr_gemm_packed_splitk_workspace_bytes(M, C, shortcut.shape[1]) == 0
+        ab_t = stats_of(shortcut, sc_weight, sc_bias, sc_norm)
+        part = torch.empty_like(out)
+        apply(y, weight, bias, ab_z, part, None, None)
+        apply(shortcut, sc_weight, sc_bias, ab_t, out, part, 'leaky')
+    return out
+
+
 DECODER_SPLIT = os.environ.get('GEOTR_DECODER_SPLIT', '1') != '0'  # same A/B switch as the native executor
 
 

@@ -160,6 +160,14 @@ size_t geotr_gemm_packed_stats_floats(const int64_t* seg_rows_host, int64_t nseg
 int geotr_gemm_packed_stats(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                             const float* bias, const int32_t* row_div, int act, int bf16_operands, const int64_t* seg_rows_host,
                             int64_t nseg, float* stats, void* stream);
+/* The ResidualBlock tail without its apply pass (kpconv/modules.py:204-224: leaky(GN(unary2(y)) + shortcut)): a product whose GroupNorm
+ * is applied in its own epilogue.  Launch 1 (C NULL, stats given): statistics only, nothing stored.  geotr_group_norm_finalize turns the
+ * records into seg_affine.  Launch 2 (seg_affine given): C = act((A W^T + bias) * scale + shift + residual), the product re-computed
+ * (small K: cheaper than writing it, re-reading it and re-writing it normalised) -- value for value what geotr_group_norm_stats would
+ * have stored (multiply, add, add, activation: the same roundings).  Rows are tiled segment by segment as in geotr_gemm_packed_stats. */
+int geotr_gemm_packed_tail(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                           const float* bias, int act, int bf16_operands, const int64_t* seg_rows_host, int64_t nseg, float* stats,
+                           const float* seg_affine, const float* residual, int64_t ldr, void* stream);
 /* C = act(A W^T + bias + G), G[row, :] = gathered[index[row * ld_index], :] where that index is < gathered_rows, else 0 (the pad row of a
  * nearest-upsample table, kpconv/functional.py:6-22): the fine-level half of a decoder layer with the coarse-level half gathered into
  * the epilogue.  Optional GroupNorm statistics as geotr_gemm_packed_stats (stats NULL: plain row tiling, segments ignored). */
@@ -252,6 +260,10 @@ int geotr_group_norm_stats(const float* x, int64_t n, int64_t c, int64_t groups,
                            const float* x_stats, int64_t x_rows_per_record, const float* residual, const float* res_stats,
                            int64_t res_rows_per_record, int64_t res_groups, const float* res_gamma, const float* res_beta, float res_eps, int act,
                            float* out, const int64_t* seg_rows_host, int64_t nseg, double* stats_ws, uint8_t* row_positive, void* stream);
+/* Only the finalize step: a producer's statistics records -> seg_affine (nseg x 2c floats: per segment the c scales, then the c shifts)
+ * for geotr_gemm_packed_tail's epilogue. */
+int geotr_group_norm_finalize(const float* stats, int64_t rows_per_record, int64_t n, int64_t c, int64_t groups, const float* gamma,
+                              const float* beta, float eps, const int64_t* seg_rows_host, int64_t nseg, float* seg_affine, void* stream);
 int geotr_layer_norm(const float* x, const float* residual, int64_t n, int64_t c, const float* gamma, const float* beta,
                      float eps, float* out, void* stream);
 

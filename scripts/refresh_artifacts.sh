@@ -50,3 +50,6 @@ timeout 300 python $ROOT/bench.py --config modelnet --no-fp32-mode > $OUT/bench_
 python $ROOT/scripts/other_configs_summary.py $OUT/other_configs.md modelnet=$OUT/bench_modelnet.json kitti=$OUT/bench_kitti.json lomatch_bf16=$OUT/bench_lomatch_bf16.json
 head -12 $OUT/other_configs.md
 ls -la $OUT | head -40
+# KITTI with the synchronous lane loop (same box): is the pipelined loop a loss for the 2 x 4 launch shape?
+GEOTR_PIPELINED=0 timeout 400 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 4 --no-fp32-mode --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('kitti_synchronous_lanes', d['value'], d['ms_per_step'])" | tee -a $OUT/ab_runs.txt
+timeout 400 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 4 --no-fp32-mode --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('kitti_default', d['value'], d['ms_per_step'])" | tee -a $OUT/ab_runs.txt

@@ -282,3 +282,32 @@ def test_decoder_linear_without_the_concatenation(lat_ch, skip_ch, n_out, nc, m,
     for rows in (segs or [m]):
         assert torch.allclose(out[r0:r0 + rows], kernels.group_norm(y[r0:r0 + rows].contiguous(), 8, gamma, beta, act='leaky'), rtol=2e-5, atol=2e-5)
         r0 += rows
+
+
+@pytest.mark.parametrize('mid,c_in,c_out,segs,linear_shortcut', [(32, 64, 128, [5000, 3333, 700], True), (64, 256, 256, [4000, 4100], False),
+                                                                 (128, 256, 512, [2100], True), (32, 128, 128, [1500, 1501], False)])
+def test_residual_tail_without_the_apply_pass_is_bitwise_the_apply_pass(mid, c_in, c_out, segs, linear_shortcut):
+    """geotr_gemm_packed_tail + geotr_group_norm_finalize (round 3): leaky(GN(unary2(y)) + shortcut) with every product launched once for
+    its statistics and once more with the GroupNorm applied in its epilogue -- bit for bit what the statistics-epilogue + apply-pass
+    path (linear_gn + group_norm_stats) stores, for an identity shortcut and for a shortcut with its own Linear + GroupNorm."""
+    from geotransformer_amd import kernels
+    g = torch.Generator().manual_seed(mid + c_out + len(segs))
+    M = sum(segs)
+    y = torch.randn(M, mid, generator=g).cuda()
+    w2, b2 = (torch.randn(c_out, mid, generator=g) * 0.2).cuda(), torch.randn(c_out, generator=g).cuda()
+    g2, be2 = (torch.rand(c_out, generator=g) + 0.5).cuda(), torch.randn(c_out, generator=g).cuda()
+    groups = 8
+    z, sz, rpr = kernels.linear_gn(y, w2, b2, seg_rows=segs)
+    if linear_shortcut:
+        x = torch.randn(M, c_in, generator=g).cuda()
+        ws, bs = (torch.randn(c_out, c_in, generator=g) * 0.1).cuda(), torch.randn(c_out, generator=g).cuda()
+        gs, bes = (torch.rand(c_out, generator=g) + 0.5).cuda(), torch.randn(c_out, generator=g).cuda()
+        t, st, _ = kernels.linear_gn(x, ws, bs, seg_rows=segs)
+        want = kernels.group_norm_stats(z, groups, g2, be2, x_stats=sz, x_rpr=rpr, residual=t, res_stats=st, res_rpr=rpr,
+                                        res_norm=(4, gs, bes, 1e-5), act='leaky', seg_rows=segs)
+        got = kernels.residual_tail(y, w2, b2, (groups, g2, be2, 1e-5), x, ws, bs, (4, gs, bes, 1e-5), seg_rows=segs)
+    else:
+        x = torch.randn(M, c_out, generator=g).cuda()
+        want = kernels.group_norm_stats(z, groups, g2, be2, x_stats=sz, x_rpr=rpr, residual=x, act='leaky', seg_rows=segs)
+        got = kernels.residual_tail(y, w2, b2, (groups, g2, be2, 1e-5), x, seg_rows=segs)
+    assert torch.equal(got, want)
