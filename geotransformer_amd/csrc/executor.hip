@@ -275,10 +275,15 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
     return !(e && e[0] == '0');
   }();
   static const bool tail_fused = [] {
-    const char* e = std::getenv("GEOTR_TAIL_FUSED");  // A/B switch for measurements: 0 = the tail's products are written, then normalised
-    return !(e && e[0] == '0');
+    // OPT-IN experiment (GEOTR_TAIL_FUSED=1), off by default: measured 2-3 % SLOWER than the apply-pass path below (1 067 / 1 062 vs
+    // 1 084 / 1 091 pairs/s, one lane 829 vs 857; profiles/r03_ab_runs.md) -- launching each small-K product twice costs more than the two
+    // passes over (m, C_out) it saves -- and the 4-lane determinism gate failed once with it on (unexplained).  Kept as a switch
+    // together with its entry points (geotr_gemm_packed_tail, geotr_group_norm_finalize: bit-identical to the apply path in the unit
+    // test) so that the negative result can be re-measured.
+    const char* e = std::getenv("GEOTR_TAIL_FUSED");
+    return e && e[0] == '1';
   }();
-  // ---- the block's tail  leaky(GN(unary2(y)) + shortcut)  WITHOUT an apply pass (round 3) -------------------------------------------
+  // ---- the block's tail  leaky(GN(unary2(y)) + shortcut)  WITHOUT an apply pass (round 3; opt-in, see the switch above) -------------
   // unary2(y) and the shortcut Linear are small-K products (K = C/4 and C_in): writing them, re-reading them for the normalisation and
   // writing the block output costs 5 passes over (m, C_out); here each product is launched twice -- once for its GroupNorm statistics
   // only (nothing stored), once more with the finalised per-column scale / shift applied in its epilogue -- so only the block output
