@@ -59,7 +59,12 @@ def test_bench_workload_stacked_lanes_match_oracle():
         # the same stack on whatever lane picked it up: bit-identical (nothing in the path depends on the stream or on timing) --
         # heads, features, superpoint patches, and every table of the stack's pyramid
         for k in keys + more:
-            assert torch.equal(got[(0, j)][k], got[(1, j)][k]), f'slot {j}: {k} differs between two runs of the same stack'
+            a, b = got[(0, j)][k], got[(1, j)][k]
+            if not (a.shape == b.shape and torch.equal(a, b)):  # say HOW it differs: last-bit noise and a wrong block look different
+                bad = (a != b) if a.shape == b.shape else None
+                detail = (f'{int(bad.sum())} of {bad.numel()} elements, max |d| {float((a.float() - b.float()).abs().max()):.3g}, first rows '
+                          f'{bad.reshape(bad.shape[0], -1).any(1).nonzero().flatten()[:8].tolist()}' if bad is not None else f'shapes {a.shape} {b.shape}')
+                raise AssertionError(f'slot {j}: {k} differs between two runs of the same stack ({detail})')
         if j % STACK == 0:
             a, b = got[(0, j)]['_stack_pyramid'], got[(1, j)]['_stack_pyramid']
             for key in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling'):
