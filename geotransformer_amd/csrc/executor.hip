@@ -277,9 +277,8 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
   static const bool tail_fused = [] {
     // OPT-IN experiment (GEOTR_TAIL_FUSED=1), off by default: measured 2-3 % SLOWER than the apply-pass path below (1 067 / 1 062 vs
     // 1 084 / 1 091 pairs/s, one lane 829 vs 857; profiles/r03_ab_runs.md) -- launching each small-K product twice costs more than the two
-    // passes over (m, C_out) it saves -- and the 4-lane determinism gate failed once with it on (unexplained).  Kept as a switch
-    // together with its entry points (geotr_gemm_packed_tail, geotr_group_norm_finalize: bit-identical to the apply path in the unit
-    // test) so that the negative result can be re-measured.
+    // passes over (m, C_out) it saves.  Kept as a switch together with its entry points (geotr_gemm_packed_tail,
+    // geotr_group_norm_finalize: bit-identical to the apply path in the unit test) so that the negative result can be re-measured.
     const char* e = std::getenv("GEOTR_TAIL_FUSED");
     return e && e[0] == '1';
   }();

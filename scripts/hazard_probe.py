@@ -58,7 +58,10 @@ def main():
     from geotransformer_amd.synthetic import make_pair
     label = os.environ.get('LABEL', 'run')
     lanes, reps, stack = int(os.environ.get('LANES', '4')), int(os.environ.get('REPS', '24')), int(os.environ.get('STACK', '8'))
-    kernels.set_precision('bf16x3')
+    if os.environ.get('GSE', 'table') == 'table':
+        kernels.set_precision('bf16x3')
+    else:
+        kernels.set_precision('bf16x3', gse=os.environ['GSE'])  # GSE=mfma: the embedding on the round-1 MFMA kernel
     cfg = make_cfg('3dmatch')
     torch.manual_seed(cfg.seed)
     np.random.seed(cfg.seed)
@@ -132,15 +135,17 @@ def main():
     runner.close()
 
     # ---- determinism: digest of every (slot, key) per submission vs the majority over submissions ----
-    bad_reps, bad_keys = set(), Counter()
+    bad_reps, bad_keys, bad_list = set(), Counter(), []
     for (j, k), per_rep in hashes.items():
         major, _ = Counter(per_rep.values()).most_common(1)[0]
         for rep, h in per_rep.items():
             if h != major:
                 bad_reps.add(rep)
                 bad_keys[k] += 1
+                bad_list.append((rep, j, k))
     res = {'label': label, 'lanes': lanes, 'stack': stack, 'submissions': reps, 'submissions_with_any_difference': len(bad_reps),
-           'differing_outputs_by_key': dict(bad_keys), 'seconds': round(dt, 1),
+           'differing_outputs_by_key': dict(bad_keys),
+           'first_differences_rep_slot_key': sorted(bad_list)[:40], 'seconds': round(dt, 1),
            'env': {k: os.environ[k] for k in sorted(os.environ) if k.startswith(('GEOTR_', 'GPU_', 'AMD_', 'HSA_', 'PYTORCH_', 'HIP_', 'ROC'))}}
 
     # ---- the probe's stale words ----

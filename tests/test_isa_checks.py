@@ -5,6 +5,7 @@ compiler does not know the destination registers are still being filled.  script
 in flight" register set over each kernel's control-flow graph and fails if any instruction touches such a register -- a violation
 would be silent data corruption that a parity test can miss when the data happens to land in time.  hipcc cross-compiles here."""
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -45,27 +46,61 @@ def test_no_instruction_touches_an_in_flight_lds_fragment(tmp_path, source, pref
     assert all(int(ln.split(': ')[1].split()[0]) > 0 for ln in lines), chk.stdout[-2000:]
 
 
-def test_matching_heads_are_compiled_without_packed_fp32_shuffles(tmp_path):
-    """profiles/r03_concurrency_hazard.md: the one build of p2n_assign that misassigned points under multi-stream load was the
-    SLP-vectorised one (ds_read2_b32 results consumed through v_pk_mov_b32 / op_sel'd v_pk_mul_f32).  matching.hip is therefore
-    compiled with -fno-slp-vectorize; this pins the shipped ISA of the kernels that take discrete decisions: no v_pk_mov_b32 anywhere
-    in the file, no packed fp32 arithmetic at all in the three consumers of the pyramid's point arrays."""
+# kernels whose packed fp32 code is WRITTEN as such (float2 / ext-vector arithmetic in the source, formed by the backend, not by the SLP
+# vectoriser); everything else must come out of the compiler as scalar fp32 VALU code
+EXPLICIT_PACKED = ('kpconv_gather_kernel', 'l2_normalize_kernel', 'lgr_score_kernel', 'nc_overlap_kernel', 'patch_sinkhorn_kernel',
+                   'attn_softmax_kernel', 'attn_softmax_grouped_kernel', 'attn_pos_softmax_kernel', 'attn_pos_softmax_grouped_kernel',
+                   'gse_embed_table_kernelILi128E')
+LANE_HALF_SHUFFLES = ('kpconv_gather_kernel',)  # op_sel'd broadcasts of one neighbour weight over a channel pair, written by hand
+
+
+def _packed_fp32_by_kernel(asm):
+    name, packed = None, {}
+    for line in open(asm):
+        label = re.match(r'^(_Z\w+):', line)  # "<mangled name>:   ; @<mangled name>"
+        if label:
+            name = label.group(1)
+        elif name and 'v_pk_' in line and not line.lstrip().startswith(';'):
+            packed.setdefault(name, []).append(line.strip())
+    return packed
+
+
+def test_no_kernel_carries_slp_vectorised_packed_fp32_code(tmp_path):
+    """profiles/r03_concurrency_hazard.md: the two builds that returned wrong values under multi-stream load (p2n_assign's distance loop,
+    the index computation of gse_embed_table) were the ones the SLP vectoriser had turned into packed fp32 sequences with lane-half
+    shuffles (v_pk_mov_b32 ... op_sel, op_sel'd v_pk_mul_f32 / v_pk_add_f32); the same sources without the vectoriser never failed.
+    Every file is therefore compiled with -fno-slp-vectorize, and this pins the shipped ISA of ALL of them: no v_pk_mov_b32 anywhere,
+    packed fp32 arithmetic only in the kernels that spell it out in the source, op_sel'd packed arithmetic only in kpconv_gather."""
     if not os.path.exists(HIPCC):
         pytest.skip('hipcc not available')
     mk = open(os.path.join(CSRC, 'Makefile')).read()
-    assert 'FLAGS_matching := -fno-slp-vectorize' in mk and '$(FLAGS_$*)' in mk
-    asm = str(tmp_path / 'matching.s')
-    cmd = [HIPCC] + _flags() + ['-fno-slp-vectorize', '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only', os.path.join(CSRC, 'matching.hip'),
-                                '-o', asm]
-    res = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
-    assert res.returncode == 0, res.stderr[-2000:]
-    name, packed = None, {}
-    for line in open(asm):
-        if line.startswith('_Z') and line.rstrip().endswith(':'):
-            name = line.strip()[:-1]
-        elif name and 'v_pk_' in line and not line.lstrip().startswith(';'):
-            packed.setdefault(name, []).append(line.split()[0])
-    assert not any(op == 'v_pk_mov_b32' for ops in packed.values() for op in ops), {k: v for k, v in packed.items() if 'v_pk_mov_b32' in v}
+    assert '-fno-slp-vectorize' in _flags() and '$(FLAGS)' in mk
+    sources = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+    assert len(sources) >= 11
+
+    def compile_one(src):
+        asm = str(tmp_path / (src[:-4] + '.s'))
+        cmd = [HIPCC] + _flags() + ['-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only', os.path.join(CSRC, src), '-o', asm]
+        res = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+        assert res.returncode == 0, res.stderr[-2000:]
+        return src, _packed_fp32_by_kernel(asm)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        per_file = dict(pool.map(compile_one, sources))
+    seen_kernels = 0
+    for src, packed in per_file.items():
+        for kernel, ops in packed.items():
+            seen_kernels += 1
+            assert not any(op.startswith('v_pk_mov_b32') for op in ops), (src, kernel)
+            arith = [op for op in ops if op.startswith(('v_pk_mul_f32', 'v_pk_add_f32', 'v_pk_fma_f32'))]
+            if arith:
+                assert any(tag in kernel for tag in EXPLICIT_PACKED), (src, kernel, arith[:4])
+            if any('op_sel' in op for op in arith):
+                assert any(tag in kernel for tag in LANE_HALF_SHUFFLES), (src, kernel, [op for op in arith if 'op_sel' in op][:4])
+    assert seen_kernels >= 10  # the explicit kernels were found at all (guards against the mnemonics changing under the check)
+    # the kernels that take discrete decisions on the pyramid's point arrays: no packed fp32 arithmetic at all
     for kernel in ('p2n_assign_kernel', 'p2n_knn_kernel', 'patch_gather_kernel'):
-        hits = {k: v for k, v in packed.items() if kernel in k and any(op.startswith(('v_pk_mul_f32', 'v_pk_add_f32', 'v_pk_fma_f32')) for op in v)}
+        hits = {k: v for k, v in per_file['matching.hip'].items() if kernel in k and
+                any(op.startswith(('v_pk_mul_f32', 'v_pk_add_f32', 'v_pk_fma_f32')) for op in v)}
         assert not hits, hits
