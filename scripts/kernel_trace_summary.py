@@ -1,5 +1,5 @@
 """profiles/rNN_kernel_trace.md from two `rocprofv3 --kernel-trace --stats` runs of bench.py (default lanes, one lane).
-usage: python scripts/kernel_trace_summary.py OUT.md STATS.csv BENCH.json STATS_ONE_LANE.csv BENCH_ONE_LANE.json"""
+usage: python scripts/kernel_trace_summary.py OUT.md STATS.csv BENCH.json STATS_ONE_LANE.csv BENCH_ONE_LANE.json [UNPROFILED_BENCH.json]"""
 import csv
 import json
 import sys
@@ -22,14 +22,41 @@ def table(stats_csv, bench_json, top=32):
     return head + body
 
 
+def agreement(stats_csv, bench_json):
+    """The bench line's live `roofline.avg_launch_us` (HIP event brackets around every 8th packed-GEMM launch, split-K reduce included)
+    against rocprofv3's kernel durations of the SAME process."""
+    d = json.load(open(bench_json))
+    r = d['roofline']
+    fam = [x for x in csv.DictReader(open(stats_csv)) if 'gemm_packed_kernel' in x['Name'] or 'gemm_splitk_reduce' in x['Name']]
+    total = sum(float(x['TotalDurationNs']) for x in fam)
+    launches = sum(int(x['Calls']) for x in fam if 'gemm_packed_kernel' in x['Name'])
+    prof = total / launches / 1e3
+    return (f"| {d['config']['lanes_per_gpu']} | {r['avg_launch_us']} ({r['launches']} bracketed launches) | {prof:.1f} ({launches} launches, "
+            f"{total / 1e6:.1f} ms) | {r['avg_launch_us'] / prof:.2f} |\n")
+
+
 def main():
     out, s4, b4, s1, b1 = sys.argv[1:6]
+    plain = ''
+    if len(sys.argv) > 6:  # the unprofiled bench line of the same session
+        plain = f"(the unprofiled bench line of the same box reads {json.load(open(sys.argv[6]))['roofline']['avg_launch_us']} us)"
     with open(out, 'w') as f:
         f.write('# `rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode` '
                 '(and the same with `--lanes 1 --steps 6 --warmup 2`)\n\nFull tables: the `rNN_rocprofv3_kernel_stats*.csv` files next to this one '
                 '(rocprofv3 stats output, unedited).\n\n'
                 '## the default configuration\n\n' + table(s4, b4) +
-                '\n## one lane (`--lanes 1`): launch durations without contention from other lanes\n\n' + table(s1, b1))
+                '\n## one lane (`--lanes 1`): launch durations without contention from other lanes\n\n' + table(s1, b1) +
+                '\n## the bench line\'s live launch duration against the profiler, same process\n\n'
+                'Dominant family = the packed GEMMs (`gemm_packed_kernel<*>` + `gemm_splitk_reduce_kernel` of a split launch).  The bench line '
+                'times a SAMPLE of launches with HIP events on the launch stream; rocprofv3 times every kernel from its first to its last wave.\n\n'
+                '| lanes | bench line: `roofline.avg_launch_us` | rocprofv3: family time / packed launches, us | ratio |\n|---|---|---|---|\n' +
+                agreement(s1, b1) + agreement(s4, b4) +
+                '\nWith one lane the two agree to a few per cent.  With four lanes the event brackets read longer than the profiler\'s per-kernel '
+                'durations.  The likely reason (not separated by a measurement): a bracket also contains the time its launch spends queued '
+                'behind the other lanes\' kernels before its first wave starts -- the previous command\'s stop event has fired, the kernel has '
+                'not been dispatched yet -- which a per-kernel duration excludes; under the profiler every dispatch is slower, which widens '
+                'that gap ' + plain + '.  The bench line\'s in-flight figure is the larger one, '
+                'i.e. its roofline fraction is the more conservative of the two; the one-lane pair is the like-for-like check.\n')
 
 
 if __name__ == '__main__':

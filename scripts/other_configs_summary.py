@@ -1,6 +1,8 @@
 """Summarise the bench lines of the non-headline configurations (BASELINE configs[0], [3], [4]) into a profiles/ markdown table.
 usage: python scripts/other_configs_summary.py OUT.md name=path.json [name=path.json ...]"""
 import json
+import os
+import re
 import sys
 
 
@@ -22,10 +24,12 @@ def main():
                     f"| {name} | {d['value']} | {d['ms_per_step']} | {shape} | {c['matrix_precision']} | not run | - |")
         details.append(f"### {name}\n\n`{c['workload']}`\n\n```json\n{json.dumps({'parity': p, 'cpu_baseline': b, 'roofline': {k: v for k, v in (d.get('roofline') or {}).items() if k in ('kernel', 'achieved', 'peak', 'frac', 'executed_tflops', 'avg_launch_us', 'launches')}}, indent=1)}\n```\n")
     with open(out, 'w') as f:
-        f.write('# Round 2: the other BASELINE configurations through the same `bench.py` line\n\n'
+        tag = re.search(r'r(\d+)', os.path.basename(out))  # profiles/r03_other_configs.md -> round 3 (scratch outputs: round from $ROUND)
+        rnd = int(tag.group(1)) if tag else int(os.environ.get('ROUND', '0'))
+        f.write(f'# Round {rnd}: the other BASELINE configurations through the same `bench.py` line\n\n'
                 'Each run: `python bench.py --config <name> [--precision bf16]` on one MI355X (synthetic pairs of the configuration\'s shape, '
                 'random weights); `parity` = pair 0 of the last timed step vs the CPU oracle (oracle/parity.py), `cpu` = the CPU baseline '
-                'of the same workload (pairs/s, collate + forward).  The headline metric is the default run (profiles/r02_bench_n1.json).\n\n'
+                'of the same workload (pairs/s, collate + forward).  The headline metric is the default run (profiles/r' + f'{rnd:02d}' + '_bench_n1.json).\n\n'
                 '| run | pairs/s | ms/step | lanes x stacked pairs | matrix precision | parity | cpu pairs/s |\n|---|---|---|---|---|---|---|\n')
         f.write('\n'.join(rows) + '\n\n' + '\n'.join(details))
 
