@@ -8,8 +8,10 @@ with one kind of load:
   gemm    this library's packed split-bf16 GEMM (v_mfma_f32_32x32x16_bf16, operands DMA'd into an LDS ring) on a tall operand
   gemm_bf16 / gemm_fp32   the same with plain bf16 operands / this library's exact-fp32 GEMM (v_mfma_f32_32x32x2_f32, no LDS DMA)
   mm / mm_bf16 / mm_f16   torch.mm in fp32 / bf16 / fp16 (the vendor library's MFMA kernels)
-  x_dma / x_mfma_bf16 / x_mfma_f32 / x_lds_reads / x_dma_mfma_bf16 / x_mfma_bf16_16x16x32
-          synthetic kernels holding ONE ingredient of the packed GEMM each (scripts/hazard_aggressors.hip; build line in its header)
+  x_dma / x_mfma_bf16 / x_mfma_f32 / x_lds_reads / x_dma_mfma_bf16 / x_mfma_bf16_16x16x32 /
+  x_dma_mfma_f32 / x_dma1_mfma_bf16 / x_regs_mfma_bf16 / x_dma_mfma_bf16_nobarrier / x_mfma_bf16_lds_reserved / x_loads_mfma_bf16 /
+  x_mfma_f32_lds_reserved / x_mfma_f16_lds_reserved / x_lds_reserved_only
+          synthetic kernels holding one or two ingredients of the packed GEMM each (scripts/hazard_aggressors.hip; build line in its header)
   copy    a large elementwise copy (no matrix pipe, HBM-bound)
   sincos  an elementwise transcendental kernel (VALU-bound, no matrix pipe)
 usage: [GEOTR_TREE=<checkout built with / without -fno-slp-vectorize>] LABEL=name python scripts/packed_hazard_repro.py
@@ -84,12 +86,15 @@ def main():
             sq = square.to(torch.float16)
             return lambda: torch.mm(sq, sq)
         if kind.startswith('x_'):  # synthetic loads of scripts/hazard_aggressors.hip, one ingredient of the packed GEMM each
-            which = {'x_dma': 0, 'x_mfma_bf16': 1, 'x_mfma_f32': 2, 'x_lds_reads': 3, 'x_dma_mfma_bf16': 4, 'x_mfma_bf16_16x16x32': 5}[kind]
+            which = {'x_dma': 0, 'x_mfma_bf16': 1, 'x_mfma_f32': 2, 'x_lds_reads': 3, 'x_dma_mfma_bf16': 4, 'x_mfma_bf16_16x16x32': 5,
+                     'x_dma_mfma_f32': 6, 'x_dma1_mfma_bf16': 7, 'x_regs_mfma_bf16': 8, 'x_dma_mfma_bf16_nobarrier': 9,
+                     'x_mfma_bf16_lds_reserved': 10, 'x_loads_mfma_bf16': 11, 'x_mfma_f32_lds_reserved': 12, 'x_mfma_f16_lds_reserved': 13,
+                     'x_lds_reserved_only': 14}[kind]
             agg = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hazard_aggressors.so'))
             agg.agg_launch.restype = ctypes.c_int
             agg.agg_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
             sink = torch.empty(256, device=dev)
-            iters = {0: 64, 1: 48, 2: 24, 3: 256, 4: 48, 5: 48}[which]
+            iters = {0: 64, 2: 24, 3: 256, 12: 24}.get(which, 48)
 
             def run():
                 rc = agg.agg_launch(which, big.data_ptr(), sink.data_ptr(), iters, 2048, _lib.stream_ptr())

@@ -1,7 +1,7 @@
 """GPU: kernels stay pure functions of their inputs while OTHER streams keep the chip busy (profiles/r03_concurrency_hazard.md).
 
 Round 3 found two kernels -- p2n_assign and gse_embed_table -- whose SLP-vectorised builds (packed fp32 code with lane-half shuffles)
-returned wrong values while packed GEMMs (LDS DMA + bf16 MFMA) ran on other streams, and never alone.  The library is built without the
+returned wrong values while packed GEMMs (double-rate bf16 MFMAs between loads) ran on other streams, and never alone.  The library is built without the
 SLP vectoriser since (tests/test_isa_checks.py pins the ISA); this is the behavioural side of the same gate: the stand-alone reproducer
 of scripts/packed_hazard_repro.py on the SHIPPED library -- 88 % of the launches were wrong with the vectorised build."""
 import threading
