@@ -132,9 +132,9 @@ class ConcurrentRegistration:
     """Keeps several independent pairs in flight on one GPU: one persistent host thread + one HIP stream per lane.
 
     A single pair's timeline contains many few-workgroup kernels (hash-order replay, LGR refinement, 300-row GEMMs ...)
-    that leave most of the 256 CUs idle, and the pyramid reads the stage sizes back on the host; pairs are independent
-    (SURVEY.md section 8e), so the lanes pull pairs from one queue and overlap them on separate streams.  All lanes
-    share the same weights.  `submit` never blocks on the GPU; `drain` waits until every queued pair has been enqueued
+    that leave most of the 256 CUs idle, and the host needs each stack's stage sizes and result counts once; pairs are
+    independent, so the lanes pull pairs from one queue and overlap them on separate streams.  All
+    lanes share the same weights.  `submit` never blocks on the GPU; `drain` waits until every queued pair has been enqueued
     and makes the caller's stream wait for the lanes.
     """
 
