@@ -65,12 +65,52 @@ def _packed_fp32_by_kernel(asm):
     return packed
 
 
+_PACKED = re.compile(r'^(v_pk_(?:add|mul|fma)_f32)\s+v\[(\d+):(\d+)\],\s*(.*)$')
+
+
+def _cross_half_reads_of_the_destination(op):
+    """The ONE instruction form that was caught returning a wrong low half (profiles/r03_concurrency_hazard.md 4e):
+    `v_pk_add_f32 v[12:13], v[26:27], v[12:13] op_sel:[0,1] ...` -- a packed fp32 instruction whose destination pair is also a source pair
+    that is read ACROSS its halves (op_sel = 1: the low lane takes the high register; op_sel_hi = 0: the high lane takes the low one).
+    Returns the indices of such sources."""
+    m = _PACKED.match(op)
+    if not m:
+        return []
+    dst = (int(m.group(2)), int(m.group(3)))
+    rest = m.group(4)
+    sel = re.search(r'op_sel:\[([\d,]+)\]', rest)
+    sel_hi = re.search(r'op_sel_hi:\[([\d,]+)\]', rest)
+    sel = [int(x) for x in sel.group(1).split(',')] if sel else [0, 0, 0]
+    sel_hi = [int(x) for x in sel_hi.group(1).split(',')] if sel_hi else [1, 1, 1]
+    hits = []
+    for k, tok in enumerate(rest.split(',')[:3]):
+        src = re.match(r'\s*v\[(\d+):(\d+)\]', tok)
+        if not src:
+            continue
+        lo, hi = int(src.group(1)), int(src.group(2))
+        overlaps = not (hi < dst[0] or lo > dst[1])
+        crosses = (k < len(sel) and sel[k] == 1) or (k < len(sel_hi) and sel_hi[k] == 0)
+        if overlaps and crosses:
+            hits.append(k)
+    return hits
+
+
+def test_cross_half_read_detector_knows_the_instruction_that_failed():
+    assert _cross_half_reads_of_the_destination('v_pk_add_f32 v[12:13], v[26:27], v[12:13] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]') == [1]
+    assert _cross_half_reads_of_the_destination('v_pk_fma_f32 v[14:15], v[14:15], v[38:39], v[24:25] op_sel:[1,0,0]') == [0]
+    assert _cross_half_reads_of_the_destination('v_pk_add_f32 v[10:11], v[24:25], v[10:11] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]') == [1]
+    assert _cross_half_reads_of_the_destination('v_pk_mul_f32 v[8:9], v[6:7], v[8:9]') == []                       # in place, straight
+    assert _cross_half_reads_of_the_destination('v_pk_mul_f32 v[22:23], v[2:3], v[6:7] op_sel:[1,0]') == []        # crossed, not in place
+    assert _cross_half_reads_of_the_destination('v_pk_fma_f32 v[4:5], v[8:9], s[2:3], v[4:5] op_sel_hi:[1,0,1]') == []
+
+
 def test_no_kernel_carries_slp_vectorised_packed_fp32_code(tmp_path):
     """profiles/r03_concurrency_hazard.md: the two builds that returned wrong values under multi-stream load (p2n_assign's distance loop,
     the index computation of gse_embed_table) were the ones the SLP vectoriser had turned into packed fp32 sequences with lane-half
     shuffles (v_pk_mov_b32 ... op_sel, op_sel'd v_pk_mul_f32 / v_pk_add_f32); the same sources without the vectoriser never failed.
     Every file is therefore compiled with -fno-slp-vectorize, and this pins the shipped ISA of ALL of them: no v_pk_mov_b32 anywhere,
-    packed fp32 arithmetic only in the kernels that spell it out in the source, op_sel'd packed arithmetic only in kpconv_gather."""
+    packed fp32 arithmetic only in the kernels that spell it out in the source, op_sel'd packed arithmetic only in kpconv_gather, and
+    NOWHERE the instruction form whose low half was caught wrong (destination pair = a source pair read across its halves)."""
     if not os.path.exists(HIPCC):
         pytest.skip('hipcc not available')
     mk = open(os.path.join(CSRC, 'Makefile')).read()
@@ -96,6 +136,8 @@ def test_no_kernel_carries_slp_vectorised_packed_fp32_code(tmp_path):
             arith = [op for op in ops if op.startswith(('v_pk_mul_f32', 'v_pk_add_f32', 'v_pk_fma_f32'))]
             if arith:
                 assert any(tag in kernel for tag in EXPLICIT_PACKED), (src, kernel, arith[:4])
+            crossed = [op for op in arith if _cross_half_reads_of_the_destination(op)]
+            assert not crossed, (src, kernel, crossed[:4])  # nowhere, the hand-written kernels included
             if any('op_sel' in op for op in arith):
                 assert any(tag in kernel for tag in LANE_HALF_SHUFFLES), (src, kernel, [op for op in arith if 'op_sel' in op][:4])
     assert seen_kernels >= 10  # the explicit kernels were found at all (guards against the mnemonics changing under the check)
