@@ -12,7 +12,8 @@
 //               scripts/packed_fp32_mfma_hazard.hip -o /tmp/hazard_slp            (what the library's Makefile used before the fix)
 //           ... the same with -fno-slp-vectorize -o /tmp/hazard_noslp            (what it uses now)
 //   run:    [VICTIM=indices] [SHOW=1] /tmp/hazard_slp [launches=300] [aggressor kinds, default "4 11 6 14"]   -> one line per aggressor kind
-//           (VICTIM=indices: only the kernel's per-pair index computation, see gse_indices_only_kernel below)
+//           (VICTIM=indices: only the kernel's per-pair index computation, see gse_indices_only_kernel below;
+//            VICTIM=instruction: only the instruction form of section 4e in a self-checking loop, see pk_add_in_place_kernel)
 #include <algorithm>
 #include <atomic>
 #include <cstdarg>
@@ -72,6 +73,28 @@ __global__ __launch_bounds__(256) void gse_indices_only_kernel(const float* __re
 #pragma unroll
     for (int s = 0; s < S; ++s) out[p * S + s] = vals[s];
   }
+}
+
+// Third victim (VICTIM=instruction): nothing but the instruction form of section 4e in a loop, checked by the lane itself against scalar
+// fp32 arithmetic:  v_pk_add_f32 vD, vA, vD op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]   (low = A.lo - D.hi, high = A.hi - D.hi, in place).
+// out[thread] = number of iterations whose low / high half came out wrong (as floats; the idle-GPU result is all zeros).
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__global__ __launch_bounds__(256) void pk_add_in_place_kernel(float* __restrict__ out, int iters, int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t * 4 + 3 >= total) return;
+  const float lane = (float)(threadIdx.x & 63);
+  float bad_lo = 0.f, bad_hi = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    const float y = lane * 0.5f + (float)it, z = lane * 0.25f + 3.0f * (float)it + 1.0f;
+    f32x2 d = {y, z};
+    const f32x2 a = {2.0f * z + lane, 5.0f * y - lane};
+    asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(d) : "v"(a));
+    float want_lo, want_hi;  // the check in scalar fp32 instructions (written as asm so that the vectoriser cannot pack it as well)
+    asm volatile("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %4" : "=&v"(want_lo), "=&v"(want_hi) : "v"(a.x), "v"(a.y), "v"(z));
+    bad_lo += d.x != want_lo ? 1.f : 0.f;
+    bad_hi += d.y != want_hi ? 1.f : 0.f;
+  }
+  out[t * 4 + 0] = bad_lo, out[t * 4 + 1] = bad_hi, out[t * 4 + 2] = 0.f, out[t * 4 + 3] = 0.f;
 }
 
 #define HIP_OK(call)                                                                              \
@@ -165,9 +188,14 @@ int main(int argc, char** argv) {
   clouds.count = 1, clouds.n[0] = n, clouds.row0[0] = 0, clouds.emb_off[0] = 0;
   hipStream_t vs;
   HIP_OK(hipStreamCreate(&vs));
-  const bool indices_only = std::getenv("VICTIM") && std::string(std::getenv("VICTIM")) == "indices";
+  const bool instruction_only = std::getenv("VICTIM") && std::string(std::getenv("VICTIM")) == "instruction";
+  const bool indices_only = instruction_only || (std::getenv("VICTIM") && std::string(std::getenv("VICTIM")) == "indices");  // 4 floats per lane
   const int64_t compared = indices_only ? (int64_t)n * n * 4 : elems;  // what the victim writes
   auto embed = [&](float* dst) {
+    if (instruction_only) {
+      pk_add_in_place_kernel<<<dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, vs>>>(dst, 4000, (int64_t)n * n * 4);
+      return;
+    }
     if (indices_only) {
       gse_indices_only_kernel<4><<<dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, vs>>>(
           pts, knn, n, 1.0f / sigma_d, (float)(180.0 / ((double)sigma_a * 3.14159265358979323846)), dst);
@@ -210,14 +238,15 @@ int main(int argc, char** argv) {
     unsigned long long host[4];
     HIP_OK(hipMemcpy(host, counters, sizeof(host), hipMemcpyDeviceToHost));
     std::printf("{\"victim\": \"%s\", \"aggressor_kind\": %d, \"aggressor_streams\": 3, \"victim_launches\": %d, \"launches_with_wrong_values\": %llu, "
-                "\"wrong_elements\": %llu}\n", indices_only ? "indices only" : "gse_embed_table", kind, launches, host[1], host[0]);
+                "\"wrong_elements\": %llu}\n", instruction_only ? "one instruction" : indices_only ? "indices only" : "gse_embed_table", kind, launches, host[1], host[0]);
     if (host[3]) {  // which lanes (and, for the indices-only victim, which of the four indices) the wrong elements belong to
       unsigned long long h[72];
       HIP_OK(hipMemcpy(h, histogram, sizeof(h), hipMemcpyDeviceToHost));
       std::printf("  wrong elements by lane:");
       for (int l = 0; l < 64; ++l) std::printf("%s%llu", l % 16 == 0 ? " | " : " ", h[l]);
       std::printf("\n");
-      if (indices_only) std::printf("  wrong elements by index (distance, angle 0, angle 1, angle 2): %llu %llu %llu %llu\n", h[64], h[65], h[66], h[67]);
+      if (instruction_only) std::printf("  threads with a wrong LOW half / a wrong HIGH half: %llu / %llu\n", h[64], h[65]);
+      else if (indices_only) std::printf("  wrong elements by index (distance, angle 0, angle 1, angle 2): %llu %llu %llu %llu\n", h[64], h[65], h[66], h[67]);
     }
     if (host[3] && std::getenv("SHOW")) {  // SHOW=1: where the first wrong values sit and what they are
       std::vector<Mismatch> m(kKeep);
