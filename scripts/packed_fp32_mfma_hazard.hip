@@ -13,7 +13,7 @@
 //           ... the same with -fno-slp-vectorize -o /tmp/hazard_noslp            (what it uses now)
 //   run:    [VICTIM=indices] [SHOW=1] /tmp/hazard_slp [launches=300] [aggressor kinds, default "4 11 6 14"]   -> one line per aggressor kind
 //           (VICTIM=indices: only the kernel's per-pair index computation, see gse_indices_only_kernel below;
-//            VICTIM=instruction: only the instruction form of section 4e in a self-checking loop, see pk_add_in_place_kernel)
+//            VICTIM=instruction [FORM=0..6]: one packed instruction form in a self-checking loop, see pk_form_kernel)
 #include <algorithm>
 #include <atomic>
 #include <cstdarg>
@@ -75,11 +75,19 @@ __global__ __launch_bounds__(256) void gse_indices_only_kernel(const float* __re
   }
 }
 
-// Third victim (VICTIM=instruction): nothing but the instruction form of section 4e in a loop, checked by the lane itself against scalar
-// fp32 arithmetic:  v_pk_add_f32 vD, vA, vD op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]   (low = A.lo - D.hi, high = A.hi - D.hi, in place).
+// Third victim (VICTIM=instruction [FORM=0..6]): nothing but ONE packed instruction in a loop, issued from inline asm and checked by the
+// lane itself against scalar fp32 instructions (also asm, so that the vectoriser cannot pack the check).  D = (y, z), A = (p, q):
+//   FORM 0  v_pk_add_f32 D, A, D op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]     (p - z, q - z)   in place, LOW lane reads the high register: section 4e
+//   FORM 1  v_pk_add_f32 R, A, D op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]     the same into another pair (not in place)
+//   FORM 2  v_pk_add_f32 D, A, D op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]  (p - y, q - y)   in place, HIGH lane reads the low register
+//   FORM 3  v_pk_add_f32 D, A, D neg_lo:[0,1] neg_hi:[0,1]                  (p - y, q - z)   in place, straight (control)
+//   FORM 4  v_pk_mul_f32 D, A, D op_sel:[0,1]                               (p * z, q * z)   the multiply of the same shape
+//   FORM 5  v_pk_add_f32 D, D, A op_sel:[1,0]                               (z + p, z + q)   in place on source 0
+//   FORM 6  v_pk_fma_f32 D, A, A, D op_sel:[0,0,1]                          (p*p + z, q*q + z) in place on source 2
 // out[thread] = number of iterations whose low / high half came out wrong (as floats; the idle-GPU result is all zeros).
 using f32x2 = __attribute__((ext_vector_type(2))) float;
-__global__ __launch_bounds__(256) void pk_add_in_place_kernel(float* __restrict__ out, int iters, int64_t total) {
+template <int FORM>
+__global__ __launch_bounds__(256) void pk_form_kernel(float* __restrict__ out, int iters, int64_t total) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t * 4 + 3 >= total) return;
   const float lane = (float)(threadIdx.x & 63);
@@ -88,9 +96,31 @@ __global__ __launch_bounds__(256) void pk_add_in_place_kernel(float* __restrict_
     const float y = lane * 0.5f + (float)it, z = lane * 0.25f + 3.0f * (float)it + 1.0f;
     f32x2 d = {y, z};
     const f32x2 a = {2.0f * z + lane, 5.0f * y - lane};
-    asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(d) : "v"(a));
-    float want_lo, want_hi;  // the check in scalar fp32 instructions (written as asm so that the vectoriser cannot pack it as well)
-    asm volatile("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %4" : "=&v"(want_lo), "=&v"(want_hi) : "v"(a.x), "v"(a.y), "v"(z));
+    float want_lo, want_hi;
+    if constexpr (FORM == 0) {
+      asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(d) : "v"(a));
+      asm volatile("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %4" : "=&v"(want_lo), "=&v"(want_hi) : "v"(a.x), "v"(a.y), "v"(z));
+    } else if constexpr (FORM == 1) {
+      f32x2 r;
+      asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(r) : "v"(a), "v"(d));
+      d = r;
+      asm volatile("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %4" : "=&v"(want_lo), "=&v"(want_hi) : "v"(a.x), "v"(a.y), "v"(z));
+    } else if constexpr (FORM == 2) {
+      asm volatile("v_pk_add_f32 %0, %1, %0 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(d) : "v"(a));
+      asm volatile("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %4" : "=&v"(want_lo), "=&v"(want_hi) : "v"(a.x), "v"(a.y), "v"(y));
+    } else if constexpr (FORM == 3) {
+      asm volatile("v_pk_add_f32 %0, %1, %0 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(d) : "v"(a));
+      asm volatile("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %5" : "=&v"(want_lo), "=&v"(want_hi) : "v"(a.x), "v"(a.y), "v"(y), "v"(z));
+    } else if constexpr (FORM == 4) {
+      asm volatile("v_pk_mul_f32 %0, %1, %0 op_sel:[0,1]" : "+v"(d) : "v"(a));
+      asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4" : "=&v"(want_lo), "=&v"(want_hi) : "v"(a.x), "v"(a.y), "v"(z));
+    } else if constexpr (FORM == 5) {
+      asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[1,0]" : "+v"(d) : "v"(a));
+      asm volatile("v_add_f32 %0, %4, %2\n\tv_add_f32 %1, %4, %3" : "=&v"(want_lo), "=&v"(want_hi) : "v"(a.x), "v"(a.y), "v"(z));
+    } else {
+      asm volatile("v_pk_fma_f32 %0, %1, %1, %0 op_sel:[0,0,1]" : "+v"(d) : "v"(a));
+      asm volatile("v_fma_f32 %0, %2, %2, %4\n\tv_fma_f32 %1, %3, %3, %4" : "=&v"(want_lo), "=&v"(want_hi) : "v"(a.x), "v"(a.y), "v"(z));
+    }
     bad_lo += d.x != want_lo ? 1.f : 0.f;
     bad_hi += d.y != want_hi ? 1.f : 0.f;
   }
@@ -189,11 +219,22 @@ int main(int argc, char** argv) {
   hipStream_t vs;
   HIP_OK(hipStreamCreate(&vs));
   const bool instruction_only = std::getenv("VICTIM") && std::string(std::getenv("VICTIM")) == "instruction";
+  const int form = std::getenv("FORM") ? std::atoi(std::getenv("FORM")) : 0;  // which instruction form (pk_form_kernel)
   const bool indices_only = instruction_only || (std::getenv("VICTIM") && std::string(std::getenv("VICTIM")) == "indices");  // 4 floats per lane
   const int64_t compared = indices_only ? (int64_t)n * n * 4 : elems;  // what the victim writes
   auto embed = [&](float* dst) {
     if (instruction_only) {
-      pk_add_in_place_kernel<<<dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, vs>>>(dst, 4000, (int64_t)n * n * 4);
+      const dim3 grid((unsigned)(((int64_t)n * n + 255) / 256));
+      const int64_t total = (int64_t)n * n * 4;
+      switch (form) {
+        case 0: pk_form_kernel<0><<<grid, dim3(256), 0, vs>>>(dst, 4000, total); break;
+        case 1: pk_form_kernel<1><<<grid, dim3(256), 0, vs>>>(dst, 4000, total); break;
+        case 2: pk_form_kernel<2><<<grid, dim3(256), 0, vs>>>(dst, 4000, total); break;
+        case 3: pk_form_kernel<3><<<grid, dim3(256), 0, vs>>>(dst, 4000, total); break;
+        case 4: pk_form_kernel<4><<<grid, dim3(256), 0, vs>>>(dst, 4000, total); break;
+        case 5: pk_form_kernel<5><<<grid, dim3(256), 0, vs>>>(dst, 4000, total); break;
+        default: pk_form_kernel<6><<<grid, dim3(256), 0, vs>>>(dst, 4000, total); break;
+      }
       return;
     }
     if (indices_only) {
@@ -237,8 +278,8 @@ int main(int argc, char** argv) {
     for (auto& t : threads) t.join();
     unsigned long long host[4];
     HIP_OK(hipMemcpy(host, counters, sizeof(host), hipMemcpyDeviceToHost));
-    std::printf("{\"victim\": \"%s\", \"aggressor_kind\": %d, \"aggressor_streams\": 3, \"victim_launches\": %d, \"launches_with_wrong_values\": %llu, "
-                "\"wrong_elements\": %llu}\n", instruction_only ? "one instruction" : indices_only ? "indices only" : "gse_embed_table", kind, launches, host[1], host[0]);
+    std::printf("{\"victim\": \"%s\", \"form\": %d, \"aggressor_kind\": %d, \"aggressor_streams\": 3, \"victim_launches\": %d, \"launches_with_wrong_values\": %llu, "
+                "\"wrong_elements\": %llu}\n", instruction_only ? "one instruction" : indices_only ? "indices only" : "gse_embed_table", instruction_only ? form : -1, kind, launches, host[1], host[0]);
     if (host[3]) {  // which lanes (and, for the indices-only victim, which of the four indices) the wrong elements belong to
       unsigned long long h[72];
       HIP_OK(hipMemcpy(h, histogram, sizeof(h), hipMemcpyDeviceToHost));
