@@ -1,0 +1,70 @@
+"""CPU: the host-side bookkeeping of the native executor's outputs (geotransformer_amd/native.py) on plain CPU tensors -- trimming the
+data-dependent lengths of every pair of a stack from ONE table of counts, in every entry point that delivers them (finalize_stack,
+finalize_stack_counts behind counts_to_host_async, finalize per pair), and the overflow flag that must raise, never warn."""
+import pytest
+import torch
+
+from geotransformer_amd.native import NativeModel
+
+
+def _stack(counts, P=6, C=9, K=4):
+    """Raw per-pair output dicts as forward_batch returns them (capacity-sized tensors + the stack's count columns)."""
+    B = len(counts)
+    num_node = torch.tensor([[p] for p, _ in counts], dtype=torch.int32)
+    num_corr = torch.tensor([[c] for _, c in counts], dtype=torch.int32)
+    outs = []
+    for b in range(B):
+        base = 100.0 * b
+        outs.append({
+            'estimated_transform': torch.eye(4) + b,
+            'matching_scores': torch.arange(P * (K + 1) * (K + 1), dtype=torch.float32).view(P, K + 1, K + 1) + base,
+            'ref_node_corr_knn_points': torch.zeros(P, K, 3) + base, 'src_node_corr_knn_points': torch.ones(P, K, 3) + base,
+            'ref_node_corr_knn_masks': torch.ones(P, K, dtype=torch.bool), 'src_node_corr_knn_masks': torch.zeros(P, K, dtype=torch.bool),
+            '_ref_node_corr_indices': torch.arange(P) + 10 * b, '_src_node_corr_indices': torch.arange(P) + 20 * b,
+            '_ref_corr_points': torch.arange(C * 3, dtype=torch.float32).view(C, 3) + base,
+            '_src_corr_points': torch.arange(C * 3, dtype=torch.float32).view(C, 3) - base, '_corr_scores': torch.arange(C, dtype=torch.float32) + base,
+            '_counts': (num_node[b], num_corr[b]), '_counts_stack': (num_node, num_corr, b),
+        })
+    return outs
+
+
+def _check(outs, counts, P=6, C=9):
+    assert len(outs) == len(counts)
+    for b, (out, (p, c)) in enumerate(zip(outs, counts)):
+        assert not [k for k in out if k.startswith('_')], 'no private key may survive finalize'
+        assert out['ref_node_corr_indices'].tolist() == [10 * b + i for i in range(p)]
+        assert out['src_node_corr_indices'].tolist() == [20 * b + i for i in range(p)]
+        for k in ('ref_node_corr_knn_points', 'src_node_corr_knn_points', 'ref_node_corr_knn_masks', 'src_node_corr_knn_masks', 'matching_scores'):
+            assert out[k].shape[0] == p, k
+        for k in ('ref_corr_points', 'src_corr_points', 'corr_scores'):
+            assert out[k].shape[0] == c, k
+        assert float(out['corr_scores'][0]) == 100.0 * b if c else out['corr_scores'].numel() == 0
+        assert torch.equal(out['estimated_transform'], torch.eye(4) + b)  # fixed-size outputs are left alone
+
+
+COUNTS = [(6, 9), (0, 0), (3, 1), (1, 9)]  # full, empty, partial, mixed
+
+
+def test_finalize_stack_trims_every_pair_from_one_table_of_counts():
+    _check(NativeModel.finalize_stack(_stack(COUNTS)), COUNTS)
+    _check(NativeModel.finalize_stack(_stack(COUNTS), overflow=torch.zeros(1, dtype=torch.int32)), COUNTS)
+    assert NativeModel.finalize_stack([]) == []
+
+
+def test_finalize_with_host_counts_is_the_same_trimming():
+    raw = _stack(COUNTS)
+    table = [[p, c, 0] for p, c in COUNTS]  # what counts_to_host_async(...).tolist() holds: num_node, num_corr, overflow per pair
+    _check(NativeModel.finalize_stack_counts(raw, table), COUNTS)
+    out = NativeModel.finalize(_stack(COUNTS)[2])
+    assert out['ref_node_corr_indices'].tolist() == [20, 21, 22] and out['corr_scores'].tolist() == [200.0]
+
+
+def test_an_overflowed_radius_search_raises_in_every_entry_point():
+    flag = torch.tensor([513], dtype=torch.int32)
+    with pytest.raises(RuntimeError, match='row capacity exceeded .513 neighbours'):
+        NativeModel.finalize_stack(_stack(COUNTS), overflow=flag)
+    with pytest.raises(RuntimeError, match='row capacity exceeded'):
+        NativeModel.finalize_stack_counts(_stack(COUNTS), [[p, c, 513] for p, c in COUNTS])
+    with pytest.raises(RuntimeError, match='row capacity exceeded'):
+        NativeModel.finalize(_stack(COUNTS)[0], overflow=flag)
+    NativeModel.raise_on_overflow(0)  # no overflow: silent
