@@ -736,7 +736,7 @@ const char* geotr_last_error(void) { return error_buffer(); }
 // 2: geotr_transformer carries the GSE lookup tables; 3: geotr_pyramid / geotr_pyramid_buffers carry the visiting order, the fused
 // KPConv entry points take it; 4: GroupNorm statistics out of the packed GEMM's epilogue (geotr_gemm_packed_stats, geotr_group_norm_stats),
 // device-resident stage sizes in the pyramid entry points
-int geotr_abi_version(void) { return 4; }
+int geotr_abi_version(void) { return GEOTR_ABI_VERSION; }
 
 size_t geotr_radius_grid_workspace_bytes(int64_t ns, int64_t batch) {
   return grid_layout(nullptr, ns, batch).bytes;

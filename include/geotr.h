@@ -32,7 +32,9 @@ extern "C" {
 #define GEOTR_E_CAPACITY (-4)  /* an internal fixed capacity would be exceeded */
 
 const char* geotr_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change.  A host compares the macro it was compiled against with what the
+ * loaded library reports. */
+#define GEOTR_ABI_VERSION 4
 int geotr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -1,0 +1,117 @@
+// A C++ consumer of the C ABI (include/geotr.h -> geotransformer_amd/libgeotr_hip.so) without Python: times the packed GEMM entry points
+// with HIP events and checks a sample of rows against an fp64 CPU product.  Two uses: (1) the shortest complete example of a non-Python
+// host on the drop-in boundary; (2) the iteration tool for kernel work -- a process that starts in milliseconds, so a
+// GPU session costs seconds instead of a Python start-up.
+//
+//   build: hipcc -O2 -std=c++17 -I include scripts/abi_bench.cpp -L geotransformer_amd -lgeotr_hip -Wl,-rpath,'$ORIGIN/../geotransformer_amd' \
+//                -o scripts/abi_bench.bin
+//   run:   scripts/abi_bench.bin gemm M N K [bf16|bf16x3] [reps=20]      one shape
+//          scripts/abi_bench.bin shapes                                  the bench workload's heaviest packed shapes
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "geotr.h"
+
+#define HIP_OK(call)                                                                              \
+  do {                                                                                            \
+    const hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                       \
+      std::fprintf(stderr, "%s:%d: %s -> %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      std::exit(2);                                                                               \
+    }                                                                                             \
+  } while (0)
+#define GEOTR_OK_OR_DIE(call)                                                                      \
+  do {                                                                                            \
+    const int rc_ = (call);                                                                       \
+    if (rc_ != 0) {                                                                               \
+      std::fprintf(stderr, "%s:%d: %s -> %d: %s\n", __FILE__, __LINE__, #call, rc_, geotr_last_error()); \
+      std::exit(3);                                                                               \
+    }                                                                                             \
+  } while (0)
+
+static int run_gemm(int64_t M, int64_t N, int64_t K, bool bf16, int reps) {
+  std::mt19937 rng(7);
+  std::uniform_real_distribution<float> sym(-1.f, 1.f);
+  std::vector<float> a((size_t)M * K), w((size_t)N * K), bias(N);
+  for (auto& x : a) x = sym(rng);
+  for (auto& x : w) x = sym(rng) / std::sqrt((float)K);
+  for (auto& x : bias) x = sym(rng);
+  float *dA, *dW, *dB, *dC;
+  void* packed;
+  HIP_OK(hipMalloc(&dA, a.size() * 4));
+  HIP_OK(hipMalloc(&dW, w.size() * 4));
+  HIP_OK(hipMalloc(&dB, bias.size() * 4));
+  HIP_OK(hipMalloc(&dC, (size_t)M * N * 4));
+  HIP_OK(hipMalloc(&packed, geotr_gemm_pack_bytes(N, K)));
+  HIP_OK(hipMemcpy(dA, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dW, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dB, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));
+  GEOTR_OK_OR_DIE(geotr_gemm_pack(dW, K, 0, N, K, packed, stream));
+  auto launch = [&] {
+    if (bf16) GEOTR_OK_OR_DIE(geotr_gemm_packed_bf16(dA, K, packed, dC, N, M, N, K, dB, nullptr, nullptr, 0, 1.0f, 0, stream));
+    else GEOTR_OK_OR_DIE(geotr_gemm_packed(dA, K, packed, dC, N, M, N, K, dB, nullptr, nullptr, 0, 1.0f, 0, stream));
+  };
+  for (int r = 0; r < 3; ++r) launch();
+  hipEvent_t t0, t1;
+  HIP_OK(hipEventCreate(&t0));
+  HIP_OK(hipEventCreate(&t1));
+  HIP_OK(hipEventRecord(t0, stream));
+  for (int r = 0; r < reps; ++r) launch();
+  HIP_OK(hipEventRecord(t1, stream));
+  HIP_OK(hipEventSynchronize(t1));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, t0, t1));
+  const double us = 1e3 * ms / reps;
+  // parity: 64 rows spread over M against an fp64 product (split-bf16: ~2^-17 relative per product; plain bf16: ~2^-8)
+  std::vector<float> c((size_t)M * N);
+  HIP_OK(hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost));
+  double worst = 0.0, scale = 0.0;
+  for (int s = 0; s < 64; ++s) {
+    const int64_t m = (M - 1) * s / 63;
+    for (int64_t n = 0; n < N; ++n) {
+      double acc = bias[n];
+      for (int64_t k = 0; k < K; ++k) acc += (double)a[m * K + k] * (double)w[n * K + k];
+      worst = std::max(worst, std::fabs(acc - (double)c[m * N + n]));
+      scale = std::max(scale, std::fabs(acc));
+    }
+  }
+  const double bytes = 4.0 * ((double)M * K + (double)M * N) + (double)geotr_gemm_pack_bytes(N, K);  // A read + C written + packed weight, once each
+  const double tol = (bf16 ? 2e-2 : 2e-5) * std::max(1.0, scale);
+  std::printf("{\"op\": \"gemm_packed%s\", \"m_n_k\": [%lld, %lld, %lld], \"us\": %.1f, \"algorithmic_gbps\": %.0f, \"algorithmic_tflops\": %.1f, "
+              "\"max_abs_error_vs_fp64\": %.3g, \"tolerance\": %.3g, \"ok\": %s}\n",
+              bf16 ? "_bf16" : "", (long long)M, (long long)N, (long long)K, us, bytes / us * 1e-3, 2.0 * M * N * K / us * 1e-6, worst, tol,
+              worst <= tol ? "true" : "false");
+  for (void* p : {(void*)dA, (void*)dW, (void*)dB, (void*)dC, packed}) HIP_OK(hipFree(p));
+  HIP_OK(hipStreamDestroy(stream));
+  return worst <= tol ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+  if (geotr_abi_version() != GEOTR_ABI_VERSION) {
+    std::fprintf(stderr, "library ABI %d, header ABI %d\n", geotr_abi_version(), GEOTR_ABI_VERSION);
+    return 4;
+  }
+  const std::string mode = argc > 1 ? argv[1] : "shapes";
+  if (mode == "gemm" && argc >= 5) {
+    const bool bf16 = argc > 5 && std::string(argv[5]) == "bf16";
+    return run_gemm(std::atoll(argv[2]), std::atoll(argv[3]), std::atoll(argv[4]), bf16, argc > 6 ? std::atoi(argv[6]) : 20);
+  }
+  if (mode == "shapes") {  // 16-pair stacks of BASELINE configs[1]: the shapes profiles/r03_bench_n1.json lists as heaviest
+    const int64_t shapes[][3] = {{640000, 128, 32}, {640000, 128, 64}, {179984, 256, 128}, {43826, 512, 128}, {43826, 128, 1920}, {9956, 256, 3840},
+                                 {5594, 256, 256}};
+    int rc = 0;
+    for (const auto& s : shapes) rc |= run_gemm(s[0], s[1], s[2], false, 20);
+    return rc;
+  }
+  std::fprintf(stderr, "usage: %s gemm M N K [bf16|bf16x3] [reps] | shapes\n", argv[0]);
+  return 64;
+}

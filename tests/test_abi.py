@@ -177,3 +177,29 @@ def test_native_descriptor_builds_without_a_gpu(monkeypatch):
             dec = getattr(net, f'decoder{i + 1}')
             skip = getattr(net, f'encoder{i + 1}_{3 if i > 0 else 2}').out_channels
             assert net.decoder_latent_channels(i) + skip == dec.mlp.weight.shape[1], (exp, i)
+
+
+def test_header_macro_library_and_python_loader_agree_on_the_abi_version():
+    from geotransformer_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'geotr.h')).read()
+    macro = int(re.search(r'^#define GEOTR_ABI_VERSION (\d+)$', text, flags=re.M).group(1))
+    lib = ctypes.CDLL(os.path.join(ROOT, 'geotransformer_amd', 'libgeotr_hip.so'))
+    lib.geotr_abi_version.restype = ctypes.c_int
+    assert macro == lib.geotr_abi_version() == _lib.ABI_VERSION
+
+
+def test_a_cpp_host_builds_against_the_header_and_the_library(tmp_path):
+    """scripts/abi_bench.cpp (INTEGRATION.md "A host without Python"): compiles with the header as a C++ translation unit, links against the
+    library, passes its ABI check and reaches its usage line -- no device call is made."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    exe = str(tmp_path / 'abi_bench')
+    lib_dir = os.path.join(ROOT, 'geotransformer_amd')
+    build = subprocess.run([hipcc, '-O1', '-std=c++17', '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'scripts', 'abi_bench.cpp'), '-L', lib_dir,
+                            '-lgeotr_hip', '-Wl,-rpath,' + lib_dir, '-o', exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, 'help'], capture_output=True, text=True)
+    assert run.returncode == 64 and 'usage:' in run.stderr, (run.returncode, run.stderr[-500:])
