@@ -7,6 +7,7 @@
 //                -o scripts/abi_bench.bin
 //   run:   scripts/abi_bench.bin gemm M N K [bf16|bf16x3] [reps=20]      one shape
 //          scripts/abi_bench.bin shapes                                  the bench workload's heaviest packed shapes
+//          scripts/abi_bench.bin pyramid [3dmatch|kitti] [pairs] [reps]   the collate-equivalent pyramid of one stack (geotr_pyramid_build)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -95,6 +96,104 @@ static int run_gemm(int64_t M, int64_t N, int64_t K, bool bf16, int reps) {
   return worst <= tol ? 0 : 1;
 }
 
+// One cloud of ~`target` points: random planar patches in a cube of edge `extent`, one point per voxel cell of the patch's own lattice
+// with a continuous jitter (tie-free, surface-like density: the shape of geotransformer_amd/synthetic.py, not its exact recipe).
+static std::vector<float> surface_cloud(int target, float extent, float voxel, std::mt19937& rng) {
+  std::uniform_real_distribution<float> u01(0.f, 1.f);
+  std::vector<float> pts;
+  while ((int)pts.size() / 3 < target) {
+    float o[3], e1[3], e2[3];
+    for (int c = 0; c < 3; ++c) o[c] = extent * u01(rng), e1[c] = u01(rng) - 0.5f, e2[c] = u01(rng) - 0.5f;
+    const float n1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    for (int c = 0; c < 3; ++c) e1[c] /= n1;
+    const float d = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
+    for (int c = 0; c < 3; ++c) e2[c] -= d * e1[c];
+    const float n2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+    for (int c = 0; c < 3; ++c) e2[c] /= n2;
+    const int side = (int)(extent * (0.2f + 0.3f * u01(rng)) / voxel);
+    for (int a = 0; a < side && (int)pts.size() / 3 < target; ++a)
+      for (int b = 0; b < side && (int)pts.size() / 3 < target; ++b) {
+        const float s = (a + 0.8f * (u01(rng) - 0.5f)) * voxel, t = (b + 0.8f * (u01(rng) - 0.5f)) * voxel;
+        float p[3];
+        bool inside = true;
+        for (int c = 0; c < 3; ++c) p[c] = o[c] + s * e1[c] + t * e2[c], inside = inside && p[c] >= 0.f && p[c] <= extent;
+        if (inside) pts.insert(pts.end(), p, p + 3);
+      }
+  }
+  return pts;
+}
+
+// The collate-equivalent pyramid of a stack of `pairs` pairs through geotr_pyramid_build (one call, one host synchronisation at its end).
+static int run_pyramid(const std::string& config, int pairs, int reps) {
+  const bool kitti = config == "kitti";
+  const int S = kitti ? 5 : 4, per_cloud = kitti ? 120000 : 20000;
+  const float voxel = kitti ? 0.3f : 0.025f, radius = kitti ? 1.275f : 0.0625f, extent = kitti ? 120.f : 3.f;
+  const int64_t limits[GEOTR_MAX_STAGES] = {kitti ? 40 : 38, kitti ? 40 : 36, kitti ? 40 : 36, kitti ? 40 : 38, 40};
+  const int B = 2 * pairs;
+  std::mt19937 rng(1000);
+  std::vector<float> all;
+  std::vector<int64_t> lengths;
+  for (int b = 0; b < B; ++b) {
+    const auto cloud = surface_cloud(per_cloud, extent, voxel, rng);
+    all.insert(all.end(), cloud.begin(), cloud.end());
+    lengths.push_back((int64_t)cloud.size() / 3);
+  }
+  const int64_t n0 = (int64_t)all.size() / 3;
+  float* d_points;
+  int64_t* d_lengths;
+  HIP_OK(hipMalloc(&d_points, all.size() * 4));
+  HIP_OK(hipMalloc(&d_lengths, B * 8));
+  HIP_OK(hipMemcpy(d_points, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_lengths, lengths.data(), B * 8, hipMemcpyHostToDevice));
+  geotr_pyramid_buffers buf = {};
+  buf.points[0] = d_points, buf.lengths[0] = d_lengths;
+  for (int i = 0; i < S; ++i) {
+    if (i) {
+      HIP_OK(hipMalloc(&buf.points[i], n0 * 12));
+      HIP_OK(hipMalloc(&buf.lengths[i], B * 8));
+    }
+    HIP_OK(hipMalloc(&buf.neighbors[i], n0 * limits[i] * 8));
+    HIP_OK(hipMalloc(&buf.order[i], n0 * 4));
+    if (i < S - 1) {
+      HIP_OK(hipMalloc(&buf.subsampling[i], n0 * limits[i] * 8));
+      HIP_OK(hipMalloc(&buf.upsampling[i], n0 * limits[i + 1] * 8));
+    }
+  }
+  const size_t ws_bytes = geotr_pyramid_workspace_bytes(n0, B, S);
+  void* ws;
+  int32_t* overflow;
+  HIP_OK(hipMalloc(&ws, ws_bytes));
+  HIP_OK(hipMalloc(&overflow, 4));
+  HIP_OK(hipMemset(overflow, 0, 4));
+  std::vector<int64_t> lengths_host((size_t)S * B);
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));
+  auto build = [&] {
+    GEOTR_OK_OR_DIE(geotr_pyramid_build(d_points, d_lengths, B, n0, S, voxel, radius, limits, &buf, lengths_host.data(), overflow, ws, ws_bytes, stream));
+  };
+  build();
+  hipEvent_t t0, t1;
+  HIP_OK(hipEventCreate(&t0));
+  HIP_OK(hipEventCreate(&t1));
+  HIP_OK(hipEventRecord(t0, stream));
+  for (int r = 0; r < reps; ++r) build();
+  HIP_OK(hipEventRecord(t1, stream));
+  HIP_OK(hipEventSynchronize(t1));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, t0, t1));
+  int32_t worst = 0;
+  HIP_OK(hipMemcpy(&worst, overflow, 4, hipMemcpyDeviceToHost));
+  std::printf("{\"op\": \"pyramid_build\", \"config\": \"%s\", \"pairs\": %d, \"rows_stage0\": %lld, \"rows_per_stage\": [", config.c_str(), pairs,
+              (long long)n0);
+  for (int i = 0; i < S; ++i) {
+    int64_t rows = 0;
+    for (int b = 0; b < B; ++b) rows += lengths_host[(size_t)i * B + b];
+    std::printf("%s%lld", i ? ", " : "", (long long)rows);
+  }
+  std::printf("], \"ms_per_stack\": %.3f, \"us_per_pair\": %.1f, \"overflow\": %d}\n", ms / reps, 1e3 * ms / reps / pairs, worst);
+  return worst == 0 ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
   if (geotr_abi_version() != GEOTR_ABI_VERSION) {
     std::fprintf(stderr, "library ABI %d, header ABI %d\n", geotr_abi_version(), GEOTR_ABI_VERSION);
@@ -112,6 +211,17 @@ int main(int argc, char** argv) {
     for (const auto& s : shapes) rc |= run_gemm(s[0], s[1], s[2], false, 20);
     return rc;
   }
-  std::fprintf(stderr, "usage: %s gemm M N K [bf16|bf16x3] [reps] | shapes\n", argv[0]);
+  if (mode == "cloud") {  // cloud [3dmatch|kitti]: one synthetic cloud as text (to look at its density without a GPU)
+    const bool kitti = argc > 2 && std::string(argv[2]) == "kitti";
+    std::mt19937 rng(1000);
+    const auto cloud = surface_cloud(kitti ? 120000 : 20000, kitti ? 120.f : 3.f, kitti ? 0.3f : 0.025f, rng);
+    for (size_t i = 0; i < cloud.size(); i += 3) std::printf("%.7g %.7g %.7g\n", cloud[i], cloud[i + 1], cloud[i + 2]);
+    return 0;
+  }
+  if (mode == "pyramid") {  // pyramid [3dmatch|kitti] [pairs per stack] [reps]
+    const std::string config = argc > 2 ? argv[2] : "3dmatch";
+    return run_pyramid(config, argc > 3 ? std::atoi(argv[3]) : (config == "kitti" ? 4 : 16), argc > 4 ? std::atoi(argv[4]) : 5);
+  }
+  std::fprintf(stderr, "usage: %s gemm M N K [bf16|bf16x3] [reps] | shapes | pyramid [3dmatch|kitti] [pairs] [reps]\n", argv[0]);
   return 64;
 }
