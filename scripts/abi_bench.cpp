@@ -8,8 +8,10 @@
 //   run:   scripts/abi_bench.bin gemm M N K [bf16|bf16x3] [reps=20]      one shape
 //          scripts/abi_bench.bin shapes                                  the bench workload's heaviest packed shapes
 //          scripts/abi_bench.bin pyramid [3dmatch|kitti] [pairs] [reps]   the collate-equivalent pyramid of one stack (geotr_pyramid_build)
+//          scripts/abi_bench.bin embedding [clouds] [superpoints] [reps]  structure embedding by table + one layer's positional softmax
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -194,6 +196,80 @@ static int run_pyramid(const std::string& config, int pairs, int reps) {
   return worst == 0 ? 0 : 1;
 }
 
+// The embedding path of one stack: tables of the two projections, the ragged structure embedding of `clouds` clouds of `n` superpoints
+// (written once: clouds x n x n x 256 floats) and ONE attention layer's positional softmax reading it (the transformer has three per cloud).
+static int run_embedding(int clouds, int n, int reps) {
+  const int d = 256, k = 3, heads = 4;
+  const float sigma_d = 0.2f, sigma_a = 15.0f;
+  const int points_d = 64 * 16 + 2, points_a = 12 * 16 + 2;
+  std::mt19937 rng(5);
+  std::uniform_real_distribution<float> u01(0.f, 1.f), sym(-1.f, 1.f);
+  auto upload = [&](size_t count, auto&& gen) {
+    std::vector<float> v(count);
+    for (auto& x : v) x = gen();
+    float* dev;
+    HIP_OK(hipMalloc(&dev, count * 4));
+    HIP_OK(hipMemcpy(dev, v.data(), count * 4, hipMemcpyHostToDevice));
+    return dev;
+  };
+  const int64_t rows = (int64_t)clouds * n;
+  float* pts = upload((size_t)rows * 3, [&] { return 3.0f * u01(rng); });
+  float* w_d = upload((size_t)d * d, [&] { return sym(rng) / 16; });
+  float* w_a = upload((size_t)d * d, [&] { return sym(rng) / 16; });
+  float* b_d = upload(d, [&] { return sym(rng); });
+  float* b_a = upload(d, [&] { return sym(rng); });
+  int t = 0;
+  float* div_term = upload(d / 2, [&] { return std::exp(-(float)(2 * t++) * 9.210340371976184f / d); });
+  float* qt = upload((size_t)rows * heads * d, [&] { return sym(rng) / 16; });
+  float* qb = upload((size_t)rows * heads, [&] { return sym(rng); });
+  float *tab_d, *tab_a, *emb, *scores;
+  void* ws;
+  const size_t tab_ws = std::max(geotr_gse_table_bytes(d, points_d), geotr_gse_table_bytes(d, points_a));
+  HIP_OK(hipMalloc(&tab_d, geotr_gse_table_bytes(d, points_d)));
+  HIP_OK(hipMalloc(&tab_a, geotr_gse_table_bytes(d, points_a)));
+  HIP_OK(hipMalloc(&ws, tab_ws));
+  const int64_t emb_floats = (int64_t)clouds * n * n * d, score_floats = (int64_t)clouds * heads * n * n;
+  HIP_OK(hipMalloc(&emb, emb_floats * 4));
+  HIP_OK(hipMalloc(&scores, score_floats * 4));
+  HIP_OK(hipMemset(scores, 0, score_floats * 4));
+  int32_t* knn;
+  HIP_OK(hipMalloc(&knn, rows * k * 4));
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));
+  GEOTR_OK_OR_DIE(geotr_gse_table_build(div_term, w_d, d, points_d, tab_d, ws, tab_ws, stream));
+  GEOTR_OK_OR_DIE(geotr_gse_table_build(div_term, w_a, d, points_a, tab_a, ws, tab_ws, stream));
+  geotr_gse_clouds gc = {};
+  geotr_attn_groups ag = {};
+  gc.count = ag.count = clouds;
+  for (int q = 0; q < clouds; ++q) {
+    gc.n[q] = n, gc.row0[q] = q * n, gc.emb_off[q] = (int64_t)q * n * n * d;
+    ag.n[q] = ag.m[q] = ag.ld[q] = n, ag.scores_off[q] = (int64_t)q * heads * n * n, ag.q_row0[q] = (int64_t)q * n, ag.emb[q] = emb + gc.emb_off[q];
+  }
+  GEOTR_OK_OR_DIE(geotr_gse_knn_clouds(pts, &gc, k, knn, stream));
+  auto time_of = [&](auto&& fn) {
+    fn();
+    hipEvent_t t0, t1;
+    HIP_OK(hipEventCreate(&t0));
+    HIP_OK(hipEventCreate(&t1));
+    HIP_OK(hipEventRecord(t0, stream));
+    for (int r = 0; r < reps; ++r) fn();
+    HIP_OK(hipEventRecord(t1, stream));
+    HIP_OK(hipEventSynchronize(t1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, t0, t1));
+    return 1e3 * ms / reps;
+  };
+  const double us_embed = time_of([&] {
+    GEOTR_OK_OR_DIE(geotr_gse_embed_table(pts, knn, &gc, k, d, tab_d, points_d, tab_a, points_a, w_d, b_d, w_a, b_a, div_term, sigma_d, sigma_a, emb, stream));
+  });
+  const double us_softmax = time_of([&] { GEOTR_OK_OR_DIE(geotr_attn_softmax_grouped(scores, &ag, qt, qb, d, heads, 0.125f, stream)); });
+  const double emb_bytes = 4.0 * emb_floats;
+  std::printf("{\"op\": \"embedding\", \"clouds\": %d, \"superpoints\": %d, \"embedding_mb\": %.0f, \"gse_embed_table_us\": %.1f, "
+              "\"gse_written_gbps\": %.0f, \"attn_pos_softmax_us\": %.1f, \"attn_read_gbps\": %.0f}\n",
+              clouds, n, emb_bytes * 1e-6, us_embed, emb_bytes / us_embed * 1e-3, us_softmax, emb_bytes / us_softmax * 1e-3);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (geotr_abi_version() != GEOTR_ABI_VERSION) {
     std::fprintf(stderr, "library ABI %d, header ABI %d\n", geotr_abi_version(), GEOTR_ABI_VERSION);
@@ -211,6 +287,8 @@ int main(int argc, char** argv) {
     for (const auto& s : shapes) rc |= run_gemm(s[0], s[1], s[2], false, 20);
     return rc;
   }
+  if (mode == "embedding")  // embedding [clouds=32] [superpoints=300] [reps=5]
+    return run_embedding(argc > 2 ? std::atoi(argv[2]) : 32, argc > 3 ? std::atoi(argv[3]) : 300, argc > 4 ? std::atoi(argv[4]) : 5);
   if (mode == "cloud") {  // cloud [3dmatch|kitti]: one synthetic cloud as text (to look at its density without a GPU)
     const bool kitti = argc > 2 && std::string(argv[2]) == "kitti";
     std::mt19937 rng(1000);
@@ -222,6 +300,6 @@ int main(int argc, char** argv) {
     const std::string config = argc > 2 ? argv[2] : "3dmatch";
     return run_pyramid(config, argc > 3 ? std::atoi(argv[3]) : (config == "kitti" ? 4 : 16), argc > 4 ? std::atoi(argv[4]) : 5);
   }
-  std::fprintf(stderr, "usage: %s gemm M N K [bf16|bf16x3] [reps] | shapes | pyramid [3dmatch|kitti] [pairs] [reps]\n", argv[0]);
+  std::fprintf(stderr, "usage: %s gemm M N K [bf16|bf16x3] [reps] | shapes | pyramid [3dmatch|kitti] [pairs] [reps] | embedding [clouds] [superpoints] [reps]\n", argv[0]);
   return 64;
 }
