@@ -58,22 +58,30 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
 #pragma unroll
   for (int a = 0; a < KT; ++a) colsum[a] = 0.f;
   const int col = lane & 31, half = lane >> 5;
-  for (int64_t r = r0; r < r1; r += 2) {  // two rows per step: lanes 0-31 hold row r, lanes 32-63 row r + 1 (zero past the end)
-    const int64_t row = r + half;
-    float v[KT];
+  // two rows per MFMA step: lanes 0-31 hold row r, lanes 32-63 row r + 1 (zero past the end).  kUnroll steps are loaded before the first
+  // of them is multiplied, so that a wave keeps kUnroll * KT loads in flight instead of one round trip per step (256 rows = 128 steps)
+  constexpr int kUnroll = KT == 4 ? 4 : 8;
+  for (int64_t r = r0; r < r1; r += 2 * kUnroll) {
+    float v[kUnroll][KT];
 #pragma unroll
-    for (int a = 0; a < KT; ++a) {
-      v[a] = row < r1 ? x[row * ld + 32 * a + col] : 0.f;
-      colsum[a] += v[a];
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t row = r + 2 * u + half;
+#pragma unroll
+      for (int a = 0; a < KT; ++a) v[u][a] = row < r1 ? x[row * ld + 32 * a + col] : 0.f;
     }
-    int t = 0;
 #pragma unroll
-    for (int a = 0; a < KT; ++a)
+    for (int u = 0; u < kUnroll; ++u) {
 #pragma unroll
-      for (int b = a; b < KT; ++b) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[a], v[b], acc[t], 0, 0, 0);
-        ++t;
-      }
+      for (int a = 0; a < KT; ++a) colsum[a] += v[u][a];
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int b = a; b < KT; ++b) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u][a], v[u][b], acc[t], 0, 0, 0);
+          ++t;
+        }
+    }
   }
   float* out = partial + (int64_t)w * gram_partial_floats(KT);
 #pragma unroll
