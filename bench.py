@@ -15,10 +15,17 @@ broadcast once from rank 0 over RCCL and the per-pair transforms are all-gathere
 `--gpus N` without a torchrun environment re-executes itself under `python -m torch.distributed.run` with N ranks (one per
 GPU) and fails if the node has fewer than N devices or a rank does not come up.
 
+The headline (`value`, `dtype`, `roofline`, `parity`) is measured in the REFERENCE'S OWN ARITHMETIC: `--precision fp32` (default) =
+IEEE fp32 products with fp32 accumulation on v_mfma_f32_32x32x2_f32 (+ the fp32 table embedding).  The split-bf16 mode of rounds 1-3
+(three bf16 MFMA terms per product, ~2^-17 relative: narrower than fp32) is re-timed over the same `--steps` / `--warmup` as a sibling
+block `split_bf16_mode` with its own roofline and parity -- never as `value`.
+
 Prints ONE JSON line on rank 0 with the contract fields plus
-  parity       : pair 0 of the LAST timed step (one of the 16 stacked pairs of a lane's launch sequence) compared with the CPU
-                 oracle run on that pair alone: feature MSE, coarse-set overlap, matching scores, transform (oracle/parity.py
-                 states the tolerances) + the stacked pyramid of that lane's stack cut back to the pair, byte-compared.
+  parity       : FOUR pairs of the LAST timed step, one per lane and in four different stack slots (`--pairs` = 64 distinct pairs,
+                 seeds 0-63 on rank 0 as SURVEY 8(d) names them, rotated through the slots step by step), each compared with the CPU
+                 oracle run on that pair alone: feature MSE, coarse selection (a differing set must be a tie at the selection boundary
+                 and is then compared in full), matching scores, transform (oracle/parity.py states the tolerances) + the stacked
+                 pyramid of that lane's stack cut back to the pair, byte-compared.
   roofline     : the kernel family with the largest summed launch time among the bracketed ones (packed GEMMs, GSE embedding, fused
                  KPConv; `other` = the runner-up), from HIP events recorded by the executor on the launch streams around every
                  `--profile-stride`-th launch of the timed region.  Packed GEMMs: BOTH roofs are computed from the recorded shapes --
@@ -30,7 +37,8 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                  + the torch-fp32 restatement of the model) timed on this box's host cores per SURVEY.md 8(d): 1 warm-up +
                  3 timed pairs, median; collate on one thread (as the reference), forward on all cores and on 16 threads
                  (the better one is `value`), the 1-thread figure and the pipelined 8-worker bound next to it.
-  exact_fp32_mode : the same workload re-timed (a few steps) with every matrix product in exact fp32 MFMA (`--precision fp32`).
+  split_bf16_mode : the same workload, same steps / warm-up, in the split-bf16 arithmetic (`--precision bf16x3`), with its own
+                 roofline and parity blocks (world size 1 only; `--no-sibling-mode` skips it).
 `--config kitti` (BASELINE configs[3]: 120k + 120k points, 5-stage backbone; 2 lanes x 4 stacked pairs by default), `--config lomatch
 --precision bf16` (configs[4]: low overlap, 1000 hypotheses, bf16 operands) and `--config modelnet` (configs[0] shape) print the same line
 with their own parity block; the headline metric is the default run.
@@ -67,10 +75,13 @@ def time_alone(fn, reps=10):
     return sum(a.elapsed_time(b) for a, b in evs[2:]) / reps / 1e3
 
 
-def gemm_bytes(m, n, k):
+def gemm_bytes(m, n, k, flags=0):
     """Algorithmic HBM bytes of one packed GEMM launch: the fp32 activation read once, the fp32 result written once, the packed weight
-    (hi + lo bf16 planes = 4 B per element) read once."""
-    return 4.0 * (m * k + m * n + n * k)
+    (hi + lo bf16 planes or one fp32 plane = 4 B per element) read once, plus what the epilogue of THIS launch really reads (`flags`, from
+    the executor's event tag: 1 = a residual tensor (m, n); 2 = the gathered coarse-level product of a split decoder layer -- one (n)-row
+    per output row + its int64 index; 4 = GroupNorm statistics records written, 2 n floats per 32 / 64 rows)."""
+    extra = (m * n if flags & 1 else 0) + (m * n + 2 * m if flags & 2 else 0) + (2.0 * n * m / (64 if n > 64 else 32) if flags & 4 else 0)
+    return 4.0 * (m * k + m * n + n * k + extra)
 
 
 def gemm_family_block(gemm, gemm_mode, lanes_note):
@@ -78,10 +89,12 @@ def gemm_family_block(gemm, gemm_mode, lanes_note):
     Both roofs are stated; `bound` / `achieved` / `peak` / `frac` are those of the roof the family sits closer to.  In this workload
     that is HBM: the tall stage-0/1 layers have k = 32 .. 64 (arithmetic intensity ~20 FLOP/B against the ~300 FLOP/B ridge), alone
     they move 3.4 TB/s.  Returns (block, the six heaviest shapes)."""
+    gemm = [(s_, tuple(w) + (0,) * (4 - len(w))) for s_, w in gemm]  # (m, n, k[, epilogue flags])
     sec = sum(s for s, _ in gemm)
-    flops = sum(2.0 * m * n * kk for _, (m, n, kk) in gemm)
-    nbytes = sum(gemm_bytes(m, n, kk) for _, (m, n, kk) in gemm)
-    peak = FP32_MATRIX_PEAK_TFLOPS if gemm_mode is False else BF16_MATRIX_PEAK_TFLOPS
+    flops = sum(2.0 * m * n * kk for _, (m, n, kk, _f) in gemm)
+    nbytes = sum(gemm_bytes(m, n, kk, f) for _, (m, n, kk, f) in gemm)
+    fp32 = gemm_mode in (False, 'fp32')
+    peak = FP32_MATRIX_PEAK_TFLOPS if fp32 else BF16_MATRIX_PEAK_TFLOPS
     ex = 3.0 if gemm_mode is True else 1.0
     shapes = {}
     for s_, w in gemm:
@@ -91,7 +104,9 @@ def gemm_family_block(gemm, gemm_mode, lanes_note):
     top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:6]
     mfma_frac = ex * flops / sec / 1e12 / peak
     hbm_frac = nbytes / sec / 1e12 / HBM_PEAK_TBS
-    blk = {'kernel': 'gemm_packed_kernel<WM,WN,TERMS> (+ split-K reduce) -- every packed Linear / KPConv contraction of the stack'}
+    blk = {'kernel': 'gemm_packed_kernel<WM,WN,TERMS> (+ split-K reduce) -- every packed Linear / KPConv contraction of the stack; '
+                     + ('TERMS = 0: exact fp32 products, v_mfma_f32_32x32x2_f32' if gemm_mode == 'fp32' else
+                        'TERMS = 3: split-bf16 products' if gemm_mode is True else 'TERMS = 1: plain bf16 operands' if gemm_mode == 'bf16' else 'unpacked fp32 kernel')}
     if hbm_frac >= mfma_frac:
         blk.update(bound='hbm', achieved=round(nbytes / sec / 1e9, 1), peak=HBM_PEAK_TBS * 1e3, unit='GB/s', frac=round(hbm_frac, 4))
     else:
@@ -101,13 +116,15 @@ def gemm_family_block(gemm, gemm_mode, lanes_note):
         'algorithmic_tflops': round(flops / sec / 1e12, 2), 'mfma_frac_algorithmic': round(flops / sec / 1e12 / peak, 4),
         'executed_tflops': round(ex * flops / sec / 1e12, 2), 'executed_frac': round(mfma_frac, 4),
         'launches': len(gemm), 'avg_launch_us': round(1e6 * sec / len(gemm), 1), 'total_ms': round(1e3 * sec, 2),
-        'top_shapes_in_flight': [{'m_n_k': list(w), 'launches': c, 'avg_us': round(1e6 * t / c, 1),
+        'top_shapes_in_flight': [{'m_n_k': list(w[:3]), 'epilogue_flags': w[3], 'launches': c, 'avg_us': round(1e6 * t / c, 1),
                                   'tflops': round(2.0 * w[0] * w[1] * w[2] * c / t / 1e12, 1),
                                   'hbm_gbps': round(gemm_bytes(*w) * c / t / 1e9, 1)} for w, (c, t) in top],
-        'note': 'both roofs over the recorded launches: hbm_* = ALGORITHMIC bytes (A read + C written + packed weight, once each) / summed '
-                'duration against the 8 TB/s HBM peak; *_tflops = ALGORITHMIC 2 m n k FLOP / summed duration, executed_* counts the 3 bf16 MFMA '
-                'products per algorithmic product of the split-bf16 path, against the dense bf16 MFMA peak; bound = the roof the family is '
-                'closer to; ' + lanes_note})
+        'note': 'both roofs over the recorded launches: hbm_* = ALGORITHMIC bytes (A read + C written + packed weight, once each, + the residual / '
+                'gathered rows / statistics records the launch really moves: epilogue_flags 1 / 2 / 4) / summed duration against the 8 TB/s HBM '
+                'peak; *_tflops = ALGORITHMIC 2 m n k FLOP / summed duration against the '
+                + ('fp32 MFMA peak (157.3 TF: every product is one fp32 MFMA product)' if fp32 else
+                   'dense bf16 MFMA peak, executed_* counts the 3 bf16 MFMA products per algorithmic product of the split-bf16 path')
+                + '; bound = the roof the family is closer to; ' + lanes_note})
     return blk, top
 
 
@@ -160,7 +177,8 @@ def roofline_blocks(events, cfg, args, pipe, out, kernels):
             d = shapes.setdefault(w, [0, 0.0])
             d[0] += 1
             d[1] += s_
-        t1, t2 = f1 / 1e12 / FP32_MATRIX_PEAK_TFLOPS, f2 / 1e12 / BF16_MATRIX_PEAK_TFLOPS * (3.0 if gemm_mode is True else 1.0)
+        t1 = f1 / 1e12 / FP32_MATRIX_PEAK_TFLOPS
+        t2 = f2 / 1e12 / FP32_MATRIX_PEAK_TFLOPS if gemm_mode == 'fp32' else f2 / 1e12 / BF16_MATRIX_PEAK_TFLOPS * (3.0 if gemm_mode is True else 1.0)
         fam['kpconv'] = {
             'bound': 'mfma', 'kernel': 'kpconv_fused_kernel<C_in,WAVES,TERMS> (KPConv layer in one kernel: fp32-MFMA neighbour contraction -> LDS -> bf16-MFMA kernel-point contraction)',
             'achieved': round((f1 + f2) / sec / 1e12, 2), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -191,14 +209,14 @@ def roofline_blocks(events, cfg, args, pipe, out, kernels):
         fam['gse']['isolated'] = iso
     if 'gemm' in fam:
         iso = []
-        for (m, n, kk), (c, t) in top[:4]:
+        for (m, n, kk, _fl), (c, t) in top[:4]:
             a = torch.randn((m, kk), dtype=torch.float32, device=out['ref_points_c'].device)
             w = torch.randn((n, kk), dtype=torch.float32, device=a.device) * 0.05
             packed = kernels.gemm_pack(w)
             y = torch.empty((m, n), dtype=torch.float32, device=a.device)
             t_iso = time_alone(lambda: kernels.gemm_packed(a, packed, n, out=y))
             iso.append({'m_n_k': [m, n, kk], 'avg_us': round(1e6 * t_iso, 1), 'tflops': round(2.0 * m * n * kk / t_iso / 1e12, 1),
-                        'mfma_frac_algorithmic': round(2.0 * m * n * kk / t_iso / 1e12 / (FP32_MATRIX_PEAK_TFLOPS if gemm_mode is False else BF16_MATRIX_PEAK_TFLOPS), 4),
+                        'mfma_frac_algorithmic': round(2.0 * m * n * kk / t_iso / 1e12 / (FP32_MATRIX_PEAK_TFLOPS if gemm_mode in (False, 'fp32') else BF16_MATRIX_PEAK_TFLOPS), 4),
                         'hbm_gbps': round(gemm_bytes(m, n, kk) / t_iso / 1e9, 1), 'hbm_frac': round(gemm_bytes(m, n, kk) / t_iso / 1e12 / HBM_PEAK_TBS, 4)})
         fam['gemm']['isolated'] = {'shapes': iso, 'note': 'the heaviest shapes re-run alone (random operands, bias-free epilogue), GPU otherwise idle'}
     order = sorted(fam, key=lambda f: -fam[f]['total_ms'])
@@ -211,11 +229,14 @@ def roofline_blocks(events, cfg, args, pipe, out, kernels):
     return main
 
 
-def pmc_traffic_bytes(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (collected in separate --pmc passes of
-    this same command; bench.py itself cannot run under the counters).  None when no summary is present."""
+def pmc_traffic_bytes(kernel_substr, precision='fp32'):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary of THIS arithmetic mode (collected in separate
+    --pmc passes of this same command; bench.py itself cannot run under the counters): profiles/r*_pmc_hbm_traffic_<precision>.json, or
+    the unsuffixed file of rounds 1-3 for the split-bf16 mode.  None when no summary of the mode is present."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_hbm_traffic_{precision}.json')))
+    if not found and precision == 'bf16x3':
+        found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))
     if not found:
         return None
     data = json.load(open(found[-1]))  # the latest round's summary
@@ -419,7 +440,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='3dmatch', choices=sorted(WORKLOADS))
     ap.add_argument('--points', type=int, default=None, help='points per cloud (default: the config\'s)')
-    ap.add_argument('--pairs', type=int, default=8, help='distinct synthetic pairs cycled through per rank')
+    ap.add_argument('--pairs', type=int, default=64,
+                    help='distinct synthetic pairs per rank (SURVEY 8(d): seeds 0-63 on rank 0), rotated through the stack slots step by step')
     ap.add_argument('--batch', type=int, default=None, help='pairs per step per GPU (independent pairs of one batch; default lanes x stack)')
     ap.add_argument('--lanes', type=int, default=None, help='pairs kept in flight concurrently (host thread + HIP stream each)')
     ap.add_argument('--stack', type=int, default=None, help='pairs stacked into one launch sequence per lane (<= 16; divides --batch)')
@@ -431,13 +453,17 @@ def main():
     ap.add_argument('--profile-stride', type=int, default=8,
                     help='bracket every Nth eligible launch: a timed event pair keeps its launch from overlapping its stream neighbours, '
                          'so the sample is spread over the whole region instead of covering every launch of its start')
+    ap.add_argument('--dump-shapes', default=None, metavar='PATH',
+                    help='write every bracketed launch shape of the timed region (family, shape, launches, average us) as JSON lines to PATH')
     ap.add_argument('--no-numa-bind', action='store_true', help="do not bind the process to the GPU's NUMA node (A/B runs)")
-    ap.add_argument('--no-fp32-mode', action='store_true', help='skip the exact-fp32 mode line')
+    ap.add_argument('--no-sibling-mode', '--no-fp32-mode', dest='no_sibling_mode', action='store_true',
+                    help='skip the split-bf16 sibling block (the same workload re-timed in the narrower arithmetic of rounds 1-3)')
     ap.add_argument('--dry-run', action='store_true',
                     help='no devices: rehearse the N-rank launcher path, rank bring-up decisions, sharding and collectives over gloo (CPU test)')
-    ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32', 'bf16'],
-                    help="matrix-pipe arithmetic: bf16x3 = split-bf16, fp32-grade (default, the headline mode); fp32 = exact fp32 MFMA; "
-                         "bf16 = plain bf16 operands (BASELINE configs[4] 'bf16 features'; not the headline metric)")
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16', 'fp32-unpacked'],
+                    help="matrix-pipe arithmetic: fp32 = exact fp32 MFMA products, the reference's arithmetic (default, the headline mode); "
+                         "bf16x3 = split-bf16 (3 bf16 MFMA terms per product, ~2^-17: narrower than fp32); bf16 = plain bf16 operands (BASELINE "
+                         "configs[4] 'bf16 features'); fp32-unpacked = fp32 on the rounds-1..3 kernels (A/B runs)")
     args = ap.parse_args()
     lanes, stack = LAUNCH_SHAPE[args.config]
     args.lanes = args.lanes or lanes
@@ -483,154 +509,183 @@ def main():
     items = [build_pair(1000 * rank + i, args.config, n_points) for i in range(args.pairs)]
     pairs = [(torch.from_numpy(it['ref_points']).to(device), torch.from_numpy(it['src_points']).to(device)) for it in items]
 
-    results = torch.zeros((args.steps, args.batch, 4, 4), dtype=torch.float32, device=device)
     info = {}
     runner = ConcurrentRegistration(pipe, lanes=args.lanes, stack=args.stack)
-
-    last = {}
-    arrivals = []  # host time at which each pair's result was handed back (stderr diagnostics only: throughput over the timed region)
+    from geotransformer_amd.native import KernelProfiler
+    from geotransformer_amd import pipeline as _pl
 
     def pair_of(i, j):
-        return (i * args.batch + j) % len(pairs)
+        """Pair in slot j of step i: the distinct pairs rotate by one slot per step, so a pair meets every lane / stack slot in turn."""
+        return (i * args.batch + j + i) % len(pairs)
 
-    def step(i, record=None):
-        """One step = one batch of `--batch` independent pairs through the whole hot path.  The batch is handed to the
-        lanes; nothing is joined per step (the timed region is bracketed once, as the contract says)."""
-        batch = [pairs[pair_of(i, j)] for j in range(args.batch)]
+    def timed_run(precision, gse):
+        """W untimed warm-up steps + K timed steps of the workload in one arithmetic mode.  Returns the measurements of that mode:
+        elapsed seconds (max over ranks), the gathered transforms, the executor's launch events and the LAST step's outputs per slot."""
+        kernels.set_precision(precision, gse=gse)
+        results = torch.zeros((args.steps, args.batch, 4, 4), dtype=torch.float32, device=device)
+        last, arrivals = {}, []  # arrivals: host time at which each pair's result was handed back (stderr diagnostics only)
 
-        def sink(j, out):
-            if record is not None:
-                results[record, j] = out['estimated_transform']
-            last[j] = (pair_of(i, j), out)  # kept for the parity block: the output of the timed run itself
-            arrivals.append(time.perf_counter())
+        def step(i, record=None):
+            """One step = one batch of `--batch` independent pairs through the whole hot path.  The batch is handed to the
+            lanes; nothing is joined per step (the timed region is bracketed once, as the contract says)."""
+            batch = [pairs[pair_of(i, j)] for j in range(args.batch)]
 
-        runner.submit(batch, sink)
+            def sink(j, out):
+                if record is not None:
+                    results[record, j] = out['estimated_transform']
+                last[j] = (pair_of(i, j), out)  # kept for the parity block: the output of the timed run itself
+                arrivals.append(time.perf_counter())
 
-    # the event pool is created BEFORE the warm-up: creating and recording 2 x 2048 events takes ~0.1 s of GPU idle time, and an idle gap
-    # right before the timed region costs its first stacks (profiles/r02_ab_runs.md: in some first runs on a fresh box the first quarter of the 1.3 s region ran at
-    # half its rate, the other three quarters at the usual one)
-    from geotransformer_amd.native import KernelProfiler
-    prof = KernelProfiler(args.profile_events, stride=args.profile_stride)  # HIP events around the GSE / packed-GEMM / fused KPConv launches
-    note(f'rank {rank}: {numa_note}; host waits: {sync_note}')
-    note(f'rank {rank}: model + {len(pairs)} pairs ready; warm-up')
-    for i in range(args.warmup):
-        step(i)
-    runner.drain()
-    torch.cuda.synchronize()
-    out = last[0][1]
-    info['superpoints'] = [int(out['ref_points_c'].shape[0]), int(out['src_points_c'].shape[0])]
+            runner.submit(batch, sink)
 
-    gd.barrier()
-    torch.cuda.synchronize()
-    arrivals.clear()
-    with prof:
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i, record=i)
-        runner.drain()  # every pair enqueued; this stream now waits for all lanes
-        gathered = gd.gather_results(results)  # (world, steps, batch, 4, 4) -- the only collective on the data path
-        gd.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    elapsed = gd.max_over_ranks(elapsed, device)
-    events = prof.results()
-    note(f'rank {rank}: timed region done ({args.steps} steps in {elapsed:.2f} s)')
-    from geotransformer_amd import pipeline as _pl
-    if _pl.HOST_TIMES:  # GEOTR_HOST_TIMING=1: where the lane threads spend their host time, per stack (all steps incl. warm-up)
-        ht = np.array(_pl.HOST_TIMES[-(args.steps * args.batch // args.stack):], dtype=np.float64)
-        note(f'rank {rank}: host ms per stack of {int(ht[:, 0].mean())} pairs over {len(ht)} stacks: pyramid call {1e3 * ht[:, 1].mean():.2f}, '
-             f'forward launches {1e3 * ht[:, 2].mean():.2f}, final read (waits for the GPU) {1e3 * ht[:, 3].mean():.2f}; '
-             f'wall per stack per lane {1e3 * elapsed * args.lanes / len(ht):.2f}')
-    if arrivals:  # pairs handed back per quarter of the timed region: a slow start (clock ramp, first-touch) shows up as a low first figure
-        edges = [t0 + elapsed * q / 4 for q in range(1, 5)]
-        quarters = [sum(1 for a in arrivals if (edges[q - 1] if q else t0) <= a < edges[q]) for q in range(4)]
-        note(f'rank {rank}: results handed back per quarter of the timed region: {quarters} (of {len(arrivals)})')
-
-    # exact-fp32 matrix arithmetic on the same workload (a few steps; a mode line next to the headline, not the headline)
-    fp32_mode = None
-    if rank == 0 and world == 1 and args.precision == 'bf16x3' and not args.no_fp32_mode:
-        timed_out = dict(last)
-        note('exact-fp32 mode leg')
-        kernels.set_precision('fp32')
-        k_steps = max(2, min(5, args.steps))
-        step(0)
-        runner.drain()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(k_steps):
+        # the event pool is created BEFORE the warm-up: creating and recording 2 x 2048 events takes ~0.1 s of GPU idle time, and an idle
+        # gap right before the timed region costs its first stacks (profiles/r02_ab_runs.md)
+        prof = KernelProfiler(args.profile_events, stride=args.profile_stride)  # HIP events around the GSE / packed-GEMM / fused KPConv launches
+        note(f'rank {rank}: [{precision}] warm-up')
+        for i in range(args.warmup):
             step(i)
         runner.drain()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        fp32_mode = {'value': round(k_steps * args.batch / dt, 3), 'unit': 'pairs/s', 'steps': k_steps,
-                     'ms_per_step': round(1e3 * dt / k_steps, 3), 'dtype': 'f32 (exact fp32 MFMA, v_mfma_f32_32x32x2_f32)',
-                     'note': 'same workload and execution shape, every matrix product in exact fp32; untimed warm-up of 1 step'}
+        out = last[0][1]
+        info['superpoints'] = [int(out['ref_points_c'].shape[0]), int(out['src_points_c'].shape[0])]
+
+        gd.barrier()
+        torch.cuda.synchronize()
+        arrivals.clear()
+        with prof:
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(args.warmup + i, record=i)
+            runner.drain()  # every pair enqueued; this stream now waits for all lanes
+            gathered = gd.gather_results(results)  # (world, steps, batch, 4, 4) -- the only collective on the data path
+            gd.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        elapsed = gd.max_over_ranks(elapsed, device)
+        events = prof.results()
+        note(f'rank {rank}: [{precision}] timed region done ({args.steps} steps in {elapsed:.2f} s)')
+        if _pl.HOST_TIMES:  # GEOTR_HOST_TIMING=1: where the lane threads spend their host time, per stack (all steps incl. warm-up)
+            ht = np.array(_pl.HOST_TIMES[-(args.steps * args.batch // args.stack):], dtype=np.float64)
+            note(f'rank {rank}: host ms per stack of {int(ht[:, 0].mean())} pairs over {len(ht)} stacks: pyramid call {1e3 * ht[:, 1].mean():.2f}, '
+                 f'forward launches {1e3 * ht[:, 2].mean():.2f}, final read (waits for the GPU) {1e3 * ht[:, 3].mean():.2f}; '
+                 f'wall per stack per lane {1e3 * elapsed * args.lanes / len(ht):.2f}')
+        if arrivals:  # pairs handed back per quarter of the timed region: a slow start (clock ramp, first-touch) shows up as a low first figure
+            edges = [t0 + elapsed * q / 4 for q in range(1, 5)]
+            quarters = [sum(1 for a in arrivals if (edges[q - 1] if q else t0) <= a < edges[q]) for q in range(4)]
+            note(f'rank {rank}: results handed back per quarter of the timed region: {quarters} (of {len(arrivals)})')
+        if args.dump_shapes and rank == 0:
+            acc = {}
+            for sec, kind, work in events:
+                d = acc.setdefault((kind, tuple(work) if isinstance(work, tuple) else (work,)), [0, 0.0])
+                d[0] += 1
+                d[1] += sec
+            with open(args.dump_shapes, 'a') as fh:
+                for (kind, work), (cnt, sec) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(json.dumps({'precision': precision, 'lanes': args.lanes, 'stack': args.stack, 'family': kind, 'shape': list(work),
+                                         'launches': cnt, 'avg_us': round(1e6 * sec / cnt, 1), 'total_ms': round(1e3 * sec, 3)}) + '\n')
+        roof = None
+        if rank == 0:
+            assert torch.isfinite(gathered).all()
+            roof = roofline_blocks(events, cfg, args, pipe, out, kernels) if events else None  # (re-runs the heaviest shapes alone: still in this mode)
+            if roof is not None:
+                name = 'gse_embed' if roof['kernel'].startswith('gse') else 'gemm_packed'
+                roof['traffic'] = pmc_traffic_bytes(name, precision)
+                roof['traffic_unit'] = ('HBM bytes/launch of this kernel family in this arithmetic mode (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes: '
+                                        'read from the latest committed profiles/r*_pmc_hbm_traffic*.json -- bench.py cannot run under the counters itself; '
+                                        'collected with --lanes 1 --stack 8: a launch there covers 8 stacked pairs, half the rows of a 16-pair launch)')
+        return {'precision': precision, 'elapsed': elapsed, 'last': dict(last), 'roofline': roof,
+                'value': args.steps * args.batch * world / elapsed, 'ms_per_step': 1e3 * elapsed / args.steps}
+
+    DTYPES = {'fp32': 'f32 (IEEE fp32 products, fp32 accumulation: v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32; fp32 storage) -- the reference\'s arithmetic',
+              'fp32-unpacked': 'f32 (exact fp32 MFMA on the rounds-1..3 unpacked kernel)',
+              'bf16x3': 'bf16x3 (split-bf16 products: 3 bf16 MFMA terms per fp32 product, ~2^-17 relative; fp32 accumulate and storage) -- narrower than the reference\'s fp32',
+              'bf16': 'bf16 (plain bf16 operands, fp32 accumulate and storage)'}
+    note(f'rank {rank}: {numa_note}; host waits: {sync_note}')
+    note(f'rank {rank}: model + {len(pairs)} pairs ready')
+    main_run = timed_run(args.precision, args.gse)
+    sibling = None
+    if world == 1 and args.precision == 'fp32' and not args.no_sibling_mode:  # the split-bf16 mode of rounds 1-3, equally complete, never the headline
+        sibling = timed_run('bf16x3', args.gse)
         kernels.set_precision(args.precision, gse=args.gse)
-        last.clear()
-        last.update(timed_out)
 
     if rank == 0:
-        assert torch.isfinite(gathered).all()
-        total_pairs = args.steps * args.batch * world
-        value = total_pairs / elapsed
         D = cfg.geotransformer.hidden_dim
-        from geotransformer_amd import kernels as _k
-        split, plain_bf16 = _k.GEMM_PACKED is True, _k.GEMM_PACKED == 'bf16'
-        roof = roofline_blocks(events, cfg, args, pipe, out, _k) if events else None
-        if roof is not None:
-            name = 'gse_embed' if roof['kernel'].startswith('gse') else 'gemm_packed'
-            roof['traffic'] = pmc_traffic_bytes(name)
-            roof['traffic_unit'] = ('HBM bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; latest profiles/r*_pmc_hbm_traffic.md; '
-                                    'collected with --lanes 1 --stack 8: a launch there covers 8 stacked pairs, half the rows of a 16-pair launch)')
         line = {
             'metric': {'3dmatch': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)',
                        'kitti': 'registration pairs/sec (120k-pt synthetic KITTI-shape pair)',
                        'modelnet': 'registration pairs/sec (1k-pt synthetic ModelNet-shape pair)',
                        'lomatch': 'registration pairs/sec (20k-pt synthetic low-overlap 3DLoMatch-shape pair, 1000 hypotheses)'}[args.config],
-            'value': round(value, 3), 'unit': 'pairs/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'value': round(main_run['value'], 3), 'unit': 'pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(main_run['ms_per_step'], 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('bf16 (plain bf16 operands, fp32 accumulate and storage)' if plain_bf16 else
-                      'bf16x3 (split-bf16 products: 3 bf16 MFMA terms per fp32 product, ~2^-17 relative; fp32 accumulate and storage)' if split else
-                      'f32 (exact fp32 MFMA)'),
+            'dtype': DTYPES[args.precision],
             'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[{baseline_index}]: synthetic {args.config} pair, {n_points}+{n_points} pts, '
                                    f'{cfg.backbone.num_stages}-stage KPConv-FPN, d={D}, '
                                    f'{info["superpoints"][0]}+{info["superpoints"][1]} superpoints, '
                                    f'P={cfg.coarse_matching.num_correspondences}, K={cfg.model.num_points_in_patch}, '
                                    f'pyramid + full forward per pair',
+                       'distinct_pairs_per_gpu': len(pairs), 'pair_seeds': f'{1000 * rank} .. {1000 * rank + len(pairs) - 1} (rank r: 1000 r + i)',
                        'pairs_per_step_per_gpu': args.batch, 'lanes_per_gpu': args.lanes, 'pairs_stacked_per_launch_sequence': args.stack,
                        'host_binding': numa_note, 'host_waits': sync_note,
                        'parallelism': f'pairs sharded over {world} rank(s), one process per GPU, no data-path collective',
                        'collective_backend': 'rccl' if backend == 'nccl' else backend,
                        'weights': 'random init, seed 7351', 'matrix_precision': args.precision, 'gse': args.gse,
                        'inputs': 'raw xyz resident in HBM before the timed region (480 KB/pair; H2D not timed)'},
-            'roofline': roof,
+            'roofline': main_run['roofline'],
         }
-        if fp32_mode is not None:
-            line['exact_fp32_mode'] = fp32_mode
         if world == 1 and not args.no_cpu_baseline:
             os.sched_setaffinity(0, all_cpus)  # the CPU legs (child processes) may use every core the box allows
-            note('CPU baseline (oracle on the host cores)')
-            base, pyr0, want0 = cpu_baseline(cfg, items, pipe.model)
-            note('parity of the timed run vs the oracle')
+            # parity sample: four slots of the LAST timed step, one per lane where the launch shape has four lanes, in different stack slots
+            n_check = min(4, args.batch)
+            slots = sorted({(q * (args.batch - 1)) // max(n_check - 1, 1) for q in range(n_check)})
+            sample = [main_run['last'][j][0] for j in slots]  # indices into items / pairs
+            note(f'CPU baseline (oracle on the host cores) on pairs {sample} = slots {slots} of the last timed step')
+            base, oracle = cpu_baseline(cfg, [items[q] for q in sample], pipe.model)
             line['cpu_baseline'] = base
-            line['speedup_vs_cpu_baseline'] = round(value / base['value'], 1) if base['value'] else None
-            # parity of the TIMED run: the last step's output for pair 0 (one of `--stack` pairs of a lane's launch sequence)
+            line['speedup_vs_cpu_baseline'] = round(main_run['value'] / base['value'], 1) if base['value'] else None
             from oracle import parity
-            slot = next(j for j in range(args.batch) if last[j][0] == 0)
-            # plain-bf16 operands (configs[4]) are held to the north-star bound; the fp32-grade modes to two orders inside it
-            rep = parity.compare_pair(last[slot][1], want0, feature_mse_bound=1e-4 if args.precision == 'bf16' else parity.FEATURE_MSE_BOUND,
-                                      score_tie_rtol=5e-2 if args.precision == 'bf16' else parity.SCORE_TIE_RTOL)
-            # that lane's stacked pyramid, rebuilt and cut back to the pair (the forward does not return its tables)
-            g0 = (slot // args.stack) * args.stack
-            stack_pairs = [pairs[last[j][0]] for j in range(g0, min(g0 + args.stack, args.batch))]
-            _, stacked = pipe.register_batch(stack_pairs, return_pyramid=True)
-            rep['pyramid_tables_identical'] = parity.pyramid_identical(RegistrationPipeline.pair_pyramid(stacked, slot - g0), pyr0)
-            rep['ok'] = bool(rep['ok'] and rep['pyramid_tables_identical'])
-            rep['what'] = (f'pair 0 as computed in the last timed step (slot {slot - g0} of a stack of {len(stack_pairs)}, {args.lanes} lanes) vs the '
-                           'CPU oracle on that pair alone; tolerances in oracle/parity.py; every stack raises on neighbour-table overflow')
-            line['parity'] = rep
+
+            def parity_block(run, precision):
+                """The TIMED run's own outputs (last step) for the sampled slots vs the oracle on each pair alone + that lane's stacked
+                pyramid, rebuilt and cut back to the pair (the forward does not return its tables)."""
+                bf16 = precision == 'bf16'
+                reports = []
+                for j, (pyr_q, want_q) in zip(slots, oracle):
+                    q, out_q = run['last'][j]
+                    # plain-bf16 operands (configs[4]) are held to the north-star bound; the fp32-grade modes to two orders inside it
+                    rep = parity.compare_pair(out_q, want_q, feature_mse_bound=1e-4 if bf16 else parity.FEATURE_MSE_BOUND,
+                                              score_tie_rtol=5e-2 if bf16 else parity.SCORE_TIE_RTOL)
+                    g0 = (j // args.stack) * args.stack
+                    stack_pairs = [pairs[run['last'][jj][0]] for jj in range(g0, min(g0 + args.stack, args.batch))]
+                    _, stacked = pipe.register_batch(stack_pairs, return_pyramid=True)
+                    rep['pyramid_tables_identical'] = parity.pyramid_identical(RegistrationPipeline.pair_pyramid(stacked, j - g0), pyr_q)
+                    rep['ok'] = bool(rep['ok'] and rep['pyramid_tables_identical'])
+                    rep.update(pair_seed=1000 * rank + q, lane_stack=j // args.stack, stack_slot=j - g0)
+                    reports.append(rep)
+                return {'ok': all(r['ok'] for r in reports), 'pairs_checked': len(reports),
+                        'transforms_compared': sum(bool(r['transform_compared']) for r in reports),
+                        'max_feature_mse': max(max(r[k] for k in r if k.startswith('mse_')) for r in reports),
+                        'max_transform_abs_diff': max((r['transform_max_abs_diff'] for r in reports if r['transform_max_abs_diff'] is not None), default=None),
+                        'what': (f'{len(reports)} pairs as computed in the LAST TIMED step (slots {slots} of {args.batch}: stacks of {args.stack}, '
+                                 f'{args.lanes} lanes) vs the CPU oracle on each pair alone; tolerances in oracle/parity.py; a differing coarse '
+                                 f'selection must be a score tie at the selection boundary and is then compared in full; every stack raises on '
+                                 f'neighbour-table overflow'),
+                        'reports': reports}
+
+            note('parity of the timed run vs the oracle')
+            kernels.set_precision(args.precision, gse=args.gse)
+            line['parity'] = parity_block(main_run, args.precision)
+            if sibling is not None:
+                kernels.set_precision('bf16x3', gse=args.gse)
+                sibling['parity'] = parity_block(sibling, 'bf16x3')
+                kernels.set_precision(args.precision, gse=args.gse)
+        if sibling is not None:
+            line['split_bf16_mode'] = {'value': round(sibling['value'], 3), 'unit': 'pairs/s', 'steps': args.steps, 'warmup': args.warmup,
+                                       'ms_per_step': round(sibling['ms_per_step'], 3), 'dtype': DTYPES['bf16x3'],
+                                       'note': 'same workload, execution shape, steps and warm-up as the headline; NOT the headline: its products '
+                                               'are narrower than the reference\'s fp32', 'roofline': sibling['roofline'],
+                                       'parity': sibling.get('parity')}
         print(json.dumps(line))
     runner.close()
     gd.shutdown()  # final barrier + process-group teardown

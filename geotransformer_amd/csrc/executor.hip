@@ -32,7 +32,7 @@ struct Ctx {
   hipStream_t stream;
   bool dry;  // size-query pass: account for allocations, launch nothing
   int rc = GEOTR_OK;
-  bool gemm_bf16 = false;  // geotr_model.gemm_bf16: packed GEMMs use plain bf16 operands (hi planes only)
+  int gemm_mode = 0;  // geotr_model.gemm_mode: arithmetic of the packed GEMMs / fused KPConv -- 0 split-bf16, 1 plain bf16, 2 exact fp32
   int nseg = 1;                                             // stacked pairs: GroupNorm statistics stay inside a pair
   int64_t seg_rows[GEOTR_MAX_STAGES][GEOTR_MAX_PAIRS] = {};  // rows of pair b at stage s (ref + src)
   const int32_t* order[GEOTR_MAX_STAGES] = {};               // grid order of each stage's rows (geotr_pyramid.order; null = row order)
@@ -61,8 +61,11 @@ static inline bool use_packed(const void* packed, const float* a, int64_t lda, i
 
 // Event bracket of one launch for bench.py's live roofline (armed by geotr_profile_gse; free when disarmed).  `tag` goes into the
 // size slot: n > 0 = a per-cloud GSE launch over n superpoints; -pairs = a ragged GSE launch over that many (i, j) pairs;
-// kProfGemm | m << 26 | n << 14 | k = a packed GEMM of that shape (m < 2^24, n < 2^12, k < 2^14; larger shapes are not recorded).
+// kProfGemm | flags << 50 | m << 26 | n << 14 | k = a packed GEMM of that shape (m < 2^24, n < 2^12, k < 2^14; larger shapes are not
+// recorded); flags = what its epilogue moves besides A, W and C: 1 a residual tensor, 2 gathered rows of a coarser product (split
+// decoder), 4 GroupNorm statistics records (bench.py gemm_bytes counts them as algorithmic bytes of the launch).
 constexpr int64_t kProfGemm = 1ll << 62;
+constexpr int64_t kProfResidual = 1ll << 50, kProfGather = 2ll << 50, kProfStats = 4ll << 50;
 constexpr int64_t kProfKpconv = 1ll << 61;  // kProfKpconv | h << 50 | m << 26 | c_out << 14 | 15 c_in = a fused KPConv layer (kpconv_fused.hip)
 struct ProfScope {
   int slot = -1;
@@ -91,9 +94,9 @@ static int packed_gemm(Ctx& c, const float* a, int64_t lda, const void* packed, 
   c.release(mk);  // stream order keeps the scratch valid until the reduce kernel has run: later allocations are written by later launches
   if (!c.live()) return GEOTR_OK;
   ProfScope prof(stream);
-  const int rc = geotr_gemm_packed_splitk(a, lda, packed, out, ldc, m, n, k, bias, row_div, residual, ldr, alpha, act, c.gemm_bf16 ? 1 : 0, sk,
+  const int rc = geotr_gemm_packed_splitk(a, lda, packed, out, ldc, m, n, k, bias, row_div, residual, ldr, alpha, act, c.gemm_mode, sk,
                                           sk_bytes, stream);
-  if (m < (1 << 24) && n < (1 << 12) && k < (1 << 14)) prof.done(kProfGemm | (m << 26) | (n << 14) | k);
+  if (m < (1 << 24) && n < (1 << 12) && k < (1 << 14)) prof.done(kProfGemm | (residual ? kProfResidual : 0) | (m << 26) | (n << 14) | k);
   else prof.done(0);
   return rc;
 }
@@ -129,9 +132,9 @@ static float* linear_gn(Ctx& c, const geotr_linear& l, const float* x, int64_t l
   float* rec = c.alloc<float>(geotr_gemm_packed_stats_floats(c.seg_rows[stage], c.nseg, l.out));
   if (c.live()) {
     ProfScope prof(c.stream);
-    c.check(geotr_gemm_packed_stats(x, lda, l.packed, y, l.out, m, l.out, l.in, l.b, nullptr, 0, c.gemm_bf16 ? 1 : 0, c.seg_rows[stage], c.nseg, rec,
+    c.check(geotr_gemm_packed_stats(x, lda, l.packed, y, l.out, m, l.out, l.in, l.b, nullptr, 0, c.gemm_mode, c.seg_rows[stage], c.nseg, rec,
                                     c.stream));
-    if (m < (1 << 24) && l.out < (1 << 12) && l.in < (1 << 14)) prof.done(kProfGemm | (m << 26) | (l.out << 14) | l.in);
+    if (m < (1 << 24) && l.out < (1 << 12) && l.in < (1 << 14)) prof.done(kProfGemm | kProfStats | (m << 26) | (l.out << 14) | l.in);
     else prof.done(0);
   }
   st.rec = rec;
@@ -219,7 +222,7 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     if (c.live()) {
       ProfScope prof(c.stream);
       c.check(geotr_kpconv_fused(s_feats, q_pts, s_pts, nb, kp.kernel_points, flag, m, ns, h, kp.in, kp.out, kp.num_kernel_points, kp.sigma,
-                                 kp.packed, kp.bias, c.gemm_bf16 ? 1 : 0, order, out, c.stream));
+                                 kp.packed, kp.bias, c.gemm_mode, order, out, c.stream));
       prof.done(kProfKpconv | (h << 50) | (m << 26) | (kp.out << 14) | kdim);
     }
     c.release(mk);
@@ -295,7 +298,7 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
   if (tail_fused && gn_epilogue_stats && tail_ok(b.unary2, b.unary2_norm, y, b.unary2.in) &&
       (!b.has_shortcut || (fuse_shortcut_norm && b.shortcut.out == b.unary2.out && tail_ok(b.shortcut, b.shortcut_norm, sc, b.shortcut.in)))) {
     const int64_t C = b.unary2.out;
-    const int bf16 = c.gemm_bf16 ? 1 : 0;
+    const int bf16 = c.gemm_mode;
     float* out = c.alloc<float>((size_t)m * C);
     const size_t mk = c.mark();
     const size_t rec_floats = geotr_gemm_packed_stats_floats(c.seg_rows[q_stage], c.nseg, C);
@@ -321,13 +324,13 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
         ProfScope prof(c.stream);
         c.check(geotr_gemm_packed_tail(sc, b.shortcut.in, b.shortcut.packed, out, C, m, C, b.shortcut.in, b.shortcut.b, 2, bf16, c.seg_rows[q_stage],
                                        c.nseg, nullptr, ab_t, part, C, c.stream));
-        if (m < (1 << 24) && C < (1 << 12) && b.shortcut.in < (1 << 14)) prof.done(kProfGemm | (m << 26) | (C << 14) | b.shortcut.in);
+        if (m < (1 << 24) && C < (1 << 12) && b.shortcut.in < (1 << 14)) prof.done(kProfGemm | kProfResidual | (m << 26) | (C << 14) | b.shortcut.in);
         else prof.done(0);
       } else {  // identity shortcut (the block input, or its max-pool): out = leaky(GN(z) + sc)
         ProfScope prof(c.stream);
         c.check(geotr_gemm_packed_tail(y, b.unary2.in, b.unary2.packed, out, C, m, C, b.unary2.in, b.unary2.b, 2, bf16, c.seg_rows[q_stage], c.nseg,
                                        nullptr, ab_z, sc, C, c.stream));
-        if (m < (1 << 24) && C < (1 << 12) && b.unary2.in < (1 << 14)) prof.done(kProfGemm | (m << 26) | (C << 14) | b.unary2.in);
+        if (m < (1 << 24) && C < (1 << 12) && b.unary2.in < (1 << 14)) prof.done(kProfGemm | kProfResidual | (m << 26) | (C << 14) | b.unary2.in);
         else prof.done(0);
       }
     }
@@ -412,9 +415,9 @@ static BackboneOut backbone_forward(Ctx& c, const geotr_backbone& net, const geo
       if (c.live()) {
         ProfScope prof(c.stream);
         c.check(geotr_gemm_packed_gather(enc[i], enc_ch[i], net.decoder_packed_skip[d], t, l.out, p.n[i], l.out, enc_ch[i], l.b, 0,
-                                         c.gemm_bf16 ? 1 : 0, coarse, l.out, p.n[i + 1], p.upsampling[i], p.upsampling_w[i], c.seg_rows[i], c.nseg, rec,
+                                         c.gemm_mode, coarse, l.out, p.n[i + 1], p.upsampling[i], p.upsampling_w[i], c.seg_rows[i], c.nseg, rec,
                                          c.stream));
-        if (p.n[i] < (1 << 24) && l.out < (1 << 12) && enc_ch[i] < (1 << 14)) prof.done(kProfGemm | (p.n[i] << 26) | (l.out << 14) | enc_ch[i]);
+        if (p.n[i] < (1 << 24) && l.out < (1 << 12) && enc_ch[i] < (1 << 14)) prof.done(kProfGemm | kProfGather | (rec ? kProfStats : 0) | (p.n[i] << 26) | (l.out << 14) | enc_ch[i]);
         else prof.done(0);
       }
       latent = last ? t : norm(c, net.decoder_norm[d], t, p.n[i], l.out, nullptr, 2, i, nullptr, nullptr, nullptr, &st_d);
@@ -899,7 +902,7 @@ size_t geotr_model_workspace_bytes(const geotr_model* net, const geotr_pyramid* 
   c.cap = 0;
   c.stream = nullptr;
   c.dry = true;
-  c.gemm_bf16 = net->gemm_bf16 != 0;
+  c.gemm_mode = net->gemm_mode;
   run(c, *net, *pyr, nullptr, nullptr);
   return c.peak + 4096;
 }
@@ -915,7 +918,7 @@ int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const 
   c.cap = ws_bytes;
   c.stream = (hipStream_t)stream;
   c.dry = false;
-  c.gemm_bf16 = net->gemm_bf16 != 0;
+  c.gemm_mode = net->gemm_mode;
   return run(c, *net, *pyr, features, out);
 }
 

@@ -554,6 +554,28 @@ __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b
   *reinterpret_cast<uint4*>(lo + v * 8) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+// Exact-fp32 packing (round 4): the same weight as ONE fp32 plane in the B-fragment order of v_mfma_f32_32x32x2_f32, for the kernel's
+// TERMS == 0 instantiation (the reference's own arithmetic: IEEE fp32 products, fp32 accumulation).  A 32x32x2 step multiplies
+// A[i = lane & 31][k = lane >> 5] by B[k = lane >> 5][j = lane & 31]; a lane's operands of FOUR consecutive steps sit in one 16-byte
+// vector: layout [ct = n / 32][k8 = k / 8][lane = n % 32 + 32 * ((k % 8) / 4)][k % 4], i.e. step e of group k8 contracts k = 8 k8 + e
+// (lanes 0-31) and k = 8 k8 + 4 + e (lanes 32-63) -- a fixed permutation of the summation order inside every 8-deep group, shared by
+// the activation fragments (one ds_read_b128 of chunk 2 (k8 % 4) + (lane >> 5) of the row).  Same bytes as the hi + lo planes
+// (4 B per element), same 1 KB chunk per (column tile, 8-deep group) where those have one per (plane, tile, 16-deep step).
+__global__ void gemm_pack_f32_kernel(const float* __restrict__ B, int64_t ldb, int b_is_kn, int N, int K, int K8, int64_t nvec,
+                                     float* __restrict__ out) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 4-element vector per thread
+  if (v >= nvec) return;
+  const int lane = (int)(v & 63), k8 = (int)((v >> 6) % K8), ct = (int)((v >> 6) / K8);
+  const int n = 32 * ct + (lane & 31), k0 = 8 * k8 + 4 * (lane >> 5);
+  float x[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + j;
+    x[j] = (n < N && k < K) ? (b_is_kn ? B[(int64_t)k * ldb + n] : B[(int64_t)n * ldb + k]) : 0.f;
+  }
+  *reinterpret_cast<float4*>(out + v * 4) = make_float4(x[0], x[1], x[2], x[3]);
+}
+
 // Pipeline: both operands of a 32-deep step are DMA'd straight into LDS (global_load_lds_dwordx4: no register staging) into a ring
 // of kPStages stages -- the activation tile raw fp32 (128 rows x 128 B, 16-byte chunks XOR-swizzled by row so the fragment reads are
 // at most 2-way conflicted), the weight fragments as packed.  The fp32 -> (hi, lo) bf16 split happens when a wave reads its A
@@ -584,10 +606,13 @@ __device__ __forceinline__ void lds_wait(u32x4& r0, u32x4& r1, u32x4& r2, u32x4&
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
 }
 
-// TERMS = 3: split-bf16 product;  TERMS = 1: plain bf16 operands (hi planes only: the lo plane is neither loaded nor multiplied).
+// TERMS = 3: split-bf16 product;  TERMS = 1: plain bf16 operands (hi planes only: the lo plane is neither loaded nor multiplied);
+// TERMS = 0: exact fp32 products on v_mfma_f32_32x32x2_f32 against the weight packed by geotr_gemm_pack_f32 (same ring, same stage
+// bytes as TERMS = 3: the four 1 KB chunks of a column tile are its four 8-deep groups instead of (plane, 16-deep step)).
 template <int WM, int WN, int TERMS>
 __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
-  constexpr int BM = 128, PLANES = TERMS == 3 ? 2 : 1;
+  constexpr int BM = 128, PLANES = TERMS == 1 ? 1 : 2;
+  constexpr bool F32 = TERMS == 0;
   constexpr int WAVES_M = BM / (32 * WM), WAVES_N = 4 / WAVES_M, NT_BLK = WN * WAVES_N;  // column tiles per block
   constexpr int A_BYTES = BM * 128, B_BYTES = NT_BLK * PLANES * 2 * 1024, STAGE = A_BYTES + B_BYTES;
   constexpr int B_INSTR = NT_BLK * PLANES * 2;     // 1 KB weight chunks per stage: (plane, ct, kk)
@@ -626,10 +651,17 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
 #pragma unroll
     for (int s = 0; s < B_PER_WAVE; ++s) {
       const int idx = min(wave + 4 * s, B_INSTR - 1);  // (tail duplicates: every wave issues the same number of DMAs)
-      const int pl = idx / (NT_BLK * 2), ctl = (idx / 2) % NT_BLK, kq = idx & 1;
-      const int ct = min(ct0 + ctl, g.NT - 1);
-      const unsigned short* src = g.Bhi + pl * plane_elems + (((int64_t)ct * g.KS + 2 * (kt_first + kt) + kq) * 64 + lane) * 8;
-      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + A_BYTES + idx * 1024), 16, 0, 0);
+      if constexpr (F32) {  // chunk (ctl, q): 8-deep group q of the stage; 2 KS groups per column tile in the packed plane
+        const int ctl = idx >> 2, q = idx & 3;
+        const int ct = min(ct0 + ctl, g.NT - 1);
+        const unsigned short* src = g.Bhi + (((int64_t)ct * 2 * g.KS + 4 * (kt_first + kt) + q) * 64 + lane) * 8;  // 16 B per lane
+        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + A_BYTES + idx * 1024), 16, 0, 0);
+      } else {
+        const int pl = idx / (NT_BLK * 2), ctl = (idx / 2) % NT_BLK, kq = idx & 1;
+        const int ct = min(ct0 + ctl, g.NT - 1);
+        const unsigned short* src = g.Bhi + pl * plane_elems + (((int64_t)ct * g.KS + 2 * (kt_first + kt) + kq) * 64 + lane) * 8;
+        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + A_BYTES + idx * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -643,10 +675,25 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
 
   static_assert(kPStages == 2, "the pipelined loop below assumes a two-slot ring");
   // fragment registers of the two 16-deep steps of a stage: step ks lives in set ks (constant after unrolling)
-  u32x4 fb[2][2][2];  // [set][plane][column tile]
-  u32x4 fa[2][2][2];  // [set][row tile][16-byte chunk]
+  u32x4 fb[2][2][2];  // [set][plane][column tile]          (fp32: [set][8-deep group of the step][column tile])
+  u32x4 fa[2][2][2];  // [set][row tile][16-byte chunk]      (fp32: [set][row tile][8-deep group of the step])
   auto issue_reads = [&](int kt, int ks) {
     const unsigned st = lds_base + (kt % kPStages) * STAGE;
+    if constexpr (F32) {  // step ks = the stage's groups 2 ks and 2 ks + 1: one 16-byte vector per (group, tile) and operand
+      const unsigned ab = st + A_BYTES + (wctl * 4 + 2 * ks) * 1024 + lane * 16;
+      lds_issue2<1024>(ab, fb[ks][0][0], fb[ks][1][0]);
+      if constexpr (WN == 2) lds_issue2<1024>(ab + 4096, fb[ks][0][1], fb[ks][1][1]);
+      const int r = wrow + fr, c0 = 4 * ks + fk;  // group 2 ks + c <-> chunk 2 (2 ks + c) + fk of the row
+      const unsigned a0 = st + (r * 8 + (c0 ^ (r & 7))) * 16, a1 = st + (r * 8 + ((c0 + 2) ^ (r & 7))) * 16;
+      if constexpr (WM == 2) {
+        lds_issue2<4096>(a0, fa[ks][0][0], fa[ks][1][0]);
+        lds_issue2<4096>(a1, fa[ks][0][1], fa[ks][1][1]);
+      } else {
+        lds_issue1(a0, fa[ks][0][0]);
+        lds_issue1(a1, fa[ks][0][1]);
+      }
+      return;
+    }
     constexpr int PL = NT_BLK * 2 * 1024, CT = 2 * 1024;  // (plane, tile) at constant offsets from the wave's first fragment
     const unsigned ab = st + A_BYTES + (wctl * 2 + ks) * 1024 + lane * 16;
     if constexpr (TERMS == 3) {
@@ -670,7 +717,7 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   auto wait_reads = [&](int ks) {  // one s_waitcnt lgkmcnt(0) covers the step; the further calls only tie the other registers to it
     if constexpr (WM == 2) lds_wait(fa[ks][0][0], fa[ks][1][0], fa[ks][0][1], fa[ks][1][1]);
     else lds_wait(fa[ks][0][0], fa[ks][0][1]);
-    if constexpr (TERMS == 3) {
+    if constexpr (TERMS != 1) {
       if constexpr (WN == 2) lds_wait(fb[ks][0][0], fb[ks][1][0], fb[ks][0][1], fb[ks][1][1]);
       else lds_wait(fb[ks][0][0], fb[ks][1][0]);
     } else {
@@ -679,6 +726,18 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
     }
   };
   auto multiply = [&](int ks) {
+    if constexpr (F32) {  // 2 groups x 4 steps of 32x32x2: the (i, j) tiles innermost, so consecutive MFMAs hit different accumulators
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[ks][i][c][e]), __uint_as_float(fb[ks][c][j][e]), acc[i][j], 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const u32x4 q0 = fa[ks][i][0], q1 = fa[ks][i][1];
@@ -847,6 +906,16 @@ extern "C" int geotr_gemm_pack(const float* B, int64_t ldb, int b_is_kn, int64_t
   return GEOTR_OK;
 }
 
+extern "C" int geotr_gemm_pack_f32(const float* B, int64_t ldb, int b_is_kn, int64_t n, int64_t k, void* packed, void* stream) {
+  GEOTR_CHECK_ARG(n >= 1 && k >= 1 && n < (1ll << 24) && k < (1ll << 24), "gemm_pack_f32: bad sizes");
+  GEOTR_CHECK_ARG(B && packed && (reinterpret_cast<uintptr_t>(packed) & 15) == 0, "gemm_pack_f32: null or unaligned pointer");
+  const int64_t np = pack_pad32(n), kp = pack_pad32(k), nvec = np * kp / 4;
+  gemm_pack_f32_kernel<<<dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(B, ldb, b_is_kn, (int)n, (int)k, (int)(kp / 8),
+                                                                                                  nvec, reinterpret_cast<float*>(packed));
+  GEOTR_CHECK_LAUNCH("gemm_pack_f32");
+  return GEOTR_OK;
+}
+
 // Split-K plan of a packed launch: how many K slices make a narrow grid fill the chip.  256 CUs x 2 resident blocks = 512 slots;
 // a launch of fewer than 256 blocks with a deep K (the coarse-stage KPConv contractions: 78 blocks x 120 stages) leaves most of
 // them empty for its whole duration.  Slices of >= 8 stages (256-deep) keep the pipeline prologue / epilogue amortised.
@@ -914,7 +983,7 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   GEOTR_CHECK_ARG(tiles <= 65535, "gemm_packed: M too large");
 #define GEOTR_PACKED(WM, WN, BN)                                                                                        \
   do {                                                                                                                  \
-    const int lds = std::max(kPStages * (128 * 128 + (BN / 32) * (TERMS == 3 ? 4096 : 2048)), 4 * 32 * WM * (32 * WN + 4) * 4); /* ring | epilogue slabs */ \
+    const int lds = std::max(kPStages * (128 * 128 + (BN / 32) * (TERMS != 1 ? 4096 : 2048)), 4 * 32 * WM * (32 * WN + 4) * 4); /* ring | epilogue slabs */ \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             lds) != hipSuccess)                                                                         \
       return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);                                      \
@@ -948,7 +1017,9 @@ extern "C" size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N,
 extern "C" int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                         const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                                         int bf16_operands, void* ws, size_t ws_bytes, void* stream) {
-  if (bf16_operands) return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream, ws, ws_bytes);
+  GEOTR_CHECK_ARG(bf16_operands >= 0 && bf16_operands <= 2, "gemm_packed: arithmetic mode must be 0 (split-bf16), 1 (bf16) or 2 (fp32)");
+  if (bf16_operands == 2) return gemm_packed_launch<0>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream, ws, ws_bytes);
+  if (bf16_operands == 1) return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream, ws, ws_bytes);
   return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream, ws, ws_bytes);
 }
 
@@ -965,8 +1036,9 @@ extern "C" int geotr_gemm_packed_stats(const float* A, int64_t lda, const void* 
                                        const float* bias, const int32_t* row_div, int act, int bf16_operands, const int64_t* seg_rows_host,
                                        int64_t nseg, float* stats, void* stream) {
   GEOTR_CHECK_ARG(stats && seg_rows_host && nseg >= 1, "gemm_packed_stats: null pointer / no segments");
-  if (bf16_operands)
-    return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, nullptr, 0, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg, stats);
+  GEOTR_CHECK_ARG(bf16_operands >= 0 && bf16_operands <= 2, "gemm_packed: arithmetic mode must be 0 (split-bf16), 1 (bf16) or 2 (fp32)");
+  if (bf16_operands == 2) return gemm_packed_launch<0>(A, lda, packed, C, ldc, M, N, K, bias, row_div, nullptr, 0, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg, stats);
+  if (bf16_operands == 1) return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, nullptr, 0, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg, stats);
   return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, row_div, nullptr, 0, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg, stats);
 }
 
@@ -976,11 +1048,13 @@ extern "C" int geotr_gemm_packed_tail(const float* A, int64_t lda, const void* p
   GEOTR_CHECK_ARG(seg_rows_host && nseg >= 1, "gemm_packed_tail: the row segments are required");
   GEOTR_CHECK_ARG((C != nullptr) || (stats != nullptr && !seg_affine && !residual), "gemm_packed_tail: no output requested");
   GEOTR_CHECK_ARG(!seg_affine || (reinterpret_cast<uintptr_t>(seg_affine) & 3) == 0, "gemm_packed_tail: unaligned affine table");
-  if (bf16_operands)
-    return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, residual, ldr, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg,
+  GEOTR_CHECK_ARG(bf16_operands >= 0 && bf16_operands <= 2, "gemm_packed: arithmetic mode must be 0 (split-bf16), 1 (bf16) or 2 (fp32)");
+  if (bf16_operands == 2) return gemm_packed_launch<0>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, residual, ldr, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg,
+                                 stats, nullptr, seg_affine);
+  if (bf16_operands == 1) return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, residual, ldr, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg,
                                  stats, nullptr, seg_affine);
   return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, residual, ldr, 1.0f, act, stream, nullptr, 0, seg_rows_host, nseg,
-                               stats, nullptr, seg_affine);
+                                 stats, nullptr, seg_affine);
 }
 
 extern "C" int geotr_gemm_packed_gather(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
@@ -993,8 +1067,9 @@ extern "C" int geotr_gemm_packed_gather(const float* A, int64_t lda, const void*
   const GatherRes gr{gathered, index, ld_gathered, ld_index, (int)gathered_rows};
   const int64_t* segs = stats ? seg_rows_host : nullptr;
   const int64_t ns = stats ? nseg : 0;
-  if (bf16_operands)
-    return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 1.0f, act, stream, nullptr, 0, segs, ns, stats, &gr);
+  GEOTR_CHECK_ARG(bf16_operands >= 0 && bf16_operands <= 2, "gemm_packed: arithmetic mode must be 0 (split-bf16), 1 (bf16) or 2 (fp32)");
+  if (bf16_operands == 2) return gemm_packed_launch<0>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 1.0f, act, stream, nullptr, 0, segs, ns, stats, &gr);
+  if (bf16_operands == 1) return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 1.0f, act, stream, nullptr, 0, segs, ns, stats, &gr);
   return gemm_packed_launch<3>(A, lda, packed, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 1.0f, act, stream, nullptr, 0, segs, ns, stats, &gr);
 }
 
@@ -1008,6 +1083,12 @@ extern "C" int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* p
                                       int64_t K, const float* bias, const int32_t* row_div, const float* residual, int64_t ldr,
                                       float alpha, int act, void* stream) {
   return gemm_packed_launch<1>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream);
+}
+
+extern "C" int geotr_gemm_packed_f32(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N,
+                                     int64_t K, const float* bias, const int32_t* row_div, const float* residual, int64_t ldr,
+                                     float alpha, int act, void* stream) {
+  return gemm_packed_launch<0>(A, lda, packed, C, ldc, M, N, K, bias, row_div, residual, ldr, alpha, act, stream);
 }
 
 extern "C" int geotr_gemm_grouped(const float* A, const float* B, int b_is_kn, float* C, const geotr_gemm_groups* groups, int64_t heads,

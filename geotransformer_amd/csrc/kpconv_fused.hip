@@ -43,7 +43,9 @@ struct FVec<4> {
   using T = float4;
 };
 
-// C = C_in; WAVES = waves per workgroup; TERMS = 3 split-bf16 / 1 plain bf16 (hi planes only)
+// C = C_in; WAVES = waves per workgroup; TERMS = 3 split-bf16 / 1 plain bf16 (hi planes only) / 0 exact fp32: the tile A stays fp32
+// in LDS (same bytes as its hi + lo halves) and phase 2 runs v_mfma_f32_32x32x2_f32 against the weight packed by geotr_gemm_pack_f32
+// (gemm.hip: four steps of an 8-deep group per 16-byte fragment) -- the reference's own arithmetic end to end (round 4).
 template <int C, int WAVES, int TERMS>
 __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
                                                                   const float* __restrict__ sp, const int64_t* __restrict__ nb,
@@ -56,10 +58,13 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   constexpr int G = C / (16 * VEC);             // loads (column-tile groups) per neighbour step
   constexpr int K = 15 * C;                     // contraction depth of phase 2
   constexpr int RS = K + 8;                     // LDS row stride in bf16 elements (16 B pad)
+  constexpr int RS32 = K + 4;                   // fp32 tile: row stride in floats (16 B pad; the tile has the bytes of the hi + lo halves)
+  constexpr bool F32 = TERMS == 0;
   constexpr int PPW = kFusedRows / WAVES;       // points per wave in phase 1
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   unsigned short* A_hi = reinterpret_cast<unsigned short*>(fsm);
   unsigned short* A_lo = A_hi + kFusedRows * RS;
+  float* A_32 = reinterpret_cast<float*>(fsm);  // TERMS == 0: [32][RS32] fp32
   float4* relw_all = reinterpret_cast<float4*>(A_lo + kFusedRows * RS);  // [WAVES][2][64] (rel.xyz, neighbour index bits), two slots per wave
   int* cnt_s = reinterpret_cast<int*>(relw_all + WAVES * 128);           // [32] neighbours with a positive feature sum
   int* row_s = cnt_s + kFusedRows;                                       // [32] the tile's query rows (visiting order applied)
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   const int CT = c_out >> 5;            // 32-column tiles of the output
   const int KPARTS = WAVES / CT;        // K ranges of phase 2
   const int ct = wave % CT, kpart = wave / CT;
-  const int nkk = K / 16;               // 16-deep steps of phase 2 (K % 32 == 0)
+  const int nkk = F32 ? K / 8 : K / 16;  // 16-deep steps of phase 2 (K % 32 == 0); fp32: 8-deep groups of four 32x32x2 steps
   const int kk_per = (nkk + KPARTS - 1) / KPARTS;
   const int kk0 = kpart * kk_per, kk1 = min(nkk, kk0 + kk_per);
 
@@ -169,6 +174,12 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
         if (kpt >= 15) continue;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+          if constexpr (F32) {  // the fp32 sums as they are
+            float* d = A_32 + row * RS32 + kpt * C + 16 * VEC * g + VEC * n16;
+            if constexpr (VEC == 2) *reinterpret_cast<float2*>(d) = make_float2(acc[g][0][r], acc[g][1][r]);
+            else *reinterpret_cast<float4*>(d) = make_float4(acc[g][0][r], acc[g][1][r], acc[g][2][r], acc[g][3][r]);
+            continue;
+          }
           unsigned h[VEC], l[VEC];
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {  // hi = bf16(x), lo = bf16(x - hi), round to nearest even (v_cvt_pk_bf16_f32, as gemm.hip)
@@ -211,7 +222,19 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-    {
+    if constexpr (F32) {
+      // group q: lane (fr, fk) holds A[fr][8 q + 4 fk + e] and W[8 q + 4 fk + e][32 ct + fr], e = 0 .. 3 = its operands of four steps
+      const float* a32 = A_32 + (lane & 31) * RS32 + 4 * (lane >> 5);
+      const int ctc = min(ct, NT - 1);
+      const float* b32 = reinterpret_cast<const float*>(Bhi) + ((int64_t)ctc * 2 * KS * 64 + lane) * 4;
+#pragma unroll 2
+      for (int q = kk0; q < kk1; ++q) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a32 + 8 * q);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b32 + (int64_t)q * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc2, 0, 0, 0);
+      }
+    } else {
       const unsigned short* a_hi = A_hi + (lane & 31) * RS + 8 * (lane >> 5);
       const unsigned short* a_lo = A_lo + (lane & 31) * RS + 8 * (lane >> 5);
       const int ctc = min(ct, NT - 1);
@@ -409,11 +432,14 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
                                                                                pos_flag, m, ns, (int)h, sigma, (int)c_out, KS, NT, bhi, \
                                                                                blo, bias, order, out);                             \
   } while (0)
+  GEOTR_CHECK_ARG(bf16_operands >= 0 && bf16_operands <= 2, "kpconv_fused: arithmetic mode must be 0 (split-bf16), 1 (bf16) or 2 (fp32)");
   if (c_in == 32) {  // 8 waves in both widths: two resident workgroups at c_in = 32 give 4 waves per SIMD, the LDS tile allows no more
-    if (bf16_operands) GEOTR_KPF(32, 8, 1);
+    if (bf16_operands == 2) GEOTR_KPF(32, 8, 0);
+    else if (bf16_operands == 1) GEOTR_KPF(32, 8, 1);
     else GEOTR_KPF(32, 8, 3);
   } else {
-    if (bf16_operands) GEOTR_KPF(64, 8, 1);
+    if (bf16_operands == 2) GEOTR_KPF(64, 8, 0);
+    else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1);
     else GEOTR_KPF(64, 8, 3);
   }
 #undef GEOTR_KPF

@@ -52,9 +52,16 @@ def gemm(a, b, b_is_kn=False, bias=None, row_div=None, residual=None, alpha=1.0,
     return out
 
 
-GEMM_PACKED = True      # True: split-bf16 (fp32-grade) packed GEMMs;  False: exact fp32 MFMA for every backbone contraction;
-                        # 'bf16': plain bf16 operands on the packed GEMMs (BASELINE configs[4] "bf16 features"; see set_precision)
-PACKED_MIN_ROWS = 1024  # activations with at least this many rows use the packed split-bf16 GEMM when a packed weight is given
+GEMM_PACKED = True      # arithmetic of the packed GEMM pipeline (see set_precision): True: split-bf16 "bf16x3";  'fp32': exact fp32 products
+                        # (v_mfma_f32_32x32x2_f32, the reference's arithmetic) on the SAME pipeline;  'bf16': plain bf16 operands (BASELINE
+                        # configs[4] "bf16 features");  False: no packed weights at all -- every contraction on the unpacked fp32 kernel
+PACKED_MIN_ROWS = 1024  # activations with at least this many rows use the packed GEMM when a packed weight is given
+
+
+def gemm_mode():
+    """The `bf16_operands` / `gemm_mode` argument of the C ABI for the current precision: 0 split-bf16, 1 plain bf16, 2 exact fp32."""
+    return {True: 0, 'bf16': 1, 'fp32': 2}.get(GEMM_PACKED, 0)
+
 
 
 def use_packed(a):
@@ -69,15 +76,16 @@ def gemm_pack(weight, b_is_kn=False, view=None):
     together with its version counter, so an in-place update re-packs and a freed tensor cannot leave a stale entry behind."""
     w2 = weight.detach() if view is None else weight.detach().view(*view)
     assert w2.dim() == 2 and w2.stride(-1) == 1 and w2.dtype == torch.float32
-    key = (weight._version, weight.data_ptr(), tuple(w2.shape), w2.stride(0), bool(b_is_kn), weight.device.index)
+    f32 = GEMM_PACKED == 'fp32'  # one fp32 plane in the 32x32x2 fragment order instead of the hi / lo bf16 planes (same bytes)
+    key = (weight._version, weight.data_ptr(), tuple(w2.shape), w2.stride(0), bool(b_is_kn), weight.device.index, f32)
     hit = getattr(weight, '_geotr_packed', None)
     if hit is not None and hit[0] == key:
         return hit[1]
     lib = _lib.load()
     n, k = (w2.shape[1], w2.shape[0]) if b_is_kn else (w2.shape[0], w2.shape[1])
     packed = torch.empty(lib.geotr_gemm_pack_bytes(n, k), dtype=torch.uint8, device=weight.device)
-    _lib.check(lib.geotr_gemm_pack(_lib.ptr(w2), w2.stride(0), int(b_is_kn), n, k, _lib.ptr(packed), _lib.stream_ptr()),
-               'geotr_gemm_pack')
+    pack = lib.geotr_gemm_pack_f32 if f32 else lib.geotr_gemm_pack
+    _lib.check(pack(_lib.ptr(w2), w2.stride(0), int(b_is_kn), n, k, _lib.ptr(packed), _lib.stream_ptr()), 'geotr_gemm_pack')
     try:
         weight._geotr_packed = (key, packed)
     except AttributeError:  # tensors that reject attributes are simply not cached
@@ -98,16 +106,17 @@ def gemm_packed(a, packed, n, bias=None, row_div=None, residual=None, alpha=1.0,
     if residual is not None:
         assert residual.stride(-1) == 1
         ldr = residual.stride(0)
-    bf16 = GEMM_PACKED == 'bf16'
+    mode = gemm_mode()
     nbytes = lib.geotr_gemm_packed_splitk_workspace_bytes(M, n, K) if split_k else 0
     if nbytes:
         ws = _lib.workspace(nbytes, a.device)
         _lib.check(lib.geotr_gemm_packed_splitk(_lib.ptr(a), a.stride(0), _lib.ptr(packed), _lib.ptr(out), out.stride(0), M, n, K,
                                                 _lib.ptr(bias), _lib.ptr(row_div), _lib.ptr(residual), ldr, float(alpha), ACT[act],
-                                                int(bf16), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'geotr_gemm_packed_splitk')
+                                                mode, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'geotr_gemm_packed_splitk')
         ws.record_stream(torch.cuda.current_stream())
         return out
-    fn, name = (lib.geotr_gemm_packed_bf16, 'geotr_gemm_packed_bf16') if bf16 else (lib.geotr_gemm_packed, 'geotr_gemm_packed')
+    fn, name = [(lib.geotr_gemm_packed, 'geotr_gemm_packed'), (lib.geotr_gemm_packed_bf16, 'geotr_gemm_packed_bf16'),
+                (lib.geotr_gemm_packed_f32, 'geotr_gemm_packed_f32')][mode]
     _lib.check(fn(_lib.ptr(a), a.stride(0), _lib.ptr(packed), _lib.ptr(out), out.stride(0), M, n, K, _lib.ptr(bias),
                   _lib.ptr(row_div), _lib.ptr(residual), ldr, float(alpha), ACT[act], _lib.stream_ptr()), name)
     return out
@@ -148,7 +157,7 @@ def linear_gn(x, weight, bias=None, seg_rows=None):
     y = torch.empty((M, n), dtype=torch.float32, device=x2.device)
     stats = torch.empty(lib.geotr_gemm_packed_stats_floats(seg_arr, len(segs), n), dtype=torch.float32, device=x2.device)
     _lib.check(lib.geotr_gemm_packed_stats(_lib.ptr(x2), x2.stride(0), _lib.ptr(gemm_pack(weight)), _lib.ptr(y), y.stride(0), M, n, K,
-                                           _lib.ptr(bias), None, 0, int(GEMM_PACKED == 'bf16'), seg_arr, len(segs), _lib.ptr(stats),
+                                           _lib.ptr(bias), None, 0, gemm_mode(), seg_arr, len(segs), _lib.ptr(stats),
                                            _lib.stream_ptr()), 'geotr_gemm_packed_stats')
     return y, stats, int(lib.geotr_gemm_packed_stats_rows_per_record(n))
 
@@ -187,7 +196,7 @@ def residual_tail(y, weight, bias, norm, shortcut, sc_weight=None, sc_bias=None,
     assert use_packed(y) and lib.geotr_gemm_packed_splitk_workspace_bytes(M, C, K) == 0
     segs = [M] if seg_rows is None else [int(r) for r in seg_rows]
     seg_arr = (ctypes.c_int64 * len(segs))(*segs)
-    bf16 = int(GEMM_PACKED == 'bf16')
+    bf16 = gemm_mode()
     rec = torch.empty(lib.geotr_gemm_packed_stats_floats(seg_arr, len(segs), C), dtype=torch.float32, device=y.device)
     rpr = int(lib.geotr_gemm_packed_stats_rows_per_record(C))
     out = torch.empty((M, C), dtype=torch.float32, device=y.device)
@@ -223,7 +232,8 @@ DECODER_SPLIT = os.environ.get('GEOTR_DECODER_SPLIT', '1') != '0'  # same A/B sw
 def decoder_packs(weight, latent_ch):
     """The decoder weight W (out, latent_ch + skip_ch) packed in its two column slices [W_latent | W_skip] (gemm_pack of strided views)."""
     w = weight.detach()
-    key = (weight._version, weight.data_ptr(), int(latent_ch))
+    f32 = GEMM_PACKED == 'fp32'
+    key = (weight._version, weight.data_ptr(), int(latent_ch), f32)
     hit = getattr(weight, '_geotr_split_packed', None)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -232,7 +242,8 @@ def decoder_packs(weight, latent_ch):
     for view in (w[:, :latent_ch], w[:, latent_ch:]):
         n, k = view.shape
         packed = torch.empty(lib.geotr_gemm_pack_bytes(n, k), dtype=torch.uint8, device=w.device)
-        _lib.check(lib.geotr_gemm_pack(view.data_ptr(), view.stride(0), 0, n, k, _lib.ptr(packed), _lib.stream_ptr()), 'geotr_gemm_pack')
+        pack = lib.geotr_gemm_pack_f32 if f32 else lib.geotr_gemm_pack
+        _lib.check(pack(view.data_ptr(), view.stride(0), 0, n, k, _lib.ptr(packed), _lib.stream_ptr()), 'geotr_gemm_pack')
         out.append(packed)
     try:
         weight._geotr_split_packed = (key, tuple(out))
@@ -266,7 +277,7 @@ def decoder_linear(latent, upsample_indices, skip, weight, bias=None, want_stats
         stats = torch.empty(lib.geotr_gemm_packed_stats_floats(seg_arr, len(segs), n_out), dtype=torch.float32, device=skip.device)
         rpr = int(lib.geotr_gemm_packed_stats_rows_per_record(n_out))
     _lib.check(lib.geotr_gemm_packed_gather(_lib.ptr(skip), skip.stride(0), _lib.ptr(p_skip), _lib.ptr(y), y.stride(0), M, n_out, skip_ch,
-                                            _lib.ptr(bias), 0, int(GEMM_PACKED == 'bf16'), _lib.ptr(coarse), coarse.stride(0), coarse.shape[0],
+                                            _lib.ptr(bias), 0, gemm_mode(), _lib.ptr(coarse), coarse.stride(0), coarse.shape[0],
                                             _lib.ptr(up), up.stride(0), seg_arr, len(segs), _lib.ptr(stats), _lib.stream_ptr()),
                'geotr_gemm_packed_gather')
     return y, stats, rpr
@@ -309,7 +320,7 @@ def kpconv_fused(s_feats, q_points, s_points, neighbor_indices, kernel_points, s
     out = torch.empty((M, c_out), dtype=torch.float32, device=s_feats.device)
     _lib.check(lib.geotr_kpconv_fused(_lib.ptr(s_feats), _lib.ptr(q_points), _lib.ptr(s_points), _lib.ptr(nb), _lib.ptr(_f32c(kernel_points)),
                                       _lib.ptr(flag), M, Ns, H, C, int(c_out), kernel_points.shape[0], float(sigma), _lib.ptr(packed),
-                                      _lib.ptr(bias), int(GEMM_PACKED == 'bf16'), _lib.ptr(_order(order, M)), _lib.ptr(out), _lib.stream_ptr()),
+                                      _lib.ptr(bias), gemm_mode(), _lib.ptr(_order(order, M)), _lib.ptr(out), _lib.stream_ptr()),
                'geotr_kpconv_fused')
     return out
 
@@ -433,17 +444,19 @@ GSE_PRECISION = 5  # 5: by table (default: proj(sinusoid(x)) tabulated as cubic 
                    # 0: fp32 MFMA (exact fp32 products); 1: split-bf16 "bf16x3" MFMA (~2^-17 relative error per product);
                    # 3: plain bf16 operands (~2^-8 per product)
 
-_PRECISIONS = {'fp32': (False, 0), 'bf16x3': (True, 5), 'bf16': ('bf16', 5)}
-_GSE_MFMA = {'fp32': 0, 'bf16x3': 1, 'bf16': 3}
+_PRECISIONS = {'fp32': ('fp32', 5), 'bf16x3': (True, 5), 'bf16': ('bf16', 5), 'fp32-unpacked': (False, 5)}
+_GSE_MFMA = {'fp32': 0, 'bf16x3': 1, 'bf16': 3, 'fp32-unpacked': 0}
 
 
 def set_precision(name, gse='table'):
     """Arithmetic of the matrix-pipe kernel family (packed GEMMs of the backbone / transformer) and of the GSE embedding:
     'bf16x3' (default): split-bf16 products, fp32-grade -- the mode every reference-parity claim is made in;
-    'fp32': exact fp32 MFMA products everywhere (GSE on the fp32 MFMA kernel);
+    'fp32': exact fp32 MFMA products everywhere -- the reference's own arithmetic (IEEE fp32 products, fp32 accumulation) -- on the
+        same packed pipeline (weights packed by geotr_gemm_pack_f32, v_mfma_f32_32x32x2_f32; round 4);
+    'fp32-unpacked': the same arithmetic on the rounds-1..3 kernel (no packed weights, no fused KPConv / epilogue statistics; A/B only);
     'bf16': plain bf16 operands with fp32 accumulation (BASELINE configs[4] "bf16 features").
-    `gse`: 'table' (default: the embedding by table lookup, fp32, independent of the GEMM mode -- except under 'fp32', which
-    keeps the all-MFMA exact path) or 'mfma' (the fused sinusoid -> MFMA kernel in the named arithmetic).
+    `gse`: 'table' (default: the embedding by table lookup -- fp32 arithmetic throughout, independent of the GEMM mode) or
+    'mfma' (the fused sinusoid -> MFMA kernel in the named arithmetic; under 'fp32' that is the exact fp32 MFMA kernel).
     Returns the previous mode's name.  Process-wide; running models pick it up at their next forward."""
     global GEMM_PACKED, GSE_PRECISION
     if name not in _PRECISIONS:

@@ -91,7 +91,7 @@ class Model(ctypes.Structure):
     _fields_ = [('backbone', Backbone), ('transformer', Transformer), ('alpha', P_F32),
                 ('num_points_in_patch', I64), ('num_correspondences', I64), ('num_sinkhorn_iterations', I64),
                 ('dual_normalization', I32), ('topk', I32), ('mutual', I32), ('correspondence_threshold', I32),
-                ('num_refinement_steps', I32), ('gemm_bf16', I32), ('confidence_threshold', F32), ('acceptance_radius', F32)]
+                ('num_refinement_steps', I32), ('gemm_mode', I32), ('confidence_threshold', F32), ('acceptance_radius', F32)]
 
 
 class Outputs(ctypes.Structure):
@@ -259,7 +259,7 @@ class NativeModel:
         f = m.fine_matching
         d.topk, d.mutual, d.correspondence_threshold = f.k, int(f.mutual), f.correspondence_threshold
         d.num_refinement_steps = f.num_refinement_steps
-        d.gemm_bf16 = int(kernels.GEMM_PACKED == 'bf16')
+        d.gemm_mode = kernels.gemm_mode()
         d.confidence_threshold, d.acceptance_radius = float(f.confidence_threshold), float(f.acceptance_radius)
         return d, self._keep
 
@@ -479,7 +479,7 @@ class KernelProfiler:
 
     Events are created here, handed to the library as raw handles and recorded by the executor on the launch stream; the first
     `capacity` such launches after arming are recorded.  `results()` -> [(seconds, kind, work)]: kind 'gse' with work = number of
-    (i, j) superpoint pairs of the launch, kind 'gemm' with work = (m, n, k), or kind 'kpconv' (a fused KPConv layer) with
+    (i, j) superpoint pairs of the launch, kind 'gemm' with work = (m, n, k, epilogue flags: 1 residual read, 2 gathered coarse rows, 4 statistics records), or kind 'kpconv' (a fused KPConv layer) with
     work = (m, c_out, 15 c_in, h)."""
     GEMM_TAG = 1 << 62
     KPCONV_TAG = 1 << 61
@@ -515,7 +515,7 @@ class KernelProfiler:
         for i in range(self.used):
             sec, tag = self.start[i].elapsed_time(self.stop[i]) * 1e-3, int(self._sizes[i])
             if tag & self.GEMM_TAG and tag > 0:
-                out.append((sec, 'gemm', ((tag >> 26) & 0xffffff, (tag >> 14) & 0xfff, tag & 0x3fff)))
+                out.append((sec, 'gemm', ((tag >> 26) & 0xffffff, (tag >> 14) & 0xfff, tag & 0x3fff, (tag >> 50) & 7)))  # (m, n, k, epilogue flags)
             elif tag & self.KPCONV_TAG and tag > 0:
                 out.append((sec, 'kpconv', ((tag >> 26) & 0xffffff, (tag >> 14) & 0xfff, tag & 0x3fff, (tag >> 50) & 0x7ff)))
             elif tag != 0:

@@ -34,7 +34,7 @@ extern "C" {
 const char* geotr_last_error(void);
 /* ABI version of this header; bumped on any signature change.  A host compares the macro it was compiled against with what the
  * loaded library reports. */
-#define GEOTR_ABI_VERSION 4
+#define GEOTR_ABI_VERSION 5
 int geotr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -145,7 +145,9 @@ int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C,
 /* Split-K variant for narrow, deep launches (fewer than 256 output tiles and K >= 512: the coarse-stage KPConv contractions):
  * gridDim.z K slices write raw fp32 partial tiles to `ws`, a second kernel sums them in slice order (deterministic) and applies the
  * epilogue.  ws = geotr_gemm_packed_splitk_workspace_bytes(M, N, K) bytes, 16-byte aligned (0 => the launch is not split and ws may
- * be NULL; identical to geotr_gemm_packed / _bf16 then).  bf16_operands: 0 = split-bf16 products, 1 = plain bf16 operands. */
+ * be NULL; identical to geotr_gemm_packed / _bf16 / _f32 then).  bf16_operands = the ARITHMETIC MODE of every entry point that takes it
+ * (ABI 5): 0 = split-bf16 products, 1 = plain bf16 operands (both on a geotr_gemm_pack weight), 2 = exact fp32 products on
+ * v_mfma_f32_32x32x2_f32 (on a geotr_gemm_pack_f32 weight) -- the reference's own arithmetic. */
 size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                              const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
@@ -177,6 +179,15 @@ int geotr_gemm_packed_gather(const float* A, int64_t lda, const void* packed, fl
                              const float* bias, int act, int bf16_operands, const float* gathered, int64_t ld_gathered,
                              int64_t gathered_rows, const int64_t* index, int64_t ld_index, const int64_t* seg_rows_host, int64_t nseg,
                              float* stats, void* stream);
+/* Exact-fp32 mode (round 4; ABI 5): the same pipeline (LDS-DMA ring, segment-aligned tiles, statistics / gather epilogues, split-K) with
+ * IEEE fp32 products and fp32 accumulation on v_mfma_f32_32x32x2_f32 -- what the reference's fp32 `F.linear` / `torch.matmul` compute
+ * (kpconv/kpconv.py:108-110, kpconv/modules.py:68,98), up to the order of the sum over k.  geotr_gemm_pack_f32 lays the weight out as ONE
+ * fp32 plane in that instruction's B-fragment order (geotr_gemm_pack_bytes(n, k) bytes as well: 4 B per element either way); it is
+ * NOT interchangeable with a geotr_gemm_pack buffer -- pass mode 2 with it and mode 0 / 1 with the other. */
+int geotr_gemm_pack_f32(const float* B, int64_t ldb, int b_is_kn, int64_t n, int64_t k, void* packed, void* stream);
+int geotr_gemm_packed_f32(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                          const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
+                          void* stream);
 /* The same launch with plain bf16 operands (hi planes of the same packed weight, a_hi*b_hi only, fp32 accumulation; ~2^-8 relative
  * error per product): the "bf16 features" mode of BASELINE configs[4].  Never the default. */
 int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
@@ -481,7 +492,8 @@ typedef struct geotr_model {
   const float* alpha;                                                /* optimal_transport.alpha (device scalar) */
   int64_t num_points_in_patch, num_correspondences, num_sinkhorn_iterations;
   int32_t dual_normalization, topk, mutual, correspondence_threshold, num_refinement_steps;
-  int32_t gemm_bf16;         /* 0: packed GEMMs are split-bf16 (fp32-grade);  1: plain bf16 operands (geotr_gemm_packed_bf16) */
+  int32_t gemm_mode;         /* arithmetic of the packed GEMMs / fused KPConv: 0 split-bf16, 1 plain bf16 operands (weights packed by
+                              * geotr_gemm_pack), 2 exact fp32 (weights packed by geotr_gemm_pack_f32) */
   float confidence_threshold, acceptance_radius;
 } geotr_model;
 typedef struct geotr_outputs {                                       /* caller-allocated device buffers (reference output dict keys) */

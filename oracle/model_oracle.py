@@ -523,7 +523,9 @@ def forward(sd, cfg, data):
                                                 cfg['fine'])
     out['ref_corr_points'], out['src_corr_points'], out['corr_scores'], out['estimated_transform'] = rcp, scp, cs, T
     out['ref_node_knn_indices'], out['src_node_knn_indices'] = ref_knn_idx, src_knn_idx
+    out['ref_node_knn_masks'], out['src_node_knn_masks'] = ref_knn_masks, src_knn_masks
     out['ref_node_masks'], out['src_node_masks'] = ref_node_masks, src_node_masks
+    out['ref_points_f'], out['src_points_f'], out['ref_points_c'], out['src_points_c'] = ref_f, src_f, ref_c, src_c
     return out
 
 

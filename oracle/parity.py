@@ -7,7 +7,13 @@ Tolerances (BASELINE.json north_star: neighbour indices bit-exact, feature MSE <
   features (4 tensors)      MSE <= 1e-6 (two orders inside the north-star bound)
   coarse correspondences    a global top-k over nearly flat scores under random weights: reported as set overlap (>= 0.95); when
                             the selected SET is identical the patches are aligned pair by pair, and every rank that differs must
-                            be explained by oracle scores that are equal to rounding (relative 1e-4; measured gap reported) -- else the pair fails
+                            be explained by oracle scores that are equal to rounding (relative 1e-4; measured gap reported) -- else the pair fails.
+                            When the SET differs (round 4: the former escape hatch -- such a pair used to pass on the overlap alone): every
+                            superpoint pair held by ONE side only must be a tie at the selection boundary -- its ORACLE score within
+                            relative 1e-4 of the oracle's rank-P score -- and this side's ranking must be the oracle's scores in
+                            non-increasing order up to the same tolerance; the oracle's fine stage (patch scores, Sinkhorn) is then
+                            re-run on THIS side's pair list, so matching scores, patches and the pose are compared on every selected
+                            pair, not skipped.  A set difference that is not such a tie fails the pair
   superpoint patches        the K nearest points of a superpoint, by the reference's expanded distance |x|^2 - 2xy + |y|^2 (a BLAS
                             product in the reference): equal-to-rounding distances may list the same points in another order
                             (aligned point by point), and may move a point across the K-th-nearest boundary or to an equidistant
@@ -42,8 +48,51 @@ def oracle_pair(cfg, state_dict, item, lib=None):
     data['features'] = torch.ones((pts.shape[0], 1))
     ocfg = mo.config_from_reference(cfg)
     want = mo.forward(state_dict, ocfg, data)
-    want['_fine_cfg'] = ocfg['fine']  # compare_pair re-runs the oracle's registration head in the HIP side's patch order
+    attach_head_config(want, ocfg, state_dict)
     return pyr, want
+
+
+def attach_head_config(want, ocfg, state_dict):
+    """What compare_pair needs to re-run the oracle's heads on this side's selection / order: the registration head's settings and
+    the matching stage's (Sinkhorn dustbin score, iteration count, coarse top-k settings)."""
+    want['_fine_cfg'] = ocfg['fine']
+    want['_head_cfg'] = {'alpha': state_dict['optimal_transport.alpha'].detach().cpu().float(),
+                         'num_sinkhorn_iterations': ocfg['num_sinkhorn_iterations'], 'num_correspondences': ocfg['num_correspondences'],
+                         'dual_normalization': ocfg['dual_normalization']}
+    return want
+
+
+def _oracle_coarse_scores(want, head_cfg):
+    """The oracle's full (n, m) superpoint score matrix (superpoint_matching.py:13-50 on the oracle's own features; masked
+    superpoints hold -1): what a pair NOT selected by the oracle scored."""
+    from . import model_oracle as mo
+    rf, sf = want['ref_feats_c'], want['src_feats_c']
+    rm, sm = want['ref_node_masks'], want['src_node_masks']
+    ri, si = torch.nonzero(rm, as_tuple=True)[0], torch.nonzero(sm, as_tuple=True)[0]
+    sc = torch.exp(-mo.pairwise_distance(rf[ri], sf[si], normalized=True))
+    if head_cfg['dual_normalization']:
+        sc = (sc / sc.sum(dim=1, keepdim=True)) * (sc / sc.sum(dim=0, keepdim=True))
+    full = torch.full((rf.shape[0], sf.shape[0]), -1.0, dtype=sc.dtype)
+    full[ri[:, None], si[None, :]] = sc
+    return full
+
+
+def _oracle_fine_stage(want, ref_idx, src_idx, head_cfg):
+    """The oracle's patch gather + optimal transport (model.py:150-188, learnable_sinkhorn.py) for an arbitrary list of superpoint
+    pairs, on the oracle's own fine features and partition -> the entries of `want` that depend on the selection."""
+    from . import model_oracle as mo
+    rk_idx, sk_idx = want['ref_node_knn_indices'][ref_idx], want['src_node_knn_indices'][src_idx]
+    rpf, spf = want['ref_points_f'], want['src_points_f']
+    rff, sff = want['ref_feats_f'], want['src_feats_f']
+    rk_masks, sk_masks = want['ref_node_knn_masks'][ref_idx], want['src_node_knn_masks'][src_idx]
+    rk_points = mo.index_select(torch.cat([rpf, torch.zeros_like(rpf[:1])], 0), rk_idx, 0)
+    sk_points = mo.index_select(torch.cat([spf, torch.zeros_like(spf[:1])], 0), sk_idx, 0)
+    rk_feats = mo.index_select(torch.cat([rff, torch.zeros_like(rff[:1])], 0), rk_idx, 0)
+    sk_feats = mo.index_select(torch.cat([sff, torch.zeros_like(sff[:1])], 0), sk_idx, 0)
+    scores = torch.einsum('bnd,bmd->bnm', rk_feats, sk_feats) / rff.shape[1] ** 0.5
+    matching = mo.optimal_transport(scores, rk_masks, sk_masks, head_cfg['alpha'], head_cfg['num_sinkhorn_iterations'])
+    return {'ref_node_corr_knn_points': rk_points, 'src_node_corr_knn_points': sk_points, 'ref_node_corr_knn_masks': rk_masks,
+            'src_node_corr_knn_masks': sk_masks, 'matching_scores': matching}
 
 
 def pyramid_identical(got, want):
@@ -130,6 +179,7 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, 
     `fine_cfg`: the oracle's registration-head settings (default: want['_fine_cfg'], put there by oracle_pair); with them the pose
     is asserted for every pair whose patches align."""
     fine_cfg = fine_cfg or want.get('_fine_cfg')
+    head_cfg = want.get('_head_cfg')
     rep = {'feature_mse_bound': feature_mse_bound}
     ok = True
     for k in ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f'):
@@ -149,7 +199,45 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, 
     rep['transform_compared'] = False
     rep['correspondences'] = [int(got['corr_scores'].shape[0]), int(want['corr_scores'].shape[0])]
     rep['coarse_same_set'] = bool(gi.shape == wi.shape and gs == ws and len(gs) == gi.shape[0])
-    if rep['coarse_same_set']:
+    if not rep['coarse_same_set'] and gi.shape == wi.shape and len(gs) == gi.shape[0]:
+        # The selected SETS differ.  Legitimate only at the selection boundary: every pair held by one side only must score -- in the
+        # ORACLE's arithmetic -- within score_tie_rtol of the oracle's rank-P score, and this side's ranking must list the oracle's
+        # scores in non-increasing order up to the same tolerance.  Then the oracle's fine stage is re-run on THIS side's pair list
+        # and everything downstream (patches, matching scores, pose) is compared on every selected pair.
+        can = head_cfg is not None and all(k in want for k in ('ref_node_knn_indices', 'src_node_knn_indices', 'ref_node_knn_masks', 'src_node_knn_masks',
+                                                               'ref_node_masks', 'src_node_masks', 'ref_points_f', 'src_points_f'))
+        rep['coarse_set_difference'] = len(gs ^ ws) // 2
+        if not can:
+            rep['coarse_set_difference_explained'] = False
+            rep['note'] = 'the selected sets differ and the oracle outputs needed to examine the difference are absent'
+            ok = False
+        else:
+            full = _oracle_coarse_scores(want, head_cfg).double()
+            kth = float(want['node_corr_scores'].double().min())
+            only = sorted(gs ^ ws)
+            sc_only = torch.stack([full[a, b] for a, b in only])
+            gap = float(((sc_only - kth).abs() / max(abs(kth), 1e-30)).max())
+            mine = torch.stack([full[a, b] for a, b in gi.tolist()])
+            order_gap = float(((mine - mine.sort(descending=True).values).abs() / mine.abs().clamp_min(1e-30)).max())
+            rep['coarse_set_difference_max_rel_gap_to_rank_P_score'] = gap
+            rep['coarse_order_max_rel_score_gap'] = order_gap
+            explained = bool((sc_only > 0).all()) and gap <= score_tie_rtol and order_gap <= score_tie_rtol
+            rep['coarse_set_difference_explained'] = explained
+            ok &= explained
+            if explained:  # the oracle's selection-dependent outputs for THIS side's list, in this side's order
+                want = dict(want)
+                want.update(_oracle_fine_stage(want, gi[:, 0], gi[:, 1], head_cfg))
+                want['ref_node_corr_indices'], want['src_node_corr_indices'] = gi[:, 0].clone(), gi[:, 1].clone()
+                want['node_corr_scores'] = mine.float()
+                if fine_cfg is not None:
+                    from . import model_oracle as mo
+                    want['estimated_transform'] = mo.local_global_registration(
+                        want['ref_node_corr_knn_points'], want['src_node_corr_knn_points'], want['ref_node_corr_knn_masks'],
+                        want['src_node_corr_knn_masks'], want['matching_scores'][:, :-1, :-1], fine_cfg)[3]
+                wi = gi.clone()
+                ws = gs
+    aligned = rep['coarse_same_set'] or rep.get('coarse_set_difference_explained', False)
+    if aligned:
         # the same superpoint pairs, possibly listed in another order (scores equal to rounding swap ranks): align patch p of the
         # oracle with the patch of the same (ref, src) pair here, then compare patch by patch
         where = {pair: i for i, pair in enumerate(map(tuple, gi.tolist()))}
@@ -235,6 +323,13 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, 
             rep['transform_compared'] = True
         if rep['transform_compared']:
             ok &= rep['transform_max_abs_diff'] <= TRANSFORM_ATOL
+        else:  # never silently: say why the pose of an accepted pair could not be asserted
+            rep['transform_not_compared_because'] = (
+                f'{tie_patches} patch(es) hold another point set, each explained by a distance tie ({tie_points} points moved)' if tie_patches and not unexplained
+                else 'unexplained patches' if unexplained else 'patch masks differ' if not masks_equal
+                else 'no registration-head settings were given and the patch order differs')
+    elif ok:
+        ok = False  # (unreachable by construction: a differing set is either explained above or has already failed)
     ok &= bool(torch.isfinite(got['estimated_transform']).all())
     rep['ok'] = bool(ok)
     return rep

@@ -38,3 +38,15 @@ def reference_lib():
     if lib is None:
         pytest.skip('oracle/_ref/libgeoref.so not built (needs /root/reference)')
     return lib
+
+
+@pytest.fixture(params=['bf16x3', 'fp32'])
+def matrix_precision(request):
+    """Both fp32-grade arithmetic modes of the matrix-pipe kernels: split-bf16 products ('bf16x3') and exact fp32 MFMA products
+    ('fp32', the reference's own arithmetic and the mode the headline is measured in).  Yields the mode's name."""
+    from geotransformer_amd import kernels
+    prev = kernels.set_precision(request.param)
+    try:
+        yield request.param
+    finally:
+        kernels.set_precision(prev)

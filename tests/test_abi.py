@@ -127,7 +127,12 @@ def test_set_precision_is_host_logic_and_invalidates_model_descriptors():
         assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == (True, 1)
         kernels.set_precision('bf16')
         assert kernels.set_precision('fp32') == 'bf16'
-        assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == (False, 0)
+        assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('fp32', 5)  # exact fp32 products on the packed pipeline + the fp32 table embedding
+        assert kernels.gemm_mode() == 2
+        kernels.set_precision('fp32', gse='mfma')
+        assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('fp32', 0)
+        assert kernels.set_precision('fp32-unpacked') == 'fp32'
+        assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == (False, 5) and kernels.gemm_mode() == 0
         with pytest.raises(ValueError):
             kernels.set_precision('fp8')
         with pytest.raises(ValueError):

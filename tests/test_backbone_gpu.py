@@ -71,7 +71,7 @@ def test_kpconv_layer_matches_oracle(C):
 
 
 @pytest.mark.parametrize('C,CO,H', [(32, 32, 36), (64, 64, 36), (32, 64, 38), (64, 128, 24), (32, 128, 40), (64, 256, 33)])
-def test_kpconv_fused_matches_oracle_and_the_two_kernel_path(C, CO, H):
+def test_kpconv_fused_matches_oracle_and_the_two_kernel_path(C, CO, H, matrix_precision):
     """geotr_kpconv_fused (one kernel: fp32-MFMA neighbour contraction into LDS + split-bf16 kernel-point contraction) vs the
     oracle and vs gather -> packed GEMM, on a strided layer (queries = coarser cloud), with pad neighbours, rows of negative
     feature sum (neighbour-count rule) and a row count that is not a multiple of the 32-point tile."""
@@ -178,7 +178,7 @@ def test_group_norm_and_layer_norm(N, C, G):
 
 
 @pytest.mark.parametrize('name', ['model_modelnet_small', 'model_3dmatch_small'])
-def test_backbone_matches_reference_golden(name):
+def test_backbone_matches_reference_golden(name, matrix_precision):
     """Whole KPConv-FPN on the GPU with the reference's weights and collated inputs vs the reference's activations."""
     from geotransformer_amd.backbone import KPConvFPN
     cfg, sd, data, out, mids = load_model_golden(name)

@@ -107,6 +107,71 @@ def test_the_pose_is_asserted_in_this_sides_order():
     assert not rep['ok'] and rep['transform_compared']
 
 
+def _oracle_like(seed=11, n=7, m=9, P=24, K=5, N=40, M=30):
+    """A `want` dict built with the oracle's own head functions (so that compare_pair can re-run them on another selection)."""
+    from oracle import model_oracle as mo
+    g = torch.Generator().manual_seed(seed)
+    F = torch.nn.functional
+    want = {'ref_feats_c': F.normalize(torch.randn(n, 8, generator=g), dim=1), 'src_feats_c': F.normalize(torch.randn(m, 8, generator=g), dim=1),
+            'ref_feats_f': torch.randn(N, 8, generator=g), 'src_feats_f': torch.randn(M, 8, generator=g),
+            'ref_points_f': torch.randn(N, 3, generator=g), 'src_points_f': torch.randn(M, 3, generator=g),
+            'ref_points_c': torch.randn(n, 3, generator=g), 'src_points_c': torch.randn(m, 3, generator=g),
+            'ref_node_masks': torch.ones(n, dtype=torch.bool), 'src_node_masks': torch.ones(m, dtype=torch.bool)}
+    want['ref_node_knn_indices'] = torch.stack([torch.randperm(N + 1, generator=g)[:K] for _ in range(n)])
+    want['src_node_knn_indices'] = torch.stack([torch.randperm(M + 1, generator=g)[:K] for _ in range(m)])
+    want['ref_node_knn_masks'], want['src_node_knn_masks'] = want['ref_node_knn_indices'] < N, want['src_node_knn_indices'] < M
+    fine = dict(topk=2, acceptance_radius=0.5, mutual=True, confidence_threshold=0.05, correspondence_threshold=2, num_refinement_steps=3)
+    head = {'alpha': torch.tensor(1.0), 'num_sinkhorn_iterations': 10, 'num_correspondences': P, 'dual_normalization': True}
+    want['_fine_cfg'], want['_head_cfg'] = fine, head
+
+    def finish(o, ri, si):
+        o['ref_node_corr_indices'], o['src_node_corr_indices'] = ri, si
+        o.update(parity._oracle_fine_stage(want, ri, si, head))
+        o['ref_corr_points'], o['src_corr_points'], o['corr_scores'], o['estimated_transform'] = mo.local_global_registration(
+            o['ref_node_corr_knn_points'], o['src_node_corr_knn_points'], o['ref_node_corr_knn_masks'], o['src_node_corr_knn_masks'],
+            o['matching_scores'][:, :-1, :-1], fine)
+        return o
+
+    ri, si, sc = mo.superpoint_matching(want['ref_feats_c'], want['src_feats_c'], want['ref_node_masks'], want['src_node_masks'], P)
+    want['node_corr_scores'] = sc
+    finish(want, ri, si)
+    return want, finish
+
+
+def test_a_differing_coarse_set_must_be_a_tie_at_the_selection_boundary_and_is_then_compared_in_full():
+    """VERDICT r3 item 2 (the former escape hatch): this side selects the oracle's rank-(P+1) pair instead of its rank-P pair."""
+    from oracle import model_oracle as mo
+    want, finish = _oracle_like()
+    P = len(want['ref_node_corr_indices'])
+    ri7, si7, sc7 = mo.superpoint_matching(want['ref_feats_c'], want['src_feats_c'], want['ref_node_masks'], want['src_node_masks'], P + 1)
+    keep = torch.tensor([i for i in range(P + 1) if i != P - 1])  # drop rank P, take rank P + 1
+    got = finish({k: v for k, v in want.items() if not k.startswith('_')}, ri7[keep], si7[keep])
+    rel = float((sc7[P - 1] - sc7[P]) / sc7[P - 1])
+    assert rel > 1e-3  # random features: not a tie
+    rep = parity.compare_pair(got, want)
+    assert not rep['ok'] and not rep['coarse_same_set'] and rep['coarse_set_difference'] == 1, rep
+    assert rep['coarse_set_difference_explained'] is False and abs(rep['coarse_set_difference_max_rel_gap_to_rank_P_score'] - rel) < 1e-6
+    # the same difference under a tolerance that calls it a tie: everything downstream is compared on THIS side's selection
+    rep = parity.compare_pair(got, want, score_tie_rtol=2 * rel)
+    assert rep['ok'] and rep['coarse_set_difference_explained'] and rep['transform_compared'], rep
+    assert rep['matching_scores_max_err'] == 0.0 and rep['transform_max_abs_diff'] <= 1e-6 and rep['patches_with_identical_point_set'] == 1.0
+    # ... so a wrong score in the patch of the pair the oracle did NOT select is caught (it used to be skipped entirely)
+    bad = dict(got)
+    bad['matching_scores'] = got['matching_scores'].clone()
+    live = (bad['matching_scores'][P - 1] > -1e11).nonzero()[0]
+    bad['matching_scores'][P - 1, live[0], live[1]] += 0.1
+    assert not parity.compare_pair(bad, want, score_tie_rtol=2 * rel)['ok']
+    # a pair that is far from the boundary is never a tie
+    far = finish({k: v for k, v in want.items() if not k.startswith('_')}, torch.cat([ri7[:P - 1], torch.tensor([0])]),
+                 torch.cat([si7[:P - 1], torch.tensor([0])]))
+    if (0, 0) not in set(zip(ri7[:P].tolist(), si7[:P].tolist())):
+        assert not parity.compare_pair(far, want, score_tie_rtol=2 * rel)['ok']
+    # without the oracle outputs needed to examine the difference the pair fails (no silent pass on the overlap)
+    thin = {k: v for k, v in want.items() if k not in ('ref_node_knn_indices', '_head_cfg')}
+    rep = parity.compare_pair(got, thin, score_tie_rtol=2 * rel)
+    assert not rep['ok'] and rep['coarse_set_difference_explained'] is False
+
+
 def test_a_patch_with_another_point_set_must_be_explained_by_a_distance_tie():
     want = _pair(seed=4)
     node = want['ref_points_c'][int(want['ref_node_corr_indices'][3])]
@@ -167,13 +232,20 @@ def test_bench_gemm_roofline_block_states_both_roofs():
     assert blk['bound'] == 'hbm' and blk['unit'] == 'GB/s' and blk['peak'] == 8000.0
     assert abs(blk['achieved'] - nbytes / 3.8e-3 / 1e9) < 0.1 and abs(blk['frac'] - blk['achieved'] / blk['peak']) < 1e-3
     assert blk['launches'] == 5 and blk['algorithmic_bytes_per_launch'] == round(nbytes / 5)
-    assert top[0][0] == (640000, 128, 64) and blk['top_shapes_in_flight'][0]['launches'] == 3
+    assert top[0][0] == (640000, 128, 64, 0) and blk['top_shapes_in_flight'][0]['launches'] == 3
     assert abs(blk['executed_tflops'] - 3 * blk['algorithmic_tflops']) < 0.05
     deep = [(50e-6, (4096, 512, 8192))] * 4
     blk, _ = bench.gemm_family_block(deep, True, 'note')
     assert blk['bound'] == 'mfma' and blk['unit'] == 'TFLOP/s' and blk['peak'] == 2500.0
     assert abs(blk['achieved'] - 2.0 * 4096 * 512 * 8192 / 50e-6 / 1e12) < 0.01
-    blk, _ = bench.gemm_family_block(deep, False, 'note')  # exact-fp32 mode: one product per product, the fp32 matrix peak
-    assert blk['peak'] == 157.3 and blk['executed_tflops'] == blk['algorithmic_tflops']
+    for mode in ('fp32', False):  # exact-fp32 modes (packed pipeline / unpacked kernel): one product per product, the fp32 matrix peak
+        blk, _ = bench.gemm_family_block(deep, mode, 'note')
+        assert blk['peak'] == 157.3 and blk['executed_tflops'] == blk['algorithmic_tflops']
+    # what the epilogue of a launch really moves is part of its algorithmic bytes (flags from the executor's event tag)
+    assert bench.gemm_bytes(1000, 128, 64, 1) == bench.gemm_bytes(1000, 128, 64) + 4.0 * 1000 * 128
+    assert bench.gemm_bytes(1000, 128, 64, 2) == bench.gemm_bytes(1000, 128, 64) + 4.0 * (1000 * 128 + 2 * 1000)
+    assert bench.gemm_bytes(1280, 128, 64, 4) == bench.gemm_bytes(1280, 128, 64) + 4.0 * 2 * 128 * 1280 / 64
+    blk, top = bench.gemm_family_block([(1e-3, (640000, 128, 64, 1))], 'fp32', 'note')
+    assert top[0][0] == (640000, 128, 64, 1) and blk['algorithmic_bytes_per_launch'] == round(bench.gemm_bytes(640000, 128, 64, 1))
     import json
     json.dumps(blk)
