@@ -275,8 +275,8 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
     """Oracle on the host CPU (both parts are checkers, see oracle/), SURVEY.md 8(d) protocol: 1 warm-up + 3 timed pairs, median;
     collate on one thread (the reference's C++ cores, as the reference runs them), forward (torch fp32 restatement) on 16 threads, on
     all cores and on one thread.  Every forward leg runs in a child process with a time budget (oracle/cpu_timing.py): a thread
-    count that oversubscribes a big host cannot be interrupted from inside.  Returns (record, pyramid of items[0], oracle outputs of
-    items[0])."""
+    count that oversubscribes a big host cannot be interrupted from inside.  `items`: the pairs of the parity sample (the timing sample
+    is 1 warm-up + 3 of them).  Returns (record, [(oracle pyramid, oracle outputs) of every item])."""
     import subprocess
     import tempfile
     from oracle import model_oracle as mo
@@ -311,13 +311,17 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
     sample = [items[i % len(items)] for i in range(4)]  # 1 warm-up + 3 timed pairs of the same workload
     collated = [collate(it) for it in sample]
     t_collate = float(np.median([c[0] for c in collated[1:]]))
-    # the parity reference (pyramid + forward of items[0]) uses the restatement's canonical (distance, index) order of equal fp32
+    # the parity references (pyramid + forward of every item) use the restatement's canonical (distance, index) order of equal fp32
     # distances, which is the product's default; the reference cores order such ties by kd-tree traversal -- same
     # sets, and the timing above is theirs
-    _, pyr0, data0 = collate_with(on.restated(), sample[0]) if lib is not on.restated() else collated[0]
+    from oracle import parity as _parity
     torch.set_num_threads(min(avail, 16))
-    out0 = mo.forward(sd, ocfg, data0)  # the parity reference for items[0] (in-process, 16 threads)
-    out0['_fine_cfg'] = ocfg['fine']    # oracle/parity.py re-runs the oracle's registration head in the HIP side's patch order
+    oracle = []
+    for i, it in enumerate(items):
+        _, pyr_i, data_i = collate_with(on.restated(), it) if lib is not on.restated() else collated[i]
+        out_i = mo.forward(sd, ocfg, data_i)  # in-process, 16 threads
+        _parity.attach_head_config(out_i, ocfg, sd)  # oracle/parity.py re-runs the oracle's heads on the HIP side's selection / order
+        oracle.append((pyr_i, out_i))
 
     legs = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -373,7 +377,7 @@ def cpu_baseline(cfg, items, model, budget_s=150.0):
         'pipelined_bound_pairs_per_s': None if t_forward is None else round(1.0 / max(t_collate / workers, t_forward), 4),
         'pipelined_note': f'1 / max(collate / {workers} workers, forward): the reference overlaps collate in DataLoader workers',
     }
-    return rec, pyr0, out0
+    return rec, oracle
 
 
 def relaunch_under_torchrun(n, need_devices=True):
@@ -523,7 +527,7 @@ def main():
         elapsed seconds (max over ranks), the gathered transforms, the executor's launch events and the LAST step's outputs per slot."""
         kernels.set_precision(precision, gse=gse)
         results = torch.zeros((args.steps, args.batch, 4, 4), dtype=torch.float32, device=device)
-        last, arrivals = {}, []  # arrivals: host time at which each pair's result was handed back (stderr diagnostics only)
+        last, any_out, arrivals = {}, {}, []  # arrivals: host time at which each pair's result was handed back (stderr diagnostics only)
 
         def step(i, record=None):
             """One step = one batch of `--batch` independent pairs through the whole hot path.  The batch is handed to the
@@ -533,7 +537,9 @@ def main():
             def sink(j, out):
                 if record is not None:
                     results[record, j] = out['estimated_transform']
-                last[j] = (pair_of(i, j), out)  # kept for the parity block: the output of the timed run itself
+                if record == args.steps - 1:  # the LAST timed step (lanes finish out of order: a slot's last writer is not its last step)
+                    last[j] = (pair_of(i, j), out)  # kept for the parity block: the output of the timed run itself
+                any_out[0] = out
                 arrivals.append(time.perf_counter())
 
             runner.submit(batch, sink)
@@ -546,7 +552,7 @@ def main():
             step(i)
         runner.drain()
         torch.cuda.synchronize()
-        out = last[0][1]
+        out = any_out[0]
         info['superpoints'] = [int(out['ref_points_c'].shape[0]), int(out['src_points_c'].shape[0])]
 
         gd.barrier()
@@ -653,9 +659,9 @@ def main():
                 reports = []
                 for j, (pyr_q, want_q) in zip(slots, oracle):
                     q, out_q = run['last'][j]
+                    assert q == main_run['last'][j][0], 'the slot holds another pair than the one the oracle was run on'
                     # plain-bf16 operands (configs[4]) are held to the north-star bound; the fp32-grade modes to two orders inside it
-                    rep = parity.compare_pair(out_q, want_q, feature_mse_bound=1e-4 if bf16 else parity.FEATURE_MSE_BOUND,
-                                              score_tie_rtol=5e-2 if bf16 else parity.SCORE_TIE_RTOL)
+                    rep = parity.compare_pair(out_q, want_q, **(parity.BF16_TOLERANCES if bf16 else {}))
                     g0 = (j // args.stack) * args.stack
                     stack_pairs = [pairs[run['last'][jj][0]] for jj in range(g0, min(g0 + args.stack, args.batch))]
                     _, stacked = pipe.register_batch(stack_pairs, return_pyramid=True)

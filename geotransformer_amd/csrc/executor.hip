@@ -125,8 +125,9 @@ static const bool gn_epilogue_stats = [] {
 static float* linear_gn(Ctx& c, const geotr_linear& l, const float* x, int64_t lda, int64_t m, int stage, GnStats& st) {
   st = GnStats();
   // unsplit packed launches only: a launch that is split over K for occupancy keeps its split (the statistics pass of such a narrow
-  // output is small) -- geotr_gemm_packed_splitk_workspace_bytes == 0 says the shape is not split
-  if (!(gn_epilogue_stats && use_packed(l.packed, x, lda, m, l.in) && geotr_gemm_packed_splitk_workspace_bytes(m, l.out, l.in) == 0))
+  // output is small) -- judged by the split-bf16 rule (mode 0) in every arithmetic mode, so that which norms take their statistics from
+  // the epilogue does not depend on the mode (the exact-fp32 plan splits more shapes)
+  if (!(gn_epilogue_stats && use_packed(l.packed, x, lda, m, l.in) && geotr_gemm_packed_splits(m, l.out, l.in, 0) == 1))
     return linear(c, l, x, lda, m, 0);
   float* y = c.alloc<float>((size_t)m * l.out);
   float* rec = c.alloc<float>(geotr_gemm_packed_stats_floats(c.seg_rows[stage], c.nseg, l.out));
@@ -293,7 +294,7 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
   // kernel (multiply, add, add, LeakyReLU), so the result is bit-identical to the path below.  Needs both products on the unsplit
   // packed path and GroupNorms on both (every reference config).
   auto tail_ok = [&](const geotr_linear& l, const geotr_norm& nm, const float* a, int64_t lda) {
-    return nm.groups > 0 && use_packed(l.packed, a, lda, m, l.in) && geotr_gemm_packed_splitk_workspace_bytes(m, l.out, l.in) == 0;
+    return nm.groups > 0 && use_packed(l.packed, a, lda, m, l.in) && geotr_gemm_packed_splits(m, l.out, l.in, 0) == 1;
   };
   if (tail_fused && gn_epilogue_stats && tail_ok(b.unary2, b.unary2_norm, y, b.unary2.in) &&
       (!b.has_shortcut || (fuse_shortcut_norm && b.shortcut.out == b.unary2.out && tail_ok(b.shortcut, b.shortcut_norm, sc, b.shortcut.in)))) {
@@ -1001,10 +1002,18 @@ int geotr_pyramid_build(const float* points, const int64_t* lengths, int64_t bat
                        stream) != hipSuccess)
       return fail(GEOTR_E_LAUNCH, "pyramid_build: memcpy failed");
   if (hipStreamSynchronize(stream) != hipSuccess) return fail(GEOTR_E_LAUNCH, "pyramid_build: reading the stage sizes failed");
+  // an empty stage is an error of THIS call, as before the device-resident sizes of round 3 (C / C++ callers got GEOTR_OK and
+  // fed a zero-row stage to geotr_model_forward); the async variant leaves this check to the caller, who reads the sizes later
+  for (int i = 0; i < (int)num_stages; ++i) {
+    int64_t rows = 0;
+    for (int64_t b = 0; b < batch; ++b) rows += lengths_host[(size_t)i * batch + b];
+    if (rows < 1) return fail(GEOTR_E_INVALID, "pyramid_build: stage %d is empty", i);
+  }
   return GEOTR_OK;
 }
 
-// The same without any host synchronisation: `lengths_pinned` must be device-accessible host memory (hipHostMalloc / a pinned torch
+// The same without any host synchronisation (and therefore WITHOUT the empty-stage check: the caller examines the sizes when it reads
+// them): `lengths_pinned` must be device-accessible host memory (hipHostMalloc / a pinned torch
 // tensor) of num_stages x batch int64; it holds the stage sizes once the stream has passed this call -- the caller reads it after its
 // next synchronisation of the stream (e.g. together with the previous stack's result counts: ONE host wait per stack).
 int geotr_pyramid_build_async(const float* points, const int64_t* lengths, int64_t batch, int64_t n0, int64_t num_stages, float voxel_size,

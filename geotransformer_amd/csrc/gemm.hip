@@ -533,6 +533,12 @@ struct PackedArgs {
   float* stats;
   GatherRes gres;  // gathered residual (src == nullptr: none); unsplit launches only
   const float* seg_affine;  // optional [nseg][2][N]: scale / shift per (row segment, column), applied after the bias (epilogue_lds)
+  // round 4: XCD-aware tile order.  The grid is 1-D in x (8 * tiles_per_xcd blocks; z = K slices): the hardware deals consecutive
+  // workgroup ids round-robin over the 8 XCDs (each with its own L2), so block b runs on XCD b % 8 and takes tile
+  // (b % 8) * tiles_per_xcd + b / 8 of the (row tile, column block) list with the COLUMN block fastest -- the nx column blocks of one
+  // row tile run back to back on ONE XCD and share the activation tile through that XCD's L2 (with blockIdx.x = column block they
+  // landed on nx different XCDs and every one of them fetched the A tile from HBM: N = 512 read A four times).
+  int nx, ny, tiles_per_xcd;
 };
 
 __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b_is_kn, int N, int K, int KS, int64_t nvec,
@@ -582,7 +588,7 @@ __global__ void gemm_pack_f32_kernel(const float* __restrict__ B, int64_t ldb, i
 // fragment (v_cvt_pk_bf16_f32).  One barrier per 32-deep stage: each wave issues its share of the stage's DMA (4 activation
 // chunks + its round-robin share of the weight chunks), waits on its own vmcnt, and the barrier publishes the stage to the other
 // waves; see the schedule note at the main loop for where that barrier sits.
-constexpr int kPStages = 2;  // 2 stages = 64-70 KB of LDS: two blocks per CU overlap each other's load / MFMA phases (4 stages with
+constexpr int kPStagesDefault = 2;  // 2 stages = 64-70 KB of LDS: two blocks per CU overlap each other's load / MFMA phases (4 stages with
                              // one block per CU was slower on the tall shapes: 58 vs 45 us for 40000x256x384)
 #define GEOTR_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | (((N) >> 4) << 14) | 0x0F70)
 // LDS reads of DMA-written data go through inline asm: the compiler's own waitcnt insertion would otherwise drain ALL
@@ -609,8 +615,12 @@ __device__ __forceinline__ void lds_wait(u32x4& r0, u32x4& r1, u32x4& r2, u32x4&
 // TERMS = 3: split-bf16 product;  TERMS = 1: plain bf16 operands (hi planes only: the lo plane is neither loaded nor multiplied);
 // TERMS = 0: exact fp32 products on v_mfma_f32_32x32x2_f32 against the weight packed by geotr_gemm_pack_f32 (same ring, same stage
 // bytes as TERMS = 3: the four 1 KB chunks of a column tile are its four 8-deep groups instead of (plane, 16-deep step)).
-template <int WM, int WN, int TERMS>
+// STAGES = slots of the LDS ring (2: two blocks per CU overlap each other; 3: one block per CU with the loads of TWO stages in flight
+// under the MFMAs -- the exact-fp32 deep-K launches, whose 4 096-cycle stages leave one stage of prefetch short of the HBM latency
+// under load while a third slot costs nothing the matrix pipe needs)
+template <int WM, int WN, int TERMS, int STAGES = 2>
 __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
+  constexpr int kPStages = STAGES;
   constexpr int BM = 128, PLANES = TERMS == 1 ? 1 : 2;
   constexpr bool F32 = TERMS == 0;
   constexpr int WAVES_M = BM / (32 * WM), WAVES_N = 4 / WAVES_M, NT_BLK = WN * WAVES_N;  // column tiles per block
@@ -619,12 +629,16 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   constexpr int B_PER_WAVE = (B_INSTR + 3) / 4;    // issued round-robin by the 4 waves
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ct0 = blockIdx.x * NT_BLK;
-  int m0 = blockIdx.y * BM, m_end = g.M;  // this block's first row and the end of its row segment
+  // XCD-aware tile order (PackedArgs): this block's (column block, row tile)
+  const int xcd = (int)blockIdx.x & 7, tile = xcd * g.tiles_per_xcd + ((int)blockIdx.x >> 3);
+  if (tile >= min(g.nx * g.ny, (xcd + 1) * g.tiles_per_xcd)) return;  // (uniform per block: before any barrier)
+  const int bx = tile % g.nx, by = tile / g.nx;
+  const int ct0 = bx * NT_BLK;
+  int m0 = by * BM, m_end = g.M;  // this block's first row and the end of its row segment
   int sgi = 0;
   if (g.nseg > 0) {
-    while (sgi + 1 < g.nseg && (int)blockIdx.y >= g.seg_tile0[sgi + 1]) ++sgi;
-    m0 = g.seg_row0[sgi] + ((int)blockIdx.y - g.seg_tile0[sgi]) * BM;
+    while (sgi + 1 < g.nseg && by >= g.seg_tile0[sgi + 1]) ++sgi;
+    m0 = g.seg_row0[sgi] + (by - g.seg_tile0[sgi]) * BM;
     m_end = g.seg_row0[sgi + 1];
   }
   const int wrow = (wave / WAVES_N) * 32 * WM, wctl = (wave % WAVES_N) * WN;  // wave's first row / local column tile
@@ -673,7 +687,8 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  static_assert(kPStages == 2, "the pipelined loop below assumes a two-slot ring");
+  static_assert(kPStages == 2 || kPStages == 3, "the pipelined loop below is written for a two- or three-slot ring");
+  constexpr int DMA_PER_STAGE = 4 + B_PER_WAVE;  // DMA instructions a wave issues per stage (vmcnt units)
   // fragment registers of the two 16-deep steps of a stage: step ks lives in set ks (constant after unrolling)
   u32x4 fb[2][2][2];  // [set][plane][column tile]          (fp32: [set][8-deep group of the step][column tile])
   u32x4 fa[2][2][2];  // [set][row tile][16-byte chunk]      (fp32: [set][row tile][8-deep group of the step])
@@ -769,7 +784,9 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   issue(0);
   GEOTR_WAIT_VMCNT(0);
   __builtin_amdgcn_s_barrier();
-  if (1 < nkt) issue(1);
+#pragma unroll
+  for (int s_ = 1; s_ < kPStages; ++s_)
+    if (s_ < nkt) issue(s_);
   issue_reads(0, 0);
   for (int kt = 0; kt + 1 < nkt; ++kt) {
     wait_reads(0);
@@ -778,9 +795,11 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
     multiply(0);
     __builtin_amdgcn_sched_barrier(0);
     wait_reads(1);
-    GEOTR_WAIT_VMCNT(0);           // this wave's part of stage kt+1 (the only DMA it has in flight)
+    // this wave's part of stage kt+1: with a three-slot ring the DMA of stage kt+2 (when there is one) stays in flight
+    if (kPStages == 3 && kt + 2 < nkt) GEOTR_WAIT_VMCNT(DMA_PER_STAGE);
+    else GEOTR_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();  // stage kt+1 complete; every wave holds its stage-kt fragments in registers
-    if (kt + 2 < nkt) issue(kt + 2);
+    if (kt + kPStages < nkt) issue(kt + kPStages);  // into the slot of stage kt
     issue_reads(kt + 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     multiply(1);
@@ -803,7 +822,7 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   float* slab = reinterpret_cast<float*>(psm) + wave * (32 * WM * (32 * WN + 4));
   if (gridDim.z == 1)
     epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act, g.C,
-                         g.ldc, g.stats ? g.stats + ((int64_t)blockIdx.y * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr, g.gres,
+                         g.ldc, g.stats ? g.stats + ((int64_t)by * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr, g.gres,
                          g.seg_affine ? g.seg_affine + (int64_t)sgi * 2 * g.N : nullptr);
   else  // raw partial sums of this K slice; the epilogue runs in the reduce kernel
     epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, 1.0f, nullptr, nullptr, nullptr, 0, 0,
@@ -919,17 +938,56 @@ extern "C" int geotr_gemm_pack_f32(const float* B, int64_t ldb, int b_is_kn, int
 // Split-K plan of a packed launch: how many K slices make a narrow grid fill the chip.  256 CUs x 2 resident blocks = 512 slots;
 // a launch of fewer than 256 blocks with a deep K (the coarse-stage KPConv contractions: 78 blocks x 120 stages) leaves most of
 // them empty for its whole duration.  Slices of >= 8 stages (256-deep) keep the pipeline prologue / epilogue amortised.
-static int packed_splits(int64_t M, int64_t N, int64_t K) {
+static bool splitk_enabled() {
   static const bool enabled = [] {
     const char* e = std::getenv("GEOTR_SPLITK");  // A/B switch for measurements: GEOTR_SPLITK=0 keeps every launch single-pass
     return !(e && e[0] == '0');
   }();
-  if (!enabled) return 1;
+  return enabled;
+}
+static int packed_splits(int64_t M, int64_t N, int64_t K) {
+  if (!splitk_enabled()) return 1;
   const int64_t bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
   const int64_t blocks = ((M + 127) / 128) * ((N + bn - 1) / bn), nkt = pack_pad32(K) / 32;
   if (blocks >= 256 || nkt < 16) return 1;
   const int64_t want = (512 + blocks - 1) / blocks, most = nkt / 8;
   return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, most), 16));
+}
+
+// Exact-fp32 launches are bound by the matrix pipe (v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate), so what a launch costs is
+// the work of its busiest compute unit: rounds = ceil(blocks / 256) blocks of (128 x BN x K / splits) each -- the blocks that share a
+// CU share its four matrix pipes.  A grid of 343 tiles of 128 x 128 keeps 87 CUs busy twice as long as the other 169 (0.67 of the
+// chip); the same product in 128 x 64 tiles is 686 blocks, 3 rounds of half the work (0.89).  Chosen per shape: the column width
+// (128 or 64; N > 64 only) and the number of K slices (>= 4 stages each; the partial tiles cost a write + a read of (M, N) per slice,
+// priced at the HBM rate) that minimise   rounds * work + reduce.  The plan is a function of (M, N, K) alone.
+struct F32Plan {
+  int bn, splits;
+};
+static F32Plan packed_plan_f32(int64_t M, int64_t N, int64_t K, bool may_split) {
+  const int64_t nkt = pack_pad32(K) / 32, row_tiles = (M + 127) / 128;
+  if (N <= 64) return F32Plan{N > 32 ? 64 : 32, may_split ? packed_splits(M, N, K) : 1};  // one column block: round 3's rule
+  static const bool enabled = [] {
+    const char* e = std::getenv("GEOTR_F32_PLAN");  // A/B switch: GEOTR_F32_PLAN=0 keeps round 3's tiling rule (128-wide, its split rule)
+    return !(e && e[0] == '0');
+  }();
+  if (!enabled) return F32Plan{128, may_split ? packed_splits(M, N, K) : 1};
+  F32Plan best{128, 1};
+  double best_cost = 1e300;
+  for (int bn : {128, 64}) {
+    const int64_t tiles = row_tiles * ((N + bn - 1) / bn);
+    for (int s = 1; s <= (may_split && splitk_enabled() ? 16 : 1); ++s) {
+      if (s > 1 && nkt / s < 4) break;
+      const int64_t kt = (nkt + s - 1) / s, blocks = tiles * ((nkt + kt - 1) / kt);
+      const double rounds = (double)((blocks + 255) / 256);
+      // cycles of the busiest CU: a stage of a 128 x bn tile = 16 MFMAs of 64 cycles per 32 x 32 sub-tile, 4 waves in parallel;
+      // + ~2500 cycles of prologue / epilogue per block;  the 64-wide tile re-reads the activation tile once more per 128 columns
+      const double per_block = (double)kt * (bn / 32) * 1024.0 + 2500.0;
+      double cost = rounds * per_block * (bn == 64 ? 1.04 : 1.0);
+      if (s > 1) cost += 2.0 * s * (double)M * (double)N * 4.0 / (5.0e12 / 2.4e9);  // partial tiles written + read, in cycles at ~5 TB/s
+      if (cost < best_cost) best_cost = cost, best = F32Plan{bn, s};
+    }
+  }
+  return best;
 }
 
 // rows of a statistics record / records per 128-row tile of a packed launch with n_cols output columns (WM = 2 above 64 columns)
@@ -969,7 +1027,14 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
     for (int64_t q = nseg; q <= GEOTR_MAX_PAIRS; ++q) g.seg_tile0[q] = (int)tiles, g.seg_row0[q] = (int)row;
     g.nseg = (int)nseg;
   }
-  int splits = ws && !stats && !g.gres.src && !seg_affine ? packed_splits(M, N, K) : 1;  // statistics / gathered residual / affine: unsplit epilogue
+  const bool may_split = ws && !stats && !g.gres.src && !seg_affine;  // statistics / gathered residual / affine: unsplit epilogue
+  int splits = may_split ? packed_splits(M, N, K) : 1;
+  int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  if (TERMS == 0) {
+    const F32Plan plan = packed_plan_f32(M, N, K, may_split);
+    bn = plan.bn, splits = plan.splits;
+    if (stats && bn == 64 && N > 64) bn = 128;  // the statistics records of an output wider than 64 columns are laid out for 64-row records (WM = 2)
+  }
   if (splits > 1 && ws_bytes < sizeof(float) * (size_t)splits * (size_t)M * (size_t)N) splits = 1;  // never more than the caller's scratch holds
   const int nkt_all = g.KS / 2;
   g.kt_split = (nkt_all + splits - 1) / splits;
@@ -981,17 +1046,31 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   hipStream_t stream = (hipStream_t)stream_;
   const unsigned gy = (unsigned)tiles;
   GEOTR_CHECK_ARG(tiles <= 65535, "gemm_packed: M too large");
-#define GEOTR_PACKED(WM, WN, BN)                                                                                        \
+#define GEOTR_PACKED(WM, WN, BN, STG)                                                                                      \
   do {                                                                                                                  \
-    const int lds = std::max(kPStages * (128 * 128 + (BN / 32) * (TERMS != 1 ? 4096 : 2048)), 4 * 32 * WM * (32 * WN + 4) * 4); /* ring | epilogue slabs */ \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+    const int lds = std::max(STG * (128 * 128 + (BN / 32) * (TERMS != 1 ? 4096 : 2048)), 4 * 32 * WM * (32 * WN + 4) * 4) + lds_pad; /* ring | epilogue slabs */ \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN, TERMS, STG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             lds) != hipSuccess)                                                                         \
       return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);                                      \
-    gemm_packed_kernel<WM, WN, TERMS><<<dim3((unsigned)((N + BN - 1) / BN), gy, (unsigned)splits), dim3(256), lds, stream>>>(g); \
+    g.nx = (int)((N + BN - 1) / BN), g.ny = (int)gy, g.tiles_per_xcd = (int)(((int64_t)g.nx * g.ny + 7) / 8);                 \
+    gemm_packed_kernel<WM, WN, TERMS, STG><<<dim3((unsigned)(8 * g.tiles_per_xcd), 1, (unsigned)splits), dim3(256), lds, stream>>>(g); \
   } while (0)
-  if (N > 64) GEOTR_PACKED(2, 2, 128);
-  else if (N > 32) GEOTR_PACKED(1, 2, 64);
-  else GEOTR_PACKED(1, 1, 32);
+  static const int lds_pad = [] {  // experiment knob (occupancy studies): extra dynamic LDS per block, KB
+    const char* e = std::getenv("GEOTR_GEMM_LDS_PAD_KB");
+    return e ? 1024 * std::atoi(e) : 0;
+  }();
+  // three-slot ring: exact-fp32 launches with at least 6 stages per block (GEOTR_F32_STAGES=2 keeps two slots everywhere: A/B switch)
+  static const int f32_stages = [] {
+    const char* e = std::getenv("GEOTR_F32_STAGES");
+    return e ? std::atoi(e) : 3;
+  }();
+  // (with the 128-wide tile a third slot is 96 KB of LDS = ONE block per CU: measured slower alone and catastrophic beside other lanes'
+  // kernels -- 501 vs 959 pairs/s; the 64-wide tile keeps two blocks per CU at 72 KB)
+  const bool deep = TERMS == 0 && f32_stages == 3 && g.kt_split >= 6 && bn == 64;
+  if (bn == 64 && deep) GEOTR_PACKED(1, 2, 64, 3);
+  else if (bn == 128) GEOTR_PACKED(2, 2, 128, 2);
+  else if (bn == 64) GEOTR_PACKED(1, 2, 64, 2);
+  else GEOTR_PACKED(1, 1, 32, 2);
 #undef GEOTR_PACKED
   GEOTR_CHECK_LAUNCH("gemm_packed");
   if (splits > 1) {
@@ -1010,8 +1089,13 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
 }
 
 extern "C" size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  const int splits = packed_splits(M, N, K);
+  // the size query does not know the arithmetic mode: room for the larger of the two plans (a launch uses what ITS plan needs)
+  const int splits = std::max(packed_splits(M, N, K), packed_plan_f32(M, N, K, true).splits);
   return splits > 1 ? sizeof(float) * (size_t)splits * (size_t)M * (size_t)N : 0;
+}
+
+extern "C" int geotr_gemm_packed_splits(int64_t M, int64_t N, int64_t K, int bf16_operands) {
+  return bf16_operands == 2 ? packed_plan_f32(M, N, K, true).splits : packed_splits(M, N, K);
 }
 
 extern "C" int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace geotr {
@@ -109,6 +111,10 @@ __global__ __launch_bounds__(256) void p2n_assign_kernel(const float* __restrict
   node_masks[bi] = 1;
 }
 
+// The hazard-investigation tooling of round 3 (load flavours GEOTR_P2N_MODE=0..6, read probes GEOTR_P2N_PROBE=1, geotr_debug_probe_read)
+// is compiled only with -DGEOTR_HAZARD_TOOLS (make FLAGS_matching=-DGEOTR_HAZARD_TOOLS; scripts/hazard_probe.py asks for it): the shipped
+// library carries the plain-load kernels alone and no environment-dependent behaviour on this path.
+#ifdef GEOTR_HAZARD_TOOLS
 // ---- diagnostic (GEOTR_P2N_PROBE=1; not part of the ABI): launched right before p2n_assign with its grid and its access pattern, every
 // word of the two point arrays is read with a PLAIN load first, then at agent scope, then plainly again; a word whose first read differs
 // from the agent-scope read is a stale read, recorded with its address, the three values, the compute unit and a timestamp
@@ -215,14 +221,21 @@ static int p2n_mode() {  // hazard investigation switch (see ld_pt); the shipped
   return mode;
 }
 static int probe_array(const float* a, int64_t words, unsigned tag, hipStream_t stream) {
-  if (!g_probe_records) {
-    if (hipMalloc(&g_probe_records, sizeof(ProbeRecord) * kProbeCap) != hipSuccess || hipMalloc(&g_probe_counters, 16) != hipSuccess ||
-        hipMemset(g_probe_counters, 0, 16) != hipSuccess)
-      return fail(GEOTR_E_LAUNCH, "probe buffers");
-  }
+  static std::once_flag once;  // lanes share the buffers: one initialisation, whichever lane gets here first
+  static bool ready = false;
+  std::call_once(once, [] {
+    ready = hipMalloc(&g_probe_records, sizeof(ProbeRecord) * kProbeCap) == hipSuccess && hipMalloc(&g_probe_counters, 16) == hipSuccess &&
+            hipMemset(g_probe_counters, 0, 16) == hipSuccess;
+  });
+  if (!ready) return fail(GEOTR_E_LAUNCH, "probe buffers");
   array_probe_kernel<<<dim3(512), dim3(256), 0, stream>>>(a, words, tag, g_probe_records, g_probe_counters);
   return GEOTR_OK;
 }
+
+#else
+static constexpr bool probe_enabled() { return false; }
+static constexpr int p2n_mode() { return 7; }
+#endif
 
 constexpr int kP2nCap = 4096;  // owned points per node kept in LDS
 
@@ -976,34 +989,46 @@ int p2n_launch(const float* points, const float* nodes, int clouds, const int64_
   hipStream_t stream = (hipStream_t)stream_;
   if (zero_async(node_masks, (size_t)c0[clouds], stream) != GEOTR_OK) return GEOTR_E_LAUNCH;
   const size_t lds = sizeof(float) * 3 * (size_t)maxm;
-  if (lds > 64 * 1024 &&
-      (hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-       hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-       hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-       hipFuncSetAttribute(reinterpret_cast<const void*>(&p2n_assign_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
-    return fail(GEOTR_E_LAUNCH, "point_to_node: cannot reserve LDS");
   const int mode = p2n_mode();
   const bool probe = probe_enabled();
   const dim3 grid((unsigned)((maxn + 255) / 256), (unsigned)clouds);
+  // the dynamic-LDS limit is raised on the instantiation that is actually launched (the default launch, <4>, had none and
+  // failed beyond 5 461 superpoints per cloud)
+  auto assign = [&](auto kernel) -> int {
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(GEOTR_E_LAUNCH, "point_to_node: cannot reserve %zu B of LDS", lds);
+    kernel<<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
+    return GEOTR_OK;
+  };
+  int rc_assign = GEOTR_OK;
+#ifdef GEOTR_HAZARD_TOOLS
   if (probe) {  // site 1: in front of p2n_assign -- the access-pattern probe and the whole-array sweeps
     if (probe_array(points, 3 * f0[clouds], 0x11, stream) != GEOTR_OK || probe_array(nodes, 3 * c0[clouds], 0x12, stream) != GEOTR_OK) return GEOTR_E_LAUNCH;
     p2n_probe_kernel<<<grid, dim3(256), 0, stream>>>(points, nodes, tb, g_probe_records, g_probe_counters);
   }
-  if (mode == 1) p2n_assign_kernel<1><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
-  else if (mode == 2) p2n_assign_kernel<2><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
-  else if (mode == 3) p2n_assign_kernel<3><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
-  else if (mode == 4 || mode == 7) p2n_assign_kernel<4><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
-  else if (mode == 5) p2n_assign_kernel<5><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
-  else if (mode == 6) p2n_assign_kernel<6><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
-  else p2n_assign_kernel<0><<<grid, dim3(256), lds, stream>>>(points, 0, nodes, 0, point_to_node, node_masks, tb);
+  if (mode == 1) rc_assign = assign(&p2n_assign_kernel<1>);
+  else if (mode == 2) rc_assign = assign(&p2n_assign_kernel<2>);
+  else if (mode == 3) rc_assign = assign(&p2n_assign_kernel<3>);
+  else if (mode == 4 || mode == 7) rc_assign = assign(&p2n_assign_kernel<4>);
+  else if (mode == 5) rc_assign = assign(&p2n_assign_kernel<5>);
+  else if (mode == 6) rc_assign = assign(&p2n_assign_kernel<6>);
+  else rc_assign = assign(&p2n_assign_kernel<0>);
   if (probe && (probe_array(points, 3 * f0[clouds], 0x13, stream) != GEOTR_OK || probe_array(nodes, 3 * c0[clouds], 0x14, stream) != GEOTR_OK))
     return GEOTR_E_LAUNCH;  // site 2: in front of p2n_knn
-  if (mode == 7)  // 7 = plain C++ loads in ALL three consumers of the point arrays (p2n_assign, p2n_knn, patch_gather)
-    p2n_knn_kernel<false><<<dim3((unsigned)maxm, (unsigned)clouds), dim3(256), 0, stream>>>(points, 0, nodes, point_to_node, (int)k, knn_indices,
-                                                                                           knn_masks, overflow, tb);
-  else
+#else
+  (void)probe;
+  rc_assign = assign(&p2n_assign_kernel<4>);  // plain C++ loads
+#endif
+  if (rc_assign != GEOTR_OK) return rc_assign;
+#ifdef GEOTR_HAZARD_TOOLS
+  if (mode != 7)  // 7 = plain C++ loads in ALL three consumers of the point arrays (p2n_assign, p2n_knn, patch_gather)
     p2n_knn_kernel<true><<<dim3((unsigned)maxm, (unsigned)clouds), dim3(256), 0, stream>>>(points, 0, nodes, point_to_node, (int)k, knn_indices,
                                                                                           knn_masks, overflow, tb);
+  else
+#endif
+    p2n_knn_kernel<false><<<dim3((unsigned)maxm, (unsigned)clouds), dim3(256), 0, stream>>>(points, 0, nodes, point_to_node, (int)k, knn_indices,
+                                                                                           knn_masks, overflow, tb);
+  (void)mode;
   GEOTR_CHECK_LAUNCH("point_to_node");
   return GEOTR_OK;
 }
@@ -1064,17 +1089,21 @@ int geotr_patch_gather(const int64_t* ref_node_knn_indices, const uint8_t* ref_n
   GEOTR_CHECK_ARG(ref_node_knn_indices && ref_node_knn_masks && ref_points && ref_corr_indices && src_node_knn_indices &&
                       src_node_knn_masks && src_points && src_corr_indices && ref_knn_indices && ref_knn_masks && ref_knn_points &&
                       src_knn_indices && src_knn_masks && src_knn_points, "patch_gather: null pointer");
+#ifdef GEOTR_HAZARD_TOOLS
   if (probe_enabled() && (probe_array(ref_points, 3 * nr, 0x15, (hipStream_t)stream) != GEOTR_OK ||
                           probe_array(src_points, 3 * ns, 0x15, (hipStream_t)stream) != GEOTR_OK ||
                           probe_array(reinterpret_cast<const float*>(ref_node_knn_indices), 2 * k * 64, 0x16, (hipStream_t)stream) != GEOTR_OK))
     return GEOTR_E_LAUNCH;  // site 3: in front of patch_gather (tag 6: the head of the per-superpoint index table, workspace memory)
-  if (p2n_mode() == 7)
-    patch_gather_kernel<false><<<dim3((unsigned)p, 2), dim3(128), 0, (hipStream_t)stream>>>(
+#endif
+#ifdef GEOTR_HAZARD_TOOLS
+  if (p2n_mode() != 7)
+    patch_gather_kernel<true><<<dim3((unsigned)p, 2), dim3(128), 0, (hipStream_t)stream>>>(
         ref_node_knn_indices, ref_node_knn_masks, ref_points, nr, ref_corr_indices, src_node_knn_indices, src_node_knn_masks, src_points,
         ns, src_corr_indices, (int)k, p_count, ref_knn_indices, ref_knn_masks, ref_knn_points, src_knn_indices, src_knn_masks,
         src_knn_points);
   else
-    patch_gather_kernel<true><<<dim3((unsigned)p, 2), dim3(128), 0, (hipStream_t)stream>>>(
+#endif
+    patch_gather_kernel<false><<<dim3((unsigned)p, 2), dim3(128), 0, (hipStream_t)stream>>>(
         ref_node_knn_indices, ref_node_knn_masks, ref_points, nr, ref_corr_indices, src_node_knn_indices, src_node_knn_masks, src_points,
         ns, src_corr_indices, (int)k, p_count, ref_knn_indices, ref_knn_masks, ref_knn_points, src_knn_indices, src_knn_masks,
         src_knn_points);
@@ -1162,6 +1191,7 @@ int geotr_node_correspondences(const float* ref_nodes, const float* src_nodes, c
   return GEOTR_OK;
 }
 
+#ifdef GEOTR_HAZARD_TOOLS
 // ---- diagnostics of the hazard investigation (not declared in include/geotr.h: not part of the ABI) ----
 // Copies up to `cap` probe records (10 x 4-byte-aligned fields: struct ProbeRecord above, 48 bytes each) to `host`, writes
 // {stale words, words compared} to counters[2], resets the device counters.  Synchronises the device.
@@ -1178,5 +1208,7 @@ int64_t geotr_debug_probe_read(void* host, int64_t cap, uint32_t* counters) {
   if (counters) counters[0] = c[0], counters[1] = c[1];
   return n;
 }
+
+#endif
 
 }  // extern "C"

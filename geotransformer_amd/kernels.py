@@ -52,7 +52,8 @@ def gemm(a, b, b_is_kn=False, bias=None, row_div=None, residual=None, alpha=1.0,
     return out
 
 
-GEMM_PACKED = True      # arithmetic of the packed GEMM pipeline (see set_precision): True: split-bf16 "bf16x3";  'fp32': exact fp32 products
+DEFAULT_PRECISION = 'fp32'  # the reference's own arithmetic (round 4): what the package, the tests and bench.py run in unless told otherwise
+GEMM_PACKED = 'fp32'    # arithmetic of the packed GEMM pipeline (see set_precision): True: split-bf16 "bf16x3";  'fp32': exact fp32 products
                         # (v_mfma_f32_32x32x2_f32, the reference's arithmetic) on the SAME pipeline;  'bf16': plain bf16 operands (BASELINE
                         # configs[4] "bf16 features");  False: no packed weights at all -- every contraction on the unpacked fp32 kernel
 PACKED_MIN_ROWS = 1024  # activations with at least this many rows use the packed GEMM when a packed weight is given
@@ -150,7 +151,7 @@ def linear_gn(x, weight, bias=None, seg_rows=None):
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     M, K = x2.shape
     n = weight.shape[0]
-    if not (GN_EPILOGUE_STATS and use_packed(x2) and lib.geotr_gemm_packed_splitk_workspace_bytes(M, n, K) == 0):
+    if not (GN_EPILOGUE_STATS and use_packed(x2) and lib.geotr_gemm_packed_splits(M, n, K, 0) == 1):  # the split-bf16 rule in every mode (as the executor)
         return linear(x2, weight, bias, packed=True), None, 0
     segs = [M] if seg_rows is None else [int(r) for r in seg_rows]
     seg_arr = (ctypes.c_int64 * len(segs))(*segs)
@@ -193,7 +194,7 @@ def residual_tail(y, weight, bias, norm, shortcut, sc_weight=None, sc_bias=None,
     y, shortcut = _f32c(y), _f32c(shortcut)
     M, K = y.shape
     C = weight.shape[0]
-    assert use_packed(y) and lib.geotr_gemm_packed_splitk_workspace_bytes(M, C, K) == 0
+    assert use_packed(y) and lib.geotr_gemm_packed_splits(M, C, K, 0) == 1
     segs = [M] if seg_rows is None else [int(r) for r in seg_rows]
     seg_arr = (ctypes.c_int64 * len(segs))(*segs)
     bf16 = gemm_mode()
@@ -218,7 +219,7 @@ def residual_tail(y, weight, bias, norm, shortcut, sc_weight=None, sc_bias=None,
     if sc_weight is None:
         apply(y, weight, bias, ab_z, out, shortcut, 'leaky')
     else:
-        assert use_packed(shortcut) and lib.geotr_gemm_packed_splitk_workspace_bytes(M, C, shortcut.shape[1]) == 0
+        assert use_packed(shortcut) and lib.geotr_gemm_packed_splits(M, C, shortcut.shape[1], 0) == 1
         ab_t = stats_of(shortcut, sc_weight, sc_bias, sc_norm)
         part = torch.empty_like(out)
         apply(y, weight, bias, ab_z, part, None, None)
@@ -450,9 +451,10 @@ _GSE_MFMA = {'fp32': 0, 'bf16x3': 1, 'bf16': 3, 'fp32-unpacked': 0}
 
 def set_precision(name, gse='table'):
     """Arithmetic of the matrix-pipe kernel family (packed GEMMs of the backbone / transformer) and of the GSE embedding:
-    'bf16x3' (default): split-bf16 products, fp32-grade -- the mode every reference-parity claim is made in;
-    'fp32': exact fp32 MFMA products everywhere -- the reference's own arithmetic (IEEE fp32 products, fp32 accumulation) -- on the
-        same packed pipeline (weights packed by geotr_gemm_pack_f32, v_mfma_f32_32x32x2_f32; round 4);
+    'fp32' (DEFAULT, round 4): exact fp32 MFMA products everywhere -- the reference's own arithmetic (IEEE fp32 products, fp32
+        accumulation) -- on the packed pipeline (weights packed by geotr_gemm_pack_f32, v_mfma_f32_32x32x2_f32); the mode every
+        reference-parity claim and the benchmark headline are made in;
+    'bf16x3': split-bf16 products (three bf16 MFMA terms per product, ~2^-17 relative: narrower than fp32; the default of rounds 1-3);
     'fp32-unpacked': the same arithmetic on the rounds-1..3 kernel (no packed weights, no fused KPConv / epilogue statistics; A/B only);
     'bf16': plain bf16 operands with fp32 accumulation (BASELINE configs[4] "bf16 features").
     `gse`: 'table' (default: the embedding by table lookup -- fp32 arithmetic throughout, independent of the GEMM mode) or

@@ -227,9 +227,12 @@ class ConcurrentRegistration:
             S, fine = len(data['points']), model.backbone.fine_stage
             keep = range(S) if self.return_pyramid else (0, fine, S - 1)
             data['points'] = [t.clone() if i in keep else t for i, t in enumerate(data['points'])]
-            if self.return_pyramid:
-                for key in ('neighbors', 'subsampling', 'upsampling', 'lengths'):
-                    data[key] = [t.clone() for t in data[key]]
+            data['lengths'] = [t.clone() for t in data['lengths']]  # tiny; read by the forward and by anyone who keeps the dict
+            if self.return_pyramid:  # the only way `data` escapes this lane (out['_stack_pyramid']): then NOTHING in it may alias the graph
+                for key in ('neighbors', 'subsampling', 'upsampling', '_order'):
+                    if data.get(key) is not None:
+                        data[key] = [t.clone() for t in data[key]]
+                data['_overflow'] = data['_overflow'].clone()
         data['features'] = torch.ones((points.shape[0], 1), dtype=torch.float32, device=points.device)
         data['batch_size'] = len(job)
         if model._native is None:

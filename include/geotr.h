@@ -149,6 +149,10 @@ int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C,
  * (ABI 5): 0 = split-bf16 products, 1 = plain bf16 operands (both on a geotr_gemm_pack weight), 2 = exact fp32 products on
  * v_mfma_f32_32x32x2_f32 (on a geotr_gemm_pack_f32 weight) -- the reference's own arithmetic. */
 size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
+/* K slices a launch of this shape is split into in the given arithmetic mode (1 = single pass).  The split-bf16 / bf16 rule fills a
+ * narrow grid (< 256 tiles, >= 16 stages); the exact-fp32 plan (matrix-pipe bound) chooses column width and slices together by the work
+ * of the busiest compute unit (gemm.hip packed_plan_f32).  geotr_gemm_packed_splitk_workspace_bytes covers either. */
+int geotr_gemm_packed_splits(int64_t M, int64_t N, int64_t K, int bf16_operands);
 int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                              const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                              int bf16_operands, void* ws, size_t ws_bytes, void* stream);

@@ -171,11 +171,19 @@ def _explain_patch(g_pts, g_mask, w_pts, w_mask, node, nodes):
     return True, len(diff)
 
 
-def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, score_tie_rtol=SCORE_TIE_RTOL):
+BF16_TOLERANCES = dict(feature_mse_bound=1e-4, score_tie_rtol=5e-2, score_atol=0.1, transform_atol=5e-2)  # compare_pair(**BF16_TOLERANCES)
+
+
+def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, score_tie_rtol=SCORE_TIE_RTOL, score_atol=SCORE_ATOL,
+                 transform_atol=TRANSFORM_ATOL):
     """Returns a JSON-able report; report['ok'] is the verdict under the tolerances in this file's header.
     `feature_mse_bound`: the default is for the fp32-grade modes; plain-bf16 operands are held to the north-star bound (1e-4).
     `score_tie_rtol`: how close two oracle coarse scores must be for a rank swap to count as a tie (plain-bf16 features carry 2^-9
     relative error, which exp(2xy - 2) turns into percents: bench.py / the bf16 tests pass 5e-2 there).
+    `score_atol` / `transform_atol`: matching-score and pose tolerances; the defaults are for the fp32-grade modes.  Plain-bf16 operands
+    (BASELINE configs[4] "bf16 features", held to the north-star feature MSE 1e-4) carry ~3e-3 rms of feature error into 256-channel
+    patch scores and from there into the pose: BF16_TOLERANCES (0.1 / 5e-2) -- since round 4 such a pair is compared in full even when its
+    coarse selection differs from the oracle's, which used to skip exactly these comparisons.
     `fine_cfg`: the oracle's registration-head settings (default: want['_fine_cfg'], put there by oracle_pair); with them the pose
     is asserted for every pair whose patches align."""
     fine_cfg = fine_cfg or want.get('_fine_cfg')
@@ -299,7 +307,7 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, 
         rep['points_moved_by_distance_ties'] = tie_points
         rep['patches_unexplained'] = unexplained[:16]
         rep['matching_scores_max_err'] = worst if masks_equal and same_set else None
-        ok &= masks_equal and worst <= SCORE_ATOL and not unexplained
+        ok &= masks_equal and worst <= score_atol and not unexplained
         T, Tw = got['estimated_transform'].cpu().numpy(), want['estimated_transform'].numpy()
         rep['transform_max_abs_diff_vs_oracle_order'] = float(np.abs(T - Tw).max())
         rep['rre_deg_vs_oracle'], rep['rte_m_vs_oracle'] = rotation_translation_error(T, Tw)
@@ -322,7 +330,7 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, 
             rep['transform_max_abs_diff'] = rep['transform_max_abs_diff_vs_oracle_order']
             rep['transform_compared'] = True
         if rep['transform_compared']:
-            ok &= rep['transform_max_abs_diff'] <= TRANSFORM_ATOL
+            ok &= rep['transform_max_abs_diff'] <= transform_atol
         else:  # never silently: say why the pose of an accepted pair could not be asserted
             rep['transform_not_compared_because'] = (
                 f'{tie_patches} patch(es) hold another point set, each explained by a distance tie ({tie_points} points moved)' if tie_patches and not unexplained

@@ -5,8 +5,10 @@
 //
 //   build: hipcc -O2 -std=c++17 -I include scripts/abi_bench.cpp -L geotransformer_amd -lgeotr_hip -Wl,-rpath,'$ORIGIN/../geotransformer_amd' \
 //                -o scripts/abi_bench.bin
-//   run:   scripts/abi_bench.bin gemm M N K [bf16|bf16x3] [reps=20]      one shape
-//          scripts/abi_bench.bin shapes                                  the bench workload's heaviest packed shapes
+//   run:   scripts/abi_bench.bin gemm M N K [fp32|bf16x3|bf16] [reps=20] one shape (default fp32: the reference's arithmetic)
+//          scripts/abi_bench.bin shapes [fp32|bf16x3|bf16] [all]         the bench workload's heaviest packed shapes; `all`:
+//                                                                        every packed shape of a 16-pair 3DMatch stack, with the time the
+//                                                                        fp32 MFMA roof and the HBM roof allow next to the measured one
 //          scripts/abi_bench.bin pyramid [3dmatch|kitti] [pairs] [reps]   the collate-equivalent pyramid of one stack (geotr_pyramid_build)
 //          scripts/abi_bench.bin embedding [clouds] [superpoints] [reps]  structure embedding by table + one layer's positional softmax
 #include <hip/hip_runtime.h>
@@ -39,7 +41,10 @@
     }                                                                                             \
   } while (0)
 
-static int run_gemm(int64_t M, int64_t N, int64_t K, bool bf16, int reps) {
+// mode: 0 split-bf16, 1 plain bf16, 2 exact fp32 (the `bf16_operands` argument of the library's packed entry points)
+static bool g_nostore = false;  // `gemm ... nostore`: the same launch without its C stores (statistics-only form): what the stores cost
+static int run_gemm(int64_t M, int64_t N, int64_t K, int mode, int reps, double* us_out = nullptr) {
+  const bool bf16 = mode == 1;
   std::mt19937 rng(7);
   std::uniform_real_distribution<float> sym(-1.f, 1.f);
   std::vector<float> a((size_t)M * K), w((size_t)N * K), bias(N);
@@ -58,10 +63,17 @@ static int run_gemm(int64_t M, int64_t N, int64_t K, bool bf16, int reps) {
   HIP_OK(hipMemcpy(dB, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
   hipStream_t stream;
   HIP_OK(hipStreamCreate(&stream));
-  GEOTR_OK_OR_DIE(geotr_gemm_pack(dW, K, 0, N, K, packed, stream));
+  if (mode == 2) GEOTR_OK_OR_DIE(geotr_gemm_pack_f32(dW, K, 0, N, K, packed, stream));
+  else GEOTR_OK_OR_DIE(geotr_gemm_pack(dW, K, 0, N, K, packed, stream));
+  const size_t ws_bytes = geotr_gemm_packed_splitk_workspace_bytes(M, N, K);  // narrow, deep launches are split over K, as in the executor
+  void* ws = nullptr;
+  if (ws_bytes) HIP_OK(hipMalloc(&ws, ws_bytes));
+  float* stats = nullptr;
+  const int64_t seg = M;
+  if (g_nostore) HIP_OK(hipMalloc(&stats, 4 * geotr_gemm_packed_stats_floats(&seg, 1, N)));
   auto launch = [&] {
-    if (bf16) GEOTR_OK_OR_DIE(geotr_gemm_packed_bf16(dA, K, packed, dC, N, M, N, K, dB, nullptr, nullptr, 0, 1.0f, 0, stream));
-    else GEOTR_OK_OR_DIE(geotr_gemm_packed(dA, K, packed, dC, N, M, N, K, dB, nullptr, nullptr, 0, 1.0f, 0, stream));
+    if (g_nostore) GEOTR_OK_OR_DIE(geotr_gemm_packed_tail(dA, K, packed, nullptr, N, M, N, K, dB, 0, mode, &seg, 1, stats, nullptr, nullptr, 0, stream));
+    else GEOTR_OK_OR_DIE(geotr_gemm_packed_splitk(dA, K, packed, dC, N, M, N, K, dB, nullptr, nullptr, 0, 1.0f, 0, mode, ws, ws_bytes, stream));
   };
   for (int r = 0; r < 3; ++r) launch();
   hipEvent_t t0, t1;
@@ -88,11 +100,16 @@ static int run_gemm(int64_t M, int64_t N, int64_t K, bool bf16, int reps) {
     }
   }
   const double bytes = 4.0 * ((double)M * K + (double)M * N) + (double)geotr_gemm_pack_bytes(N, K);  // A read + C written + packed weight, once each
-  const double tol = (bf16 ? 2e-2 : 2e-5) * std::max(1.0, scale);
+  const double tol = (bf16 ? 2e-2 : mode == 2 ? 2e-6 : 2e-5) * std::max(1.0, scale);
+  // what the two roofs allow: exact fp32 products at 157.3 TFLOP/s (mode 2) / 3 or 1 bf16 products at 2500, and the bytes at 8 TB/s
+  const double us_mfma = 2.0 * M * N * K * (mode == 0 ? 3.0 : 1.0) / ((mode == 2 ? 157.3 : 2500.0) * 1e6), us_hbm = bytes / 8e6;
   std::printf("{\"op\": \"gemm_packed%s\", \"m_n_k\": [%lld, %lld, %lld], \"us\": %.1f, \"algorithmic_gbps\": %.0f, \"algorithmic_tflops\": %.1f, "
+              "\"roof_us_mfma\": %.1f, \"roof_us_hbm\": %.1f, \"frac_of_the_tighter_roof\": %.3f, \"split_k\": %s, "
               "\"max_abs_error_vs_fp64\": %.3g, \"tolerance\": %.3g, \"ok\": %s}\n",
-              bf16 ? "_bf16" : "", (long long)M, (long long)N, (long long)K, us, bytes / us * 1e-3, 2.0 * M * N * K / us * 1e-6, worst, tol,
-              worst <= tol ? "true" : "false");
+              mode == 1 ? "_bf16" : mode == 2 ? "_f32" : "", (long long)M, (long long)N, (long long)K, us, bytes / us * 1e-3, 2.0 * M * N * K / us * 1e-6,
+              us_mfma, us_hbm, std::max(us_mfma, us_hbm) / us, ws_bytes ? "true" : "false", worst, tol, worst <= tol ? "true" : "false");
+  if (us_out) *us_out = us;
+  if (ws) HIP_OK(hipFree(ws));
   for (void* p : {(void*)dA, (void*)dW, (void*)dB, (void*)dC, packed}) HIP_OK(hipFree(p));
   HIP_OK(hipStreamDestroy(stream));
   return worst <= tol ? 0 : 1;
@@ -276,15 +293,37 @@ int main(int argc, char** argv) {
     return 4;
   }
   const std::string mode = argc > 1 ? argv[1] : "shapes";
-  if (mode == "gemm" && argc >= 5) {
-    const bool bf16 = argc > 5 && std::string(argv[5]) == "bf16";
-    return run_gemm(std::atoll(argv[2]), std::atoll(argv[3]), std::atoll(argv[4]), bf16, argc > 6 ? std::atoi(argv[6]) : 20);
-  }
-  if (mode == "shapes") {  // 16-pair stacks of BASELINE configs[1]: the shapes profiles/r03_bench_n1.json lists as heaviest
+  auto arithmetic = [](const std::string& a) { return a == "bf16" ? 1 : a == "bf16x3" ? 0 : 2; };
+  if (mode == "gemm" && argc >= 5) g_nostore = argc > 7 && std::string(argv[7]) == "nostore";
+  if (mode == "gemm" && argc >= 5)
+    return run_gemm(std::atoll(argv[2]), std::atoll(argv[3]), std::atoll(argv[4]), arithmetic(argc > 5 ? argv[5] : "fp32"),
+                    argc > 6 ? std::atoi(argv[6]) : 20);
+  if (mode == "shapes") {  // 16-pair stacks of BASELINE configs[1]
+    const int am = arithmetic(argc > 2 ? argv[2] : "fp32");
+    int rc = 0;
+    if (argc > 3 && std::string(argv[3]) == "all") {
+      // every packed launch of one stack's forward (executor.hip: KPConv-FPN blocks, split decoders, transformer), {m, n, k, launches}
+      const int64_t all[][4] = {
+          {640000, 32, 64, 1}, {640000, 128, 32, 1}, {640000, 128, 64, 1}, {640000, 32, 128, 1},                               // stage 0
+          {179984, 128, 32, 1}, {179984, 64, 128, 1}, {179984, 256, 64, 2}, {179984, 256, 128, 1}, {179984, 64, 256, 2},        // stage 1
+          {43826, 256, 64, 1}, {43826, 128, 256, 1}, {43826, 128, 1920, 2}, {43826, 512, 128, 2}, {43826, 512, 256, 1},        // stage 2
+          {43826, 128, 512, 2},
+          {9956, 128, 1920, 1}, {9956, 512, 128, 1}, {9956, 256, 512, 1}, {9956, 256, 3840, 2}, {9956, 1024, 256, 2},          // stage 3
+          {9956, 1024, 512, 1}, {9956, 256, 1024, 1},
+          {9956, 512, 1024, 1}, {43826, 512, 512, 1}, {43826, 256, 512, 1}, {179984, 256, 256, 1},                              // decoders
+          {8704, 256, 1024, 1}, {8704, 768, 256, 3}, {8704, 256, 256, 10}, {8704, 512, 256, 9}, {8704, 256, 512, 6}};           // transformer
+      double total = 0.0;
+      for (const auto& s : all) {
+        double us = 0.0;
+        rc |= run_gemm(s[0], s[1], s[2], am, 10, &us);
+        total += us * s[3];
+      }
+      std::printf("{\"op\": \"packed_gemm_shapes_of_a_16_pair_stack\", \"us_per_stack_alone\": %.0f, \"us_per_pair\": %.1f}\n", total, total / 16);
+      return rc;
+    }
     const int64_t shapes[][3] = {{640000, 128, 32}, {640000, 128, 64}, {179984, 256, 128}, {43826, 512, 128}, {43826, 128, 1920}, {9956, 256, 3840},
                                  {5594, 256, 256}};
-    int rc = 0;
-    for (const auto& s : shapes) rc |= run_gemm(s[0], s[1], s[2], false, 20);
+    for (const auto& s : shapes) rc |= run_gemm(s[0], s[1], s[2], am, 20);
     return rc;
   }
   if (mode == "embedding")  // embedding [clouds=32] [superpoints=300] [reps=5]
@@ -300,6 +339,6 @@ int main(int argc, char** argv) {
     const std::string config = argc > 2 ? argv[2] : "3dmatch";
     return run_pyramid(config, argc > 3 ? std::atoi(argv[3]) : (config == "kitti" ? 4 : 16), argc > 4 ? std::atoi(argv[4]) : 5);
   }
-  std::fprintf(stderr, "usage: %s gemm M N K [bf16|bf16x3] [reps] | shapes | pyramid [3dmatch|kitti] [pairs] [reps] | embedding [clouds] [superpoints] [reps]\n", argv[0]);
+  std::fprintf(stderr, "usage: %s gemm M N K [fp32|bf16x3|bf16] [reps] | shapes [fp32|bf16x3|bf16] [all] | pyramid [3dmatch|kitti] [pairs] [reps] | embedding [clouds] [superpoints] [reps]\n", argv[0]);
   return 64;
 }

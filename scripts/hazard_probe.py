@@ -1,6 +1,9 @@
 """Round 3: what IS the multi-stream stale read of profiles/r02_concurrency_hazard.md?  (writes the evidence for profiles/r03_concurrency_hazard.md)
 
 One process = one experiment (the switches are environment variables read at start-up):
+  NEEDS the library built with the investigation tooling: make -C geotransformer_amd/csrc clean all FLAGS_matching=-DGEOTR_HAZARD_TOOLS
+  (round 4: the shipped library carries the plain-load kernels only; without the flag the switches below are ignored and
+  geotr_debug_probe_read is absent)
   GEOTR_P2N_MODE   0 agent-scope loads in p2n_assign (shipped) | 1 plain | 2 plain behind an agent acquire fence at kernel entry | 3 nt
   GEOTR_P2N_PROBE  1: a probe kernel in front of p2n_assign reads every word of the two point arrays plain / agent / plain and records
                    the words whose first read differs from the agent-scope read (csrc/matching.hip, geotr_debug_probe_read)

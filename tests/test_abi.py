@@ -114,13 +114,15 @@ def test_set_precision_is_host_logic_and_invalidates_model_descriptors():
     import torch
     from geotransformer_amd import kernels
     from geotransformer_amd.native import NativeModel
-    assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == (True, 5)  # the default: split-bf16 GEMMs + the embedding by table (fp32)
+    assert kernels.DEFAULT_PRECISION == 'fp32'
+    assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('fp32', 5)  # the default: exact fp32 products (the reference's arithmetic) + the embedding by table (fp32)
     model = NativeModel(torch.nn.Linear(4, 4))
     default_key = model._version_key()
     try:
-        assert kernels.set_precision('bf16') == 'bf16x3'
+        assert kernels.set_precision('bf16') == 'fp32'
         assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 5)
         assert model._version_key() != default_key
+        assert kernels.set_precision('bf16x3') == 'bf16' and kernels.gemm_mode() == 0 and model._version_key() != default_key
         kernels.set_precision('bf16', gse='mfma')
         assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 3)
         kernels.set_precision('bf16x3', gse='mfma')
@@ -138,7 +140,7 @@ def test_set_precision_is_host_logic_and_invalidates_model_descriptors():
         with pytest.raises(ValueError):
             kernels.set_precision('fp32', gse='lut')
     finally:
-        kernels.set_precision('bf16x3')
+        kernels.set_precision(kernels.DEFAULT_PRECISION)
     assert model._version_key() == default_key
 
 

@@ -23,13 +23,14 @@ def bf16_mode(request):
 
 def test_set_precision_round_trip():
     from geotransformer_amd import kernels
-    assert kernels.set_precision('bf16') == 'bf16x3'
+    assert kernels.set_precision('bf16') == kernels.DEFAULT_PRECISION == 'fp32'
     assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 5)   # GEMMs in bf16; the embedding stays on its fp32 table
     assert kernels.set_precision('bf16', gse='mfma') == 'bf16'
     assert (kernels.GEMM_PACKED, kernels.GSE_PRECISION) == ('bf16', 3)   # ... unless the MFMA embedding kernel is asked for
-    assert kernels.set_precision('fp32') == 'bf16'
-    assert kernels.set_precision('bf16x3') == 'fp32'
+    assert kernels.set_precision('bf16x3') == 'bf16'
     assert kernels.GEMM_PACKED is True and kernels.GSE_PRECISION == 5
+    assert kernels.set_precision('fp32') == 'bf16x3'
+    assert kernels.GEMM_PACKED == 'fp32' and kernels.GSE_PRECISION == 5
     with pytest.raises(ValueError):
         kernels.set_precision('fp8')
 

@@ -42,9 +42,10 @@ def test_split_k_packed_gemm(M, N, K, b_is_kn, matrix_precision):
     (the same products, summed in another association: 4e-6 of the scale); run-to-run bit-identical (no atomics)."""
     from geotransformer_amd import _lib, kernels
     lib = _lib.load()
-    assert lib.geotr_gemm_packed_splitk_workspace_bytes(M, N, K) > 0, 'this shape is expected to split'
-    assert lib.geotr_gemm_packed_splitk_workspace_bytes(40000, 256, 384) == 0  # wide launches never split
-    assert lib.geotr_gemm_packed_splitk_workspace_bytes(300, 128, 256) == 0    # shallow ones neither
+    mode = kernels.gemm_mode()
+    assert lib.geotr_gemm_packed_splits(M, N, K, mode) > 1 and lib.geotr_gemm_packed_splitk_workspace_bytes(M, N, K) > 0, 'this shape is expected to split'
+    assert lib.geotr_gemm_packed_splits(40000, 256, 384, mode) == 1  # wide launches never split
+    assert lib.geotr_gemm_packed_splits(300, 128, 256, 0) == 1       # shallow ones neither (split-bf16 rule)
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g).cuda()
     w = (torch.randn(K, N, generator=g) if b_is_kn else torch.randn(N, K, generator=g)).cuda()

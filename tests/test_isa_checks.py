@@ -28,7 +28,7 @@ def _flags():
 
 @pytest.mark.parametrize('source,prefix,min_kernels', [
     ('transformer.hip', '_ZN5geotr23gse_embed_bf16x3_kernel', 32),  # D in {32,64,128,256} x S in {2..5} x TERMS in {3,1}
-    ('gemm.hip', '_ZN5geotr18gemm_packed_kernel', 6),               # three tilings x TERMS in {3,1}
+    ('gemm.hip', '_ZN5geotr18gemm_packed_kernel', 9),               # three tilings x TERMS in {3,1,0}
 ])
 def test_no_instruction_touches_an_in_flight_lds_fragment(tmp_path, source, prefix, min_kernels):
     if not os.path.exists(HIPCC):
@@ -95,6 +95,33 @@ def _cross_half_reads_of_the_destination(op):
     return hits
 
 
+def _low_lane_reads_the_high_register_of_source_1_or_2(op):
+    """Round 4, the instruction-form matrix (profiles/r04_hazard_form_matrix.md; scripts/packed_fp32_mfma_hazard.hip VICTIM=instruction):
+    next to kernels issuing double-rate bf16 MFMAs between loads, a packed fp32 instruction returns a wrong LOW half in lanes 48-63
+    exactly when `op_sel` is set for source 1 or source 2 -- the low lane takes the HIGH register of that source pair -- whether or not
+    the destination is one of the sources (forms 0, 1, 4, 6: 161-169 of 200 launches wrong).  `op_sel` on source 0 (form 5), any
+    `op_sel_hi` pattern (form 2: what kpconv_gather's broadcasts use) and straight reads (form 3) never failed.  Returns the indices of
+    the offending sources."""
+    m = _PACKED.match(op)
+    if not m:
+        return []
+    sel = re.search(r'op_sel:\[([\d,]+)\]', m.group(4))
+    sel = [int(x) for x in sel.group(1).split(',')] if sel else []
+    return [k for k in (1, 2) if k < len(sel) and sel[k] == 1]
+
+
+def test_unsafe_form_detector_follows_the_measured_form_matrix():
+    bad = _low_lane_reads_the_high_register_of_source_1_or_2
+    assert bad('v_pk_add_f32 v[12:13], v[26:27], v[12:13] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]') == [1]       # form 0: failed
+    assert bad('v_pk_add_f32 v[30:31], v[26:27], v[12:13] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]') == [1]       # form 1 (not in place): failed
+    assert bad('v_pk_mul_f32 v[12:13], v[26:27], v[12:13] op_sel:[0,1]') == [1]                                  # form 4: failed
+    assert bad('v_pk_fma_f32 v[12:13], v[26:27], v[26:27], v[12:13] op_sel:[0,0,1]') == [2]                      # form 6: failed
+    assert bad('v_pk_add_f32 v[10:11], v[24:25], v[10:11] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]') == []     # form 2: never
+    assert bad('v_pk_add_f32 v[10:11], v[24:25], v[10:11] neg_lo:[0,1] neg_hi:[0,1]') == []                      # form 3: never
+    assert bad('v_pk_add_f32 v[10:11], v[10:11], v[24:25] op_sel:[1,0]') == []                                   # form 5 (source 0): never
+    assert bad('v_pk_fma_f32 v[4:5], v[8:9], v[2:3], v[4:5] op_sel_hi:[1,0,1]') == []                            # kpconv_gather's broadcast
+
+
 def test_cross_half_read_detector_knows_the_instruction_that_failed():
     assert _cross_half_reads_of_the_destination('v_pk_add_f32 v[12:13], v[26:27], v[12:13] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]') == [1]
     assert _cross_half_reads_of_the_destination('v_pk_fma_f32 v[14:15], v[14:15], v[38:39], v[24:25] op_sel:[1,0,0]') == [0]
@@ -138,6 +165,9 @@ def test_no_kernel_carries_slp_vectorised_packed_fp32_code(tmp_path):
                 assert any(tag in kernel for tag in EXPLICIT_PACKED), (src, kernel, arith[:4])
             crossed = [op for op in arith if _cross_half_reads_of_the_destination(op)]
             assert not crossed, (src, kernel, crossed[:4])  # nowhere, the hand-written kernels included
+            # round 4: every form the instruction-level matrix caught, in place or not -- nowhere, EXPLICIT_PACKED kernels included
+            unsafe = [op for op in arith if _low_lane_reads_the_high_register_of_source_1_or_2(op)]
+            assert not unsafe, (src, kernel, unsafe[:4])
             if any('op_sel' in op for op in arith):
                 assert any(tag in kernel for tag in LANE_HALF_SHUFFLES), (src, kernel, [op for op in arith if 'op_sel' in op][:4])
     assert seen_kernels >= 10  # the explicit kernels were found at all (guards against the mnemonics changing under the check)

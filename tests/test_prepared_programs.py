@@ -1,4 +1,4 @@
-"""CPU: the stand-alone GPU programs under scripts/ (hazard reproducer, Gram-statistics prototype, tail A/B) still compile for gfx950 against
+"""CPU: the stand-alone GPU programs under scripts/ (hazard reproducer, C++ ABI consumer) still compile for gfx950 against
 the current sources, header and library -- they are launched through scripts/prepared_gpu_runs.sh, where a build error would cost a GPU session."""
 import os
 import shutil
@@ -10,10 +10,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 COMMON = ['--offload-arch=gfx950', '-O1', '-std=c++17', '-ffp-contract=off', '-I', os.path.join(ROOT, 'include'),
-          '-I', os.path.join(ROOT, 'geotransformer_amd', 'csrc'), '-I', os.path.join(ROOT, 'geotransformer_amd', 'csrc', 'experimental'),
+          '-I', os.path.join(ROOT, 'geotransformer_amd', 'csrc'),
           '-I', os.path.join(ROOT, 'scripts')]
 LINK = ['-L', os.path.join(ROOT, 'geotransformer_amd'), '-lgeotr_hip', '-Wl,-rpath,' + os.path.join(ROOT, 'geotransformer_amd')]
-PROGRAMS = {'packed_fp32_mfma_hazard.hip': [], 'proto_gram_stats.hip': ['-fno-slp-vectorize'], 'proto_tail_ab.hip': ['-fno-slp-vectorize'] + LINK}
+PROGRAMS = {'packed_fp32_mfma_hazard.hip': [], 'abi_bench.cpp': LINK}
 
 
 def test_prepared_gpu_programs_compile(tmp_path):
@@ -33,5 +33,5 @@ def test_prepared_gpu_programs_compile(tmp_path):
         assert os.path.getsize(exe) > 10000, name
     # every program the launcher script names exists
     text = open(os.path.join(ROOT, 'scripts', 'prepared_gpu_runs.sh')).read()
-    for name in list(PROGRAMS) + ['abi_bench.cpp']:
+    for name in list(PROGRAMS):
         assert 'scripts/' + name in text, name
