@@ -558,6 +558,7 @@ def main():
         gd.barrier()
         torch.cuda.synchronize()
         arrivals.clear()
+        cpu0 = os.times()
         with prof:
             t0 = time.perf_counter()
             for i in range(args.steps):
@@ -567,6 +568,8 @@ def main():
             gd.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
+        cpu1 = os.times()
+        host_busy = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(elapsed, 1e-9)  # CPUs this rank kept busy in the region
         elapsed = gd.max_over_ranks(elapsed, device)
         events = prof.results()
         note(f'rank {rank}: [{precision}] timed region done ({args.steps} steps in {elapsed:.2f} s)')
@@ -599,7 +602,7 @@ def main():
                 roof['traffic_unit'] = ('HBM bytes/launch of this kernel family in this arithmetic mode (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes: '
                                         'read from the latest committed profiles/r*_pmc_hbm_traffic*.json -- bench.py cannot run under the counters itself; '
                                         'collected with --lanes 1 --stack 8: a launch there covers 8 stacked pairs, half the rows of a 16-pair launch)')
-        return {'precision': precision, 'elapsed': elapsed, 'last': dict(last), 'roofline': roof,
+        return {'precision': precision, 'elapsed': elapsed, 'last': dict(last), 'roofline': roof, 'host_cpus_busy': round(host_busy, 2),
                 'value': args.steps * args.batch * world / elapsed, 'ms_per_step': 1e3 * elapsed / args.steps}
 
     DTYPES = {'fp32': 'f32 (IEEE fp32 products, fp32 accumulation: v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32; fp32 storage) -- the reference\'s arithmetic',
@@ -634,6 +637,7 @@ def main():
                        'distinct_pairs_per_gpu': len(pairs), 'pair_seeds': f'{1000 * rank} .. {1000 * rank + len(pairs) - 1} (rank r: 1000 r + i)',
                        'pairs_per_step_per_gpu': args.batch, 'lanes_per_gpu': args.lanes, 'pairs_stacked_per_launch_sequence': args.stack,
                        'host_binding': numa_note, 'host_waits': sync_note,
+                       'host_cpus_busy_in_timed_region': main_run['host_cpus_busy'],
                        'parallelism': f'pairs sharded over {world} rank(s), one process per GPU, no data-path collective',
                        'collective_backend': 'rccl' if backend == 'nccl' else backend,
                        'weights': 'random init, seed 7351', 'matrix_precision': args.precision, 'gse': args.gse,

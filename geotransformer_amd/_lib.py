@@ -78,6 +78,7 @@ SIGNATURES = {
     'geotr_gemm_packed_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
     'geotr_gemm_packed_splitk_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
     'geotr_gemm_packed_splits': (c_int, [c_i64, c_i64, c_i64, c_int]),
+    'geotr_gemm_packed_tile_width': (c_int, [c_i64, c_i64, c_i64, c_int, c_int]),
     'geotr_gemm_packed_splitk': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_int,
                                          c_ptr, c_size, c_ptr]),
     'geotr_gemm_packed_stats_rows_per_record': (c_i64, [c_i64]),

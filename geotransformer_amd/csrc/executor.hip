@@ -973,15 +973,17 @@ static int pyramid_enqueue(const float* points, const int64_t* lengths, int64_t 
   const int64_t kRowCap = 512;
   for (int i = 0; i < S; ++i) {
     GEOTR_CHECK_ARG(limits_host[i] >= 1 && limits_host[i] < (1 << 20), "pyramid_build: bad neighbour limit at stage %d", i);
+    // (the visiting order of the QUERY rows -- their own stage's grid order -- selects the LDS-staged tile kernel: neighbours in that
+    // order share their candidate cells)
     int rc = radius_query_hinted(false, grids[i], pts[i], len[i], batch, n0, hint[i], n0, hint[i], r, limits_host[i], kRowCap, buf->neighbors[i],
-                                 nullptr, nullptr, overflow, stream);
+                                 nullptr, nullptr, overflow, stream, buf->order[i]);
     if (rc != GEOTR_OK) return rc;
     if (i < S - 1) {
       rc = radius_query_hinted(false, grids[i], pts[i + 1], len[i + 1], batch, n0, hint[i + 1], n0, hint[i], r, limits_host[i], kRowCap,
-                               buf->subsampling[i], nullptr, nullptr, overflow, stream);
+                               buf->subsampling[i], nullptr, nullptr, overflow, stream, buf->order[i + 1]);
       if (rc != GEOTR_OK) return rc;
       rc = radius_query_hinted(false, grids[i + 1], pts[i], len[i], batch, n0, hint[i], n0, hint[i + 1], 2.0f * r, limits_host[i + 1], kRowCap,
-                               buf->upsampling[i], nullptr, nullptr, overflow, stream);
+                               buf->upsampling[i], nullptr, nullptr, overflow, stream, buf->order[i]);
       if (rc != GEOTR_OK) return rc;
     }
     r *= 2.0f;

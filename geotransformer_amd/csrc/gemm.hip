@@ -539,6 +539,7 @@ struct PackedArgs {
   // row tile run back to back on ONE XCD and share the activation tile through that XCD's L2 (with blockIdx.x = column block they
   // landed on nx different XCDs and every one of them fetched the A tile from HBM: N = 512 read A four times).
   int nx, ny, tiles_per_xcd;
+  int stagger;  // experiment (GEOTR_GEMM_STAGGER=1): the blocks that fill the second resident slot of each CU start half a block late
 };
 
 __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b_is_kn, int N, int K, int KS, int64_t nvec,
@@ -633,6 +634,13 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   const int xcd = (int)blockIdx.x & 7, tile = xcd * g.tiles_per_xcd + ((int)blockIdx.x >> 3);
   if (tile >= min(g.nx * g.ny, (xcd + 1) * g.tiles_per_xcd)) return;  // (uniform per block: before any barrier)
   const int bx = tile % g.nx, by = tile / g.nx;
+  if (g.stagger && blockIdx.z == 0 &&
+      (g.stagger > 0 ? (((int)blockIdx.x >> 3) >= 32 && ((int)blockIdx.x >> 3) < 64) : ((((int)blockIdx.x >> 3) & 1) && ((int)blockIdx.x >> 3) < 64))) {
+    // the first 32 blocks of an XCD take one slot of its 32 CUs each, the next 32 the second slot: delay those by ~half a block's
+    // matrix time so that the two co-resident blocks of a CU are out of phase (one computes while the other loads / stores)
+    const int naps = abs(g.stagger) * min(g.kt_split, g.KS / 2) / 2;
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int ct0 = bx * NT_BLK;
   int m0 = by * BM, m_end = g.M;  // this block's first row and the end of its row segment
   int sgi = 0;
@@ -971,9 +979,14 @@ static F32Plan packed_plan_f32(int64_t M, int64_t N, int64_t K, bool may_split) 
     return !(e && e[0] == '0');
   }();
   if (!enabled) return F32Plan{128, may_split ? packed_splits(M, N, K) : 1};
+  static const int force_bn = [] {
+    const char* e = std::getenv("GEOTR_F32_BN");  // experiment: GEOTR_F32_BN=64 / 128 restricts the plan to one column width
+    return e ? std::atoi(e) : 0;
+  }();
   F32Plan best{128, 1};
   double best_cost = 1e300;
   for (int bn : {128, 64}) {
+    if (force_bn && bn != force_bn) continue;
     const int64_t tiles = row_tiles * ((N + bn - 1) / bn);
     for (int s = 1; s <= (may_split && splitk_enabled() ? 16 : 1); ++s) {
       if (s > 1 && nkt / s < 4) break;
@@ -1010,6 +1023,11 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   g.lda = lda; g.ldc = ldc; g.ldr = residual ? ldr : 0;
   g.M = (int)M; g.N = (int)N; g.K = (int)K; g.KS = (int)(kp / 16); g.NT = (int)(np / 32); g.alpha = alpha; g.act = act;
   g.nseg = 0;
+  static const int stagger = [] {
+    const char* e = std::getenv("GEOTR_GEMM_STAGGER");
+    return e ? std::atoi(e) : 0;
+  }();
+  g.stagger = stagger;
   g.stats = stats;
   g.gres = gres ? *gres : GatherRes{nullptr, nullptr, 0, 0, 0};
   g.seg_affine = seg_affine;
@@ -1096,6 +1114,14 @@ extern "C" size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N,
 
 extern "C" int geotr_gemm_packed_splits(int64_t M, int64_t N, int64_t K, int bf16_operands) {
   return bf16_operands == 2 ? packed_plan_f32(M, N, K, true).splits : packed_splits(M, N, K);
+}
+
+extern "C" int geotr_gemm_packed_tile_width(int64_t M, int64_t N, int64_t K, int bf16_operands, int unsplit_epilogue) {
+  // column width of the block tile a launch of this shape uses (128 / 64 / 32): which gemm_packed_kernel<WM, WN, TERMS> instantiation
+  // runs it (<2,2,.> / <1,2,.> / <1,1,.>) -- for tools that attribute profiler records to shapes (scripts/gemm_traffic_table.py)
+  if (N <= 64) return N > 32 ? 64 : 32;
+  if (bf16_operands != 2) return 128;
+  return packed_plan_f32(M, N, K, !unsplit_epilogue).bn;
 }
 
 extern "C" int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

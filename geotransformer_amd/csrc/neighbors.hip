@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
                                                        const int64_t* __restrict__ q_len, int batch, int64_t nq_cap,
                                                        float r2, int width, int cap,
                                                        int64_t* __restrict__ out, int* __restrict__ counts,
-                                                       int* __restrict__ max_count, int* __restrict__ overflow) {
+                                                       int* __restrict__ max_count, int* __restrict__ overflow, int variant) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t ns_total = rg_rows(hdr, batch);
@@ -257,11 +257,13 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
   // wave scan, ONCE per wave), and the cloud of a query is the number of clouds that end at or before it -- one ballot.  The serial
   // walk over the lengths it replaces cost a dependent scalar load per cloud (~16 on average for a 16-pair stack, up to 32: a third of
   // a query's ~8 000 cycles -- rocprofv3 SQ counters, profiles/r03_rg_query_counters.md -- and an empty wave paid all 32).
+  // `variant` (experiment, GEOTR_RG_VARIANT): bit 0 = find the cloud by the serial walk over the lengths (round 2's form), bit 1 = one
+  // query per wave and out (no stride loop)
   int cloud_end = 0x7fffffff;
-  if (batch <= 64) cloud_end = wave_inclusive_scan(lane < batch ? (int)q_len[lane] : 0);
+  if (batch <= 64 && !(variant & 1)) cloud_end = wave_inclusive_scan(lane < batch ? (int)q_len[lane] : 0);
   for (int64_t qi = (int64_t)blockIdx.x * 4 + w; qi < nq_cap; qi += (int64_t)gridDim.x * 4) {
     int b;
-    if (batch <= 64) {
+    if (batch <= 64 && !(variant & 1)) {
       b = __popcll(__ballot(lane < batch && qi >= (int64_t)cloud_end));
     } else {
       int64_t qstart;
@@ -339,10 +341,230 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
       if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
     }
     for (int j = count + lane; j < width; j += 64) row[j] = ns_total;  // pad (radius_neighbors_cpu.cpp:85)
+    if (variant & 2) return;
     // the next query of this wave overwrites the key row: every lane's reads above come first
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// ---- round 4: LDS-staged point tiles (north_star's design) ---------------------------------------------------
+// The one-query-per-wave kernel above spends ~500 VALU instructions per query, most of them on flattening nine cell runs into one
+// candidate index space per lane and on dependent global loads (profiles/r03_rg_query_counters.md).  Here a wave takes kTileQ CONSECUTIVE
+// queries of a visiting order in which neighbours are spatial neighbours (the grid order of the query cloud, carried by the pyramid:
+// geotr_radius_grid_order), so that they share their cell neighbourhood:
+//   1. lane j < kTileQ owns query j: row, coordinates, cell in the support grid of its cloud;
+//   2. the queries that fall within a few cells of the first one (same cloud) form a sub-tile; its candidate BOX = the union of
+//      their 3 x 3 x 3 neighbourhoods, visited as x-contiguous runs (lane k owns run k; one wave scan gives the flat offsets);
+//   3. the box's points -- the cell-sorted float4 {x, y, z, local index} -- are staged ONCE into LDS, kTileC at a time;
+//   4. every query of the sub-tile tests every staged point (FMA-free d^2, strict d^2 < r^2; points outside its own 27 cells cannot
+//      pass: cell >= 1.001 r) and compacts its accepted (d^2, index) keys into its own LDS row by ballot + popcount;
+//   5. rows are ranked two queries at a time (half a wave each) and stored.
+// A query with more than kTileK accepted points (dense raw clouds) takes the one-query path below on the wave's whole key area, so the
+// capacity / overflow semantics are those of rg_query_kernel.  Results are bit-identical to it (same arithmetic, same canonical order).
+// Two shapes: <8 queries, 96 keys each> for neighbour limits up to 48 (3DMatch / ModelNet: 24 .. 40) and <4, 192> above (KITTI's
+// calibrated limits reach ~80; rows hold about twice the limit before they take the one-query path); 768 keys per wave either way.
+constexpr int kTileC = 256;   // staged candidates per chunk (float4: 4 KB per wave)
+constexpr int kTileRuns = 64; // runs of a box (one per lane)
+constexpr int kTileKeys = 768;
+
+template <int kTileQ, int kTileK>
+struct TileLds {
+  float4 cand[kTileC];
+  unsigned long long keys[kTileQ * kTileK];
+  int run_pre[kTileRuns + 1];  // exclusive prefix of the run lengths; [nruns] = total
+  int run_start[kTileRuns];
+};
+
+template <int kTileQ, int kTileK>
+__global__ __launch_bounds__(256) void rg_query_tile_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
+                                                            const float4* __restrict__ sorted, const float* __restrict__ q,
+                                                            const int64_t* __restrict__ q_len, const int* __restrict__ q_order, int batch,
+                                                            float r2, int width, int cap, int64_t* __restrict__ out,
+                                                            int* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  static_assert(kTileQ * kTileK == kTileKeys && (kTileQ & (kTileQ - 1)) == 0 && kTileQ % 2 == 0, "tile shape");
+  using Lds = TileLds<kTileQ, kTileK>;
+  Lds& L = reinterpret_cast<Lds*>(tile_raw)[w];
+  const int64_t ns_total = rg_rows(hdr, batch);
+  const int cloud_end = wave_inclusive_scan(lane < batch ? (int)q_len[lane] : 0);  // batch <= 64 (host)
+  const int nq_total = __shfl(cloud_end, batch - 1, 64);
+  const int64_t tiles = ((int64_t)nq_total + kTileQ - 1) / kTileQ;
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    // 1. lane j: query j of the tile
+    const int pos = (int)(tile * kTileQ) + lane;
+    const bool has_q = lane < kTileQ && pos < nq_total;
+    const int qi = has_q ? (q_order ? q_order[pos] : pos) : 0;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (has_q) qx = q[3 * (int64_t)qi], qy = q[3 * (int64_t)qi + 1], qz = q[3 * (int64_t)qi + 2];
+    unsigned pending = (unsigned)(__ballot(has_q) & ((1ull << kTileQ) - 1ull));  // queries not yet processed
+    while (pending) {
+      const int j0 = __builtin_ctz(pending);
+      // cloud of the first pending query (one ballot over the lane-held cloud ends) and the queries that share it
+      const int qi0 = __shfl(qi, j0, 64);
+      const int b = __popcll(__ballot(lane < batch && qi0 >= cloud_end));
+      const int row_lo = b > 0 ? __shfl(cloud_end, b - 1, 64) : 0, row_hi = __shfl(cloud_end, b, 64);
+      const CloudGrid g = hdr[b];
+      int cx = 0, cy = 0, cz = 0;
+      if (has_q) cx = cell_coord(qx, g.mn[0], g.cs), cy = cell_coord(qy, g.mn[1], g.cs), cz = cell_coord(qz, g.mn[2], g.cs);
+      const int cx0 = __shfl(cx, j0, 64), cy0 = __shfl(cy, j0, 64), cz0 = __shfl(cz, j0, 64);
+      // sub-tile: pending queries of cloud b within (4, 1, 1) cells of the first one -> at most 11 x 5 x 5 cells, 25 runs
+      const bool near = has_q && ((pending >> lane) & 1u) && qi >= row_lo && qi < row_hi && abs(cx - cx0) <= 4 && abs(cy - cy0) <= 1 &&
+                        abs(cz - cz0) <= 1;
+      const unsigned sub = (unsigned)(__ballot(near) & ((1ull << kTileQ) - 1ull));  // (contains j0)
+      pending &= ~sub;
+      // 2. the candidate box (clamped to the grid; an empty support cloud or a box outside the grid has no runs)
+      int lo[3] = {cx, cy, cz}, hi[3] = {cx, cy, cz};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (!near) lo[c] = 0x7fffffff, hi[c] = -0x7fffffff;
+#pragma unroll
+        for (int o = 1; o < kTileQ; o <<= 1) {
+          lo[c] = min(lo[c], __shfl_xor(lo[c], o, 64));
+          hi[c] = max(hi[c], __shfl_xor(hi[c], o, 64));
+        }
+        lo[c] = __shfl(lo[c], 0, 64), hi[c] = __shfl(hi[c], 0, 64);
+        lo[c] = max(lo[c] - 1, 0), hi[c] = min(hi[c] + 1, g.dim[c] - 1);
+      }
+      const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+      const int nruns = (g.s_len > 0 && lo[0] <= hi[0] && ny > 0 && nz > 0) ? ny * nz : 0;  // <= 25
+      int seg_start = 0, seg_len = 0;
+      if (lane < nruns) {
+        const int ry = lo[1] + lane % ny, rz = lo[2] + lane / ny;
+        const int row = g.cell_base + g.dim[0] * (ry + g.dim[1] * rz);
+        seg_start = cell_start[row + lo[0]];
+        seg_len = cell_start[row + hi[0] + 1] - seg_start;
+      }
+      const int inc = wave_inclusive_scan(seg_len);
+      const int total = __shfl(inc, 63, 64);
+      L.run_pre[lane] = inc - seg_len;  // lanes >= nruns hold `total`: a search never lands on them
+      L.run_start[lane] = seg_start;
+      if (lane == 0) L.run_pre[kTileRuns] = total;
+      int base[kTileQ];
+#pragma unroll
+      for (int j = 0; j < kTileQ; ++j) base[j] = 0;
+      wave_sync();
+      for (int c0 = 0; c0 < total; c0 += kTileC) {
+        const int chunk = min(kTileC, total - c0);
+        // 3. stage the chunk: flat candidate t -> its run by a binary search over the prefix array
+        for (int t = lane; t < chunk; t += 64) {
+          const int f = c0 + t;
+          int k = 0;
+#pragma unroll
+          for (int step = 32; step > 0; step >>= 1)
+            if (k + step < kTileRuns && L.run_pre[k + step] <= f) k += step;
+          L.cand[t] = sorted[L.run_start[k] + (f - L.run_pre[k])];
+        }
+        wave_sync();
+        // 4. every query of the sub-tile against every staged point
+#pragma unroll
+        for (int j = 0; j < kTileQ; ++j) {
+          if (!((sub >> j) & 1u)) continue;  // (wave-uniform)
+          const float ax = __shfl(qx, j, 64), ay = __shfl(qy, j, 64), az = __shfl(qz, j, 64);
+          for (int t0 = 0; t0 < chunk; t0 += 64) {
+            const int t = t0 + lane;
+            bool accept = false;
+            unsigned long long key = 0;
+            if (t < chunk) {
+              const float4 p = L.cand[t];
+              // L2_Simple_Adaptor::evalMetric (nanoflann.hpp:432-440): ((dx*dx) + dy*dy) + dz*dz, no FMA
+              const float dx = __fsub_rn(ax, p.x), dy = __fsub_rn(ay, p.y), dz = __fsub_rn(az, p.z);
+              const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+              accept = d < r2;  // strict (nanoflann.hpp:249-253)
+              key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+            }
+            const unsigned long long ballot = __ballot(accept);
+            const int rank = base[j] + __popcll(ballot & ((1ull << lane) - 1ull));
+            if (accept && rank < kTileK) L.keys[j * kTileK + rank] = key;
+            base[j] += __popcll(ballot);
+          }
+        }
+        wave_sync();  // the next chunk overwrites the staged points
+      }
+      // 5. rank + store: keys in registers (lane e holds keys e and e + 64 of the row), every key broadcast by v_readlane -- no LDS round
+      // trip per comparison; rows longer than kTileK go through the one-query path afterwards
+      unsigned slow = 0;
+#pragma unroll
+      for (int j = 0; j < kTileQ; ++j) {
+        if (!((sub >> j) & 1u)) continue;  // (wave-uniform)
+        const int count = base[j];
+        if (count > (kTileK < 128 ? kTileK : 128)) {  // (two key registers per lane)
+          slow |= 1u << j;
+          continue;
+        }
+        const unsigned long long* kr = L.keys + j * kTileK;
+        const unsigned long long k0 = lane < count ? kr[lane] : ~0ull, k1 = lane + 64 < count ? kr[lane + 64] : ~0ull;
+        int r0 = 0, r1 = 0;
+        const int n0 = min(count, 64);
+        for (int i = 0; i < n0; ++i) {
+          const unsigned long long ki = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(k0 >> 32), i) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k0, i);
+          r0 += ki < k0;
+          r1 += ki < k1;
+        }
+        for (int i = 64; i < count; ++i) {
+          const unsigned long long ki = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(k1 >> 32), i - 64) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k1, i - 64);
+          r0 += ki < k0;
+          r1 += ki < k1;
+        }
+        const int qrow = __shfl(qi, j, 64);
+        int64_t* row = out + (int64_t)qrow * width;
+        if (lane < count && r0 < width) row[r0] = (int64_t)(unsigned)(k0 & 0xffffffffull) + g.s_start;
+        if (lane + 64 < count && r1 < width) row[r1] = (int64_t)(unsigned)(k1 & 0xffffffffull) + g.s_start;
+        for (int i = count + lane; i < width; i += 64) row[i] = ns_total;  // pad (radius_neighbors_cpu.cpp:85)
+      }
+      wave_sync();
+      // one-query path for the dense rows: rg_query_kernel's loop, keys in the wave's whole key area (kTileQ * kTileK >= cap by the host)
+      while (slow) {
+        const int j = __builtin_ctz(slow);
+        slow &= slow - 1;
+        const float ax = __shfl(qx, j, 64), ay = __shfl(qy, j, 64), az = __shfl(qz, j, 64);
+        const int qrow = __shfl(qi, j, 64);
+        int count = 0;
+        for (int t0 = 0; t0 < total; t0 += 64) {
+          const int f = t0 + lane;
+          bool accept = false;
+          unsigned long long key = 0;
+          if (f < total) {
+            int k = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+              if (k + step < kTileRuns && L.run_pre[k + step] <= f) k += step;
+            const float4 p = sorted[L.run_start[k] + (f - L.run_pre[k])];
+            const float dx = __fsub_rn(ax, p.x), dy = __fsub_rn(ay, p.y), dz = __fsub_rn(az, p.z);
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            accept = d < r2;
+            key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+          }
+          const unsigned long long ballot = __ballot(accept);
+          const int rank = count + __popcll(ballot & ((1ull << lane) - 1ull));
+          if (accept && rank < cap) L.keys[rank] = key;
+          count += __popcll(ballot);
+        }
+        if (count > cap) {
+          if (lane == 0 && overflow) atomicMax(overflow, count);
+          count = cap;
+        }
+        wave_sync();
+        int64_t* row = out + (int64_t)qrow * width;
+        for (int e = lane; e < count; e += 64) {
+          const unsigned long long mine = L.keys[e];
+          int rank = 0;
+          for (int i = 0; i < count; ++i) rank += L.keys[i] < mine;
+          if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
+        }
+        for (int i = count + lane; i < width; i += 64) row[i] = ns_total;
+        wave_sync();
+      }
+    }
   }
 }
 
@@ -810,18 +1032,44 @@ int radius_grid_order_hinted(const void* grid_ws, int64_t ns, int64_t ns_hint, i
 // nq = capacity of the query rows (>= the sum of q_len; the real count is read on the device), nq_hint = expected count (0 = nq): the
 // grid holds one wave per EXPECTED query -- a first version with a fixed grid of 4096 blocks walking ~40 queries per wave measured 24 %
 // slower (211 vs 170 us per launch, profiles/r03_ab_runs.md) -- and the waves stride on if there are more
+// q_order (optional): a visiting order of the query rows in which neighbours are spatial neighbours (the grid order of the QUERY cloud,
+// geotr_radius_grid_order) -- selects the LDS-staged tile kernel (round 4); without it, or for counting, the one-query-per-wave kernel
 int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
                         int64_t batch, int64_t nq, int64_t nq_hint, int64_t ns, int64_t ns_hint, float radius, int64_t width, int64_t cap,
-                        int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_) {
+                        int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_, const int32_t* q_order) {
   hipStream_t stream = (hipStream_t)stream_;
   GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns, batch, ns_hint);
   if (nq == 0) return GEOTR_OK;
   const float r2 = radius * radius;  // fp32 product, as radius_neighbors_cpu.cpp:12
   const int64_t expect = nq_hint > 0 ? std::min(nq_hint, nq) : nq;
   const unsigned nb = (unsigned)((expect + 3) / 4);
+  static const bool tile_enabled = [] {
+    // OPT-IN (GEOTR_RG_TILE=1): bit-identical results (tests/test_neighbors_gpu.py runs both), measured SLOWER than the one-query-per-wave
+    // kernel -- 192 vs 111 us per pair, 418-729 vs 961 pairs/s (profiles/r04_ab_runs.md): a wave that walks 8 queries one after the
+    // other serialises their ranking loops, which are the longest dependent chain of a query
+    const char* e = std::getenv("GEOTR_RG_TILE");
+    return e && e[0] == '1';
+  }();
+  static const int variant = [] {
+    const char* e = std::getenv("GEOTR_RG_VARIANT");  // experiment switch of rg_query_kernel (see there); default 0
+    return e ? std::atoi(e) : 0;
+  }();
+  if (!count_only && q_order && tile_enabled && batch <= 64 && cap <= kTileKeys && nq < (1ll << 31)) {
+    if (width <= 48) {
+      const int64_t tiles = (expect + 7) / 8;
+      rg_query_tile_kernel<8, 96><<<dim3((unsigned)((tiles + 3) / 4)), dim3(256), 4 * sizeof(TileLds<8, 96>), stream>>>(
+          L.hdr, L.cell_start, L.sorted, q, q_len, q_order, (int)batch, r2, (int)width, (int)cap, out, overflow);
+    } else {
+      const int64_t tiles = (expect + 3) / 4;
+      rg_query_tile_kernel<4, 192><<<dim3((unsigned)((tiles + 3) / 4)), dim3(256), 4 * sizeof(TileLds<4, 192>), stream>>>(
+          L.hdr, L.cell_start, L.sorted, q, q_len, q_order, (int)batch, r2, (int)width, (int)cap, out, overflow);
+    }
+    GEOTR_CHECK_LAUNCH("radius_query(tile)");
+    return GEOTR_OK;
+  }
   if (count_only) {
     rg_query_kernel<true><<<dim3(nb), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
-                                                             r2, 0, 0, nullptr, counts, max_count, nullptr);
+                                                             r2, 0, 0, nullptr, counts, max_count, nullptr, 0);
   } else {
     const size_t lds = (size_t)cap * 4 * sizeof(unsigned long long);
     if (lds > 64 * 1024) {
@@ -831,7 +1079,7 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
     }
     rg_query_kernel<false><<<dim3(nb), dim3(256), lds, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
                                                                 r2, (int)width, (int)cap, out, nullptr,
-                                                                nullptr, overflow);
+                                                                nullptr, overflow, variant);
   }
   GEOTR_CHECK_LAUNCH("radius_query");
   return GEOTR_OK;
@@ -844,7 +1092,7 @@ int geotr_radius_grid_order(const void* grid_ws, int64_t ns, int64_t batch, int3
 static int radius_query_common(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
                                int64_t batch, int64_t nq, int64_t ns, float radius, int64_t width, int64_t cap,
                                int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_) {
-  return radius_query_hinted(count_only, grid_ws, q, q_len, batch, nq, 0, ns, 0, radius, width, cap, out, counts, max_count, overflow, stream_);
+  return radius_query_hinted(count_only, grid_ws, q, q_len, batch, nq, 0, ns, 0, radius, width, cap, out, counts, max_count, overflow, stream_, nullptr);
 }
 
 int geotr_radius_count(const void* grid_ws, int64_t ns, const float* q_points, const int64_t* q_len, int64_t batch,

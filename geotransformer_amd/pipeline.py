@@ -161,6 +161,11 @@ class ConcurrentRegistration:
         # GEOTR_PYRAMID_PRIORITY=1 (experiment): a second, high-priority queue per lane for the pyramid's small dependent kernels
         self.pyramid_streams = ([torch.cuda.Stream(device=self.device, priority=-1) for _ in range(self.lanes)]
                                 if os.environ.get('GEOTR_PYRAMID_PRIORITY') == '1' else [None] * self.lanes)
+        # Lanes that start together stay in phase (equal stacks take equal time): every lane then runs the same kind of kernel at the same
+        # moment -- pyramid next to pyramid, GEMM next to GEMM -- and they compete for the same unit instead of filling each other's gaps
+        # (rocprofv3 timeline, profiles/r04_ab_runs.md: a stage-0 radius query overlaps another lane's radius query for 52-62 % of its
+        # duration).  `lane_stagger_ms`: lane i starts its FIRST job i x that many milliseconds late; the offset then persists.
+        self.lane_stagger_s = 1e-3 * float(os.environ.get('GEOTR_LANE_STAGGER_MS', '0'))
         self._queue = queue.SimpleQueue()
         self._pending = 0
         self._cv = threading.Condition()
@@ -257,6 +262,7 @@ class ConcurrentRegistration:
         with torch.cuda.stream(stream), torch.no_grad():
             begun = None   # (job, plan, points, event): pyramid enqueued, its sizes not yet on the host
             flying = None  # (job, raw, data, counts): forward launched, its counts not yet on the host
+            first = True
 
             def land():  # nothing else to overlap with: wait for the stack in flight and deliver it
                 nonlocal flying
@@ -280,6 +286,9 @@ class ConcurrentRegistration:
                     if job is None:
                         land()
                         return
+                    if first and self.lane_stagger_s > 0 and lane > 0:
+                        time.sleep(lane * self.lane_stagger_s)  # phase offset against the other lanes (see __init__)
+                    first = False
                     if len(job) == 1:  # a single pair: the one-pair entry point, synchronously
                         land()
                         index, ref, src, sink, ready = job[0]

@@ -153,6 +153,9 @@ size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K)
  * narrow grid (< 256 tiles, >= 16 stages); the exact-fp32 plan (matrix-pipe bound) chooses column width and slices together by the work
  * of the busiest compute unit (gemm.hip packed_plan_f32).  geotr_gemm_packed_splitk_workspace_bytes covers either. */
 int geotr_gemm_packed_splits(int64_t M, int64_t N, int64_t K, int bf16_operands);
+/* Column width (128 / 64 / 32) of the block tile such a launch uses = which kernel instantiation runs it (<2,2,.> / <1,2,.> / <1,1,.>);
+ * unsplit_epilogue: the launch carries statistics / gathered rows / an affine table and is therefore never split.  For profiling tools. */
+int geotr_gemm_packed_tile_width(int64_t M, int64_t N, int64_t K, int bf16_operands, int unsplit_epilogue);
 int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                              const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                              int bf16_operands, void* ws, size_t ws_bytes, void* stream);

@@ -156,6 +156,51 @@ def test_native_pyramid_matches_oracle(oracle_lib):
     assert out['lengths_host'] == [l.tolist() for l in want['lengths']]
 
 
+_TILE_CHILD = """
+import hashlib, json, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from geotransformer_amd.native import build_pyramid
+from geotransformer_amd.synthetic import CONFIGS, make_pair
+out = {{}}
+for name, stack, limits in (('3dmatch', 3, None), ('kitti', 1, None), ('3dmatch', 2, [64, 60, 56, 52])):
+    cfg = dict(CONFIGS[name])
+    if limits is not None:
+        cfg['limits'] = limits
+        name += '_wide'
+    items = [make_pair(40 + i, name.split('_')[0]) for i in range(stack)]
+    pts = np.concatenate([c for it in items for c in (it['ref_points'], it['src_points'])])
+    lens = np.array([len(c) for it in items for c in (it['ref_points'], it['src_points'])], dtype=np.int64)
+    pyr = build_pyramid(torch.from_numpy(pts).cuda(), torch.from_numpy(lens).cuda(), cfg['num_stages'], cfg['voxel'], cfg['radius'], cfg['limits'])
+    h = hashlib.sha256()
+    for k in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling'):
+        for t in pyr[k]:
+            h.update(np.ascontiguousarray(t.cpu().numpy()).tobytes())
+    out[name] = [h.hexdigest(), int(pyr['_overflow'].item()), [int(t.shape[1]) for t in pyr['neighbors']]]
+print('RESULT ' + json.dumps(out))
+"""
+
+
+def test_lds_staged_tile_kernel_is_bit_identical_to_the_one_query_kernel():
+    """Round 4's rg_query_tile_kernel (north_star's LDS-staged point tiles: a wave stages the cell box of 8 / 4 neighbouring queries once;
+    opt-in GEOTR_RG_TILE=1 -- measured slower, profiles/r04_ab_runs.md) writes every table of the pyramid bit for bit as the default
+    one-query-per-wave kernel: a 3-pair 3DMatch-shape stack and a 120k + 120k KITTI-shape pair (limits <= 40: the <8 queries, 96 keys>
+    shape; rows of more than 96 neighbours take the dense-row path) and a stack with limits of 52 .. 64 (the <4, 192> shape).  The switch
+    is read once per process: two children."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for tile in ('0', '1'):
+        env = dict(os.environ, GEOTR_RG_TILE=tile)
+        res = subprocess.run([sys.executable, '-c', _TILE_CHILD.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        got[tile] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('RESULT ')][-1][7:])
+    assert got['0'] == got['1'], (got['0'], got['1'])
+    assert all(v[1] == 0 for v in got['0'].values()) and len(got['0']) == 3  # no row overflowed its capacity
+
+
 def test_calibrate_neighbors_matches_reference_recipe(oracle_lib):
     """calibrate_neighbors_stack_mode (utils/data.py:192-217 of the reference) vs the same recipe on the CPU oracle."""
     from geotransformer_amd.synthetic import CONFIGS, make_pair
