@@ -262,7 +262,8 @@ WORKLOADS = {
 }
 
 # (lanes, pairs stacked per launch sequence) per configuration: measured in profiles/r02_ab_runs.md and r02_other_configs.md
-LAUNCH_SHAPE = {'3dmatch': (4, 16), 'lomatch': (4, 16), 'modelnet': (4, 16), 'kitti': (2, 4)}
+# (round 4: kitti 3 lanes -- 144.0 vs 137.3 pairs/s with 2, 118.1 with 1; profiles/r04_ab_runs.md section 7)
+LAUNCH_SHAPE = {'3dmatch': (4, 16), 'lomatch': (4, 16), 'modelnet': (4, 16), 'kitti': (3, 4)}
 
 
 def build_pair(seed, config, n_points):
@@ -457,6 +458,10 @@ def main():
     ap.add_argument('--profile-stride', type=int, default=8,
                     help='bracket every Nth eligible launch: a timed event pair keeps its launch from overlapping its stream neighbours, '
                          'so the sample is spread over the whole region instead of covering every launch of its start')
+    ap.add_argument('--prewarm-seconds', type=float, default=2.0,
+                    help='untimed steps of the same workload before the W warm-up steps, until this much wall time has passed: the FIRST GPU '
+                         'process on a fresh box reads up to 40 %% low for its first seconds (clock / power-state ramp; profiles/r04_ab_runs.md), '
+                         'which W = 3 steps (0.2 s) do not cover')
     ap.add_argument('--dump-shapes', default=None, metavar='PATH',
                     help='write every bracketed launch shape of the timed region (family, shape, launches, average us) as JSON lines to PATH')
     ap.add_argument('--no-numa-bind', action='store_true', help="do not bind the process to the GPU's NUMA node (A/B runs)")
@@ -548,6 +553,13 @@ def main():
         # gap right before the timed region costs its first stacks (profiles/r02_ab_runs.md)
         prof = KernelProfiler(args.profile_events, stride=args.profile_stride)  # HIP events around the GSE / packed-GEMM / fused KPConv launches
         note(f'rank {rank}: [{precision}] warm-up')
+        t_pre, n_pre = time.perf_counter(), 0
+        while precision == args.precision and time.perf_counter() - t_pre < args.prewarm_seconds:  # box warm-up (untimed, before the W steps)
+            step(n_pre)
+            runner.drain()
+            torch.cuda.synchronize()
+            n_pre += 1
+        info.setdefault('prewarm_steps', n_pre)
         for i in range(args.warmup):
             step(i)
         runner.drain()
@@ -638,6 +650,7 @@ def main():
                        'pairs_per_step_per_gpu': args.batch, 'lanes_per_gpu': args.lanes, 'pairs_stacked_per_launch_sequence': args.stack,
                        'host_binding': numa_note, 'host_waits': sync_note,
                        'host_cpus_busy_in_timed_region': main_run['host_cpus_busy'],
+                       'untimed_prewarm': f'{info.get("prewarm_steps", 0)} steps (~{args.prewarm_seconds} s) before the {args.warmup} warm-up steps',
                        'parallelism': f'pairs sharded over {world} rank(s), one process per GPU, no data-path collective',
                        'collective_backend': 'rccl' if backend == 'nccl' else backend,
                        'weights': 'random init, seed 7351', 'matrix_precision': args.precision, 'gse': args.gse,

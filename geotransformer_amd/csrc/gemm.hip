@@ -350,11 +350,15 @@ struct SkinnyGroups {
   int64_t a_hs[GEOTR_MAX_GROUPS], b_hs[GEOTR_MAX_GROUPS], c_hs[GEOTR_MAX_GROUPS];  // per-head strides
 };
 
-template <bool VEC, bool GROUPED>
+// NOSPLIT (round 4; shallow products: K <= 64, the attention cores' q k^T with 64 channels per head): every wave owns its OWN 32 x 32
+// tile of a 64 x 64 block tile and walks the whole K -- with K = 64 the K-split left two of the four waves idle and the block count was
+// four times what the product needs (12 800 blocks of which half the waves did nothing).  No block-level barrier on this path.
+template <bool VEC, bool GROUPED, bool NOSPLIT = false>
 __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const SkinnyGroups* gr) {
   __shared__ float slab[4][2 * 32 * kSStride];  // per wave: A chunk [32][33], B chunk [32][33]; reused for the reduction
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int m0 = NOSPLIT ? (blockIdx.y * 2 + (wave >> 1)) * 32 : blockIdx.y * 32;
+  const int n0 = NOSPLIT ? (blockIdx.x * 2 + (wave & 1)) * 32 : blockIdx.x * 32;
   int M = g.M, N = g.N, K = g.K;
   int64_t lda = g.lda, ldb = g.ldb, ldc = g.ldc;
   const float* A = g.A + (int64_t)blockIdx.z * g.strideA;
@@ -363,7 +367,7 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const Skinny
   if (GROUPED) {
     const int grp = blockIdx.z / gr->heads, head = blockIdx.z % gr->heads;
     M = gr->m[grp], N = gr->n[grp], K = gr->k[grp];
-    if (m0 >= M || n0 >= N) return;  // the grid covers the largest group
+    if (!NOSPLIT && (m0 >= M || n0 >= N)) return;  // the grid covers the largest group (NOSPLIT: per wave, below)
     lda = gr->lda[grp], ldb = gr->ldb[grp], ldc = gr->ldc[grp];
     A = g.A + gr->a_off[grp] + head * gr->a_hs[grp];
     B = g.B + gr->b_off[grp] + head * gr->b_hs[grp];
@@ -441,28 +445,53 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const Skinny
       }
     }
   };
-  f32x16 acc;
+  // (NOSPLIT keeps one accumulator per K chunk -- at most two -- and adds them at the end: the K-split form's wave 0 / wave 1 partials
+  // and their sum, i.e. the SAME bits whichever form a launch takes)
+  f32x16 acc, acc_b;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f, acc_b[r] = 0.f;
   const int nchunks = (K + kSK - 1) / kSK;
   const int fr = lane & 31, fk = lane >> 5;
-  int c = wave;
+  constexpr int STEP = NOSPLIT ? 1 : 4;
+  int c = NOSPLIT ? 0 : wave;
+  if (NOSPLIT && (m0 >= M || n0 >= N)) return;  // (whole wave; this path has no block-level barrier)
   if (c < nchunks) load_chunk(c * kSK);
-  for (; c < nchunks; c += 4) {
+  for (; c < nchunks; c += STEP) {
     store_chunk();  // wave-private slab: only wave-level ordering is needed
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (c + 4 < nchunks) load_chunk((c + 4) * kSK);  // next chunk's loads fly under this chunk's MFMAs
+    if (c + STEP < nchunks) load_chunk((c + STEP) * kSK);  // next chunk's loads fly under this chunk's MFMAs
 #pragma unroll
     for (int ks = 0; ks < kSK / 2; ++ks) {
       const float a = As[fr * kSStride + 2 * ks + fk];
       const float b = Bs[fr * kSStride + 2 * ks + fk];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      if (NOSPLIT && c == 1) acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc_b, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if constexpr (NOSPLIT) {  // the wave's own tile: through its slab to row-contiguous stores
+#pragma unroll
+    for (int r = 0; r < 16; ++r) As[((r & 3) + 8 * (r >> 2) + 4 * fk) * kSStride + fr] = acc[r] + acc_b[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = lane; e < 32 * 32; e += 64) {
+      const int row = e >> 5, col = e & 31;
+      const int gm = m0 + row, gn = n0 + col;
+      if (gm >= M || gn >= N) continue;
+      float v = As[row * kSStride + col] * g.alpha;
+      if (g.row_div) v = v / (float)max(g.row_div[gm], 1);
+      if (g.bias) v += g.bias[gn];
+      if (g.residual) v += g.residual[(int64_t)blockIdx.z * g.strideC + (int64_t)gm * g.ldr + gn];
+      if (g.act == 1) v = fmaxf(v, 0.f);
+      if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+      C[(int64_t)gm * ldc + gn] = v;
+    }
+    return;
   }
   // reduce the 4 partial tiles: slab[w] holds wave w's 32x32 partial, element (row, col) at row * 33 + col
   __syncthreads();
@@ -484,13 +513,13 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const Skinny
   }
 }
 
-template <bool VEC>
+template <bool VEC, bool NOSPLIT = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
-  gemm_skinny_body<VEC, false>(g, nullptr);
+  gemm_skinny_body<VEC, false, NOSPLIT>(g, nullptr);
 }
-template <bool VEC>
+template <bool VEC, bool NOSPLIT = false>
 __global__ __launch_bounds__(256) void gemm_skinny_grouped_kernel(GemmArgs g, SkinnyGroups gr) {
-  gemm_skinny_body<VEC, true>(g, &gr);
+  gemm_skinny_body<VEC, true, NOSPLIT>(g, &gr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -909,9 +938,18 @@ extern "C" int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t l
     if (vec) gemm_kernel<64, 128, 1, 2, true><<<grid, dim3(256), 0, stream>>>(g);
     else gemm_kernel<64, 128, 1, 2, false><<<grid, dim3(256), 0, stream>>>(g);
   } else {
-    dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32), (unsigned)batch);
+    static const bool nosplit_enabled = [] {
+      const char* e = std::getenv("GEOTR_SKINNY_NOSPLIT");  // A/B switch for measurements: 0 = the K-split kernel for every depth
+      return !(e && e[0] == '0');
+    }();
+    const bool nosplit = nosplit_enabled && K <= 64;  // shallow products: one tile per wave (same rule as geotr_gemm_grouped: bit-identical)
+    const int tile = nosplit ? 64 : 32;
+    dim3 grid((unsigned)((N + tile - 1) / tile), (unsigned)((M + tile - 1) / tile), (unsigned)batch);
     GEOTR_CHECK_ARG(grid.y <= 65535, "gemm: M too large for the skinny kernel");
-    if (vec) gemm_skinny_kernel<true><<<grid, dim3(256), 0, stream>>>(g);
+    if (nosplit) {
+      if (vec) gemm_skinny_kernel<true, true><<<grid, dim3(256), 0, stream>>>(g);
+      else gemm_skinny_kernel<false, true><<<grid, dim3(256), 0, stream>>>(g);
+    } else if (vec) gemm_skinny_kernel<true><<<grid, dim3(256), 0, stream>>>(g);
     else gemm_skinny_kernel<false><<<grid, dim3(256), 0, stream>>>(g);
   }
   GEOTR_CHECK_LAUNCH("gemm");
@@ -1227,10 +1265,21 @@ extern "C" int geotr_gemm_grouped(const float* A, const float* B, int b_is_kn, f
   g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.row_div = nullptr; g.residual = nullptr;
   g.lda = g.ldb = g.ldc = g.ldr = 0; g.strideA = g.strideB = g.strideC = 0;
   g.M = g.N = g.K = 0; g.b_is_kn = b_is_kn; g.alpha = alpha; g.act = 0;
-  dim3 grid((unsigned)((maxn + 31) / 32), (unsigned)((maxm + 31) / 32), (unsigned)(groups->count * heads));
+  int maxk = 0;
+  for (int i = 0; i < groups->count; ++i) maxk = std::max(maxk, gr.k[i]);
+  static const bool nosplit_enabled = [] {
+    const char* e = std::getenv("GEOTR_SKINNY_NOSPLIT");  // A/B switch for measurements: 0 = the K-split kernel for every depth
+    return !(e && e[0] == '0');
+  }();
+  const bool nosplit = nosplit_enabled && maxk <= 64;  // shallow products (q k^T): one 32 x 32 tile per WAVE, no K split
+  const int tile = nosplit ? 64 : 32;
+  dim3 grid((unsigned)((maxn + tile - 1) / tile), (unsigned)((maxm + tile - 1) / tile), (unsigned)(groups->count * heads));
   GEOTR_CHECK_ARG(grid.y <= 65535, "gemm_grouped: group too tall for the skinny kernel");
   hipStream_t stream = (hipStream_t)stream_;
-  if (vec) gemm_skinny_grouped_kernel<true><<<grid, dim3(256), 0, stream>>>(g, gr);
+  if (nosplit) {
+    if (vec) gemm_skinny_grouped_kernel<true, true><<<grid, dim3(256), 0, stream>>>(g, gr);
+    else gemm_skinny_grouped_kernel<false, true><<<grid, dim3(256), 0, stream>>>(g, gr);
+  } else if (vec) gemm_skinny_grouped_kernel<true><<<grid, dim3(256), 0, stream>>>(g, gr);
   else gemm_skinny_grouped_kernel<false><<<grid, dim3(256), 0, stream>>>(g, gr);
   GEOTR_CHECK_LAUNCH("gemm_grouped");
   return GEOTR_OK;

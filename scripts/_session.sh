@@ -1,12 +1,23 @@
-O=$GRAFT_REPO_ROOT/gpurun_out/s10; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/s12; mkdir -p $O
 R=$GRAFT_REPO_ROOT
+cd $R
+timeout 900 python -m pytest tests/test_gemm_gpu.py tests/test_transformer_gpu.py tests/test_neighbors_gpu.py tests/test_heads_gpu.py -m gpu -x -q -p no:cacheprovider > $O/tests.log 2>&1; tail -3 $O/tests.log
 cd /tmp && export TMPDIR=/tmp
-(cd $R/.ab_old/r2 && timeout 300 python bench.py --config kitti --steps 3 --warmup 1 --pairs 4 --no-cpu-baseline --no-fp32-mode > /dev/null 2>&1)
-for t in r2 c06 c07 c14 c18 c19 r3; do
-  (cd $R/.ab_old/$t && timeout 300 python bench.py --config kitti --steps 5 --warmup 1 --pairs 4 --no-cpu-baseline --no-fp32-mode > $O/kitti_$t.json 2> $O/kitti_$t.err)
-  python -c "
+B="--no-cpu-baseline --no-sibling-mode"
+run() { name=$1; shift; timeout 300 env "$@" python $R/bench.py $B ${EXTRA:-} > $O/$name.json 2> $O/$name.err; python -c "
 import json
 try:
-    d=json.load(open('$O/kitti_$t.json')); print('$t', d['value'], d['ms_per_step'])
-except Exception as e: print('$t FAILED', e)"
-done
+    d=json.load(open('$O/$name.json')); print('$name', d['value'], 'pairs/s', d['ms_per_step'],'ms/step', d['config'].get('untimed_prewarm'))
+except Exception as e: print('$name FAILED', e)"; }
+EXTRA="" run first_run_with_prewarm X=1
+EXTRA="" run nosplit_on X=1
+EXTRA="" run nosplit_off GEOTR_SKINNY_NOSPLIT=0
+EXTRA="" run nosplit_on2 X=1
+EXTRA="" run stagger16 GEOTR_LANE_STAGGER_MS=16
+EXTRA="" run stagger8 GEOTR_LANE_STAGGER_MS=8
+EXTRA="--config kitti --steps 5 --warmup 1 --pairs 8" run kitti_base X=1
+EXTRA="--config kitti --steps 5 --warmup 1 --pairs 8" run kitti_stagger13 GEOTR_LANE_STAGGER_MS=13
+EXTRA="--config kitti --steps 5 --warmup 1 --pairs 8 --lanes 3" run kitti_3lanes X=1
+EXTRA="--config kitti --steps 5 --warmup 1 --pairs 8 --lanes 1" run kitti_1lane X=1
+timeout 400 python $R/bench.py --config lomatch --precision bf16 --no-sibling-mode > $O/bench_lomatch_bf16.json 2> $O/bench_lomatch_bf16.err; python -c "
+import json; d=json.load(open('$O/bench_lomatch_bf16.json')); print('lomatch bf16', d['value'], d['parity']['ok'])"

@@ -41,7 +41,7 @@ def main():
     if len(sys.argv) > 6:  # the unprofiled bench line of the same session
         plain = f"(the unprofiled bench line of the same box reads {json.load(open(sys.argv[6]))['roofline']['avg_launch_us']} us)"
     with open(out, 'w') as f:
-        f.write('# `rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode` '
+        f.write('# `rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sibling-mode` (exact-fp32 default) '
                 '(and the same with `--lanes 1 --steps 6 --warmup 2`)\n\nFull tables: the `rNN_rocprofv3_kernel_stats*.csv` files next to this one '
                 '(rocprofv3 stats output, unedited).\n\n'
                 '## the default configuration\n\n' + table(s4, b4) +

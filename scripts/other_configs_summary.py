@@ -17,18 +17,22 @@ def main():
             continue
         c, p, b = d['config'], d.get('parity') or {}, d.get('cpu_baseline') or {}
         shape = f"{c['lanes_per_gpu']} x {c['pairs_stacked_per_launch_sequence']}"
-        mse = max((p.get(k) or 0.0) for k in ('mse_ref_feats_c', 'mse_src_feats_c', 'mse_ref_feats_f', 'mse_src_feats_f')) if p else None
+        reports = p.get('reports') or ([p] if p else [])  # round 4: several pairs of the last timed step; rounds 1-3: pair 0 only
+        mse = max((r.get(k) or 0.0) for r in reports for k in ('mse_ref_feats_c', 'mse_src_feats_c', 'mse_ref_feats_f', 'mse_src_feats_f')) if p else None
+        bound = reports[0].get('feature_mse_bound') if reports else None
+        dT = [r.get('transform_max_abs_diff') for r in reports if r.get('transform_max_abs_diff') is not None]
         rows.append(f"| {name} | {d['value']} | {d['ms_per_step']} | {shape} | {c['matrix_precision']} | "
-                    f"{'ok' if p.get('ok') else ('-' if not p else 'NOT ok')} (max feature MSE {mse:.2e}, bound {p.get('feature_mse_bound')}) | "
-                    f"{b.get('value', '-')} |" if p else
+                    f"{'ok' if p.get('ok') else ('-' if not p else 'NOT ok')} ({len(reports)} pair(s); max feature MSE {mse:.2e}, bound {bound}; "
+                    f"max pose |d| {max(dT) if dT else None}) | {b.get('value', '-')} |" if p else
                     f"| {name} | {d['value']} | {d['ms_per_step']} | {shape} | {c['matrix_precision']} | not run | - |")
+        p = {k: v for k, v in p.items() if k != 'reports'}
         details.append(f"### {name}\n\n`{c['workload']}`\n\n```json\n{json.dumps({'parity': p, 'cpu_baseline': b, 'roofline': {k: v for k, v in (d.get('roofline') or {}).items() if k in ('kernel', 'achieved', 'peak', 'frac', 'executed_tflops', 'avg_launch_us', 'launches')}}, indent=1)}\n```\n")
     with open(out, 'w') as f:
         tag = re.search(r'r(\d+)', os.path.basename(out))  # profiles/r03_other_configs.md -> round 3 (scratch outputs: round from $ROUND)
         rnd = int(tag.group(1)) if tag else int(os.environ.get('ROUND', '0'))
         f.write(f'# Round {rnd}: the other BASELINE configurations through the same `bench.py` line\n\n'
                 'Each run: `python bench.py --config <name> [--precision bf16]` on one MI355X (synthetic pairs of the configuration\'s shape, '
-                'random weights); `parity` = pair 0 of the last timed step vs the CPU oracle (oracle/parity.py), `cpu` = the CPU baseline '
+                'random weights); `parity` = four pairs of the last timed step (one per lane where there are four) vs the CPU oracle (oracle/parity.py), `cpu` = the CPU baseline '
                 'of the same workload (pairs/s, collate + forward).  The headline metric is the default run (profiles/r' + f'{rnd:02d}' + '_bench_n1.json).\n\n'
                 '| run | pairs/s | ms/step | lanes x stacked pairs | matrix precision | parity | cpu pairs/s |\n|---|---|---|---|---|---|---|\n')
         f.write('\n'.join(rows) + '\n\n' + '\n'.join(details))
