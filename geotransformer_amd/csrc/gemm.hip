@@ -59,7 +59,11 @@ struct GatherRes {
 // `stats_rec` (optional): this wave's GroupNorm record -- per column the sum and the sum of squares of the values it STORES, over its
 // 32 * WM rows in ascending row order per lane, lanes combined by a fixed xor tree: [0, N) sums, [N, 2N) sums of squares (rows past M
 // and columns past N contribute nothing; a wave entirely past M writes zeros).  The record is a function of the tile's rows alone.
-template <int WM, int WN>
+// PIECE (round 4): rows that travel through the slab at a time -- 32 * WM (default: the whole accumulator block, slab of (32 * WM) x
+// (32 * WN + 4) floats) or 8 (the persistent kernel: a slab of 8 x (32 * WN + 4) floats per wave that is NOT carved from the staging
+// ring, so the ring keeps loading the next tile under the epilogue).  Either way a lane visits its rows in the same ascending sequence
+// (rl, rl + RPI, ...), so the values stored and the statistics records are the same bits.
+template <int WM, int WN, int PIECE = 32 * WM>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float* slab, int lane, int row0, int col0, int M, int N,
                                              float alpha, const float* __restrict__ bias, const int32_t* __restrict__ row_div,
                                              const float* __restrict__ residual, int64_t ldr, int act, float* __restrict__ C, int64_t ldc,
@@ -67,15 +71,18 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
                                              const float* __restrict__ col_affine = nullptr) {
   constexpr int TW = 32 * WN, TS = TW + 4;
   const int fr = lane & 31, fk = lane >> 5;
+  static_assert(PIECE == 32 * WM || PIECE == 8, "whole block or 8-row pieces");
+  if constexpr (PIECE == 32 * WM) {
 #pragma unroll
-  for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < WN; ++j)
+      for (int j = 0; j < WN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) slab[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk) * TS + 32 * j + fr] = acc[i][j][r];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int r = 0; r < 16; ++r) slab[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk) * TS + 32 * j + fr] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   constexpr int V4 = TW / 4, RPI = 64 / V4;  // float4 per row, rows per wave instruction
   const int cq = (lane % V4) * 4, rl = lane / V4;
   const int gn = col0 + cq;
@@ -101,11 +108,34 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
     }
   }
   float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
+  static_assert(PIECE % RPI == 0, "a piece holds whole row groups of a wave instruction");
+#pragma unroll 1
+  for (int pb = 0; pb < 32 * WM; pb += PIECE) {  // one trip with the whole-block slab
+  if constexpr (PIECE != 32 * WM) {
+    // registers r = 4 q .. 4 q + 3 of row tile i hold its rows 8 q + (r & 3) + 4 fk: piece (i, q) -> slab rows (r & 3) + 4 fk
+    const int i = pb >> 5, q = (pb >> 3) & 3;
+#pragma unroll
+    for (int ii = 0; ii < WM; ++ii)
+      if (ii == i) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq)
+            if (qq == q) {
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) slab[(r4 + 4 * fk) * TS + 32 * j + fr] = acc[ii][j][4 * qq + r4];
+            }
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 #pragma unroll 4
-  for (int rr = rl; rr < 32 * WM; rr += RPI) {
+  for (int rs = rl; rs < PIECE; rs += RPI) {
+    const int rr = pb + rs;
     const int gm = row0 + rr;
     if (gm >= M || gn >= N) continue;
-    const float4 a = *reinterpret_cast<const float4*>(slab + rr * TS + cq);
+    const float4 a = *reinterpret_cast<const float4*>(slab + rs * TS + cq);
     float x[4] = {a.x * alpha, a.y * alpha, a.z * alpha, a.w * alpha};
     if (row_div) {
       const float d = (float)max(row_div[gm], 1);
@@ -166,6 +196,12 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
       }
     }
   }
+  if constexpr (PIECE != 32 * WM) {  // the next piece overwrites the slab: every lane's reads above come first
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  }  // pieces
   if (stats_rec) {  // (wave-uniform: every lane takes part in the shuffles)
 #pragma unroll
     for (int o = V4; o < 64; o <<= 1)
@@ -648,9 +684,14 @@ __device__ __forceinline__ void lds_wait(u32x4& r0, u32x4& r1, u32x4& r2, u32x4&
 // STAGES = slots of the LDS ring (2: two blocks per CU overlap each other; 3: one block per CU with the loads of TWO stages in flight
 // under the MFMAs -- the exact-fp32 deep-K launches, whose 4 096-cycle stages leave one stage of prefetch short of the HBM latency
 // under load while a third slot costs nothing the matrix pipe needs)
-template <int WM, int WN, int TERMS, int STAGES = 2>
+// PERSIST (round 4): the block walks SEVERAL tiles of its XCD's tile list (a grid of 2 resident blocks per CU).  After the last stage of
+// a tile it starts the DMA of the NEXT tile's first two stages and only then runs the epilogue -- through a wave-private 8-row slab that is
+// not carved from the ring (epilogue_lds<.., 8>) -- so the loads of tile t + 1 and the stores of tile t overlap, and the launch cost, the
+// first-load latency and the grid's last partial round are paid once per block instead of once per tile.  Two-slot ring, unsplit only.
+template <int WM, int WN, int TERMS, int STAGES = 2, bool PERSIST = false>
 __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   constexpr int kPStages = STAGES;
+  static_assert(!PERSIST || STAGES == 2, "the persistent form uses the two-slot ring");
   constexpr int BM = 128, PLANES = TERMS == 1 ? 1 : 2;
   constexpr bool F32 = TERMS == 0;
   constexpr int WAVES_M = BM / (32 * WM), WAVES_N = 4 / WAVES_M, NT_BLK = WN * WAVES_N;  // column tiles per block
@@ -659,10 +700,12 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   constexpr int B_PER_WAVE = (B_INSTR + 3) / 4;    // issued round-robin by the 4 waves
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware tile order (PackedArgs): this block's (column block, row tile)
-  const int xcd = (int)blockIdx.x & 7, tile = xcd * g.tiles_per_xcd + ((int)blockIdx.x >> 3);
-  if (tile >= min(g.nx * g.ny, (xcd + 1) * g.tiles_per_xcd)) return;  // (uniform per block: before any barrier)
-  const int bx = tile % g.nx, by = tile / g.nx;
+  // XCD-aware tile order (PackedArgs): this block's (column block, row tile) -- its FIRST one in the persistent form
+  const int xcd = (int)blockIdx.x & 7;
+  const int tile_end = min(g.nx * g.ny, (xcd + 1) * g.tiles_per_xcd);
+  const int tile_step = PERSIST ? (int)(gridDim.x >> 3) : (1 << 30);
+  int tile = xcd * g.tiles_per_xcd + ((int)blockIdx.x >> 3);
+  if (tile >= tile_end) return;  // (uniform per block: before any barrier)
   if (g.stagger && blockIdx.z == 0 &&
       (g.stagger > 0 ? (((int)blockIdx.x >> 3) >= 32 && ((int)blockIdx.x >> 3) < 64) : ((((int)blockIdx.x >> 3) & 1) && ((int)blockIdx.x >> 3) < 64))) {
     // the first 32 blocks of an XCD take one slot of its 32 CUs each, the next 32 the second slot: delay those by ~half a block's
@@ -670,14 +713,20 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
     const int naps = abs(g.stagger) * min(g.kt_split, g.KS / 2) / 2;
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
   }
-  const int ct0 = bx * NT_BLK;
-  int m0 = by * BM, m_end = g.M;  // this block's first row and the end of its row segment
-  int sgi = 0;
-  if (g.nseg > 0) {
-    while (sgi + 1 < g.nseg && by >= g.seg_tile0[sgi + 1]) ++sgi;
-    m0 = g.seg_row0[sgi] + (by - g.seg_tile0[sgi]) * BM;
-    m_end = g.seg_row0[sgi + 1];
-  }
+  // geometry of a tile: first column tile, first row, end of its row segment, segment index, row-tile index
+  int ct0, m0, m_end, sgi, by;
+  auto set_tile = [&](int t) {
+    const int bx = t % g.nx;
+    by = t / g.nx;
+    ct0 = bx * NT_BLK;
+    m0 = by * BM, m_end = g.M, sgi = 0;
+    if (g.nseg > 0) {
+      while (sgi + 1 < g.nseg && by >= g.seg_tile0[sgi + 1]) ++sgi;
+      m0 = g.seg_row0[sgi] + (by - g.seg_tile0[sgi]) * BM;
+      m_end = g.seg_row0[sgi + 1];
+    }
+  };
+  set_tile(tile);
   const int wrow = (wave / WAVES_N) * 32 * WM, wctl = (wave % WAVES_N) * WN;  // wave's first row / local column tile
   const int fr = lane & 31, fk = lane >> 5;
   const int kt_first = blockIdx.z * g.kt_split;              // this block's K range in 32-deep stages (split-K: gridDim.z slices)
@@ -687,13 +736,16 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
 
   // per-lane source addresses of the A DMA: instruction t covers rows 8t .. 8t+7, lane -> (row, swizzled 16-byte chunk)
   const float* a_src[4];
+  auto set_sources = [&]() {  // (of the tile set_tile selected)
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int r = 8 * (4 * wave + s) + (lane >> 3);
-    const int c = (lane & 7) ^ (r & 7);
-    const int gm = min(m0 + r, m_end - 1);  // rows past the segment's end: any valid row (never stored)
-    a_src[s] = g.A + (int64_t)gm * g.lda + 4 * c + (int64_t)kt_first * 32;
-  }
+    for (int s = 0; s < 4; ++s) {
+      const int r = 8 * (4 * wave + s) + (lane >> 3);
+      const int c = (lane & 7) ^ (r & 7);
+      const int gm = min(m0 + r, m_end - 1);  // rows past the segment's end: any valid row (never stored)
+      a_src[s] = g.A + (int64_t)gm * g.lda + 4 * c + (int64_t)kt_first * 32;
+    }
+  };
+  set_sources();
   auto issue = [&](int kt) {
     unsigned char* st = psm + (kt % kPStages) * STAGE;
 #pragma unroll
@@ -818,12 +870,16 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   //   wait R(kt,0) | issue R(kt,1) | M(kt,0) | wait R(kt,1) | stage kt+1 landed + barrier | DMA(kt+2) | issue R(kt+1,0) | M(kt,1)
   // so both steps' LDS reads are in flight under the previous step's MFMAs.  A wave reaches the barrier only after its last read of
   // stage kt has landed in registers, so the slot of stage kt is free for DMA(kt+2) right after it.
-  issue(0);
-  GEOTR_WAIT_VMCNT(0);
+  bool primed = false;  // PERSIST: the first two stages of the current tile were already issued at the end of the previous tile
+  for (;;) {
+  if (!primed) issue(0);
+  GEOTR_WAIT_VMCNT(0);  // (primed: stages 0 and 1 of this tile AND the previous tile's stores)
   __builtin_amdgcn_s_barrier();
+  if (!primed) {
 #pragma unroll
-  for (int s_ = 1; s_ < kPStages; ++s_)
-    if (s_ < nkt) issue(s_);
+    for (int s_ = 1; s_ < kPStages; ++s_)
+      if (s_ < nkt) issue(s_);
+  }
   issue_reads(0, 0);
   for (int kt = 0; kt + 1 < nkt; ++kt) {
     wait_reads(0);
@@ -856,6 +912,31 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
 
   // epilogue through LDS (the ring is free once every wave has read the last stage)
   __builtin_amdgcn_s_barrier();
+  if constexpr (PERSIST) {
+    // this tile's geometry for the epilogue, then the NEXT tile's first stages go into the (free) ring before the epilogue runs
+    const int e_m0 = m0, e_ct0 = ct0, e_m_end = m_end, e_sgi = sgi, e_by = by;
+    tile += tile_step;
+    const bool more = tile < tile_end;
+    if (more) {
+      set_tile(tile);
+      set_sources();
+      issue(0);
+      if (1 < nkt) issue(1);
+    }
+    float* slab = reinterpret_cast<float*>(psm + kPStages * STAGE) + wave * (8 * (32 * WN + 4));  // wave-private, beside the ring
+    epilogue_lds<WM, WN, 8>(acc, slab, lane, e_m0 + wrow, 32 * (e_ct0 + wctl), e_m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act,
+                            g.C, g.ldc, g.stats ? g.stats + ((int64_t)e_by * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr, g.gres,
+                            g.seg_affine ? g.seg_affine + (int64_t)e_sgi * 2 * g.N : nullptr);
+    if (!more) return;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    primed = true;
+    continue;
+  }
   float* slab = reinterpret_cast<float*>(psm) + wave * (32 * WM * (32 * WN + 4));
   if (gridDim.z == 1)
     epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act, g.C,
@@ -864,6 +945,8 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   else  // raw partial sums of this K slice; the epilogue runs in the reduce kernel
     epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, 1.0f, nullptr, nullptr, nullptr, 0, 0,
                          g.partial + (int64_t)blockIdx.z * g.M * g.N, g.N);
+  return;
+  }  // tiles
 }
 
 // out = act(alpha * (sum over z, in z order) partial[z] / row_div + bias + residual): the epilogue of a split-K launch.  One float4
@@ -1123,10 +1206,34 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   // (with the 128-wide tile a third slot is 96 KB of LDS = ONE block per CU: measured slower alone and catastrophic beside other lanes'
   // kernels -- 501 vs 959 pairs/s; the 64-wide tile keeps two blocks per CU at 72 KB)
   const bool deep = TERMS == 0 && f32_stages == 3 && g.kt_split >= 6 && bn == 64;
-  if (bn == 64 && deep) GEOTR_PACKED(1, 2, 64, 3);
+  // persistent form (round 4), OPT-IN (GEOTR_GEMM_PERSIST=1; 2 = also the split-bf16 / bf16 launches): unsplit launches of more tiles
+  // than the chip has resident slots (2 blocks x 256 CUs).  Bit-identical (tests/test_gemm_gpu.py passes with it) and measured to change
+  // NOTHING: 252.6 vs 255.7 us (43 826 x 512 x 512), 282.4 vs 284.7 (179 984 x 256 x 256), 317.7 vs 317.0 us per pair over all shapes,
+  // 973 / 975 vs 978 / 974 pairs/s (profiles/r04_ab_runs.md section 6) -- with staggering, occupancy and ring depth it is the fourth
+  // structural change the exact-fp32 kernel does not respond to: its ~0.58 of the matrix roof is not a pipelining loss of this code.
+  static const int persist_mode = [] {
+    const char* e = std::getenv("GEOTR_GEMM_PERSIST");
+    return e ? std::atoi(e) : 0;
+  }();
+  const int64_t n_tiles = (int64_t)((N + bn - 1) / bn) * gy;
+  const bool persist = persist_mode > 0 && (TERMS == 0 || persist_mode == 2) && splits == 1 && !deep && n_tiles > 512 && bn >= 64;
+#define GEOTR_PACKED_PERSIST(WM, WN, BN)                                                                                 \
+  do {                                                                                                                  \
+    const int lds = 2 * (128 * 128 + (BN / 32) * (TERMS != 1 ? 4096 : 2048)) + 4 * 8 * (32 * WN + 4) * 4 + lds_pad; /* ring + 8-row slabs */ \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN, TERMS, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            lds) != hipSuccess)                                                                         \
+      return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);                                      \
+    g.nx = (int)((N + BN - 1) / BN), g.ny = (int)gy, g.tiles_per_xcd = (int)(((int64_t)g.nx * g.ny + 7) / 8);          \
+    const int bpx = std::min(g.tiles_per_xcd, 64); /* 2 resident blocks on each of an XCD's 32 CUs */                   \
+    gemm_packed_kernel<WM, WN, TERMS, 2, true><<<dim3((unsigned)(8 * bpx), 1, 1), dim3(256), lds, stream>>>(g);         \
+  } while (0)
+  if (persist && bn == 128) GEOTR_PACKED_PERSIST(2, 2, 128);
+  else if (persist && bn == 64) GEOTR_PACKED_PERSIST(1, 2, 64);
+  else if (bn == 64 && deep) GEOTR_PACKED(1, 2, 64, 3);
   else if (bn == 128) GEOTR_PACKED(2, 2, 128, 2);
   else if (bn == 64) GEOTR_PACKED(1, 2, 64, 2);
   else GEOTR_PACKED(1, 1, 32, 2);
+#undef GEOTR_PACKED_PERSIST
 #undef GEOTR_PACKED
   GEOTR_CHECK_LAUNCH("gemm_packed");
   if (splits > 1) {
