@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void gemm_packed_kernel(PackedArgs g) {
   const int tile_step = PERSIST ? (int)(gridDim.x >> 3) : (1 << 30);
   int tile = xcd * g.tiles_per_xcd + ((int)blockIdx.x >> 3);
   if (tile >= tile_end) return;  // (uniform per block: before any barrier)
-  if (g.stagger && blockIdx.z == 0 &&
+  if (g.stagger && abs(g.stagger) < 100 && blockIdx.z == 0 &&
       (g.stagger > 0 ? (((int)blockIdx.x >> 3) >= 32 && ((int)blockIdx.x >> 3) < 64) : ((((int)blockIdx.x >> 3) & 1) && ((int)blockIdx.x >> 3) < 64))) {
     // the first 32 blocks of an XCD take one slot of its 32 CUs each, the next 32 the second slot: delay those by ~half a block's
     // matrix time so that the two co-resident blocks of a CU are out of phase (one computes while the other loads / stores)

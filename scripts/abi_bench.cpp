@@ -42,6 +42,7 @@
   } while (0)
 
 // mode: 0 split-bf16, 1 plain bf16, 2 exact fp32 (the `bf16_operands` argument of the library's packed entry points)
+static bool g_lda0 = false;     // `gemm ... lda0`: every row of A is row 0 (lda = 0): the activation stream comes from L2, not HBM (what the DMA latency costs)
 static bool g_nostore = false;  // `gemm ... nostore`: the same launch without its C stores (statistics-only form): what the stores cost
 static int run_gemm(int64_t M, int64_t N, int64_t K, int mode, int reps, double* us_out = nullptr) {
   const bool bf16 = mode == 1;
@@ -73,7 +74,7 @@ static int run_gemm(int64_t M, int64_t N, int64_t K, int mode, int reps, double*
   if (g_nostore) HIP_OK(hipMalloc(&stats, 4 * geotr_gemm_packed_stats_floats(&seg, 1, N)));
   auto launch = [&] {
     if (g_nostore) GEOTR_OK_OR_DIE(geotr_gemm_packed_tail(dA, K, packed, nullptr, N, M, N, K, dB, 0, mode, &seg, 1, stats, nullptr, nullptr, 0, stream));
-    else GEOTR_OK_OR_DIE(geotr_gemm_packed_splitk(dA, K, packed, dC, N, M, N, K, dB, nullptr, nullptr, 0, 1.0f, 0, mode, ws, ws_bytes, stream));
+    else GEOTR_OK_OR_DIE(geotr_gemm_packed_splitk(dA, g_lda0 ? 0 : K, packed, dC, N, M, N, K, dB, nullptr, nullptr, 0, 1.0f, 0, mode, ws, ws_bytes, stream));
   };
   for (int r = 0; r < 3; ++r) launch();
   hipEvent_t t0, t1;
@@ -94,7 +95,7 @@ static int run_gemm(int64_t M, int64_t N, int64_t K, int mode, int reps, double*
     const int64_t m = (M - 1) * s / 63;
     for (int64_t n = 0; n < N; ++n) {
       double acc = bias[n];
-      for (int64_t k = 0; k < K; ++k) acc += (double)a[m * K + k] * (double)w[n * K + k];
+      for (int64_t k = 0; k < K; ++k) acc += (double)a[(g_lda0 ? 0 : m) * K + k] * (double)w[n * K + k];
       worst = std::max(worst, std::fabs(acc - (double)c[m * N + n]));
       scale = std::max(scale, std::fabs(acc));
     }
@@ -295,6 +296,7 @@ int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "shapes";
   auto arithmetic = [](const std::string& a) { return a == "bf16" ? 1 : a == "bf16x3" ? 0 : 2; };
   if (mode == "gemm" && argc >= 5) g_nostore = argc > 7 && std::string(argv[7]) == "nostore";
+  if (mode == "gemm" && argc >= 5) g_lda0 = argc > 7 && std::string(argv[7]) == "lda0";
   if (mode == "gemm" && argc >= 5)
     return run_gemm(std::atoll(argv[2]), std::atoll(argv[3]), std::atoll(argv[4]), arithmetic(argc > 5 ? argv[5] : "fp32"),
                     argc > 6 ? std::atoi(argv[6]) : 20);
