@@ -70,7 +70,7 @@ int radius_grid_build_hinted(const float* s_points, const int64_t* s_len, int64_
 int radius_grid_order_hinted(const void* grid_ws, int64_t ns, int64_t ns_hint, int64_t batch, int32_t* order, void* stream);
 int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len, int64_t batch, int64_t nq, int64_t nq_hint,
                         int64_t ns, int64_t ns_hint, float radius, int64_t width, int64_t cap, int64_t* out, int32_t* counts, int32_t* max_count,
-                        int32_t* overflow, void* stream, const int32_t* q_order = nullptr);
+                        int32_t* overflow, void* stream, const int32_t* q_order = nullptr, int sparse_hint = 0);
 
 int p2n_launch(const float* points, const float* nodes, int clouds, const int64_t* f0, const int64_t* c0, int64_t k, int64_t* point_to_node,
                uint8_t* node_masks, int64_t* knn_indices, uint8_t* knn_masks, int32_t* overflow, void* stream);

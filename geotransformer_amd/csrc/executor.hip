@@ -968,6 +968,8 @@ static int pyramid_enqueue(const float* points, const int64_t* lengths, int64_t 
     r *= 2.0f;
   }
   r = radius;
+  // every search of the pyramid has radius / (voxel of the support stage) = radius / voxel_size; <= 3 voxels = a sparse candidate set
+  const int sparse = radius <= 3.0f * voxel_size ? 1 : 0;
   // Row capacity of the fixed-width searches: after grid subsampling a ball of 2.5 voxels holds at most the voxels within
   // 2.5 + sqrt(3) voxel sizes of its centre (~320), so 512 cannot overflow from stage 1 on; stage 0 (raw input) raises if it does.
   const int64_t kRowCap = 512;
@@ -976,14 +978,14 @@ static int pyramid_enqueue(const float* points, const int64_t* lengths, int64_t 
     // (the visiting order of the QUERY rows -- their own stage's grid order -- selects the LDS-staged tile kernel: neighbours in that
     // order share their candidate cells)
     int rc = radius_query_hinted(false, grids[i], pts[i], len[i], batch, n0, hint[i], n0, hint[i], r, limits_host[i], kRowCap, buf->neighbors[i],
-                                 nullptr, nullptr, overflow, stream, buf->order[i]);
+                                 nullptr, nullptr, overflow, stream, buf->order[i], sparse);
     if (rc != GEOTR_OK) return rc;
     if (i < S - 1) {
       rc = radius_query_hinted(false, grids[i], pts[i + 1], len[i + 1], batch, n0, hint[i + 1], n0, hint[i], r, limits_host[i], kRowCap,
-                               buf->subsampling[i], nullptr, nullptr, overflow, stream, buf->order[i + 1]);
+                               buf->subsampling[i], nullptr, nullptr, overflow, stream, buf->order[i + 1], sparse);
       if (rc != GEOTR_OK) return rc;
       rc = radius_query_hinted(false, grids[i + 1], pts[i], len[i], batch, n0, hint[i], n0, hint[i + 1], 2.0f * r, limits_host[i + 1], kRowCap,
-                               buf->upsampling[i], nullptr, nullptr, overflow, stream, buf->order[i]);
+                               buf->upsampling[i], nullptr, nullptr, overflow, stream, buf->order[i], sparse);
       if (rc != GEOTR_OK) return rc;
     }
     r *= 2.0f;

@@ -349,6 +349,171 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
   }
 }
 
+// ---- round 4: four queries SIDE BY SIDE in a wave --------------------------------------------------------------
+// The one-query kernel is latency-bound on ONE dependent chain per wave (query -> cloud header -> cell runs -> candidates -> compaction ->
+// ranking -> store; profiles/r03_rg_query_counters.md), and both attempts to shorten the chain lost (profiles/r04_ab_runs.md section 5).
+// Here a wave carries FOUR such chains at once: lanes 16 g .. 16 g + 15 own query g of four consecutive ones of the visiting order.  Every
+// step of the one-query kernel is done per 16-lane group -- 9 run lanes + a 16-wide scan, candidates 16 at a time, the group's slice of
+// the wave ballot for the compaction, a 128-key LDS row per group, ranking with 16 lanes -- so a wave issues the loads of four queries
+// back to back and a quarter as many waves carry the same work.  Same arithmetic, same (d^2, index) order: bit-identical rows.  A query
+// with more than 128 hits is redone by the whole wave on the wave's 512 keys (= the one-query kernel's capacity).
+constexpr int kQuadKeys = 128;
+
+__global__ __launch_bounds__(256) void rg_query_quad_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
+                                                            const float4* __restrict__ sorted, const float* __restrict__ q,
+                                                            const int64_t* __restrict__ q_len, const int* __restrict__ q_order, int batch,
+                                                            float r2, int width, int cap, int64_t* __restrict__ out,
+                                                            int* __restrict__ overflow) {
+  __shared__ __attribute__((aligned(16))) unsigned long long quad_keys[4][4 * kQuadKeys];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int grp = lane >> 4, l = lane & 15;
+  unsigned long long* wave_keys = quad_keys[w];
+  unsigned long long* keys = wave_keys + grp * kQuadKeys;
+  const int64_t ns_total = rg_rows(hdr, batch);
+  const int cloud_end = wave_inclusive_scan(lane < batch ? (int)q_len[lane] : 0);  // batch <= 64 (host)
+  const int nq_total = __shfl(cloud_end, batch - 1, 64);
+  const int64_t quads = ((int64_t)nq_total + 3) / 4;
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  for (int64_t quad = (int64_t)blockIdx.x * 4 + w; quad < quads; quad += (int64_t)gridDim.x * 4) {
+    const int pos = (int)(quad * 4) + grp;
+    const bool has_q = pos < nq_total;
+    const int qi = has_q ? (q_order ? q_order[pos] : pos) : 0;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (has_q) qx = q[3 * (int64_t)qi], qy = q[3 * (int64_t)qi + 1], qz = q[3 * (int64_t)qi + 2];
+    // cloud of each group's query: one ballot over the lane-held cloud ends per group
+    int b = 0;
+#pragma unroll
+    for (int g2 = 0; g2 < 4; ++g2) {
+      const int row = __shfl(qi, 16 * g2, 64);
+      const int bg = __popcll(__ballot(lane < batch && row >= cloud_end));
+      b = grp == g2 ? bg : b;
+    }
+    b = min(b, batch - 1);
+    const CloudGrid g = hdr[b];
+    // --- the 9 runs of the group's query (lane l < 9 owns run l) ---
+    int seg_start = 0, seg_len = 0;
+    if (has_q && l < 9 && g.s_len > 0) {
+      const int cx = cell_coord(qx, g.mn[0], g.cs), cy = cell_coord(qy, g.mn[1], g.cs) + (l % 3) - 1,
+                cz = cell_coord(qz, g.mn[2], g.cs) + (l / 3) - 1;
+      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+      if (cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2] && x0 <= x1) {
+        const int row = g.cell_base + g.dim[0] * (cy + g.dim[1] * cz);
+        seg_start = cell_start[row + x0];
+        seg_len = cell_start[row + x1 + 1] - seg_start;
+      }
+    }
+    int inc = seg_len;  // inclusive scan inside the 16-lane group
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int t = __shfl_up(inc, o, 16);
+      if (l >= o) inc += t;
+    }
+    const int total = __shfl(inc, 8, 16);
+    int pre[9], st[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      pre[k] = __shfl(inc - seg_len, k, 16);
+      st[k] = __shfl(seg_start, k, 16);
+    }
+    int most = total;  // the longest candidate list of the four
+    most = max(most, __shfl_xor(most, 16, 64));
+    most = max(most, __shfl_xor(most, 32, 64));
+    int base = 0;
+    for (int t0 = 0; t0 < most; t0 += 16) {
+      const int t = t0 + l;
+      bool accept = false;
+      unsigned long long key = 0;
+      if (t < total) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < 9; ++j) k = (t >= pre[j]) ? j : k;
+        int pk = pre[0], sk = st[0];
+#pragma unroll
+        for (int j = 1; j < 9; ++j) pk = (k == j) ? pre[j] : pk, sk = (k == j) ? st[j] : sk;
+        const float4 p = sorted[sk + (t - pk)];
+        // L2_Simple_Adaptor::evalMetric (nanoflann.hpp:432-440): ((dx*dx) + dy*dy) + dz*dz, no FMA
+        const float dx = __fsub_rn(qx, p.x), dy = __fsub_rn(qy, p.y), dz = __fsub_rn(qz, p.z);
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        accept = d < r2;  // strict (nanoflann.hpp:249-253)
+        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+      }
+      const unsigned field = (unsigned)(__ballot(accept) >> (16 * grp)) & 0xffffu;  // this group's 16 lanes
+      const int rank = base + __popc(field & ((1u << l) - 1u));
+      if (accept && rank < kQuadKeys) keys[rank] = key;
+      base += __popc(field);
+    }
+    const int count = base;
+    const bool dense = has_q && count > kQuadKeys;
+    wave_sync();
+    // ranking inside the group: lane l takes keys l, l + 16, ...; every key of the row is read as a broadcast within the group
+    int64_t* row = out + (int64_t)qi * width;
+    if (has_q && !dense) {
+      for (int e = l; e < count; e += 16) {
+        const unsigned long long mine = keys[e];
+        int rank = 0;
+        for (int j = 0; j < count; ++j) rank += keys[j] < mine;
+        if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
+      }
+      for (int j = count + l; j < width; j += 16) row[j] = ns_total;  // pad (radius_neighbors_cpu.cpp:85)
+    }
+    wave_sync();
+    // dense rows (> 128 hits): the whole wave redoes the query on the wave's 512 keys, exactly as rg_query_kernel does
+    unsigned long long dense_groups = __ballot(dense) & 0x0001000100010001ull;  // lane 16 g speaks for group g
+    while (dense_groups) {
+      const int lead = __builtin_ctzll(dense_groups);
+      dense_groups &= dense_groups - 1;
+      const float ax = __shfl(qx, lead, 64), ay = __shfl(qy, lead, 64), az = __shfl(qz, lead, 64);
+      const int qrow = __shfl(qi, lead, 64);
+      const int tot1 = __shfl(total, lead, 64);
+      const long long s_start1 = __shfl((long long)g.s_start, lead, 64);
+      int pre1[9], st1[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) pre1[k] = __shfl(pre[k], lead, 64), st1[k] = __shfl(st[k], lead, 64);
+      int cnt1 = 0;
+      for (int t0 = 0; t0 < tot1; t0 += 64) {
+        const int t = t0 + lane;
+        bool accept = false;
+        unsigned long long key = 0;
+        if (t < tot1) {
+          int k = 0;
+#pragma unroll
+          for (int j = 1; j < 9; ++j) k = (t >= pre1[j]) ? j : k;
+          int pk = pre1[0], sk = st1[0];
+#pragma unroll
+          for (int j = 1; j < 9; ++j) pk = (k == j) ? pre1[j] : pk, sk = (k == j) ? st1[j] : sk;
+          const float4 p = sorted[sk + (t - pk)];
+          const float dx = __fsub_rn(ax, p.x), dy = __fsub_rn(ay, p.y), dz = __fsub_rn(az, p.z);
+          const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+          accept = d < r2;
+          key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+        }
+        const unsigned long long ballot = __ballot(accept);
+        const int rank = cnt1 + __popcll(ballot & ((1ull << lane) - 1ull));
+        if (accept && rank < cap) wave_keys[rank] = key;
+        cnt1 += __popcll(ballot);
+      }
+      if (cnt1 > cap) {
+        if (lane == 0 && overflow) atomicMax(overflow, cnt1);
+        cnt1 = cap;
+      }
+      wave_sync();
+      int64_t* row1 = out + (int64_t)qrow * width;
+      for (int e = lane; e < cnt1; e += 64) {
+        const unsigned long long mine = wave_keys[e];
+        int rank = 0;
+        for (int j = 0; j < cnt1; ++j) rank += wave_keys[j] < mine;
+        if (rank < width) row1[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + s_start1;
+      }
+      for (int j = cnt1 + lane; j < width; j += 64) row1[j] = ns_total;
+      wave_sync();
+    }
+  }
+}
+
 // ---- round 4: LDS-staged point tiles (north_star's design) ---------------------------------------------------
 // The one-query-per-wave kernel above spends ~500 VALU instructions per query, most of them on flattening nine cell runs into one
 // candidate index space per lane and on dependent global loads (profiles/r03_rg_query_counters.md).  Here a wave takes kTileQ CONSECUTIVE
@@ -1036,7 +1201,8 @@ int radius_grid_order_hinted(const void* grid_ws, int64_t ns, int64_t ns_hint, i
 // geotr_radius_grid_order) -- selects the LDS-staged tile kernel (round 4); without it, or for counting, the one-query-per-wave kernel
 int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
                         int64_t batch, int64_t nq, int64_t nq_hint, int64_t ns, int64_t ns_hint, float radius, int64_t width, int64_t cap,
-                        int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_, const int32_t* q_order) {
+                        int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_, const int32_t* q_order,
+                        int sparse_hint) {
   hipStream_t stream = (hipStream_t)stream_;
   GridLayout L = grid_layout(const_cast<void*>(grid_ws), ns, batch, ns_hint);
   if (nq == 0) return GEOTR_OK;
@@ -1054,6 +1220,22 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
     const char* e = std::getenv("GEOTR_RG_VARIANT");  // experiment switch of rg_query_kernel (see there); default 0
     return e ? std::atoi(e) : 0;
   }();
+  static const int quad_mode = [] {
+    const char* e = std::getenv("GEOTR_RG_QUAD");  // A/B switch: 0 = one query per wave everywhere; 2 = quad in row order; 3 = quad even for dense searches
+    return e ? std::atoi(e) : 1;
+  }();
+  // sparse_hint (the pyramid: radius <= 3 voxels, i.e. ~60 candidates per query on a voxel-thinned surface): four queries per wave pay
+  // off there (3DMatch / ModelNet: -19 % per launch); with ~160 candidates per query (KITTI: 4.25 voxels) 16 lanes per query make the
+  // candidate loop four times as long and the one-query kernel wins by 21 % (profiles/r04_ab_runs.md section 5)
+  if (!count_only && quad_mode && (sparse_hint || quad_mode >= 3) && !(tile_enabled && q_order) && batch <= 64 && cap <= 4 * kQuadKeys &&
+      nq < (1ll << 31)) {
+    const int64_t quads = (expect + 3) / 4;
+    rg_query_quad_kernel<<<dim3((unsigned)((quads + 3) / 4)), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len,
+                                                                                     (quad_mode == 2 || quad_mode == 4) ? nullptr : q_order, (int)batch, r2,
+                                                                                     (int)width, (int)cap, out, overflow);
+    GEOTR_CHECK_LAUNCH("radius_query(quad)");
+    return GEOTR_OK;
+  }
   if (!count_only && q_order && tile_enabled && batch <= 64 && cap <= kTileKeys && nq < (1ll << 31)) {
     if (width <= 48) {
       const int64_t tiles = (expect + 7) / 8;
@@ -1092,7 +1274,7 @@ int geotr_radius_grid_order(const void* grid_ws, int64_t ns, int64_t batch, int3
 static int radius_query_common(bool count_only, const void* grid_ws, const float* q, const int64_t* q_len,
                                int64_t batch, int64_t nq, int64_t ns, float radius, int64_t width, int64_t cap,
                                int64_t* out, int32_t* counts, int32_t* max_count, int32_t* overflow, void* stream_) {
-  return radius_query_hinted(count_only, grid_ws, q, q_len, batch, nq, 0, ns, 0, radius, width, cap, out, counts, max_count, overflow, stream_, nullptr);
+  return radius_query_hinted(count_only, grid_ws, q, q_len, batch, nq, 0, ns, 0, radius, width, cap, out, counts, max_count, overflow, stream_, nullptr, 0);
 }
 
 int geotr_radius_count(const void* grid_ws, int64_t ns, const float* q_points, const int64_t* q_len, int64_t batch,

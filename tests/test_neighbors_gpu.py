@@ -182,7 +182,8 @@ print('RESULT ' + json.dumps(out))
 
 
 def test_lds_staged_tile_kernel_is_bit_identical_to_the_one_query_kernel():
-    """Round 4's rg_query_tile_kernel (north_star's LDS-staged point tiles: a wave stages the cell box of 8 / 4 neighbouring queries once;
+    """The three radius-query kernels write the same bits: rg_query_quad_kernel (round 4 default: four queries side by side in a wave),
+    rg_query_kernel (one query per wave) and round 4's rg_query_tile_kernel (north_star's LDS-staged point tiles: a wave stages the cell box of 8 / 4 neighbouring queries once;
     opt-in GEOTR_RG_TILE=1 -- measured slower, profiles/r04_ab_runs.md) writes every table of the pyramid bit for bit as the default
     one-query-per-wave kernel: a 3-pair 3DMatch-shape stack and a 120k + 120k KITTI-shape pair (limits <= 40: the <8 queries, 96 keys>
     shape; rows of more than 96 neighbours take the dense-row path) and a stack with limits of 52 .. 64 (the <4, 192> shape).  The switch
@@ -192,12 +193,12 @@ def test_lds_staged_tile_kernel_is_bit_identical_to_the_one_query_kernel():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for tile in ('0', '1'):
-        env = dict(os.environ, GEOTR_RG_TILE=tile)
+    for tile in ('0', '1', 'one-query'):  # default (four queries per wave), the tile kernel, round 3's one-query-per-wave kernel
+        env = dict(os.environ, GEOTR_RG_TILE='1' if tile == '1' else '0', GEOTR_RG_QUAD='0' if tile == 'one-query' else '3')  # 3: the quad kernel for the dense (KITTI) searches as well
         res = subprocess.run([sys.executable, '-c', _TILE_CHILD.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         got[tile] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('RESULT ')][-1][7:])
-    assert got['0'] == got['1'], (got['0'], got['1'])
+    assert got['0'] == got['1'] == got['one-query'], got
     assert all(v[1] == 0 for v in got['0'].values()) and len(got['0']) == 3  # no row overflowed its capacity
 
 
