@@ -462,6 +462,9 @@ def main():
                     help='untimed steps of the same workload before the W warm-up steps, until this much wall time has passed: the FIRST GPU '
                          'process on a fresh box reads up to 40 %% low for its first seconds (clock / power-state ramp; profiles/r04_ab_runs.md), '
                          'which W = 3 steps (0.2 s) do not cover')
+    ap.add_argument('--prewarm-cap-seconds', type=float, default=12.0,
+                    help='after --prewarm-seconds the untimed steps go on until the last four joined steps agree within 4 %%, at most this long '
+                         '(a box that is still ramping after 2 s showed 900 against 976 pairs/s, profiles/r04_ab_runs.md section 8)')
     ap.add_argument('--dump-shapes', default=None, metavar='PATH',
                     help='write every bracketed launch shape of the timed region (family, shape, launches, average us) as JSON lines to PATH')
     ap.add_argument('--no-numa-bind', action='store_true', help="do not bind the process to the GPU's NUMA node (A/B runs)")
@@ -553,12 +556,29 @@ def main():
         # gap right before the timed region costs its first stacks (profiles/r02_ab_runs.md)
         prof = KernelProfiler(args.profile_events, stride=args.profile_stride)  # HIP events around the GSE / packed-GEMM / fused KPConv launches
         note(f'rank {rank}: [{precision}] warm-up')
-        t_pre, n_pre = time.perf_counter(), 0
-        while precision == args.precision and time.perf_counter() - t_pre < args.prewarm_seconds:  # box warm-up (untimed, before the W steps)
+        t_pre, n_pre, pre_ms = time.perf_counter(), 0, []
+
+        def settled():
+            """The last four untimed steps agree within 4 %: the box has left its ramp (clocks, first-touch, host governor)."""
+            tail = sorted(pre_ms[-4:])
+            return len(pre_ms) >= 6 and (tail[-1] - tail[0]) <= 0.04 * tail[1]
+
+        # box warm-up (untimed, before the W steps): at least --prewarm-seconds of the same workload, then until the step time has settled,
+        # at most --prewarm-cap-seconds
+        while precision == args.precision and args.prewarm_seconds > 0:
+            spent = time.perf_counter() - t_pre
+            if spent >= args.prewarm_cap_seconds or (spent >= args.prewarm_seconds and settled()):
+                break
+            t_s = time.perf_counter()
             step(n_pre)
             runner.drain()
             torch.cuda.synchronize()
+            pre_ms.append(1e3 * (time.perf_counter() - t_s))
             n_pre += 1
+        if pre_ms:
+            info.setdefault('prewarm_seconds', round(time.perf_counter() - t_pre, 1))
+            note(f'rank {rank}: [{precision}] {n_pre} untimed prewarm steps in {time.perf_counter() - t_pre:.1f} s; ms per joined step, first 4: '
+                 f'{[round(x, 1) for x in pre_ms[:4]]}, last 4: {[round(x, 1) for x in pre_ms[-4:]]}')
         info.setdefault('prewarm_steps', n_pre)
         for i in range(args.warmup):
             step(i)
@@ -650,7 +670,8 @@ def main():
                        'pairs_per_step_per_gpu': args.batch, 'lanes_per_gpu': args.lanes, 'pairs_stacked_per_launch_sequence': args.stack,
                        'host_binding': numa_note, 'host_waits': sync_note,
                        'host_cpus_busy_in_timed_region': main_run['host_cpus_busy'],
-                       'untimed_prewarm': f'{info.get("prewarm_steps", 0)} steps (~{args.prewarm_seconds} s) before the {args.warmup} warm-up steps',
+                       'untimed_prewarm': f'{info.get("prewarm_steps", 0)} steps (~{info.get("prewarm_seconds", 0.0)} s: >= {args.prewarm_seconds} s, then until four joined '
+                                          f'steps agree within 4 %, <= {args.prewarm_cap_seconds} s) before the {args.warmup} warm-up steps',
                        'parallelism': f'pairs sharded over {world} rank(s), one process per GPU, no data-path collective',
                        'collective_backend': 'rccl' if backend == 'nccl' else backend,
                        'weights': 'random init, seed 7351', 'matrix_precision': args.precision, 'gse': args.gse,
