@@ -28,7 +28,7 @@ def _flags():
 
 @pytest.mark.parametrize('source,prefix,min_kernels', [
     ('transformer.hip', '_ZN5geotr23gse_embed_bf16x3_kernel', 32),  # D in {32,64,128,256} x S in {2..5} x TERMS in {3,1}
-    ('gemm.hip', '_ZN5geotr18gemm_packed_kernel', 9),               # three tilings x TERMS in {3,1,0}
+    ('gemm.hip', '_ZN5geotr18gemm_packed_kernel', 21),              # three tilings x TERMS in {3,1,0} x {two-slot, three-slot, persistent} + the 3 weights-from-L2 forms (asm global loads, vmcnt queue)
 ])
 def test_no_instruction_touches_an_in_flight_lds_fragment(tmp_path, source, prefix, min_kernels):
     if not os.path.exists(HIPCC):
@@ -176,3 +176,31 @@ def test_no_kernel_carries_slp_vectorised_packed_fp32_code(tmp_path):
         hits = {k: v for k, v in per_file['matching.hip'].items() if kernel in k and
                 any(op.startswith(('v_pk_mul_f32', 'v_pk_add_f32', 'v_pk_fma_f32')) for op in v)}
         assert not hits, hits
+
+
+def test_the_in_flight_checker_sees_loop_back_edges_and_counted_vmcnt_waits(tmp_path):
+    """The checker itself, on a hand-written kernel text: (1) a label followed by a comment is a block (round 4: such labels -- every loop
+    header the compiler emits -- were dropped, so a register still in flight at the back edge went unseen); (2) an asm global load is in
+    flight until a vmcnt wait that leaves FEWER younger operations outstanding than were issued after it."""
+    checker = os.path.join(ROOT, 'scripts', 'check_inflight_regs.py')
+
+    def run(body):
+        asm = tmp_path / 'k.s'
+        asm.write_text('_ZN5geotr4testEv:\n' + body + '\ts_endpgm\n')
+        return subprocess.run([sys.executable, checker, str(asm), '_ZN5geotr4test'], capture_output=True, text=True)
+
+    loop = ('\tv_mov_b32_e32 v4, 0\n'
+            '.LBB0_1:                                ; %loop header with a comment\n'
+            '\tv_add_f32_e32 v8, v4, v4\n'           # reads v4: clean on entry, in flight on the back edge (issued below, never waited for)
+            '\t;;#ASMSTART\n\tds_read_b128 v[4:7], v1\n\t;;#ASMEND\n'
+            '\ts_cbranch_scc1 .LBB0_1\n'
+            '\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n')
+    res = run(loop)
+    assert res.returncode == 1 and 'v_add_f32_e32 v8, v4, v4' in res.stdout, res.stdout
+    counted = ('\t;;#ASMSTART\n\tglobal_load_dwordx4 v[4:7], v[2:3], off\n\t;;#ASMEND\n'
+               '\tglobal_load_lds_dwordx4 v[10:11], off\n\tglobal_load_lds_dwordx4 v[12:13], off\n'
+               '\t;;#ASMSTART\n\ts_waitcnt vmcnt({n})\n\t;;#ASMEND\n'
+               '\tv_mfma_f32_32x32x2_f32 v[16:31], v4, v5, v[16:31]\n')
+    assert run(counted.format(n=2)).returncode == 0          # the two younger DMA operations may stay outstanding
+    bad = run(counted.format(n=3))
+    assert bad.returncode == 1 and 'v_mfma' in bad.stdout, bad.stdout
