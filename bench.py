@@ -8,40 +8,45 @@ A "step" is one pass of the whole hot path over one batch of `--batch` independe
 (default 64 per GPU; `--lanes` persistent host threads with a HIP stream each pull stacks of `--stack` pairs from one queue,
 and a stack goes through ONE launch sequence; BASELINE configs[1]: ~20k + 20k points, 4-stage KPConv-FPN, d = 256): the
 collate-equivalent pyramid (3 grid subsamples + 10 radius searches) plus the full GeoTransformer forward through
-`estimated_transform`.  Inputs (raw xyz) are resident in HBM when the timed region starts; weights are random-init
-(seed 7351), data synthetic.  At N > 1 every rank processes its own pairs (weak scaling, pairs are independent): weights are
-broadcast once from rank 0 over RCCL and the per-pair transforms are all-gathered inside the timed region.
+`estimated_transform`.  Inputs (raw xyz, 480 KB per pair) start in PINNED HOST memory and are copied to the device per stack on the
+lane's stream INSIDE the timed region (the reference's per-item to_cuda, geotransformer/engine/single_tester.py:52; `--inputs device`
+keeps them resident in HBM for the A/B); weights are random-init (seed 7351), data synthetic.  At N > 1 every rank processes its own
+pairs (weak scaling, pairs are independent): weights are broadcast once from rank 0 over RCCL and the per-pair transforms are
+all-gathered inside the timed region.
 
 `--gpus N` without a torchrun environment re-executes itself under `python -m torch.distributed.run` with N ranks (one per
 GPU) and fails if the node has fewer than N devices or a rank does not come up.
 
 The headline (`value`, `dtype`, `roofline`, `parity`) is measured in the REFERENCE'S OWN ARITHMETIC: `--precision fp32` (default) =
-IEEE fp32 products with fp32 accumulation on v_mfma_f32_32x32x2_f32 (+ the fp32 table embedding).  The split-bf16 mode of rounds 1-3
-(three bf16 MFMA terms per product, ~2^-17 relative: narrower than fp32) is re-timed over the same `--steps` / `--warmup` as a sibling
-block `split_bf16_mode` with its own roofline and parity -- never as `value`.
+IEEE fp32 products with fp32 accumulation on v_mfma_f32_32x32x2_f32; the geometric structure embedding is evaluated by cubic-Taylor
+tables (<= 3e-7 relative of proj(sinusoid(x)); `--gse mfma` = the exact contraction) and `dtype` says so.  The split-bf16 mode of rounds
+1-3 (three bf16 MFMA terms per product, ~2^-17 relative: narrower than fp32) is re-timed over the same `--steps` / `--warmup` as a
+sibling block `split_bf16_mode` -- never as `value`.
 
-Prints ONE JSON line on rank 0 with the contract fields plus
-  parity       : FOUR pairs of the LAST timed step, one per lane and in four different stack slots (`--pairs` = 64 distinct pairs,
-                 seeds 0-63 on rank 0 as SURVEY 8(d) names them, rotated through the slots step by step), each compared with the CPU
-                 oracle run on that pair alone: feature MSE, coarse selection (a differing set must be a tie at the selection boundary
-                 and is then compared in full), matching scores, transform (oracle/parity.py states the tolerances) + the stacked
-                 pyramid of that lane's stack cut back to the pair, byte-compared.
+stdout ends with ONE JSON line of <= 3 KB on rank 0 (`compact_line`: the contract fields + short roofline / cpu_baseline / parity /
+split_bf16_mode blocks); the FULL record -- everything described below -- is written to bench_detail.json next to this file:
+  parity       : index parity of ALL pairs of the LAST timed step (`--pairs` = 64 distinct pairs, seeds 0-63 on rank 0 as SURVEY 8(d)
+                 names them, rotated through the slots step by step): the pyramid tables the timed run itself produced, cut out of their
+                 stacks, byte-compared with the oracle's collate of each pair (`pyramids_checked`); forward parity of FOUR of them, one per
+                 lane and in four different stack slots, each compared with the CPU oracle run on that pair alone: feature MSE, coarse
+                 selection (a differing set must be a tie at the selection boundary and is then compared in full), matching scores,
+                 transform (oracle/parity.py states the tolerances; RRE / RTE in fp64).  `--precision bf16`: the pose is gated by the
+                 reference's registration-success criterion against the oracle's pose + the oracle head re-run on this side's scores.
   roofline     : the kernel family with the largest summed launch time among the bracketed ones (packed GEMMs, GSE embedding, fused
                  KPConv; `other` = the runner-up), from HIP events recorded by the executor on the launch streams around every
                  `--profile-stride`-th launch of the timed region.  Packed GEMMs: BOTH roofs are computed from the recorded shapes --
                  ALGORITHMIC bytes (A read + C written + packed weight) and ALGORITHMIC 2 m n k FLOP over the summed durations --
-                 and `bound` / `achieved` / `peak` / `frac` are those of the roof the family is closer to (HBM in this workload: the
-                 tall layers have k = 32 .. 64); `executed_*` counts the 3 bf16 MFMA products of the split-bf16 path; `isolated` =
-                 the heaviest shapes re-run with the GPU otherwise idle; `traffic` = HBM bytes per launch from the committed PMC passes.
+                 and `bound` / `achieved` / `peak` / `frac` are those of the roof the family is closer to; `isolated` = the heaviest
+                 shapes re-run with the GPU otherwise idle; `traffic` = HBM bytes per launch from the committed PMC passes.
   cpu_baseline : the CPU oracle (reference C++ neighbour cores from oracle/_ref when present, else the restatement,
                  + the torch-fp32 restatement of the model) timed on this box's host cores per SURVEY.md 8(d): 1 warm-up +
-                 3 timed pairs, median; collate on one thread (as the reference), forward on all cores and on 16 threads
-                 (the better one is `value`), the 1-thread figure and the pipelined 8-worker bound next to it.
+                 3 timed pairs, median; collate on one thread (as the reference), forward on all cores the container's CPU quota
+                 allows (`cores`, `cpu_budget`; `nproc` = the host's logical cores), the 1-thread figure and the pipelined 8-worker bound.
   split_bf16_mode : the same workload, same steps / warm-up, in the split-bf16 arithmetic (`--precision bf16x3`), with its own
                  roofline and parity blocks (world size 1 only; `--no-sibling-mode` skips it).
-`--config kitti` (BASELINE configs[3]: 120k + 120k points, 5-stage backbone; 2 lanes x 4 stacked pairs by default), `--config lomatch
---precision bf16` (configs[4]: low overlap, 1000 hypotheses, bf16 operands) and `--config modelnet` (configs[0] shape) print the same line
-with their own parity block; the headline metric is the default run.
+`--config kitti` (BASELINE configs[3]: 120k + 120k points, 5-stage backbone), `--config lomatch --precision bf16` (configs[4]: low
+overlap, 1000 hypotheses, bf16 operands) and `--config modelnet` (configs[0] shape) print the same line with their own parity block; the
+headline metric is the default run.
 """
 import argparse
 import json
@@ -245,6 +250,59 @@ def pmc_traffic_bytes(kernel_substr, precision='fp32'):
         return None
     launches = sum(r['launches'] for r in hits)  # every instantiation of the family, weighted by its launches
     return round(sum(r['hbm_mb_per_launch'] * r['launches'] for r in hits) / launches * 1024 * 1024)
+
+
+LINE_BUDGET_BYTES = 3072  # the driver keeps ~8 KB of stdout tail; round 4's 24.8 KB line was cut and could not be parsed
+
+
+def _short_roofline(roof):
+    """The contract keys of a roofline block (+ the launch statistics they are derived from); the per-shape tables stay in the detail file."""
+    if not roof:
+        return None
+    keep = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_us', 'algorithmic_bytes_per_launch')
+    out = {'kernel': str(roof.get('kernel', '')).split(' (')[0].split(' -- ')[0][:80]}
+    out.update({k: roof[k] for k in keep if k in roof})
+    out.setdefault('traffic', None)
+    return out
+
+
+def compact_line(detail):
+    """The ONE stdout line: the contract fields + short `roofline`, `cpu_baseline`, `parity` and `split_bf16_mode` blocks, <= 3 KB.
+    Everything else (per-pair parity reports, per-shape launch tables, isolated re-runs, the sibling mode's roofline and parity, notes)
+    is in `detail`, which bench.py writes to bench_detail.json next to itself.  Pure function of `detail` (tests/test_bench_line.py)."""
+    line = {k: detail[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                   'vs_baseline', 'dtype', 'data') if k in detail}
+    cfg = detail.get('config', {})
+    line['config'] = {k: cfg[k] for k in ('workload', 'pairs_per_step_per_gpu', 'lanes_per_gpu', 'pairs_stacked_per_launch_sequence',
+                                          'parallelism', 'collective_backend', 'matrix_precision', 'gse', 'inputs') if k in cfg}
+    if detail.get('per_rank_pairs_per_s') is not None:
+        line['per_rank_pairs_per_s'] = detail['per_rank_pairs_per_s']
+    line['roofline'] = _short_roofline(detail.get('roofline'))
+    other = (detail.get('roofline') or {}).get('other')
+    if other:
+        line['roofline']['runner_up'] = {k: v for k, v in _short_roofline(other).items() if k in ('kernel', 'bound', 'frac', 'avg_launch_us')}
+    base = detail.get('cpu_baseline')
+    if base:
+        line['cpu_baseline'] = {k: base[k] for k in ('value', 'unit', 'cores', 'kind', 'cpu_budget', 'nproc', 'collate_s', 'forward_s') if k in base}
+        line['cpu_baseline']['value'] = None if base.get('value') is None else round(base['value'], 4)
+        line['cpu_baseline']['sample'] = '1 warm-up + 3 timed pairs of this workload, median; collate 1 thread + forward on `cores` threads'
+    par = detail.get('parity')
+    if par:
+        line['parity'] = {k: par[k] for k in ('ok', 'pairs_checked', 'pyramids_checked', 'pyramids_identical', 'pose_gated', 'max_feature_mse',
+                                              'max_transform_abs_diff', 'max_rre_deg', 'max_rte_m') if k in par}
+    sib = detail.get('split_bf16_mode')
+    if sib:
+        line['split_bf16_mode'] = {'value': sib.get('value'), 'parity_ok': (sib.get('parity') or {}).get('ok'),
+                                   'roofline_frac': (sib.get('roofline') or {}).get('frac')}
+    line['detail'] = detail.get('detail_file')
+    text = json.dumps(line)
+    if len(text) > LINE_BUDGET_BYTES:  # never again an unparsable line: drop the optional blocks, longest first, until it fits
+        for key in ('split_bf16_mode', 'per_rank_pairs_per_s', 'detail'):
+            line.pop(key, None)
+            if len(json.dumps(line)) <= LINE_BUDGET_BYTES:
+                break
+        line['config'] = {'workload': str(line['config'].get('workload', ''))[:300]}
+    return line
 
 
 def note(msg):
@@ -467,6 +525,9 @@ def main():
                          '(a box that is still ramping after 2 s showed 900 against 976 pairs/s, profiles/r04_ab_runs.md section 8)')
     ap.add_argument('--dump-shapes', default=None, metavar='PATH',
                     help='write every bracketed launch shape of the timed region (family, shape, launches, average us) as JSON lines to PATH')
+    ap.add_argument('--inputs', default='host', choices=['host', 'device'],
+                    help='where the raw xyz of the pairs lives when the timed region starts: pinned host memory, copied to the device per stack '
+                         'inside the region (default, as the reference does per item), or already resident in HBM (A/B)')
     ap.add_argument('--no-numa-bind', action='store_true', help="do not bind the process to the GPU's NUMA node (A/B runs)")
     ap.add_argument('--no-sibling-mode', '--no-fp32-mode', dest='no_sibling_mode', action='store_true',
                     help='skip the split-bf16 sibling block (the same workload re-timed in the narrower arithmetic of rounds 1-3)')
@@ -519,7 +580,13 @@ def main():
 
     # synthetic pairs of this rank, resident in HBM before the timed region
     items = [build_pair(1000 * rank + i, args.config, n_points) for i in range(args.pairs)]
-    pairs = [(torch.from_numpy(it['ref_points']).to(device), torch.from_numpy(it['src_points']).to(device)) for it in items]
+    # the pairs live in PINNED HOST memory: every stack's 32 clouds are copied to the device on its lane's stream INSIDE the timed region
+    # (the reference moves every item to the device per iteration: to_cuda(data_dict), geotransformer/engine/single_tester.py:52);
+    # --inputs device keeps them resident in HBM instead (A/B of the copy's cost)
+    if args.inputs == 'host':
+        pairs = [(torch.from_numpy(it['ref_points']).pin_memory(), torch.from_numpy(it['src_points']).pin_memory()) for it in items]
+    else:
+        pairs = [(torch.from_numpy(it['ref_points']).to(device), torch.from_numpy(it['src_points']).to(device)) for it in items]
 
     info = {}
     runner = ConcurrentRegistration(pipe, lanes=args.lanes, stack=args.stack)
@@ -594,14 +661,20 @@ def main():
         with prof:
             t0 = time.perf_counter()
             for i in range(args.steps):
+                if i == args.steps - 1:
+                    # the LAST step's outputs keep a reference to their stack's pyramid tables (no extra GPU work, nothing copied): the
+                    # parity block byte-compares the tables the timed run itself computed, for every pair of the step
+                    runner.return_pyramid = True
                 step(args.warmup + i, record=i)
             runner.drain()  # every pair enqueued; this stream now waits for all lanes
             gathered = gd.gather_results(results)  # (world, steps, batch, 4, 4) -- the only collective on the data path
             gd.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
+        runner.return_pyramid = False
         cpu1 = os.times()
         host_busy = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(elapsed, 1e-9)  # CPUs this rank kept busy in the region
+        per_rank = gd.gather_results(torch.tensor([args.steps * args.batch / elapsed], dtype=torch.float64, device=device)).flatten().tolist()
         elapsed = gd.max_over_ranks(elapsed, device)
         events = prof.results()
         note(f'rank {rank}: [{precision}] timed region done ({args.steps} steps in {elapsed:.2f} s)')
@@ -635,12 +708,14 @@ def main():
                                         'read from the latest committed profiles/r*_pmc_hbm_traffic*.json -- bench.py cannot run under the counters itself; '
                                         'collected with --lanes 1 --stack 8: a launch there covers 8 stacked pairs, half the rows of a 16-pair launch)')
         return {'precision': precision, 'elapsed': elapsed, 'last': dict(last), 'roofline': roof, 'host_cpus_busy': round(host_busy, 2),
+                'per_rank': [round(v, 1) for v in per_rank],
                 'value': args.steps * args.batch * world / elapsed, 'ms_per_step': 1e3 * elapsed / args.steps}
 
-    DTYPES = {'fp32': 'f32 (IEEE fp32 products, fp32 accumulation: v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32; fp32 storage) -- the reference\'s arithmetic',
-              'fp32-unpacked': 'f32 (exact fp32 MFMA on the rounds-1..3 unpacked kernel)',
-              'bf16x3': 'bf16x3 (split-bf16 products: 3 bf16 MFMA terms per fp32 product, ~2^-17 relative; fp32 accumulate and storage) -- narrower than the reference\'s fp32',
-              'bf16': 'bf16 (plain bf16 operands, fp32 accumulate and storage)'}
+    gse_note = 'GSE embedding by cubic-Taylor table, <= 3e-7 rel. of proj(sinusoid)' if args.gse == 'table' else 'GSE embedding on the MFMA kernels'
+    DTYPES = {'fp32': f'f32 (IEEE fp32 MFMA products + fp32 accumulate, as the reference; {gse_note})',
+              'fp32-unpacked': f'f32 (exact fp32 MFMA on the rounds-1..3 unpacked kernel; {gse_note})',
+              'bf16x3': f'bf16x3 (3 bf16 MFMA terms per product, ~2^-17 rel.: narrower than fp32; fp32 accumulate and storage; {gse_note})',
+              'bf16': f'bf16 (plain bf16 operands, fp32 accumulate and storage; {gse_note})'}
     note(f'rank {rank}: {numa_note}; host waits: {sync_note}')
     note(f'rank {rank}: model + {len(pairs)} pairs ready')
     main_run = timed_run(args.precision, args.gse)
@@ -651,6 +726,7 @@ def main():
 
     if rank == 0:
         D = cfg.geotransformer.hidden_dim
+        detail_path = os.path.join(ROOT, 'bench_detail.json')
         line = {
             'metric': {'3dmatch': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)',
                        'kitti': 'registration pairs/sec (120k-pt synthetic KITTI-shape pair)',
@@ -661,6 +737,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': DTYPES[args.precision],
             'data': 'synthetic',
+            'per_rank_pairs_per_s': main_run['per_rank'],
             'config': {'workload': f'BASELINE configs[{baseline_index}]: synthetic {args.config} pair, {n_points}+{n_points} pts, '
                                    f'{cfg.backbone.num_stages}-stage KPConv-FPN, d={D}, '
                                    f'{info["superpoints"][0]}+{info["superpoints"][1]} superpoints, '
@@ -672,15 +749,17 @@ def main():
                        'host_cpus_busy_in_timed_region': main_run['host_cpus_busy'],
                        'untimed_prewarm': f'{info.get("prewarm_steps", 0)} steps (~{info.get("prewarm_seconds", 0.0)} s: >= {args.prewarm_seconds} s, then until four joined '
                                           f'steps agree within 4 %, <= {args.prewarm_cap_seconds} s) before the {args.warmup} warm-up steps',
-                       'parallelism': f'pairs sharded over {world} rank(s), one process per GPU, no data-path collective',
+                       'parallelism': f'pairs sharded over {world} rank(s), 1 process/GPU, no data-path collective',
                        'collective_backend': 'rccl' if backend == 'nccl' else backend,
                        'weights': 'random init, seed 7351', 'matrix_precision': args.precision, 'gse': args.gse,
-                       'inputs': 'raw xyz resident in HBM before the timed region (480 KB/pair; H2D not timed)'},
+                       'inputs': ('raw xyz in pinned host memory; H2D timed (480 KB/pair, hipMemcpyAsync per cloud on the lane stream)'
+                                  if args.inputs == 'host' else 'raw xyz resident in HBM before the timed region (H2D not timed)')},
             'roofline': main_run['roofline'],
+            'detail_file': os.path.basename(detail_path),
         }
         if world == 1 and not args.no_cpu_baseline:
             os.sched_setaffinity(0, all_cpus)  # the CPU legs (child processes) may use every core the box allows
-            # parity sample: four slots of the LAST timed step, one per lane where the launch shape has four lanes, in different stack slots
+            # forward-parity sample: four slots of the LAST timed step, one per lane where the launch shape has four lanes, in different stack slots
             n_check = min(4, args.batch)
             slots = sorted({(q * (args.batch - 1)) // max(n_check - 1, 1) for q in range(n_check)})
             sample = [main_run['last'][j][0] for j in slots]  # indices into items / pairs
@@ -690,31 +769,55 @@ def main():
             line['speedup_vs_cpu_baseline'] = round(main_run['value'] / base['value'], 1) if base['value'] else None
             from oracle import parity
 
+            # index parity of EVERY pair of the last timed step: the oracle's collate (restated C++ cores, canonical tie order; ~0.2 s per
+            # pair, one pair per host thread) against the tables the timed run itself produced
+            note(f'oracle pyramids of all {args.batch} pairs of the last timed step')
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import neighbors as on
+            b_ = cfg.backbone
+
+            def oracle_pyramid(q):
+                it = items[q]
+                pts = np.concatenate([it['ref_points'], it['src_points']])
+                lens = np.array([len(it['ref_points']), len(it['src_points'])], dtype=np.int64)
+                return on.precompute_pyramid(on.restated(), pts, lens, b_.num_stages, b_.init_voxel_size, b_.init_radius, list(cfg.neighbor_limits))
+
+            with ThreadPoolExecutor(max_workers=max(1, min(16, int(base.get('cpu_budget', 1))))) as pool:
+                step_pyramids = list(pool.map(oracle_pyramid, [main_run['last'][j][0] for j in range(args.batch)]))
+
             def parity_block(run, precision):
-                """The TIMED run's own outputs (last step) for the sampled slots vs the oracle on each pair alone + that lane's stacked
-                pyramid, rebuilt and cut back to the pair (the forward does not return its tables)."""
+                """The TIMED run's own outputs (last step): the stacked pyramid tables of every pair of the step, cut back to the pair,
+                byte-compared with the oracle's collate of that pair; the forward outputs of the sampled slots vs the oracle on each pair alone."""
                 bf16 = precision == 'bf16'
+                identical = []
+                for j in range(args.batch):
+                    q, out_q = run['last'][j]
+                    assert q == main_run['last'][j][0], 'the slot holds another pair than the one the oracle was run on'
+                    g0 = (j // args.stack) * args.stack
+                    identical.append(bool(parity.pyramid_identical(RegistrationPipeline.pair_pyramid(out_q['_stack_pyramid'], j - g0), step_pyramids[j])))
                 reports = []
                 for j, (pyr_q, want_q) in zip(slots, oracle):
                     q, out_q = run['last'][j]
-                    assert q == main_run['last'][j][0], 'the slot holds another pair than the one the oracle was run on'
-                    # plain-bf16 operands (configs[4]) are held to the north-star bound; the fp32-grade modes to two orders inside it
+                    # plain-bf16 operands (configs[4]) are held to the north-star bound + the pose gates; the fp32-grade modes to two orders inside it
                     rep = parity.compare_pair(out_q, want_q, **(parity.BF16_TOLERANCES if bf16 else {}))
-                    g0 = (j // args.stack) * args.stack
-                    stack_pairs = [pairs[run['last'][jj][0]] for jj in range(g0, min(g0 + args.stack, args.batch))]
-                    _, stacked = pipe.register_batch(stack_pairs, return_pyramid=True)
-                    rep['pyramid_tables_identical'] = parity.pyramid_identical(RegistrationPipeline.pair_pyramid(stacked, j - g0), pyr_q)
+                    rep['pyramid_tables_identical'] = identical[j]
                     rep['ok'] = bool(rep['ok'] and rep['pyramid_tables_identical'])
-                    rep.update(pair_seed=1000 * rank + q, lane_stack=j // args.stack, stack_slot=j - g0)
+                    rep.update(pair_seed=1000 * rank + q, lane_stack=j // args.stack, stack_slot=j - (j // args.stack) * args.stack)
                     reports.append(rep)
-                return {'ok': all(r['ok'] for r in reports), 'pairs_checked': len(reports),
+                rres = [r['rre_deg_vs_oracle'] for r in reports if r.get('rre_deg_vs_oracle') is not None]
+                rtes = [r['rte_m_vs_oracle'] for r in reports if r.get('rte_m_vs_oracle') is not None]
+                return {'ok': all(r['ok'] for r in reports) and all(identical), 'pairs_checked': len(reports),
+                        'pyramids_checked': len(identical), 'pyramids_identical': sum(identical),
+                        'pose_gated': all(bool(r.get('pose_gated')) for r in reports),
                         'transforms_compared': sum(bool(r['transform_compared']) for r in reports),
                         'max_feature_mse': max(max(r[k] for k in r if k.startswith('mse_')) for r in reports),
                         'max_transform_abs_diff': max((r['transform_max_abs_diff'] for r in reports if r['transform_max_abs_diff'] is not None), default=None),
-                        'what': (f'{len(reports)} pairs as computed in the LAST TIMED step (slots {slots} of {args.batch}: stacks of {args.stack}, '
-                                 f'{args.lanes} lanes) vs the CPU oracle on each pair alone; tolerances in oracle/parity.py; a differing coarse '
-                                 f'selection must be a score tie at the selection boundary and is then compared in full; every stack raises on '
-                                 f'neighbour-table overflow'),
+                        'max_rre_deg': max(rres, default=None), 'max_rte_m': max(rtes, default=None),
+                        'what': (f'pyramid tables of ALL {len(identical)} pairs of the LAST TIMED step (the tables the timed run computed, cut out of their '
+                                 f'stacks) byte-compared with the oracle collate; forward outputs of {len(reports)} of them (slots {slots} of {args.batch}: '
+                                 f'stacks of {args.stack}, {args.lanes} lanes) vs the CPU oracle on each pair alone; tolerances in oracle/parity.py; a '
+                                 f'differing coarse selection must be a score tie at the selection boundary and is then compared in full; every stack '
+                                 f'raises on neighbour-table overflow; RRE / RTE in fp64'),
                         'reports': reports}
 
             note('parity of the timed run vs the oracle')
@@ -730,7 +833,16 @@ def main():
                                        'note': 'same workload, execution shape, steps and warm-up as the headline; NOT the headline: its products '
                                                'are narrower than the reference\'s fp32', 'roofline': sibling['roofline'],
                                        'parity': sibling.get('parity')}
-        print(json.dumps(line))
+        # the full record (per-pair parity reports, per-shape launch tables, isolated re-runs, the sibling mode's blocks) goes to a file;
+        # stdout ends with ONE line of <= 3 KB that the driver can parse (round 4's 24.8 KB line could not be)
+        try:
+            with open(detail_path, 'w') as fh:
+                json.dump(line, fh, indent=1)
+            note(f'full record -> {detail_path}')
+        except OSError as exc:
+            note(f'full record not written ({exc})')
+        sys.stderr.flush()
+        print(json.dumps(compact_line(line)), flush=True)
     runner.close()
     gd.shutdown()  # final barrier + process-group teardown
 

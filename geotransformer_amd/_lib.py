@@ -75,8 +75,10 @@ SIGNATURES = {
     'geotr_gemm_packed': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
     'geotr_gemm_packed_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
     'geotr_gemm_pack_f32': (c_int, [c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr, c_ptr]),
+    'geotr_gemm_pack_format': (c_int, [c_ptr]),
     'geotr_gemm_packed_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
     'geotr_gemm_packed_splitk_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
+    'geotr_gemm_packed_splitk_workspace_bytes_mode': (c_size, [c_i64, c_i64, c_i64, c_int]),
     'geotr_gemm_packed_splits': (c_int, [c_i64, c_i64, c_i64, c_int]),
     'geotr_gemm_packed_tile_width': (c_int, [c_i64, c_i64, c_i64, c_int, c_int]),
     'geotr_gemm_packed_splitk': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_int,

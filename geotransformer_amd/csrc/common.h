@@ -27,6 +27,14 @@ int fail(int code, const char* fmt, ...);
     if (e__ != hipSuccess) return geotr::fail(GEOTR_E_LAUNCH, "%s: %s", what, hipGetErrorString(e__)); \
   } while (0)
 
+// Format of a packed-weight buffer (gemm.hip): the two pack entry points write buffers of the SAME size in different layouts
+// (geotr_gemm_pack: hi / lo bf16 planes = format 1; geotr_gemm_pack_f32: one fp32 plane = format 2), so every entry point that consumes
+// one checks the buffer's recorded format against its arithmetic mode (0 / 1 need format 1, 2 needs format 2) and refuses a mismatch.
+// The record is host-side (address -> format, written by the pack calls); an address that was never packed here is not refused.
+void pack_format_note(const void* packed, int format);
+int pack_format_of(const void* packed);                            // 0 = unknown, 1 = bf16 planes, 2 = fp32 plane
+int pack_format_check(const void* packed, int gemm_mode, const char* what);  // GEOTR_OK, or GEOTR_E_INVALID with the error string set
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // carve typed arrays out of a caller-provided workspace

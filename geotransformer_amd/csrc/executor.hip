@@ -89,7 +89,7 @@ struct ProfScope {
 static int packed_gemm(Ctx& c, const float* a, int64_t lda, const void* packed, float* out, int64_t ldc, int64_t m, int64_t n, int64_t k,
                        const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act, hipStream_t stream) {
   const size_t mk = c.mark();
-  const size_t sk_bytes = geotr_gemm_packed_splitk_workspace_bytes(m, n, k);
+  const size_t sk_bytes = geotr_gemm_packed_splitk_workspace_bytes_mode(m, n, k, c.gemm_mode);
   char* sk = sk_bytes ? c.alloc<char>(sk_bytes) : nullptr;
   c.release(mk);  // stream order keeps the scratch valid until the reduce kernel has run: later allocations are written by later launches
   if (!c.live()) return GEOTR_OK;

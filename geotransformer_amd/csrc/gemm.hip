@@ -12,6 +12,8 @@
 // current one.  Two instances: 128x128 (4 waves, 2x2 tiles per wave) for tall operands, 64x64 (4 waves, 1 tile
 // per wave) for the few-hundred-row superpoint matrices.
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -1129,6 +1131,31 @@ extern "C" int geotr_gemm(const float* A, int64_t lda, const float* B, int64_t l
 
 static inline int64_t pack_pad32(int64_t x) { return (x + 31) / 32 * 32; }
 
+// ---- format record of the packed-weight buffers (common.h) -------------------------------------------------------------------------
+static std::mutex g_pack_mutex;
+static std::unordered_map<const void*, int> g_pack_format;
+
+void geotr::pack_format_note(const void* packed, int format) {
+  std::lock_guard<std::mutex> lock(g_pack_mutex);
+  g_pack_format[packed] = format;
+}
+
+int geotr::pack_format_of(const void* packed) {
+  std::lock_guard<std::mutex> lock(g_pack_mutex);
+  const auto it = g_pack_format.find(packed);
+  return it == g_pack_format.end() ? 0 : it->second;
+}
+
+int geotr::pack_format_check(const void* packed, int gemm_mode, const char* what) {
+  const int have = pack_format_of(packed), need = gemm_mode == 2 ? 2 : 1;
+  if (have != 0 && have != need)
+    return fail(GEOTR_E_INVALID, "%s: arithmetic mode %d needs a weight packed by %s, this buffer was packed by %s", what, gemm_mode,
+                need == 2 ? "geotr_gemm_pack_f32" : "geotr_gemm_pack", have == 2 ? "geotr_gemm_pack_f32" : "geotr_gemm_pack");
+  return GEOTR_OK;
+}
+
+extern "C" int geotr_gemm_pack_format(const void* packed) { return geotr::pack_format_of(packed); }
+
 extern "C" size_t geotr_gemm_pack_bytes(int64_t n, int64_t k) { return (size_t)(2 * 2 * pack_pad32(n) * pack_pad32(k)); }
 
 extern "C" int geotr_gemm_pack(const float* B, int64_t ldb, int b_is_kn, int64_t n, int64_t k, void* packed, void* stream) {
@@ -1139,6 +1166,7 @@ extern "C" int geotr_gemm_pack(const float* B, int64_t ldb, int b_is_kn, int64_t
   gemm_pack_kernel<<<dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(B, ldb, b_is_kn, (int)n, (int)k, (int)(kp / 16),
                                                                                               nvec, hi, hi + np * kp);
   GEOTR_CHECK_LAUNCH("gemm_pack");
+  pack_format_note(packed, 1);
   return GEOTR_OK;
 }
 
@@ -1149,6 +1177,7 @@ extern "C" int geotr_gemm_pack_f32(const float* B, int64_t ldb, int b_is_kn, int
   gemm_pack_f32_kernel<<<dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(B, ldb, b_is_kn, (int)n, (int)k, (int)(kp / 8),
                                                                                                   nvec, reinterpret_cast<float*>(packed));
   GEOTR_CHECK_LAUNCH("gemm_pack_f32");
+  pack_format_note(packed, 2);
   return GEOTR_OK;
 }
 
@@ -1223,6 +1252,7 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   GEOTR_CHECK_ARG(M >= 0 && N >= 1 && K >= 1, "gemm_packed: bad sizes");
   if (M == 0) return GEOTR_OK;
   GEOTR_CHECK_ARG(A && packed && (C || stats), "gemm_packed: null pointer");
+  if (const int rc = pack_format_check(packed, TERMS == 0 ? 2 : TERMS == 1 ? 1 : 0, "gemm_packed")) return rc;
   GEOTR_CHECK_ARG(M < (1ll << 31) && N < (1ll << 24) && K < (1ll << 24), "gemm_packed: size out of range");
   GEOTR_CHECK_ARG(act >= 0 && act <= 2, "gemm_packed: unknown activation %d", act);
   const int64_t np = pack_pad32(N), kp = pack_pad32(K);
@@ -1368,6 +1398,12 @@ extern "C" size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N,
   return splits > 1 ? sizeof(float) * (size_t)splits * (size_t)M * (size_t)N : 0;
 }
 
+extern "C" size_t geotr_gemm_packed_splitk_workspace_bytes_mode(int64_t M, int64_t N, int64_t K, int bf16_operands) {
+  // what a launch of THIS arithmetic mode needs (the mode-blind query above reserves the larger of the two plans)
+  const int splits = bf16_operands == 2 ? packed_plan_f32(M, N, K, true).splits : packed_splits(M, N, K);
+  return splits > 1 ? sizeof(float) * (size_t)splits * (size_t)M * (size_t)N : 0;
+}
+
 extern "C" int geotr_gemm_packed_splits(int64_t M, int64_t N, int64_t K, int bf16_operands) {
   return bf16_operands == 2 ? packed_plan_f32(M, N, K, true).splits : packed_splits(M, N, K);
 }
@@ -1377,7 +1413,10 @@ extern "C" int geotr_gemm_packed_tile_width(int64_t M, int64_t N, int64_t K, int
   // runs it (<2,2,.> / <1,2,.> / <1,1,.>) -- for tools that attribute profiler records to shapes (scripts/gemm_traffic_table.py)
   if (N <= 64) return N > 32 ? 64 : 32;
   if (bf16_operands != 2) return 128;
-  return packed_plan_f32(M, N, K, !unsplit_epilogue).bn;
+  // unsplit_epilogue: 1 = a launch that cannot be split over K (gathered residual / affine tail), 2 = one that also writes GroupNorm
+  // statistics records -- those are laid out for the 128-wide tile above 64 columns (mirrors gemm_packed_launch)
+  const int bn = packed_plan_f32(M, N, K, !unsplit_epilogue).bn;
+  return unsplit_epilogue == 2 && bn == 64 && N > 64 ? 128 : bn;
 }
 
 extern "C" int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

@@ -413,6 +413,8 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
   GEOTR_CHECK_ARG((reinterpret_cast<uintptr_t>(s_feats) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed) & 15) == 0,
                   "kpconv_fused: features and packed weights must be 16-byte aligned");
   GEOTR_CHECK_ARG(ns * c_in < (1ll << 31), "kpconv_fused: more than 2^31 feature elements");
+  GEOTR_CHECK_ARG(bf16_operands >= 0 && bf16_operands <= 2, "kpconv_fused: arithmetic mode must be 0 (split-bf16), 1 (bf16) or 2 (fp32)");
+  if (const int rc = pack_format_check(packed, bf16_operands, "kpconv_fused")) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t kdim = 15 * c_in, kp_pad = pad32(kdim), np_pad = pad32(c_out);
   const unsigned short* bhi = reinterpret_cast<const unsigned short*>(packed);

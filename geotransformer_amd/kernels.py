@@ -108,7 +108,7 @@ def gemm_packed(a, packed, n, bias=None, row_div=None, residual=None, alpha=1.0,
         assert residual.stride(-1) == 1
         ldr = residual.stride(0)
     mode = gemm_mode()
-    nbytes = lib.geotr_gemm_packed_splitk_workspace_bytes(M, n, K) if split_k else 0
+    nbytes = lib.geotr_gemm_packed_splitk_workspace_bytes_mode(M, n, K, mode) if split_k else 0
     if nbytes:
         ws = _lib.workspace(nbytes, a.device)
         _lib.check(lib.geotr_gemm_packed_splitk(_lib.ptr(a), a.stride(0), _lib.ptr(packed), _lib.ptr(out), out.stride(0), M, n, K,
@@ -449,26 +449,42 @@ _PRECISIONS = {'fp32': ('fp32', 5), 'bf16x3': (True, 5), 'bf16': ('bf16', 5), 'f
 _GSE_MFMA = {'fp32': 0, 'bf16x3': 1, 'bf16': 3, 'fp32-unpacked': 0}
 
 
-def set_precision(name, gse='table'):
-    """Arithmetic of the matrix-pipe kernel family (packed GEMMs of the backbone / transformer) and of the GSE embedding:
-    'fp32' (DEFAULT, round 4): exact fp32 MFMA products everywhere -- the reference's own arithmetic (IEEE fp32 products, fp32
-        accumulation) -- on the packed pipeline (weights packed by geotr_gemm_pack_f32, v_mfma_f32_32x32x2_f32); the mode every
+class PrecisionName(str):
+    """A precision mode's name that remembers the GSE form it was set with: `set_precision(prev)` restores both."""
+    gse = 'table'
+
+    def __new__(cls, name, gse='table'):
+        obj = super().__new__(cls, name)
+        obj.gse = gse
+        return obj
+
+
+def set_precision(name, gse=None):
+    """Arithmetic of the matrix-pipe kernel family (packed GEMMs of the backbone / transformer) and form of the GSE embedding:
+    'fp32' (DEFAULT): IEEE fp32 MFMA products with fp32 accumulation in every GEMM / KPConv / attention contraction -- the reference's
+        own arithmetic -- on the packed pipeline (weights packed by geotr_gemm_pack_f32, v_mfma_f32_32x32x2_f32); the mode every
         reference-parity claim and the benchmark headline are made in;
     'bf16x3': split-bf16 products (three bf16 MFMA terms per product, ~2^-17 relative: narrower than fp32; the default of rounds 1-3);
     'fp32-unpacked': the same arithmetic on the rounds-1..3 kernel (no packed weights, no fused KPConv / epilogue statistics; A/B only);
     'bf16': plain bf16 operands with fp32 accumulation (BASELINE configs[4] "bf16 features").
-    `gse`: 'table' (default: the embedding by table lookup -- fp32 arithmetic throughout, independent of the GEMM mode) or
-    'mfma' (the fused sinusoid -> MFMA kernel in the named arithmetic; under 'fp32' that is the exact fp32 MFMA kernel).
-    Returns the previous mode's name.  Process-wide; running models pick it up at their next forward."""
+    `gse`: 'table' (default) = the geometric structure embedding proj(sinusoid(x)) is read from cubic-Taylor tables in fp32 -- an
+        APPROXIMATION of the reference's contraction (remainder <= 3.2e-7 max|W|, ~1e-6 of the embedding), independent of the GEMM mode;
+        'mfma' = the fused sinusoid -> MFMA kernel in the named arithmetic (under 'fp32': exact fp32 MFMA products, the reference's
+        arithmetic end to end).  None: the form carried by `name` when it is a value this function returned, else 'table'.
+    Returns the previous mode as a PrecisionName (a str that carries its GSE form), so `set_precision(prev)` restores both.
+    Process-wide; running models pick it up at their next forward."""
     global GEMM_PACKED, GSE_PRECISION
     if name not in _PRECISIONS:
         raise ValueError(f'unknown precision {name!r}: expected one of {sorted(_PRECISIONS)}')
+    if gse is None:
+        gse = getattr(name, 'gse', 'table')
     if gse not in ('table', 'mfma'):
         raise ValueError("gse must be 'table' or 'mfma'")
-    prev = next((k for k, v in _PRECISIONS.items() if v[0] == GEMM_PACKED), 'custom')
-    GEMM_PACKED, GSE_PRECISION = _PRECISIONS[name]
+    prev_name = next((k for k, v in _PRECISIONS.items() if v[0] == GEMM_PACKED), 'custom')
+    prev = PrecisionName(prev_name, 'table' if GSE_PRECISION == 5 else 'mfma')
+    GEMM_PACKED, GSE_PRECISION = _PRECISIONS[str(name)]
     if gse == 'mfma':
-        GSE_PRECISION = _GSE_MFMA[name]
+        GSE_PRECISION = _GSE_MFMA[str(name)]
     return prev
 
 

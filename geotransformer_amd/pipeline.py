@@ -19,11 +19,27 @@ from .utils.data import precompute_data_stack_mode
 HOST_TIMES = [] if os.environ.get('GEOTR_HOST_TIMING') == '1' else None
 
 
-def _check_cloud(points):
+def _check_cloud(points, host_ok=False):
+    """`host_ok`: a PINNED host tensor is accepted too (ConcurrentRegistration copies it to the device on the lane's stream: the
+    reference's per-item `to_cuda(data_dict)`, geotransformer/engine/single_tester.py:52)."""
     if not (torch.is_tensor(points) and points.dim() == 2 and points.shape[1] == 3 and points.shape[0] > 0
-            and points.dtype == torch.float32 and points.is_cuda):
-        raise ValueError('a cloud must be a non-empty (N, 3) float32 device tensor, got '
+            and points.dtype == torch.float32 and (points.is_cuda or (host_ok and points.is_pinned()))):
+        raise ValueError('a cloud must be a non-empty (N, 3) float32 device tensor' + (' or pinned host tensor' if host_ok else '') + ', got '
                          f'{tuple(points.shape) if torch.is_tensor(points) else type(points)}')
+
+
+def stack_clouds(clouds, device):
+    """(sum N, 3) device tensor of the clouds in order, on the current stream.  Device clouds: one concatenation kernel.  Pinned host
+    clouds: one asynchronous host-to-device copy each, straight into its rows of the stack (no host staging copy, no host wait)."""
+    if all(c.is_cuda for c in clouds):
+        return torch.cat(clouds, dim=0)
+    points = torch.empty((sum(int(c.shape[0]) for c in clouds), 3), dtype=torch.float32, device=device)
+    row = 0
+    for c in clouds:
+        n = int(c.shape[0])
+        points[row:row + n].copy_(c if c.is_contiguous() else c.contiguous(), non_blocking=True)
+        row += n
+    return points
 
 
 class RegistrationPipeline:
@@ -196,7 +212,7 @@ class ConcurrentRegistration:
             stream.wait_event(ready)  # inputs produced on the submitter's stream
         clouds = [c for _, ref, src, _, _ in job for c in (ref, src)]
         for c in clouds:
-            _check_cloud(c)
+            _check_cloud(c, host_ok=True)
         if self.pyramid_graphs:
             from .native import PyramidGraph
             key = threading.get_ident()
@@ -211,7 +227,7 @@ class ConcurrentRegistration:
             event = torch.cuda.Event()
             event.record(stream)
             return job, plan, plan.pts[0], event
-        points = torch.cat(clouds, dim=0)
+        points = stack_clouds(clouds, self.device)
         # (a torch.tensor(..., device=...) from a Python list is a pageable host-to-device copy: it would block the host until the
         # stream has drained, i.e. until the previous stack's forward is done -- pinned + non_blocking keeps the host running ahead)
         lengths = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64).pin_memory().to(points.device, non_blocking=True)
@@ -294,6 +310,7 @@ class ConcurrentRegistration:
                         index, ref, src, sink, ready = job[0]
                         try:
                             stream.wait_event(ready)
+                            ref, src = (c if c.is_cuda else c.to(self.device, non_blocking=True) for c in (ref, src))
                             sink(index, self.pipeline(ref, src))
                             self._job_done(job)
                         except BaseException as exc:

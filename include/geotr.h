@@ -149,12 +149,16 @@ int geotr_gemm_packed(const float* A, int64_t lda, const void* packed, float* C,
  * (ABI 5): 0 = split-bf16 products, 1 = plain bf16 operands (both on a geotr_gemm_pack weight), 2 = exact fp32 products on
  * v_mfma_f32_32x32x2_f32 (on a geotr_gemm_pack_f32 weight) -- the reference's own arithmetic. */
 size_t geotr_gemm_packed_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
+/* The same for ONE arithmetic mode (bf16_operands as below): what a launch in that mode really uses; the mode-blind query above returns
+ * the larger of the split-bf16 and exact-fp32 plans. */
+size_t geotr_gemm_packed_splitk_workspace_bytes_mode(int64_t M, int64_t N, int64_t K, int bf16_operands);
 /* K slices a launch of this shape is split into in the given arithmetic mode (1 = single pass).  The split-bf16 / bf16 rule fills a
  * narrow grid (< 256 tiles, >= 16 stages); the exact-fp32 plan (matrix-pipe bound) chooses column width and slices together by the work
  * of the busiest compute unit (gemm.hip packed_plan_f32).  geotr_gemm_packed_splitk_workspace_bytes covers either. */
 int geotr_gemm_packed_splits(int64_t M, int64_t N, int64_t K, int bf16_operands);
 /* Column width (128 / 64 / 32) of the block tile such a launch uses = which kernel instantiation runs it (<2,2,.> / <1,2,.> / <1,1,.>);
- * unsplit_epilogue: the launch carries statistics / gathered rows / an affine table and is therefore never split.  For profiling tools. */
+ * unsplit_epilogue: 1 = the launch carries gathered rows / an affine table and is therefore never split; 2 = it (also) writes GroupNorm
+ * statistics records (laid out for the 128-wide tile above 64 columns).  For profiling tools. */
 int geotr_gemm_packed_tile_width(int64_t M, int64_t N, int64_t K, int bf16_operands, int unsplit_epilogue);
 int geotr_gemm_packed_splitk(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                              const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
@@ -192,6 +196,11 @@ int geotr_gemm_packed_gather(const float* A, int64_t lda, const void* packed, fl
  * fp32 plane in that instruction's B-fragment order (geotr_gemm_pack_bytes(n, k) bytes as well: 4 B per element either way); it is
  * NOT interchangeable with a geotr_gemm_pack buffer -- pass mode 2 with it and mode 0 / 1 with the other. */
 int geotr_gemm_pack_f32(const float* B, int64_t ldb, int b_is_kn, int64_t n, int64_t k, void* packed, void* stream);
+/* Which of the two layouts the buffer at `packed` was written in by THIS library: 1 = geotr_gemm_pack (hi / lo bf16 planes), 2 =
+ * geotr_gemm_pack_f32 (one fp32 plane), 0 = never packed here (e.g. a copy of a packed buffer).  The two layouts have the same size;
+ * every entry point that takes a packed weight and an arithmetic mode (geotr_gemm_packed*, geotr_kpconv_fused, the model forward)
+ * returns GEOTR_E_INVALID when the recorded format contradicts the mode (0 / 1 need format 1, 2 needs format 2). */
+int geotr_gemm_pack_format(const void* packed);
 int geotr_gemm_packed_f32(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                           const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                           void* stream);

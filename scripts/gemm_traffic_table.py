@@ -27,7 +27,7 @@ def main(pmc_json, shapes_jsonl, precision, out_md):
         if rec['family'] != 'gemm' or rec['precision'] != precision:
             continue
         m, n, k, flags = (rec['shape'] + [0])[:4]
-        unsplit = 1 if flags & 6 else 0
+        unsplit = 2 if flags & 4 else 1 if flags & 2 else 0  # 4: statistics records written (128-wide tile above 64 columns); 2: gathered rows
         bn = lib.geotr_gemm_packed_tile_width(m, n, k, mode, unsplit)
         splits = 1 if unsplit else lib.geotr_gemm_packed_splits(m, n, k, mode)
         wm, wn = {128: (2, 2), 64: (1, 2), 32: (1, 1)}[bn]

@@ -12,12 +12,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _split_bf16_aggressor():
-    """The trigger is a co-running kernel that issues double-rate bf16 MFMAs between loads: the packed GEMM in its SPLIT-BF16 mode (the
-    exact-fp32 default of round 4 issues fp32 MFMAs only, next to which no instruction form ever failed: profiles/r04_hazard_form_matrix.md)."""
+@pytest.fixture(autouse=True, params=['bf16x3', 'fp32'])
+def _aggressor_arithmetic(request):
+    """The known trigger is a co-running kernel that issues double-rate bf16 MFMAs between loads: the packed GEMM in its SPLIT-BF16 mode.
+    The shipped default (exact fp32: TERMS = 0 packed GEMM with its 3-stage ring, fused KPConv fp32 phase 2) issues fp32 MFMAs only, next to
+    which no instruction form ever failed (profiles/r04_hazard_form_matrix.md) -- it is run under co-running streams as well:
+    every test here runs once per arithmetic, as aggressor and as victim."""
     from geotransformer_amd import kernels
-    prev = kernels.set_precision('bf16x3')
+    prev = kernels.set_precision(request.param)
     yield
     kernels.set_precision(prev)
 

@@ -372,3 +372,28 @@ def test_weight_fragments_from_l2_form_is_bitwise_the_lds_form():
         got[mode] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('RESULT ')][-1][7:])
     assert len(got['0']) == 15
     assert got['0'] == got['1'] == got['2'], got
+
+
+def test_packed_weight_format_is_checked_against_the_arithmetic_mode():
+    """the two pack layouts have the same size; a buffer packed for one arithmetic must not be consumed by the other.  The
+    library records the layout per buffer address (geotr_gemm_pack_format) and every packed entry point refuses a mismatch."""
+    from geotransformer_amd import _lib, kernels
+    lib = _lib.load()
+    w = torch.randn(64, 64).cuda()
+    a = torch.randn(2048, 64).cuda()
+    prev = kernels.set_precision('fp32')
+    try:
+        p32 = kernels.gemm_pack(w)
+        assert lib.geotr_gemm_pack_format(_lib.ptr(p32)) == 2
+        kernels.gemm_packed(a, p32, 64)  # matching mode: fine
+        kernels.set_precision('bf16x3')
+        with pytest.raises(RuntimeError, match='geotr_gemm_pack_f32'):
+            kernels.gemm_packed(a, p32, 64)  # fp32 plane read as bf16 planes: refused
+        p16 = kernels.gemm_pack(w)  # (the cache key carries the mode: a fresh buffer in the other layout)
+        assert p16.data_ptr() != p32.data_ptr() and lib.geotr_gemm_pack_format(_lib.ptr(p16)) == 1
+        kernels.set_precision('fp32')
+        with pytest.raises(RuntimeError, match='geotr_gemm_pack'):
+            kernels.gemm_packed(a, p16, 64)
+        assert lib.geotr_gemm_pack_format(_lib.ptr(a)) == 0  # never packed here
+    finally:
+        kernels.set_precision(prev)
