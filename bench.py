@@ -516,13 +516,13 @@ def main():
     ap.add_argument('--profile-stride', type=int, default=8,
                     help='bracket every Nth eligible launch: a timed event pair keeps its launch from overlapping its stream neighbours, '
                          'so the sample is spread over the whole region instead of covering every launch of its start')
-    ap.add_argument('--prewarm-seconds', type=float, default=2.0,
-                    help='untimed steps of the same workload before the W warm-up steps, until this much wall time has passed: the FIRST GPU '
+    ap.add_argument('--prewarm-seconds', type=float, default=4.0,
+                    help='untimed steps of the same workload before the W warm-up steps, for at least this much wall time: the FIRST GPU '
                          'process on a fresh box reads up to 40 %% low for its first seconds (clock / power-state ramp; profiles/r04_ab_runs.md), '
                          'which W = 3 steps (0.2 s) do not cover')
-    ap.add_argument('--prewarm-cap-seconds', type=float, default=12.0,
-                    help='after --prewarm-seconds the untimed steps go on until the last four joined steps agree within 4 %%, at most this long '
-                         '(a box that is still ramping after 2 s showed 900 against 976 pairs/s, profiles/r04_ab_runs.md section 8)')
+    ap.add_argument('--prewarm-cap-seconds', type=float, default=20.0,
+                    help='after --prewarm-seconds the untimed chunks go on until the last three agree within 2 %%, at most this long')
+    ap.add_argument('--prewarm-chunk', type=int, default=5, help='steps per untimed prewarm chunk (pipelined like the timed region, one join per chunk)')
     ap.add_argument('--dump-shapes', default=None, metavar='PATH',
                     help='write every bracketed launch shape of the timed region (family, shape, launches, average us) as JSON lines to PATH')
     ap.add_argument('--inputs', default='host', choices=['host', 'device'],
@@ -623,29 +623,33 @@ def main():
         # gap right before the timed region costs its first stacks (profiles/r02_ab_runs.md)
         prof = KernelProfiler(args.profile_events, stride=args.profile_stride)  # HIP events around the GSE / packed-GEMM / fused KPConv launches
         note(f'rank {rank}: [{precision}] warm-up')
-        t_pre, n_pre, pre_ms = time.perf_counter(), 0, []
+        t_pre, n_pre, pre_rate = time.perf_counter(), 0, []
+        chunk = max(2, args.prewarm_chunk)
 
         def settled():
-            """The last four untimed steps agree within 4 %: the box has left its ramp (clocks, first-touch, host governor)."""
-            tail = sorted(pre_ms[-4:])
-            return len(pre_ms) >= 6 and (tail[-1] - tail[0]) <= 0.04 * tail[1]
+            """The last three chunks' rates agree within 2 %: the box has left its ramp (clocks / power state, first-touch, host governor)."""
+            tail = sorted(pre_rate[-3:])
+            return len(pre_rate) >= 3 and (tail[-1] - tail[0]) <= 0.02 * tail[1]
 
-        # box warm-up (untimed, before the W steps): at least --prewarm-seconds of the same workload, then until the step time has settled,
-        # at most --prewarm-cap-seconds
+        # box warm-up (untimed, before the W steps): chunks of `chunk` steps run exactly like the timed region (lanes pipelined across
+        # the steps, one join per chunk) for at least --prewarm-seconds, then until the chunk rate has settled, at most
+        # --prewarm-cap-seconds.  (Round 4 joined every prewarm step: a joined step pays the pipeline's fill and drain, reads 73 ms where
+        # the pipelined region runs at 62, and hides a ramp -- the driver's fresh-box run then started its timed region 40 % low.)
         while precision == args.precision and args.prewarm_seconds > 0:
             spent = time.perf_counter() - t_pre
             if spent >= args.prewarm_cap_seconds or (spent >= args.prewarm_seconds and settled()):
                 break
             t_s = time.perf_counter()
-            step(n_pre)
+            for _ in range(chunk):
+                step(n_pre)
+                n_pre += 1
             runner.drain()
             torch.cuda.synchronize()
-            pre_ms.append(1e3 * (time.perf_counter() - t_s))
-            n_pre += 1
-        if pre_ms:
+            pre_rate.append(chunk * args.batch / (time.perf_counter() - t_s))
+        if pre_rate:
             info.setdefault('prewarm_seconds', round(time.perf_counter() - t_pre, 1))
-            note(f'rank {rank}: [{precision}] {n_pre} untimed prewarm steps in {time.perf_counter() - t_pre:.1f} s; ms per joined step, first 4: '
-                 f'{[round(x, 1) for x in pre_ms[:4]]}, last 4: {[round(x, 1) for x in pre_ms[-4:]]}')
+            note(f'rank {rank}: [{precision}] {n_pre} untimed prewarm steps in {time.perf_counter() - t_pre:.1f} s; pairs/s per chunk of {chunk} steps, '
+                 f'first 3: {[round(x) for x in pre_rate[:3]]}, last 3: {[round(x) for x in pre_rate[-3:]]}')
         info.setdefault('prewarm_steps', n_pre)
         for i in range(args.warmup):
             step(i)
@@ -747,8 +751,8 @@ def main():
                        'pairs_per_step_per_gpu': args.batch, 'lanes_per_gpu': args.lanes, 'pairs_stacked_per_launch_sequence': args.stack,
                        'host_binding': numa_note, 'host_waits': sync_note,
                        'host_cpus_busy_in_timed_region': main_run['host_cpus_busy'],
-                       'untimed_prewarm': f'{info.get("prewarm_steps", 0)} steps (~{info.get("prewarm_seconds", 0.0)} s: >= {args.prewarm_seconds} s, then until four joined '
-                                          f'steps agree within 4 %, <= {args.prewarm_cap_seconds} s) before the {args.warmup} warm-up steps',
+                       'untimed_prewarm': f'{info.get("prewarm_steps", 0)} steps (~{info.get("prewarm_seconds", 0.0)} s: >= {args.prewarm_seconds} s, then until three chunks of '
+                                          f'{args.prewarm_chunk} pipelined steps agree within 2 %, <= {args.prewarm_cap_seconds} s) before the {args.warmup} warm-up steps',
                        'parallelism': f'pairs sharded over {world} rank(s), 1 process/GPU, no data-path collective',
                        'collective_backend': 'rccl' if backend == 'nccl' else backend,
                        'weights': 'random init, seed 7351', 'matrix_precision': args.precision, 'gse': args.gse,

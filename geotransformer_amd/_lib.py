@@ -116,6 +116,7 @@ SIGNATURES = {
     'geotr_gse_knn_clouds': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geotr_gse_embed_table': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                       c_f32, c_f32, c_ptr, c_ptr]),
+    'geotr_stack_clouds': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geotr_apply_transform': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'geotr_pairwise_distance': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),
     'geotr_index_select': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),

@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
 // with more than 128 hits is redone by the whole wave on the wave's 512 keys (= the one-query kernel's capacity).
 constexpr int kQuadKeys = 128;
 
-__global__ __launch_bounds__(256) void rg_query_quad_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
+template <int OCC>  // waves per SIMD the register allocation is held to: 98 VGPRs uncapped = 4; 5 -> 96 (no spill); 6 -> 80 (5 dwords spilled)
+__global__ __launch_bounds__(256, OCC) void rg_query_quad_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
                                                             const float4* __restrict__ sorted, const float* __restrict__ q,
                                                             const int64_t* __restrict__ q_len, const int* __restrict__ q_order, int batch,
                                                             float r2, int width, int cap, int64_t* __restrict__ out,
@@ -1230,9 +1231,18 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
   if (!count_only && quad_mode && (sparse_hint || quad_mode >= 3) && !(tile_enabled && q_order) && batch <= 64 && cap <= 4 * kQuadKeys &&
       nq < (1ll << 31)) {
     const int64_t quads = (expect + 3) / 4;
-    rg_query_quad_kernel<<<dim3((unsigned)((quads + 3) / 4)), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len,
-                                                                                     (quad_mode == 2 || quad_mode == 4) ? nullptr : q_order, (int)batch, r2,
-                                                                                     (int)width, (int)cap, out, overflow);
+    static const int quad_occ = [] {
+      const char* e = std::getenv("GEOTR_RG_QUAD_OCC");  // experiment (round 5): 4 = round 4's allocation, 5 (default), 6
+      return e ? std::atoi(e) : 5;
+    }();
+    const int* order = (quad_mode == 2 || quad_mode == 4) ? nullptr : q_order;
+    const dim3 grid((unsigned)((quads + 3) / 4));
+    if (quad_occ >= 6)
+      rg_query_quad_kernel<6><<<grid, dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, order, (int)batch, r2, (int)width, (int)cap, out, overflow);
+    else if (quad_occ == 5)
+      rg_query_quad_kernel<5><<<grid, dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, order, (int)batch, r2, (int)width, (int)cap, out, overflow);
+    else
+      rg_query_quad_kernel<4><<<grid, dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, order, (int)batch, r2, (int)width, (int)cap, out, overflow);
     GEOTR_CHECK_LAUNCH("radius_query(quad)");
     return GEOTR_OK;
   }

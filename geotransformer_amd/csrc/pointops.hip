@@ -143,11 +143,48 @@ int copy_async(void* dst, const void* src, size_t bytes, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? GEOTR_OK : fail(GEOTR_E_LAUNCH, "copy launch failed");
 }
 
+// ---- stack_clouds: up to GEOTR_MAX_STACK_CLOUDS (n_i, 3) fp32 clouds -> one (sum n_i, 3) stack, ONE launch -----------------------
+// The sources may live in device memory or in PINNED (device-mapped) host memory: a plain in-order kernel of the caller's stream reads
+// them over PCIe with coalesced dword loads -- no copy-engine transfer, no cross-queue ordering -- and writes the stack to HBM.
+struct StackSources {
+  const uint32_t* src[GEOTR_MAX_STACK_CLOUDS];
+  int64_t word0[GEOTR_MAX_STACK_CLOUDS + 1];  // first 4-byte word of cloud i in the stack; word0[count] = all words
+  int count;
+};
+__global__ __launch_bounds__(256) void stack_clouds_kernel(StackSources s, uint32_t* __restrict__ dst) {
+  const int64_t total = s.word0[s.count];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int c = 0;
+  for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < total; w += stride) {
+    while (w >= s.word0[c + 1]) ++c;  // words only move forward: the scan resumes where it stopped
+    dst[w] = __builtin_nontemporal_load(s.src[c] + (w - s.word0[c]));
+  }
+}
+
 }  // namespace geotr
 
 using namespace geotr;
 
 extern "C" {
+
+int geotr_stack_clouds(const float* const* clouds, const int64_t* rows, int64_t count, float* stacked, void* stream_) {
+  GEOTR_CHECK_ARG(clouds && rows && stacked && count >= 1 && count <= GEOTR_MAX_STACK_CLOUDS, "stack_clouds: 1..%d clouds", GEOTR_MAX_STACK_CLOUDS);
+  StackSources s;
+  s.count = (int)count;
+  s.word0[0] = 0;
+  for (int64_t i = 0; i < count; ++i) {
+    GEOTR_CHECK_ARG(clouds[i] && rows[i] >= 0 && (reinterpret_cast<uintptr_t>(clouds[i]) & 3) == 0, "stack_clouds: cloud %lld is null, unaligned or negative-sized", (long long)i);
+    s.src[i] = reinterpret_cast<const uint32_t*>(clouds[i]);
+    s.word0[i + 1] = s.word0[i] + 3 * rows[i];
+  }
+  for (int64_t i = count; i < GEOTR_MAX_STACK_CLOUDS; ++i) s.src[i] = nullptr, s.word0[i + 1] = s.word0[count];
+  const int64_t total = s.word0[count];
+  if (total == 0) return GEOTR_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+  stack_clouds_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream_>>>(s, reinterpret_cast<uint32_t*>(stacked));
+  GEOTR_CHECK_LAUNCH("stack_clouds");
+  return GEOTR_OK;
+}
 
 int geotr_apply_transform(const float* points, const float* normals, const float* transform, int64_t batch, int64_t n_per_batch,
                           int64_t num_transforms, float* out_points, float* out_normals, void* stream_) {

@@ -551,6 +551,13 @@ int geotr_model_forward(const geotr_model* net, const geotr_pyramid* pyr, const 
  *       and a flattened index (n_index) -- the caller reshapes to the index's rank    modules/ops/index_select.py:4-31
  *       *error_flag (device int32, zeroed by the caller) is set to 1 if an index is outside [-size, size).
  * ---------------------------------------------------------------------------------------------- */
+/* Stack `count` (<= GEOTR_MAX_STACK_CLOUDS) clouds (rows[i], 3) fp32 into one (sum rows, 3) device array in ONE launch on `stream`:
+ * what the reference's collate does with np.concatenate before `to_cuda` (geotransformer/utils/data.py:332-337,
+ * engine/single_tester.py:52).  Every clouds[i] may be a device pointer OR a pointer into pinned, device-mapped host memory
+ * (hipHostMalloc / torch pin_memory): the kernel reads it over PCIe, so the host-to-device transfer of a stack is an ordinary in-order
+ * kernel of the caller's stream.  `clouds` and `rows` are HOST arrays (read during the call). */
+#define GEOTR_MAX_STACK_CLOUDS 32
+int geotr_stack_clouds(const float* const* clouds, const int64_t* rows, int64_t count, float* stacked, void* stream);
 int geotr_apply_transform(const float* points, const float* normals, const float* transform, int64_t batch, int64_t n_per_batch,
                           int64_t num_transforms, float* out_points, float* out_normals, void* stream);
 int geotr_pairwise_distance(const float* x, const float* y, int64_t batch, int64_t n, int64_t m, int64_t c, int normalized,

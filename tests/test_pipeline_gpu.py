@@ -143,3 +143,52 @@ def test_pipelined_lanes_match_the_synchronous_stack_call(lanes, graph, monkeypa
     for i in range(3):
         assert torch.equal(got[i]['estimated_transform'], want[3][0][i]['estimated_transform'])
     runner.close()
+
+
+def test_pinned_host_inputs_are_bitwise_the_device_inputs():
+    """Round 5: the lanes accept clouds in PINNED HOST memory and copy them to the device inside the stack's launch
+    sequence (geotr_stack_clouds reads the pinned pages over PCIe, one launch per stack) -- the reference's per-item to_cuda
+    (engine/single_tester.py:52).  Same bits as device-resident inputs, mixed stacks included."""
+    from geotransformer_amd.config import make_cfg
+    from geotransformer_amd.pipeline import ConcurrentRegistration, RegistrationPipeline, stack_clouds
+    from geotransformer_amd.synthetic import make_pair
+    cfg = make_cfg('3dmatch', {'backbone.init_dim': 16, 'backbone.group_norm': 4, 'backbone.output_dim': 64,
+                               'geotransformer.input_dim': 256, 'geotransformer.hidden_dim': 64, 'geotransformer.output_dim': 64})
+    torch.manual_seed(cfg.seed)
+    pipe = RegistrationPipeline(cfg, device='cuda:0')
+    items = [make_pair(170 + i, '3dmatch', n_points=2100 + 333 * i) for i in range(6)]
+    host = [(torch.from_numpy(it['ref_points']).pin_memory(), torch.from_numpy(it['src_points']).pin_memory()) for it in items]
+    dev = [(r.cuda(), s.cuda()) for r, s in host]
+    mixed = [(h[0], d[1]) if i % 2 else (d[0], h[1]) for i, (h, d) in enumerate(zip(host, dev))]
+    # the stacking kernel alone: device, pinned and mixed sources, 1..32 clouds, an empty cloud in the middle
+    flat_h = [c for pr in host for c in pr] + [torch.empty((0, 3)).pin_memory()] + [host[0][0][:7]]
+    flat_d = [c.cuda() for c in flat_h]
+    want = torch.cat(flat_d)
+    assert torch.equal(stack_clouds(flat_h, 'cuda:0'), want) and torch.equal(stack_clouds(flat_d, 'cuda:0'), want)
+    assert torch.equal(stack_clouds([a if i % 3 else b for i, (a, b) in enumerate(zip(flat_h, flat_d))], 'cuda:0'), want)
+    many = [flat_h[i % len(flat_h)] for i in range(70)]  # more than GEOTR_MAX_STACK_CLOUDS: several launches
+    assert torch.equal(stack_clouds(many, 'cuda:0'), torch.cat([c.cuda() for c in many]))
+    torch.cuda.synchronize()
+    runner = ConcurrentRegistration(pipe, lanes=2, stack=3)
+    got = {}
+    for name, pairs in (('dev', dev), ('host', host), ('mixed', mixed)):
+        runner.submit(pairs, lambda i, out, name=name: got.__setitem__((name, i), out))
+    runner.submit(host[:1], lambda i, out: got.__setitem__(('single', i), out))  # a job of one pair: the one-pair entry point
+    runner.drain()
+    torch.cuda.synchronize()
+    runner.close()
+    keys = ('estimated_transform', 'ref_node_corr_indices', 'src_node_corr_indices', 'matching_scores', 'ref_feats_c', 'src_feats_f',
+            'ref_corr_points', 'corr_scores', 'ref_points', 'src_points')
+    for i in range(len(items)):
+        for name in ('host', 'mixed'):
+            for k in keys:
+                assert torch.equal(got[('dev', i)][k], got[(name, i)][k]), (name, i, k)
+    assert torch.equal(got[('single', 0)]['estimated_transform'], pipe(*dev[0])['estimated_transform'])
+    with pytest.raises(ValueError):  # pageable host memory is refused (the copy would not be asynchronous)
+        runner2 = ConcurrentRegistration(pipe, lanes=1, stack=2)
+        try:
+            pageable = (torch.from_numpy(items[0]['ref_points']), torch.from_numpy(items[0]['src_points']))
+            runner2.submit([pageable] * 2, lambda i, out: None)
+            runner2.drain()
+        finally:
+            runner2.close()
