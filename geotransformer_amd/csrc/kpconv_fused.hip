@@ -20,8 +20,14 @@
 //            per step (a_hi b_lo + a_lo b_hi + a_hi b_hi) against the SAME packed weight planes geotr_gemm_pack builds for the
 //            two-kernel path, streamed fragment by fragment from L2.  Waves split (column tile, K range); the K partials meet in
 //            LDS, the epilogue (/ count + bias) writes whole rows.
-// Supported: C_in in {32, 64} (the stage-0 .. 2 layers: three quarters of the backbone's KPConv work), C_out a multiple of 32 with
-// C_out / 32 dividing the wave count, H <= 40.  Everything else stays on the two-kernel path.
+// Wider layers (round 5: C_in = 128, 256, ... = NH channel blocks of 64) run the same tile NH times: block h takes channels
+// 64 h .. 64 h + 63 of every neighbour row through phase 1 into the SAME LDS tile and phase 2 adds its 15 x 64 slice of the contraction
+// (rows k C_in + 64 h + c of the packed weight) to the accumulators it keeps across the blocks -- the (M, 15 C_in) operand of those
+// layers (207 + 128 MB per 8-pair stack, profiles/r04_pmc_hbm_traffic_fp32.md) never exists, and LDS stays at the 64-channel size.
+// Supported: C_in = 32 or a multiple of 64, C_out a multiple of 32 with C_out / 32 dividing the wave count (32 .. 256), H <= 40.
+// Everything else stays on the two-kernel path.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace geotr {
@@ -46,11 +52,13 @@ struct FVec<4> {
 // C = C_in; WAVES = waves per workgroup; TERMS = 3 split-bf16 / 1 plain bf16 (hi planes only) / 0 exact fp32: the tile A stays fp32
 // in LDS (same bytes as its hi + lo halves) and phase 2 runs v_mfma_f32_32x32x2_f32 against the weight packed by geotr_gemm_pack_f32
 // (gemm.hip: four steps of an 8-deep group per 16-byte fragment) -- the reference's own arithmetic end to end (round 4).
-template <int C, int WAVES, int TERMS>
+// MULTI: the layer has several channel blocks (c_total = NH C, NH > 1); false: c_total == C and the block loop is a single pass at
+// compile time (phase 2's accumulators are then not live across phase 1: the register allocation of the C_in = 32 / 64 layers is unchanged).
+template <int C, int WAVES, int TERMS, bool MULTI>
 __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
                                                                   const float* __restrict__ sp, const int64_t* __restrict__ nb,
                                                                   const float* __restrict__ kp, const unsigned char* __restrict__ pos,
-                                                                  int64_t M, int64_t Ns, int H, float sigma, int c_out, int KS, int NT,
+                                                                  int64_t M, int64_t Ns, int H, float sigma, int c_total, int c_out, int KS, int NT,
                                                                   const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo,
                                                                   const float* __restrict__ bias, const int* __restrict__ order,
                                                                   float* __restrict__ out) {
@@ -82,6 +90,10 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   const int KPARTS = WAVES / CT;        // K ranges of phase 2
   const int ct = wave % CT, kpart = wave / CT;
   const int nkk = F32 ? K / 8 : K / 16;  // 16-deep steps of phase 2 (K % 32 == 0); fp32: 8-deep groups of four 32x32x2 steps
+  // channel blocks (c_total = NH C): steps of a block's LOCAL contraction index -> steps of the packed weight, whose rows are k c_total + c
+  const int NH = MULTI ? c_total / C : 1;
+  constexpr int GP = F32 ? C / 8 : C / 16;           // steps per kernel point inside a block
+  const int gp_total = MULTI ? (F32 ? c_total / 8 : c_total / 16) : GP;  // steps per kernel point of the packed weight
   const int kk_per = (nkk + KPARTS - 1) / KPARTS;
   const int kk0 = kpart * kk_per, kk1 = min(nkk, kk0 + kk_per);
 
@@ -104,6 +116,10 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
     const int64_t m0 = tile * kFusedRows;
     const int rows_nxt = tile + 1 < tile_end ? load_rows(tile + 1) : 0;  // in flight under this tile's work
     if (lane < PPW) row_s[wave * PPW + lane] = rows_cur;                 // read by the epilogue, three barriers later
+    f32x16 acc2;  // phase 2's accumulators: kept across the channel blocks
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    for (int hb = 0; hb < NH; ++hb) {  // ---- channel block hb: channels C hb .. C hb + C - 1 of every neighbour row
     // ------------------------------------------------------------------ phase 1: g = w . f per point, software-pipelined over the wave's points
     // Three dependent global round trips lead to a point's first MFMA (neighbour index -> support position -> feature row); done
     // one point after the other they cost ~2 us each and the kernel was latency-bound at 3.7x its matrix-pipe time.  Pipeline:
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
           const float dx = rv.x - kx, dy = rv.y - ky, dz = rv.z - kz;
           a[u] = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);  // as kpconv_gather_kernel
         }
-        const float* fr = feats + (unsigned)((ok ? id : 0) * C + VEC * n16);  // < 2^31 elements (checked by the host)
+        const float* fr = feats + (unsigned)((ok ? id : 0) * (MULTI ? c_total : C) + C * hb + VEC * n16);  // < 2^31 elements (checked by the host)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const typename FVec<VEC>::T v = *reinterpret_cast<const typename FVec<VEC>::T*>(fr + 16 * VEC * g);
@@ -218,10 +234,8 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
       }
     }
     __syncthreads();  // A tile complete
-    // ------------------------------------------------------------------ phase 2: out = A . W  (this wave: column tile ct, steps kk0 .. kk1)
-    f32x16 acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    // ------------------------------------------------------------------ phase 2: out += A . W  (this wave: column tile ct, steps kk0 .. kk1)
+    auto wstep = [&](int q) { return MULTI ? (q / GP) * gp_total + hb * GP + (q % GP) : q; };  // local step -> step of the packed weight
     if constexpr (F32) {
       // group q: lane (fr, fk) holds A[fr][8 q + 4 fk + e] and W[8 q + 4 fk + e][32 ct + fr], e = 0 .. 3 = its operands of four steps
       const float* a32 = A_32 + (lane & 31) * RS32 + 4 * (lane >> 5);
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
 #pragma unroll 2
       for (int q = kk0; q < kk1; ++q) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(a32 + 8 * q);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(b32 + (int64_t)q * 256);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b32 + (int64_t)wstep(q) * 256);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc2, 0, 0, 0);
       }
@@ -243,17 +257,18 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
 #pragma unroll 2
       for (int kk = kk0; kk < kk1; ++kk) {
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_hi + 16 * kk);
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_hi + (int64_t)kk * 512);
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_hi + (int64_t)wstep(kk) * 512);
         if constexpr (TERMS == 3) {
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(a_lo + 16 * kk);
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_lo + (int64_t)kk * 512);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_lo + (int64_t)wstep(kk) * 512);
           acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
           acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
         }
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2, 0, 0, 0);
       }
     }
-    __syncthreads();  // every wave has read its A fragments: the tile's memory now takes the K partials
+    __syncthreads();  // every wave has read its A fragments: the tile's memory takes the next channel block / the K partials
+    }  // channel blocks
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[(wave * 16 + r) * 64 + lane] = acc2[r];
     __syncthreads();
@@ -378,7 +393,12 @@ using namespace geotr;
 extern "C" {
 
 int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h) {
-  if (!(c_in == 32 || c_in == 64) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 4 * kMaxSteps) return 0;
+  static const bool wide = [] {
+    const char* e = std::getenv("GEOTR_KPCONV_FUSED_WIDE");  // A/B switch for measurements: 0 keeps C_in > 64 on the two-kernel path
+    return !(e && e[0] == '0');
+  }();
+  if (c_in > 64 && !wide) return 0;
+  if (!(c_in == 32 || (c_in >= 64 && c_in % 64 == 0 && c_in <= 4096)) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 4 * kMaxSteps) return 0;
   const int waves = 8;
   const int64_t ct = c_out / 32;
   return ct <= waves && waves % ct == 0;
@@ -421,28 +441,33 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
   const unsigned short* blo = bhi + np_pad * kp_pad;
   const int KS = (int)(kp_pad / 16), NT = (int)(np_pad / 32);
   const int waves = 8;
-  const size_t lds = (size_t)2 * kFusedRows * (kdim + 8) * 2 + (size_t)waves * 128 * 16 + 2 * kFusedRows * 4;
+  const int64_t cb = c_in == 32 ? 32 : 64;  // channel block: what one pass of a tile holds in LDS
+  const size_t lds = (size_t)2 * kFusedRows * (15 * cb + 8) * 2 + (size_t)waves * 128 * 16 + 2 * kFusedRows * 4;
   const int64_t tiles = (m + kFusedRows - 1) / kFusedRows;
   // persistent: a few tiles per resident workgroup; a multiple of 8 blocks, one share of the tile range per XCD
   const unsigned grid = (unsigned)((std::min<int64_t>(tiles, 256 * (c_in == 32 ? 8 : 4)) + 7) / 8 * 8);
-#define GEOTR_KPF(CC, WW, TT)                                                                                                      \
+#define GEOTR_KPF(CC, WW, TT, MM)                                                                                                  \
   do {                                                                                                                             \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<CC, WW, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<CC, WW, TT, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)lds) != hipSuccess)                                                                               \
       return fail(GEOTR_E_LAUNCH, "kpconv_fused: cannot reserve %zu B of LDS", lds);                                               \
-    kpconv_fused_kernel<CC, WW, TT><<<dim3(grid), dim3(64 * WW), lds, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points,  \
-                                                                               pos_flag, m, ns, (int)h, sigma, (int)c_out, KS, NT, bhi, \
+    kpconv_fused_kernel<CC, WW, TT, MM><<<dim3(grid), dim3(64 * WW), lds, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points,  \
+                                                                               pos_flag, m, ns, (int)h, sigma, (int)c_in, (int)c_out, KS, NT, bhi, \
                                                                                blo, bias, order, out);                             \
   } while (0)
   GEOTR_CHECK_ARG(bf16_operands >= 0 && bf16_operands <= 2, "kpconv_fused: arithmetic mode must be 0 (split-bf16), 1 (bf16) or 2 (fp32)");
   if (c_in == 32) {  // 8 waves in both widths: two resident workgroups at c_in = 32 give 4 waves per SIMD, the LDS tile allows no more
-    if (bf16_operands == 2) GEOTR_KPF(32, 8, 0);
-    else if (bf16_operands == 1) GEOTR_KPF(32, 8, 1);
-    else GEOTR_KPF(32, 8, 3);
-  } else {
-    if (bf16_operands == 2) GEOTR_KPF(64, 8, 0);
-    else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1);
-    else GEOTR_KPF(64, 8, 3);
+    if (bf16_operands == 2) GEOTR_KPF(32, 8, 0, false);
+    else if (bf16_operands == 1) GEOTR_KPF(32, 8, 1, false);
+    else GEOTR_KPF(32, 8, 3, false);
+  } else if (c_in == 64) {
+    if (bf16_operands == 2) GEOTR_KPF(64, 8, 0, false);
+    else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1, false);
+    else GEOTR_KPF(64, 8, 3, false);
+  } else {  // several channel blocks of 64
+    if (bf16_operands == 2) GEOTR_KPF(64, 8, 0, true);
+    else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1, true);
+    else GEOTR_KPF(64, 8, 3, true);
   }
 #undef GEOTR_KPF
   GEOTR_CHECK_LAUNCH("kpconv_fused");

@@ -173,7 +173,8 @@ int geotr_stack_clouds(const float* const* clouds, const int64_t* rows, int64_t 
   s.count = (int)count;
   s.word0[0] = 0;
   for (int64_t i = 0; i < count; ++i) {
-    GEOTR_CHECK_ARG(clouds[i] && rows[i] >= 0 && (reinterpret_cast<uintptr_t>(clouds[i]) & 3) == 0, "stack_clouds: cloud %lld is null, unaligned or negative-sized", (long long)i);
+    GEOTR_CHECK_ARG(rows[i] >= 0 && (clouds[i] || rows[i] == 0) && (reinterpret_cast<uintptr_t>(clouds[i]) & 3) == 0,
+                    "stack_clouds: cloud %lld is null, unaligned or negative-sized", (long long)i);
     s.src[i] = reinterpret_cast<const uint32_t*>(clouds[i]);
     s.word0[i + 1] = s.word0[i] + 3 * rows[i];
   }
