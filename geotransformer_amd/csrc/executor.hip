@@ -172,22 +172,6 @@ static float* norm(Ctx& c, const geotr_norm& nm, const float* x, int64_t n, int6
   return y;
 }
 
-// Rows of a KPConv layer processed per gather -> GEMM round.  The (rows, 15 C_in) gathered operand is written by one kernel and read
-// by the next; the idea of bounding it to a few tens of MB so that it stays in the 256 MB Infinity Cache between the two was MEASURED
-// not to pay (profiles/r02_ab_runs.md: 918 pairs/s unchunked, 912 at 48 MB, 896 at 16 MB -- with four lanes in flight the cache is
-// shared by four such operands and the extra launches cost more than the traffic saved), so the default is one round per layer;
-// GEOTR_KPCONV_CHUNK_MB=<MB> enables the chunking for experiments.
-static int64_t kpconv_chunk_rows(int64_t m, int64_t kdim) {
-  static const int64_t budget_mb = [] {
-    const char* e = std::getenv("GEOTR_KPCONV_CHUNK_MB");
-    return e ? (int64_t)std::atoll(e) : (int64_t)0;
-  }();
-  if (budget_mb <= 0) return m;
-  int64_t rows = budget_mb * (1 << 20) / (4 * kdim);
-  rows = std::max<int64_t>(rows / 2048 * 2048, 8192);  // whole GEMM tiles, and never a launch too small to fill the chip
-  return rows >= m || m - rows < 4096 ? m : rows;
-}
-
 // `s_flags` (optional): (row sum > 0) of s_feats, already produced by the GroupNorm that wrote them; else computed here
 // `order`: visiting order of the m query rows (the grid order of their stage) or null
 static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64_t ns, const float* q_pts, int64_t m,
@@ -195,7 +179,6 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
   float* out = c.alloc<float>((size_t)m * kp.out);
   const size_t mk = c.mark();
   const int64_t kdim = kp.num_kernel_points * kp.in;
-  const int64_t chunk = kpconv_chunk_rows(m, kdim);
   const uint8_t* flag = s_flags;
   if (kp.in > 1 && !flag) {
     uint8_t* f = c.alloc<uint8_t>((size_t)ns);
@@ -207,11 +190,7 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     const char* e = std::getenv("GEOTR_KPCONV_FUSED");  // A/B switch for measurements: GEOTR_KPCONV_FUSED=0 keeps the two-kernel path
     return !(e && e[0] == '0');
   }();
-  static const bool c1_fused_enabled = [] {
-    const char* e = std::getenv("GEOTR_KPCONV_C1_FUSED");  // A/B switch of the first-layer kernel alone
-    return !(e && e[0] == '0');
-  }();
-  if (fused_enabled && c1_fused_enabled && kp.in == 1 && kp.num_kernel_points == 15 && h <= 64) {  // first layer: exact fp32, bitwise the two-kernel result
+  if (fused_enabled && kp.in == 1 && kp.num_kernel_points == 15 && h <= 64) {  // first layer: exact fp32, bitwise the two-kernel result
     if (c.live())
       c.check(geotr_kpconv_c1_fused(s_feats, q_pts, s_pts, nb, kp.kernel_points, m, ns, h, kp.out, kp.num_kernel_points, kp.sigma, kp.weights,
                                     kp.bias, order, out, c.stream));
@@ -229,20 +208,17 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     c.release(mk);
     return out;
   }
-  float* weighted = c.alloc<float>((size_t)chunk * kdim);
+  // two-kernel path (shapes the fused kernel does not take): the (m, 15 c_in) operand is written once and read by the GEMM.  (Bounding
+  // it to an Infinity-Cache-sized chunk per round was measured not to pay -- profiles/r02_ab_runs.md -- and the switch is gone.)
+  float* weighted = c.alloc<float>((size_t)m * kdim);
   int32_t* nnum = c.alloc<int32_t>((size_t)m);
-  for (int64_t r0 = 0; r0 < m; r0 += chunk) {
-    const int64_t rows = std::min(chunk, m - r0);
-    if (c.live())
-      c.check(geotr_kpconv_gather(s_feats, q_pts + 3 * r0, s_pts, nb + r0 * h, kp.kernel_points, flag, rows, ns, h, kp.in, kp.num_kernel_points,
-                                  kp.sigma, weighted, nnum + r0, c.stream));
-    float* o = out + r0 * kp.out;
-    if (use_packed(kp.packed, weighted, kdim, rows, kdim))
-      c.check(packed_gemm(c, weighted, kdim, kp.packed, o, kp.out, rows, kp.out, kdim, kp.bias, nnum + r0, nullptr, 0, 1.0f, 0, c.stream));
-    else if (c.live())
-      c.check(geotr_gemm(weighted, kdim, kp.weights, kp.out, 1, o, kp.out, rows, kp.out, kdim, 1, 0, 0, 0, kp.bias, nnum + r0, nullptr, 0, 1.0f,
-                         0, c.stream));
-  }
+  if (c.live())
+    c.check(geotr_kpconv_gather(s_feats, q_pts, s_pts, nb, kp.kernel_points, flag, m, ns, h, kp.in, kp.num_kernel_points, kp.sigma, weighted, nnum,
+                                c.stream));
+  if (use_packed(kp.packed, weighted, kdim, m, kdim))
+    c.check(packed_gemm(c, weighted, kdim, kp.packed, out, kp.out, m, kp.out, kdim, kp.bias, nnum, nullptr, 0, 1.0f, 0, c.stream));
+  else if (c.live())
+    c.check(geotr_gemm(weighted, kdim, kp.weights, kp.out, 1, out, kp.out, m, kp.out, kdim, 1, 0, 0, 0, kp.bias, nnum, nullptr, 0, 1.0f, 0, c.stream));
   c.release(mk);
   return out;
 }
@@ -278,66 +254,9 @@ static float* block(Ctx& c, const geotr_block& b, const float* s_feats, int64_t 
     const char* e = std::getenv("GEOTR_GN_SHORTCUT_FUSED");  // A/B switch for measurements: 0 = normalise the shortcut in its own pass
     return !(e && e[0] == '0');
   }();
-  static const bool tail_fused = [] {
-    // OPT-IN experiment (GEOTR_TAIL_FUSED=1), off by default: measured 2-3 % SLOWER than the apply-pass path below (1 067 / 1 062 vs
-    // 1 084 / 1 091 pairs/s, one lane 829 vs 857; profiles/r03_ab_runs.md) -- launching each small-K product twice costs more than the two
-    // passes over (m, C_out) it saves.  Kept as a switch together with its entry points (geotr_gemm_packed_tail,
-    // geotr_group_norm_finalize: bit-identical to the apply path in the unit test) so that the negative result can be re-measured.
-    const char* e = std::getenv("GEOTR_TAIL_FUSED");
-    return e && e[0] == '1';
-  }();
-  // ---- the block's tail  leaky(GN(unary2(y)) + shortcut)  WITHOUT an apply pass (round 3; opt-in, see the switch above) -------------
-  // unary2(y) and the shortcut Linear are small-K products (K = C/4 and C_in): writing them, re-reading them for the normalisation and
-  // writing the block output costs 5 passes over (m, C_out); here each product is launched twice -- once for its GroupNorm statistics
-  // only (nothing stored), once more with the finalised per-column scale / shift applied in its epilogue -- so only the block output
-  // (and, with a shortcut Linear, one normalised partial) is ever written: 2-3 passes.  Value for value the arithmetic of the apply
-  // kernel (multiply, add, add, LeakyReLU), so the result is bit-identical to the path below.  Needs both products on the unsplit
-  // packed path and GroupNorms on both (every reference config).
-  auto tail_ok = [&](const geotr_linear& l, const geotr_norm& nm, const float* a, int64_t lda) {
-    return nm.groups > 0 && use_packed(l.packed, a, lda, m, l.in) && geotr_gemm_packed_splits(m, l.out, l.in, 0) == 1;
-  };
-  if (tail_fused && gn_epilogue_stats && tail_ok(b.unary2, b.unary2_norm, y, b.unary2.in) &&
-      (!b.has_shortcut || (fuse_shortcut_norm && b.shortcut.out == b.unary2.out && tail_ok(b.shortcut, b.shortcut_norm, sc, b.shortcut.in)))) {
-    const int64_t C = b.unary2.out;
-    const int bf16 = c.gemm_mode;
-    float* out = c.alloc<float>((size_t)m * C);
-    const size_t mk = c.mark();
-    const size_t rec_floats = geotr_gemm_packed_stats_floats(c.seg_rows[q_stage], c.nseg, C);
-    const int64_t rpr = geotr_gemm_packed_stats_rows_per_record(C);
-    float* rec = c.alloc<float>(rec_floats);
-    float* ab_z = c.alloc<float>((size_t)c.nseg * 2 * C);
-    float* ab_t = b.has_shortcut ? c.alloc<float>((size_t)c.nseg * 2 * C) : nullptr;
-    float* part = b.has_shortcut ? c.alloc<float>((size_t)m * C) : nullptr;
-    if (c.live()) {
-      // statistics of z = unary2(y), then of t = shortcut(sc): the records are free again once their finalize kernel has run
-      c.check(geotr_gemm_packed_tail(y, b.unary2.in, b.unary2.packed, nullptr, C, m, C, b.unary2.in, b.unary2.b, 0, bf16, c.seg_rows[q_stage], c.nseg,
-                                     rec, nullptr, nullptr, 0, c.stream));
-      c.check(geotr_group_norm_finalize(rec, rpr, m, C, b.unary2_norm.groups, b.unary2_norm.gamma, b.unary2_norm.beta, b.unary2_norm.eps,
-                                        c.seg_rows[q_stage], c.nseg, ab_z, c.stream));
-      if (b.has_shortcut) {
-        c.check(geotr_gemm_packed_tail(sc, b.shortcut.in, b.shortcut.packed, nullptr, C, m, C, b.shortcut.in, b.shortcut.b, 0, bf16,
-                                       c.seg_rows[q_stage], c.nseg, rec, nullptr, nullptr, 0, c.stream));
-        c.check(geotr_group_norm_finalize(rec, rpr, m, C, b.shortcut_norm.groups, b.shortcut_norm.gamma, b.shortcut_norm.beta, b.shortcut_norm.eps,
-                                          c.seg_rows[q_stage], c.nseg, ab_t, c.stream));
-        // part = GN(z);  out = leaky(GN(t) + part)
-        c.check(geotr_gemm_packed_tail(y, b.unary2.in, b.unary2.packed, part, C, m, C, b.unary2.in, b.unary2.b, 0, bf16, c.seg_rows[q_stage], c.nseg,
-                                       nullptr, ab_z, nullptr, 0, c.stream));
-        ProfScope prof(c.stream);
-        c.check(geotr_gemm_packed_tail(sc, b.shortcut.in, b.shortcut.packed, out, C, m, C, b.shortcut.in, b.shortcut.b, 2, bf16, c.seg_rows[q_stage],
-                                       c.nseg, nullptr, ab_t, part, C, c.stream));
-        if (m < (1 << 24) && C < (1 << 12) && b.shortcut.in < (1 << 14)) prof.done(kProfGemm | kProfResidual | (m << 26) | (C << 14) | b.shortcut.in);
-        else prof.done(0);
-      } else {  // identity shortcut (the block input, or its max-pool): out = leaky(GN(z) + sc)
-        ProfScope prof(c.stream);
-        c.check(geotr_gemm_packed_tail(y, b.unary2.in, b.unary2.packed, out, C, m, C, b.unary2.in, b.unary2.b, 2, bf16, c.seg_rows[q_stage], c.nseg,
-                                       nullptr, ab_z, sc, C, c.stream));
-        if (m < (1 << 24) && C < (1 << 12) && b.unary2.in < (1 << 14)) prof.done(kProfGemm | kProfResidual | (m << 26) | (C << 14) | b.unary2.in);
-        else prof.done(0);
-      }
-    }
-    c.release(mk);
-    return out;
-  }
+  // (The block's tail without an apply pass -- each small-K product launched twice, once for its statistics and once with the finalised
+  // scale / shift in its epilogue -- was built in round 3, measured 2-3 % slower than the path below and removed from the executor in
+  // round 5; its entry points geotr_gemm_packed_tail / geotr_group_norm_finalize stay in the ABI with their bit-identity test.)
   if (b.has_shortcut) {
     GnStats st_sc;
     float* t = b.shortcut_norm.groups > 0 ? linear_gn(c, b.shortcut, sc, b.shortcut.in, m, q_stage, st_sc) : linear(c, b.shortcut, sc, b.shortcut.in, m, 0);

@@ -61,11 +61,7 @@ struct GatherRes {
 // `stats_rec` (optional): this wave's GroupNorm record -- per column the sum and the sum of squares of the values it STORES, over its
 // 32 * WM rows in ascending row order per lane, lanes combined by a fixed xor tree: [0, N) sums, [N, 2N) sums of squares (rows past M
 // and columns past N contribute nothing; a wave entirely past M writes zeros).  The record is a function of the tile's rows alone.
-// PIECE (round 4): rows that travel through the slab at a time -- 32 * WM (default: the whole accumulator block, slab of (32 * WM) x
-// (32 * WN + 4) floats) or 8 (the persistent kernel: a slab of 8 x (32 * WN + 4) floats per wave that is NOT carved from the staging
-// ring, so the ring keeps loading the next tile under the epilogue).  Either way a lane visits its rows in the same ascending sequence
-// (rl, rl + RPI, ...), so the values stored and the statistics records are the same bits.
-template <int WM, int WN, int PIECE = 32 * WM>
+template <int WM, int WN>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float* slab, int lane, int row0, int col0, int M, int N,
                                              float alpha, const float* __restrict__ bias, const int32_t* __restrict__ row_div,
                                              const float* __restrict__ residual, int64_t ldr, int act, float* __restrict__ C, int64_t ldc,
@@ -73,18 +69,16 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
                                              const float* __restrict__ col_affine = nullptr) {
   constexpr int TW = 32 * WN, TS = TW + 4;
   const int fr = lane & 31, fk = lane >> 5;
-  static_assert(PIECE == 32 * WM || PIECE == 8, "whole block or 8-row pieces");
-  if constexpr (PIECE == 32 * WM) {
+  constexpr int PIECE = 32 * WM;  // the whole accumulator block travels through the slab of (32 * WM) x (32 * WN + 4) floats at once
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+    for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk) * TS + 32 * j + fr] = acc[i][j][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
+      for (int r = 0; r < 16; ++r) slab[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk) * TS + 32 * j + fr] = acc[i][j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   constexpr int V4 = TW / 4, RPI = 64 / V4;  // float4 per row, rows per wave instruction
   const int cq = (lane % V4) * 4, rl = lane / V4;
   const int gn = col0 + cq;
@@ -112,26 +106,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
   float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
   static_assert(PIECE % RPI == 0, "a piece holds whole row groups of a wave instruction");
 #pragma unroll 1
-  for (int pb = 0; pb < 32 * WM; pb += PIECE) {  // one trip with the whole-block slab
-  if constexpr (PIECE != 32 * WM) {
-    // registers r = 4 q .. 4 q + 3 of row tile i hold its rows 8 q + (r & 3) + 4 fk: piece (i, q) -> slab rows (r & 3) + 4 fk
-    const int i = pb >> 5, q = (pb >> 3) & 3;
-#pragma unroll
-    for (int ii = 0; ii < WM; ++ii)
-      if (ii == i) {
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq)
-            if (qq == q) {
-#pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4) slab[(r4 + 4 * fk) * TS + 32 * j + fr] = acc[ii][j][4 * qq + r4];
-            }
-      }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
+  for (int pb = 0; pb < 32 * WM; pb += PIECE) {
 #pragma unroll 4
   for (int rs = rl; rs < PIECE; rs += RPI) {
     const int rr = pb + rs;
@@ -198,12 +173,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
       }
     }
   }
-  if constexpr (PIECE != 32 * WM) {  // the next piece overwrites the slab: every lane's reads above come first
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  }  // pieces
+  }  // (single trip: kept as a loop so that the row loop inside keeps its unroll-by-4 form)
   if (stats_rec) {  // (wave-uniform: every lane takes part in the shuffles)
 #pragma unroll
     for (int o = V4; o < 64; o <<= 1)
@@ -606,7 +576,6 @@ struct PackedArgs {
   // row tile run back to back on ONE XCD and share the activation tile through that XCD's L2 (with blockIdx.x = column block they
   // landed on nx different XCDs and every one of them fetched the A tile from HBM: N = 512 read A four times).
   int nx, ny, tiles_per_xcd;
-  int stagger;  // experiment (GEOTR_GEMM_STAGGER=1): the blocks that fill the second resident slot of each CU start half a block late
 };
 
 __global__ void gemm_pack_kernel(const float* __restrict__ B, int64_t ldb, int b_is_kn, int N, int K, int KS, int64_t nvec,
@@ -656,7 +625,7 @@ __global__ void gemm_pack_f32_kernel(const float* __restrict__ B, int64_t ldb, i
 // fragment (v_cvt_pk_bf16_f32).  One barrier per 32-deep stage: each wave issues its share of the stage's DMA (4 activation
 // chunks + its round-robin share of the weight chunks), waits on its own vmcnt, and the barrier publishes the stage to the other
 // waves; see the schedule note at the main loop for where that barrier sits.
-constexpr int kPStagesDefault = 2;  // 2 stages = 64-70 KB of LDS: two blocks per CU overlap each other's load / MFMA phases (4 stages with
+// (2 stages = 64-70 KB of LDS: two blocks per CU overlap each other's load / MFMA phases (4 stages with
                              // one block per CU was slower on the tall shapes: 58 vs 45 us for 40000x256x384)
 #define GEOTR_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | (((N) >> 4) << 14) | 0x0F70)
 // LDS reads of DMA-written data go through inline asm: the compiler's own waitcnt insertion would otherwise drain ALL
@@ -674,19 +643,6 @@ __device__ __forceinline__ void lds_issue2(unsigned addr, u32x4& r0, u32x4& r1) 
 __device__ __forceinline__ void lds_issue1(unsigned addr, u32x4& r0) {
   asm volatile("ds_read_b128 %0, %1" : "=&v"(r0) : "v"(addr) : "memory");
 }
-// BREG: a 16-byte weight fragment straight from global memory (L2) into its register, issued and waited for by hand like the LDS reads
-// (a plain C++ load makes the compiler's waitcnt pass drain the queue -- s_waitcnt vmcnt(0) in front of the first MFMA, the activation
-// DMA included -- because it does not count across this loop's conditional DMA issue).  vmcnt retires in order: vm_wait<N> returns when at
-// most N younger VMEM operations (the DMA instructions of the next stage) are still outstanding.
-__device__ __forceinline__ void gl_issue(const void* p, u32x4& r0) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r0) : "v"(p) : "memory"); }
-template <int N>
-__device__ __forceinline__ void vm_wait(u32x4& r0, u32x4& r1) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void vm_wait(u32x4& r0, u32x4& r1, u32x4& r2, u32x4& r3) {
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(N) : "memory");
-}
 __device__ __forceinline__ void lds_wait(u32x4& r0) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0) : : "memory"); }
 __device__ __forceinline__ void lds_wait(u32x4& r0, u32x4& r1) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1) : : "memory"); }
 __device__ __forceinline__ void lds_wait(u32x4& r0, u32x4& r1, u32x4& r2, u32x4& r3) {
@@ -699,44 +655,23 @@ __device__ __forceinline__ void lds_wait(u32x4& r0, u32x4& r1, u32x4& r2, u32x4&
 // STAGES = slots of the LDS ring (2: two blocks per CU overlap each other; 3: one block per CU with the loads of TWO stages in flight
 // under the MFMAs -- the exact-fp32 deep-K launches, whose 4 096-cycle stages leave one stage of prefetch short of the HBM latency
 // under load while a third slot costs nothing the matrix pipe needs)
-// PERSIST (round 4): the block walks SEVERAL tiles of its XCD's tile list (a grid of 2 resident blocks per CU).  After the last stage of
-// a tile it starts the DMA of the NEXT tile's first two stages and only then runs the epilogue -- through a wave-private 8-row slab that is
-// not carved from the ring (epilogue_lds<.., 8>) -- so the loads of tile t + 1 and the stores of tile t overlap, and the launch cost, the
-// first-load latency and the grid's last partial round are paid once per block instead of once per tile.  Two-slot ring, unsplit only.
-// BREG (round 4, exact fp32 only, OPT-IN: GEOTR_GEMM_BREG=1): the weight fragments do not travel through LDS.  They are a wave's private
-// 16-byte vectors in the packed plane (1 KB per wave instruction, contiguous, L2-resident: the whole weight is at most a few MB), so each
-// wave loads the fragments of step s + 1 straight into the registers the LDS path would read them into, one step (2 048 matrix cycles)
-// ahead, with counted vmcnt waits the compiler inserts (the loads are plain C++: the activation DMA that follows them in program order
-// stays in flight across the wait).  The ring then holds the activation tile only (2 x 16 KB) and the epilogue goes through the 8-row
-// slabs beside it: 41 KB per block instead of 70 -- THREE blocks per CU (the kernel stays within 512 / 3 = 168 registers) instead of two.  Same operand
-// values, same MFMA order: bit-identical to the LDS form.
-template <int WM, int WN, int TERMS, int STAGES = 2, bool PERSIST = false, bool BREG = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BREG ? 3 : 1)))  // BREG: at most 512 / 3 = 168 registers (1 = the default)
+template <int WM, int WN, int TERMS, int STAGES = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1)))
 void gemm_packed_kernel(PackedArgs g) {
   constexpr int kPStages = STAGES;
-  static_assert(!PERSIST || STAGES == 2, "the persistent form uses the two-slot ring");
-  static_assert(!BREG || (TERMS == 0 && STAGES == 2 && !PERSIST), "weight fragments from L2: exact-fp32, two-slot, one tile per block");
   constexpr int BM = 128, PLANES = TERMS == 1 ? 1 : 2;
   constexpr bool F32 = TERMS == 0;
   constexpr int WAVES_M = BM / (32 * WM), WAVES_N = 4 / WAVES_M, NT_BLK = WN * WAVES_N;  // column tiles per block
-  constexpr int A_BYTES = BM * 128, B_BYTES = BREG ? 0 : NT_BLK * PLANES * 2 * 1024, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = BM * 128, B_BYTES = NT_BLK * PLANES * 2 * 1024, STAGE = A_BYTES + B_BYTES;
   constexpr int B_INSTR = NT_BLK * PLANES * 2;     // 1 KB weight chunks per stage: (plane, ct, kk)
-  constexpr int B_PER_WAVE = BREG ? 0 : (B_INSTR + 3) / 4;    // issued round-robin by the 4 waves
+  constexpr int B_PER_WAVE = (B_INSTR + 3) / 4;    // issued round-robin by the 4 waves
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware tile order (PackedArgs): this block's (column block, row tile) -- its FIRST one in the persistent form
+  // XCD-aware tile order (PackedArgs): this block's (column block, row tile)
   const int xcd = (int)blockIdx.x & 7;
   const int tile_end = min(g.nx * g.ny, (xcd + 1) * g.tiles_per_xcd);
-  const int tile_step = PERSIST ? (int)(gridDim.x >> 3) : (1 << 30);
-  int tile = xcd * g.tiles_per_xcd + ((int)blockIdx.x >> 3);
+  const int tile = xcd * g.tiles_per_xcd + ((int)blockIdx.x >> 3);
   if (tile >= tile_end) return;  // (uniform per block: before any barrier)
-  if (g.stagger && abs(g.stagger) < 100 && blockIdx.z == 0 &&
-      (g.stagger > 0 ? (((int)blockIdx.x >> 3) >= 32 && ((int)blockIdx.x >> 3) < 64) : ((((int)blockIdx.x >> 3) & 1) && ((int)blockIdx.x >> 3) < 64))) {
-    // the first 32 blocks of an XCD take one slot of its 32 CUs each, the next 32 the second slot: delay those by ~half a block's
-    // matrix time so that the two co-resident blocks of a CU are out of phase (one computes while the other loads / stores)
-    const int naps = abs(g.stagger) * min(g.kt_split, g.KS / 2) / 2;
-    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   // geometry of a tile: first column tile, first row, end of its row segment, segment index, row-tile index
   int ct0, m0, m_end, sgi, by;
   auto set_tile = [&](int t) {
@@ -754,13 +689,6 @@ void gemm_packed_kernel(PackedArgs g) {
   const int wrow = (wave / WAVES_N) * 32 * WM, wctl = (wave % WAVES_N) * WN;  // wave's first row / local column tile
   const int fr = lane & 31, fk = lane >> 5;
   const int kt_first = blockIdx.z * g.kt_split;              // this block's K range in 32-deep stages (split-K: gridDim.z slices)
-  // BREG: this lane's 16-byte vector of (column tile j, 8-deep group 0 of the block's K range) in the packed fp32 plane
-  const u32x4* bfrag[WN];
-  if constexpr (BREG) {
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-      bfrag[j] = reinterpret_cast<const u32x4*>(g.Bhi) + ((int64_t)min(ct0 + wctl + j, g.NT - 1) * 2 * g.KS + 4 * kt_first) * 64 + lane;
-  }
   const int nkt = min(g.KS / 2 - kt_first, g.kt_split);     // >= 1 by construction of the grid; `kt` below is relative to kt_first
   const int64_t plane_elems = (int64_t)g.NT * g.KS * 512;  // bf16 elements per plane
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)psm;
@@ -812,26 +740,12 @@ void gemm_packed_kernel(PackedArgs g) {
   // fragment registers of the two 16-deep steps of a stage: step ks lives in set ks (constant after unrolling)
   u32x4 fb[2][2][2];  // [set][plane][column tile]          (fp32: [set][8-deep group of the step][column tile])
   u32x4 fa[2][2][2];  // [set][row tile][16-byte chunk]      (fp32: [set][row tile][8-deep group of the step])
-  auto issue_b = [&](int kt, int ks) {  // BREG: the step's weight fragments, L2 -> registers (groups 2 ks, 2 ks + 1 of stage kt)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int j = 0; j < WN; ++j) gl_issue(bfrag[j] + (int64_t)(4 * kt + 2 * ks + c) * 64, fb[ks][c][j]);
-  };
-  // the step's weight fragments have landed; YOUNGER = VMEM operations issued after them that may stay in flight (the next stage's DMA)
-  auto wait_b = [&](int ks, auto younger) {
-    constexpr int YOUNGER = decltype(younger)::value;
-    if constexpr (WN == 2) vm_wait<YOUNGER>(fb[ks][0][0], fb[ks][1][0], fb[ks][0][1], fb[ks][1][1]);
-    else vm_wait<YOUNGER>(fb[ks][0][0], fb[ks][1][0]);
-  };
   auto issue_reads = [&](int kt, int ks) {
     const unsigned st = lds_base + (kt % kPStages) * STAGE;
     if constexpr (F32) {  // step ks = the stage's groups 2 ks and 2 ks + 1: one 16-byte vector per (group, tile) and operand
-      if constexpr (!BREG) {
-        const unsigned ab = st + A_BYTES + (wctl * 4 + 2 * ks) * 1024 + lane * 16;
-        lds_issue2<1024>(ab, fb[ks][0][0], fb[ks][1][0]);
-        if constexpr (WN == 2) lds_issue2<1024>(ab + 4096, fb[ks][0][1], fb[ks][1][1]);
-      }
+      const unsigned ab = st + A_BYTES + (wctl * 4 + 2 * ks) * 1024 + lane * 16;
+      lds_issue2<1024>(ab, fb[ks][0][0], fb[ks][1][0]);
+      if constexpr (WN == 2) lds_issue2<1024>(ab + 4096, fb[ks][0][1], fb[ks][1][1]);
       const int r = wrow + fr, c0 = 4 * ks + fk;  // group 2 ks + c <-> chunk 2 (2 ks + c) + fk of the row
       const unsigned a0 = st + (r * 8 + (c0 ^ (r & 7))) * 16, a1 = st + (r * 8 + ((c0 + 2) ^ (r & 7))) * 16;
       if constexpr (WM == 2) {
@@ -866,9 +780,7 @@ void gemm_packed_kernel(PackedArgs g) {
   auto wait_reads = [&](int ks) {  // one s_waitcnt lgkmcnt(0) covers the step; the further calls only tie the other registers to it
     if constexpr (WM == 2) lds_wait(fa[ks][0][0], fa[ks][1][0], fa[ks][0][1], fa[ks][1][1]);
     else lds_wait(fa[ks][0][0], fa[ks][0][1]);
-    if constexpr (BREG) {
-      // (wait_b: the weight fragments wait on vmcnt, by count)
-    } else if constexpr (TERMS != 1) {
+    if constexpr (TERMS != 1) {
       if constexpr (WN == 2) lds_wait(fb[ks][0][0], fb[ks][1][0], fb[ks][0][1], fb[ks][1][1]);
       else lds_wait(fb[ks][0][0], fb[ks][1][0]);
     } else {
@@ -917,52 +829,13 @@ void gemm_packed_kernel(PackedArgs g) {
   //   wait R(kt,0) | issue R(kt,1) | M(kt,0) | wait R(kt,1) | stage kt+1 landed + barrier | DMA(kt+2) | issue R(kt+1,0) | M(kt,1)
   // so both steps' LDS reads are in flight under the previous step's MFMAs.  A wave reaches the barrier only after its last read of
   // stage kt has landed in registers, so the slot of stage kt is free for DMA(kt+2) right after it.
-  bool primed = false;  // PERSIST: the first two stages of the current tile were already issued at the end of the previous tile
-  // BREG: the weight loads of a step are issued BEFORE the activation DMA of the same point of the schedule (sched_barrier pins the order):
-  // vmcnt retires in order, so waiting for them (the compiler's counted wait in front of the step's first MFMA) then leaves the younger
-  // DMA -- which needs a whole stage of cover, not a step -- in flight.
-  for (;;) {
-  if constexpr (BREG) {
-    issue_b(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (!primed) issue(0);
-  GEOTR_WAIT_VMCNT(0);  // (primed: stages 0 and 1 of this tile AND the previous tile's stores)
+  issue(0);
+  GEOTR_WAIT_VMCNT(0);
   __builtin_amdgcn_s_barrier();
-  if (!primed) {
 #pragma unroll
-    for (int s_ = 1; s_ < kPStages; ++s_)
-      if (s_ < nkt) issue(s_);
-  }
+  for (int s_ = 1; s_ < kPStages; ++s_)
+    if (s_ < nkt) issue(s_);
   issue_reads(0, 0);
-  if constexpr (BREG) {
-    // The same schedule with the conditional DMA issue peeled out of the loop: every iteration of the loop issues DMA(kt + 2), the
-    // second-to-last stage (no DMA left) is a copy without it.  The queue of outstanding VMEM operations is then the same on every path
-    // into a wait -- W(kt, 0) | DMA(kt + 1) at the top of a stage -- which is what lets scripts/check_inflight_regs.py prove the counted
-    // waits on the ISA (it cannot know that "no DMA issued" implies "the loop ends").
-    auto stage = [&](int kt, auto with_dma) {
-      wait_reads(0);
-      wait_b(0, std::integral_constant<int, DMA_PER_STAGE>{});  // queue: W(kt, 0), DMA(kt + 1) -- the DMA stays in flight
-      issue_b(kt, 1);
-      issue_reads(kt, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(0);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_reads(1);
-      wait_b(1, std::integral_constant<int, 0>{});  // queue: DMA(kt + 1), W(kt, 1): everything (the barrier needs the DMA anyway)
-      GEOTR_WAIT_VMCNT(0);
-      __builtin_amdgcn_s_barrier();  // stage kt+1 complete; every wave holds its stage-kt fragments in registers
-      issue_b(kt + 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (decltype(with_dma)::value) issue(kt + kPStages);  // into the slot of stage kt
-      issue_reads(kt + 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(1);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int kt = 0; kt + 2 < nkt; ++kt) stage(kt, std::true_type{});
-    if (nkt >= 2) stage(nkt - 2, std::false_type{});
-  } else {
   for (int kt = 0; kt + 1 < nkt; ++kt) {
     wait_reads(0);
     issue_reads(kt, 1);
@@ -980,63 +853,28 @@ void gemm_packed_kernel(PackedArgs g) {
     multiply(1);
     __builtin_amdgcn_sched_barrier(0);
   }
-  }
   // last stage, peeled: nothing is left to prefetch, and no fragment read is in flight when the loop is left
   // (scripts/check_inflight_regs.py proves that on the ISA)
   wait_reads(0);
-  if constexpr (BREG) {
-    wait_b(0, std::integral_constant<int, 0>{});  // nothing younger: the last stage's DMA was issued before these loads
-    issue_b(nkt - 1, 1);
-  }
   issue_reads(nkt - 1, 1);
   __builtin_amdgcn_sched_barrier(0);
   multiply(0);
   __builtin_amdgcn_sched_barrier(0);
   wait_reads(1);
-  if constexpr (BREG) wait_b(1, std::integral_constant<int, 0>{});
   __builtin_amdgcn_sched_barrier(0);
   multiply(1);
   __builtin_amdgcn_sched_barrier(0);
 
   // epilogue through LDS (the ring is free once every wave has read the last stage)
   __builtin_amdgcn_s_barrier();
-  if constexpr (PERSIST) {
-    // this tile's geometry for the epilogue, then the NEXT tile's first stages go into the (free) ring before the epilogue runs
-    const int e_m0 = m0, e_ct0 = ct0, e_m_end = m_end, e_sgi = sgi, e_by = by;
-    tile += tile_step;
-    const bool more = tile < tile_end;
-    if (more) {
-      set_tile(tile);
-      set_sources();
-      issue(0);
-      if (1 < nkt) issue(1);
-    }
-    float* slab = reinterpret_cast<float*>(psm + kPStages * STAGE) + wave * (8 * (32 * WN + 4));  // wave-private, beside the ring
-    epilogue_lds<WM, WN, 8>(acc, slab, lane, e_m0 + wrow, 32 * (e_ct0 + wctl), e_m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act,
-                            g.C, g.ldc, g.stats ? g.stats + ((int64_t)e_by * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr, g.gres,
-                            g.seg_affine ? g.seg_affine + (int64_t)e_sgi * 2 * g.N : nullptr);
-    if (!more) return;
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-      for (int j = 0; j < WN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    primed = true;
-    continue;
-  }
-  constexpr int PIECE = BREG ? 8 : 32 * WM;  // BREG: 8-row slabs beside the (activation-only) ring, as in the persistent form
-  float* slab = BREG ? reinterpret_cast<float*>(psm + kPStages * STAGE) + wave * (8 * (32 * WN + 4))
-                     : reinterpret_cast<float*>(psm) + wave * (32 * WM * (32 * WN + 4));
+  float* slab = reinterpret_cast<float*>(psm) + wave * (32 * WM * (32 * WN + 4));
   if (gridDim.z == 1)
-    epilogue_lds<WM, WN, PIECE>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act,
+    epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act,
                                 g.C, g.ldc, g.stats ? g.stats + ((int64_t)by * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr, g.gres,
                                 g.seg_affine ? g.seg_affine + (int64_t)sgi * 2 * g.N : nullptr);
   else  // raw partial sums of this K slice; the epilogue runs in the reduce kernel
-    epilogue_lds<WM, WN, PIECE>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, 1.0f, nullptr, nullptr, nullptr, 0, 0,
+    epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, 1.0f, nullptr, nullptr, nullptr, 0, 0,
                                 g.partial + (int64_t)blockIdx.z * g.M * g.N, g.N);
-  return;
-  }  // tiles
 }
 
 // out = act(alpha * (sum over z, in z order) partial[z] / row_div + bias + residual): the epilogue of a split-K launch.  One float4
@@ -1262,11 +1100,6 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   g.lda = lda; g.ldc = ldc; g.ldr = residual ? ldr : 0;
   g.M = (int)M; g.N = (int)N; g.K = (int)K; g.KS = (int)(kp / 16); g.NT = (int)(np / 32); g.alpha = alpha; g.act = act;
   g.nseg = 0;
-  static const int stagger = [] {
-    const char* e = std::getenv("GEOTR_GEMM_STAGGER");
-    return e ? std::atoi(e) : 0;
-  }();
-  g.stagger = stagger;
   g.stats = stats;
   g.gres = gres ? *gres : GatherRes{nullptr, nullptr, 0, 0, 0};
   g.seg_affine = seg_affine;
@@ -1305,76 +1138,23 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   GEOTR_CHECK_ARG(tiles <= 65535, "gemm_packed: M too large");
 #define GEOTR_PACKED(WM, WN, BN, STG)                                                                                      \
   do {                                                                                                                  \
-    const int lds = std::max(STG * (128 * 128 + (BN / 32) * (TERMS != 1 ? 4096 : 2048)), 4 * 32 * WM * (32 * WN + 4) * 4) + lds_pad; /* ring | epilogue slabs */ \
+    const int lds = std::max(STG * (128 * 128 + (BN / 32) * (TERMS != 1 ? 4096 : 2048)), 4 * 32 * WM * (32 * WN + 4) * 4); /* ring | epilogue slabs */ \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN, TERMS, STG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             lds) != hipSuccess)                                                                         \
       return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);                                      \
     g.nx = (int)((N + BN - 1) / BN), g.ny = (int)gy, g.tiles_per_xcd = (int)(((int64_t)g.nx * g.ny + 7) / 8);                 \
     gemm_packed_kernel<WM, WN, TERMS, STG><<<dim3((unsigned)(8 * g.tiles_per_xcd), 1, (unsigned)splits), dim3(256), lds, stream>>>(g); \
   } while (0)
-  static const int lds_pad = [] {  // experiment knob (occupancy studies): extra dynamic LDS per block, KB
-    const char* e = std::getenv("GEOTR_GEMM_LDS_PAD_KB");
-    return e ? 1024 * std::atoi(e) : 0;
-  }();
-  // three-slot ring: exact-fp32 launches with at least 6 stages per block (GEOTR_F32_STAGES=2 keeps two slots everywhere: A/B switch)
-  static const int f32_stages = [] {
-    const char* e = std::getenv("GEOTR_F32_STAGES");
-    return e ? std::atoi(e) : 3;
-  }();
-  // (with the 128-wide tile a third slot is 96 KB of LDS = ONE block per CU: measured slower alone and catastrophic beside other lanes'
-  // kernels -- 501 vs 959 pairs/s; the 64-wide tile keeps two blocks per CU at 72 KB)
-  const bool deep = TERMS == 0 && f32_stages == 3 && g.kt_split >= 6 && bn == 64;
-  // persistent form (round 4), OPT-IN (GEOTR_GEMM_PERSIST=1; 2 = also the split-bf16 / bf16 launches): unsplit launches of more tiles
-  // than the chip has resident slots (2 blocks x 256 CUs).  Bit-identical (tests/test_gemm_gpu.py passes with it) and measured to change
-  // NOTHING: 252.6 vs 255.7 us (43 826 x 512 x 512), 282.4 vs 284.7 (179 984 x 256 x 256), 317.7 vs 317.0 us per pair over all shapes,
-  // 973 / 975 vs 978 / 974 pairs/s (profiles/r04_ab_runs.md section 6) -- with staggering, occupancy and ring depth it is the fourth
-  // structural change the exact-fp32 kernel does not respond to: its ~0.58 of the matrix roof is not a pipelining loss of this code.
-  static const int persist_mode = [] {
-    const char* e = std::getenv("GEOTR_GEMM_PERSIST");
-    return e ? std::atoi(e) : 0;
-  }();
-  const int64_t n_tiles = (int64_t)((N + bn - 1) / bn) * gy;
-  const bool persist = persist_mode > 0 && (TERMS == 0 || persist_mode == 2) && splits == 1 && !deep && n_tiles > 512 && bn >= 64;
-#define GEOTR_PACKED_PERSIST(WM, WN, BN)                                                                                 \
-  do {                                                                                                                  \
-    const int lds = 2 * (128 * 128 + (BN / 32) * (TERMS != 1 ? 4096 : 2048)) + 4 * 8 * (32 * WN + 4) * 4 + lds_pad; /* ring + 8-row slabs */ \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN, TERMS, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            lds) != hipSuccess)                                                                         \
-      return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);                                      \
-    g.nx = (int)((N + BN - 1) / BN), g.ny = (int)gy, g.tiles_per_xcd = (int)(((int64_t)g.nx * g.ny + 7) / 8);          \
-    const int bpx = std::min(g.tiles_per_xcd, 64); /* 2 resident blocks on each of an XCD's 32 CUs */                   \
-    gemm_packed_kernel<WM, WN, TERMS, 2, true><<<dim3((unsigned)(8 * bpx), 1, 1), dim3(256), lds, stream>>>(g);         \
-  } while (0)
-  // weight fragments from L2 (round 4), OPT-IN (GEOTR_GEMM_BREG=1; 2 = also instead of the three-slot deep launches; 3 = only the shallow,
-  // wide launches it was measured to help): exact fp32 only.  Bit-identical (tests/test_gemm_gpu.py); alone, per launch
-  // (profiles/r04_ab_runs.md section 11): K <= 64 with 128-wide tiles -6 ... -12 % (640 000 x 128 x 32: 157 -> 142 us), deep shapes
-  // +3 ... +16 % (179 984 x 256 x 256: 278 -> 321 us), all shapes of a stack 313.5 -> 322.4 us per pair (mode 2: 345.2); bench 981 / 993
-  // -> 970 / 969 (mode 2: 958).  A third block per CU does not help the matrix-bound launches either.
-  static const int breg_mode = [] {
-    const char* e = std::getenv("GEOTR_GEMM_BREG");
-    return e ? std::atoi(e) : 0;
-  }();
-  const bool breg = TERMS == 0 && breg_mode > 0 && !persist && (!deep || breg_mode == 2) && (breg_mode != 3 || (g.kt_split <= 2 && bn == 128));
-#define GEOTR_PACKED_BREG(WM, WN, BN)                                                                                    \
-  do {                                                                                                                  \
-    const int lds = 2 * 128 * 128 + 4 * 8 * (32 * WN + 4) * 4 + lds_pad; /* activation ring + 8-row slabs */              \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_kernel<WM, WN, 0, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            lds) != hipSuccess)                                                                         \
-      return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);                                      \
-    g.nx = (int)((N + BN - 1) / BN), g.ny = (int)gy, g.tiles_per_xcd = (int)(((int64_t)g.nx * g.ny + 7) / 8);          \
-    gemm_packed_kernel<WM, WN, 0, 2, false, true><<<dim3((unsigned)(8 * g.tiles_per_xcd), 1, (unsigned)splits), dim3(256), lds, stream>>>(g); \
-  } while (0)
-  if (breg && bn == 128) GEOTR_PACKED_BREG(2, 2, 128);
-  else if (breg && bn == 64) GEOTR_PACKED_BREG(1, 2, 64);
-  else if (breg) GEOTR_PACKED_BREG(1, 1, 32);
-  else if (persist && bn == 128) GEOTR_PACKED_PERSIST(2, 2, 128);
-  else if (persist && bn == 64) GEOTR_PACKED_PERSIST(1, 2, 64);
-  else if (bn == 64 && deep) GEOTR_PACKED(1, 2, 64, 3);
+  // three-slot ring: exact-fp32 launches with at least 6 stages per block on the 64-wide tile (two blocks per CU at 72 KB; with the
+  // 128-wide tile a third slot is 96 KB of LDS = ONE block per CU: measured slower alone and catastrophic beside other lanes' kernels,
+  // 501 vs 959 pairs/s).  Variants of this launch that were built, measured within +-3 % and removed in round 5 (git history; numbers in
+  // profiles/r04_ab_runs.md sections 6, 8, 11): a persistent multi-tile form, weight fragments straight from L2 (three blocks per CU),
+  // a half-block start stagger of the second resident block, a two-slot ring for the deep launches.
+  const bool deep = TERMS == 0 && g.kt_split >= 6 && bn == 64;
+  if (bn == 64 && deep) GEOTR_PACKED(1, 2, 64, 3);
   else if (bn == 128) GEOTR_PACKED(2, 2, 128, 2);
   else if (bn == 64) GEOTR_PACKED(1, 2, 64, 2);
   else GEOTR_PACKED(1, 1, 32, 2);
-#undef GEOTR_PACKED_BREG
-#undef GEOTR_PACKED_PERSIST
 #undef GEOTR_PACKED
   GEOTR_CHECK_LAUNCH("gemm_packed");
   if (splits > 1) {

@@ -393,11 +393,6 @@ using namespace geotr;
 extern "C" {
 
 int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h) {
-  static const bool wide = [] {
-    const char* e = std::getenv("GEOTR_KPCONV_FUSED_WIDE");  // A/B switch for measurements: 0 keeps C_in > 64 on the two-kernel path
-    return !(e && e[0] == '0');
-  }();
-  if (c_in > 64 && !wide) return 0;
   if (!(c_in == 32 || (c_in >= 64 && c_in % 64 == 0 && c_in <= 4096)) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 4 * kMaxSteps) return 0;
   const int waves = 8;
   const int64_t ct = c_out / 32;

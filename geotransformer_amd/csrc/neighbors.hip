@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
                                                        const int64_t* __restrict__ q_len, int batch, int64_t nq_cap,
                                                        float r2, int width, int cap,
                                                        int64_t* __restrict__ out, int* __restrict__ counts,
-                                                       int* __restrict__ max_count, int* __restrict__ overflow, int variant) {
+                                                       int* __restrict__ max_count, int* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t ns_total = rg_rows(hdr, batch);
@@ -257,13 +257,11 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
   // wave scan, ONCE per wave), and the cloud of a query is the number of clouds that end at or before it -- one ballot.  The serial
   // walk over the lengths it replaces cost a dependent scalar load per cloud (~16 on average for a 16-pair stack, up to 32: a third of
   // a query's ~8 000 cycles -- rocprofv3 SQ counters, profiles/r03_rg_query_counters.md -- and an empty wave paid all 32).
-  // `variant` (experiment, GEOTR_RG_VARIANT): bit 0 = find the cloud by the serial walk over the lengths (round 2's form), bit 1 = one
-  // query per wave and out (no stride loop)
   int cloud_end = 0x7fffffff;
-  if (batch <= 64 && !(variant & 1)) cloud_end = wave_inclusive_scan(lane < batch ? (int)q_len[lane] : 0);
+  if (batch <= 64) cloud_end = wave_inclusive_scan(lane < batch ? (int)q_len[lane] : 0);
   for (int64_t qi = (int64_t)blockIdx.x * 4 + w; qi < nq_cap; qi += (int64_t)gridDim.x * 4) {
     int b;
-    if (batch <= 64 && !(variant & 1)) {
+    if (batch <= 64) {
       b = __popcll(__ballot(lane < batch && qi >= (int64_t)cloud_end));
     } else {
       int64_t qstart;
@@ -341,7 +339,6 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
       if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
     }
     for (int j = count + lane; j < width; j += 64) row[j] = ns_total;  // pad (radius_neighbors_cpu.cpp:85)
-    if (variant & 2) return;
     // the next query of this wave overwrites the key row: every lane's reads above come first
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -359,8 +356,10 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
 // with more than 128 hits is redone by the whole wave on the wave's 512 keys (= the one-query kernel's capacity).
 constexpr int kQuadKeys = 128;
 
-template <int OCC>  // waves per SIMD the register allocation is held to: 98 VGPRs uncapped = 4; 5 -> 96 (no spill); 6 -> 80 (5 dwords spilled)
-__global__ __launch_bounds__(256, OCC) void rg_query_quad_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
+// __launch_bounds__(256, 5): the register allocation is held to 5 waves per SIMD (96 VGPRs, nothing spilled; uncapped the kernel took 98
+// = 4 waves).  Measured on a 16-pair 3DMatch stack (scripts/abi_bench.bin pyramid, profiles/r05_ab_runs.md): the whole pyramid 150.3 ->
+// 138.9 us per pair; 6 waves (80 VGPRs, 5 dwords spilled) 134.7 alone but 4 % slower with four lanes in flight.
+__global__ __launch_bounds__(256, 5) void rg_query_quad_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
                                                             const float4* __restrict__ sorted, const float* __restrict__ q,
                                                             const int64_t* __restrict__ q_len, const int* __restrict__ q_order, int batch,
                                                             float r2, int width, int cap, int64_t* __restrict__ out,
@@ -1217,10 +1216,6 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
     const char* e = std::getenv("GEOTR_RG_TILE");
     return e && e[0] == '1';
   }();
-  static const int variant = [] {
-    const char* e = std::getenv("GEOTR_RG_VARIANT");  // experiment switch of rg_query_kernel (see there); default 0
-    return e ? std::atoi(e) : 0;
-  }();
   static const int quad_mode = [] {
     const char* e = std::getenv("GEOTR_RG_QUAD");  // A/B switch: 0 = one query per wave everywhere; 2 = quad in row order; 3 = quad even for dense searches
     return e ? std::atoi(e) : 1;
@@ -1231,18 +1226,9 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
   if (!count_only && quad_mode && (sparse_hint || quad_mode >= 3) && !(tile_enabled && q_order) && batch <= 64 && cap <= 4 * kQuadKeys &&
       nq < (1ll << 31)) {
     const int64_t quads = (expect + 3) / 4;
-    static const int quad_occ = [] {
-      const char* e = std::getenv("GEOTR_RG_QUAD_OCC");  // experiment (round 5): 4 = round 4's allocation, 5 (default), 6
-      return e ? std::atoi(e) : 5;
-    }();
     const int* order = (quad_mode == 2 || quad_mode == 4) ? nullptr : q_order;
-    const dim3 grid((unsigned)((quads + 3) / 4));
-    if (quad_occ >= 6)
-      rg_query_quad_kernel<6><<<grid, dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, order, (int)batch, r2, (int)width, (int)cap, out, overflow);
-    else if (quad_occ == 5)
-      rg_query_quad_kernel<5><<<grid, dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, order, (int)batch, r2, (int)width, (int)cap, out, overflow);
-    else
-      rg_query_quad_kernel<4><<<grid, dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, order, (int)batch, r2, (int)width, (int)cap, out, overflow);
+    rg_query_quad_kernel<<<dim3((unsigned)((quads + 3) / 4)), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, order, (int)batch, r2,
+                                                                                     (int)width, (int)cap, out, overflow);
     GEOTR_CHECK_LAUNCH("radius_query(quad)");
     return GEOTR_OK;
   }
@@ -1261,7 +1247,7 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
   }
   if (count_only) {
     rg_query_kernel<true><<<dim3(nb), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
-                                                             r2, 0, 0, nullptr, counts, max_count, nullptr, 0);
+                                                             r2, 0, 0, nullptr, counts, max_count, nullptr);
   } else {
     const size_t lds = (size_t)cap * 4 * sizeof(unsigned long long);
     if (lds > 64 * 1024) {
@@ -1271,7 +1257,7 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
     }
     rg_query_kernel<false><<<dim3(nb), dim3(256), lds, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
                                                                 r2, (int)width, (int)cap, out, nullptr,
-                                                                nullptr, overflow, variant);
+                                                                nullptr, overflow);
   }
   GEOTR_CHECK_LAUNCH("radius_query");
   return GEOTR_OK;

@@ -599,62 +599,6 @@ def build_pyramid_async(points, lengths, num_stages, voxel_size, radius, neighbo
     return PyramidPlan(pts, lens, nb, sub, up, order, overflow, host, B, S, ws)
 
 
-class PyramidGraph:
-    """The pyramid's launch sequence (~60 dependent kernels) captured ONCE in a hipGraph and replayed per stack (round 3, opt-in:
-    GEOTR_PYRAMID_GRAPH=1 in pipeline.ConcurrentRegistration).  Possible because the sequence no longer depends on anything the host
-    would have to read: every launch is sized from a row CAPACITY and the kernels take the stage sizes from device memory
-    (geotr_pyramid_build_async).  A graph bakes its pointers in, so the stacked input, every stage buffer, the workspace and the pinned
-    size array are persistent; `launch(clouds)` copies a stack's clouds into the input buffer and replays.  The caller must not let
-    results alias these buffers beyond the next launch (pipeline._launch clones the three point arrays the output dicts refer to).
-    One graph serves every stack of `batch` clouds with at most `capacity` points in total."""
-
-    def __init__(self, capacity, batch, num_stages, voxel_size, radius, neighbor_limits, device):
-        lib = _lib.load()
-        self.capacity, self.B, self.S = int(capacity), int(batch), int(num_stages)
-        self.limits = [int(x) for x in neighbor_limits]
-        dev = torch.device(device)
-        self.input = torch.zeros((self.capacity, 3), dtype=torch.float32, device=dev)
-        self.lengths = torch.zeros(self.B, dtype=torch.int64, device=dev)
-        self.pts, self.lens, self.nb, self.sub, self.up, self.order, buf = _pyramid_buffers(self.input, self.lengths, self.S, self.limits)
-        self.host = torch.zeros(self.S * self.B, dtype=torch.int64).pin_memory()
-        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
-        nbytes = lib.geotr_pyramid_workspace_bytes(self.capacity, self.B, self.S)
-        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        limits = (ctypes.c_int64 * self.S)(*self.limits)
-        self._keep = (buf, limits)
-        # a valid stack for the warm-up / capture run: one point per cloud
-        self.lengths.fill_(1)
-        stream = torch.cuda.current_stream(dev)
-
-        def enqueue():
-            self.overflow.zero_()
-            rc = lib.geotr_pyramid_build_async(self.input.data_ptr(), self.lengths.data_ptr(), self.B, self.capacity, self.S, float(voxel_size),
-                                               float(radius), limits, ctypes.byref(buf), self.host.data_ptr(), self.overflow.data_ptr(),
-                                               self.ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(rc, 'geotr_pyramid_build_async')
-
-        enqueue()  # once outside the capture: module loading, function attributes and the host-side bucket schedule are settled
-        stream.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):  # other lanes keep allocating / launching meanwhile
-            enqueue()
-
-    def fits(self, clouds):
-        return len(clouds) == self.B and sum(c.shape[0] for c in clouds) <= self.capacity
-
-    @torch.no_grad()
-    def launch(self, clouds):
-        """Enqueue the pyramid of `clouds` (device tensors (n_i, 3)) on the current stream: two copies and one graph launch, no host
-        synchronisation.  Returns a PyramidPlan (finish() after the stream has been synchronised past this point)."""
-        assert self.fits(clouds)
-        total = sum(c.shape[0] for c in clouds)
-        torch.cat(clouds, dim=0, out=self.input[:total])
-        self.lengths.copy_(torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64).pin_memory(), non_blocking=True)
-        self.graph.replay()
-        pts = [self.input[:total]] + self.pts[1:]
-        return PyramidPlan(pts, self.lens, self.nb, self.sub, self.up, self.order, self.overflow, self.host, self.B, self.S, None)
-
-
 @torch.no_grad()
 def build_pyramid(points, lengths, num_stages, voxel_size, radius, neighbor_limits):
     """precompute_data_stack_mode in one native call (fixed-width neighbour tables).  Device tensors in; returns the

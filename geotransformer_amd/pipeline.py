@@ -109,7 +109,7 @@ class RegistrationPipeline:
         }
 
     @torch.no_grad()
-    def register_batch(self, pairs, return_pyramid=False, pyramid_stream=None):
+    def register_batch(self, pairs, return_pyramid=False):
         """Several independent pairs through ONE launch sequence: the clouds are stacked (ref_0, src_0, ref_1, ...), the
         pyramid and the KPConv-FPN run once over the stack (GroupNorm statistics stay per pair), the heads run pair by
         pair.  `pairs` = [(ref_points, src_points), ...] (at most 16); returns one output dict per pair.  Per-pair results
@@ -123,16 +123,7 @@ class RegistrationPipeline:
         points = torch.cat(clouds, dim=0)
         lengths = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64, device=points.device)
         t0 = time.perf_counter()
-        if pyramid_stream is None:
-            data = build_pyramid(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.neighbor_limits)
-        else:
-            # the pyramid's chain of small dependent kernels on a high-priority queue of the lane (ConcurrentRegistration): they do not
-            # queue behind the other lanes' long kernels.  Its tensors stay alive until this call's final read of the lane's stream.
-            current = torch.cuda.current_stream(points.device)
-            pyramid_stream.wait_stream(current)
-            with torch.cuda.stream(pyramid_stream):
-                data = build_pyramid(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.neighbor_limits)
-            current.wait_stream(pyramid_stream)
+        data = build_pyramid(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.neighbor_limits)
         data['features'] = torch.ones((points.shape[0], 1), dtype=torch.float32, device=points.device)
         data['batch_size'] = len(pairs)
         if self.model._native is None:
@@ -168,18 +159,10 @@ class ConcurrentRegistration:
         # and waits on the host ONCE per stack: for that pyramid's stage sizes, which arrive together with the previous stack's result
         # counts.  Only stacked jobs (stack > 1) are pipelined.
         self.pipelined = os.environ.get('GEOTR_PIPELINED', '1') != '0' and int(stack) > 1
-        # GEOTR_PYRAMID_GRAPH=1 (opt-in, pipelined lanes only): each lane replays ONE captured hipGraph per stack for the pyramid's ~60
-        # dependent launches (native.PyramidGraph) instead of issuing them one by one
-        self.pyramid_graphs = self.pipelined and os.environ.get('GEOTR_PYRAMID_GRAPH') == '1'
-        self._graphs = {}
-        self._graph_lock = threading.Lock()
         self.lanes = max(1, int(lanes))
         self.stack = max(1, min(16, int(stack)))
         self.device = pipeline.device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
-        # GEOTR_PYRAMID_PRIORITY=1 (experiment): a second, high-priority queue per lane for the pyramid's small dependent kernels
-        self.pyramid_streams = ([torch.cuda.Stream(device=self.device, priority=-1) for _ in range(self.lanes)]
-                                if os.environ.get('GEOTR_PYRAMID_PRIORITY') == '1' else [None] * self.lanes)
         # Lanes that start together stay in phase (equal stacks take equal time): every lane then runs the same kind of kernel at the same
         # moment -- pyramid next to pyramid, GEMM next to GEMM -- and they compete for the same unit instead of filling each other's gaps
         # (rocprofv3 timeline, profiles/r04_ab_runs.md: a stage-0 radius query overlaps another lane's radius query for 52-62 % of its
@@ -216,20 +199,6 @@ class ConcurrentRegistration:
         clouds = [c for _, ref, src, _, _ in job for c in (ref, src)]
         for c in clouds:
             _check_cloud(c, host_ok=True)
-        if self.pyramid_graphs:
-            from .native import PyramidGraph
-            key = threading.get_ident()
-            graph = self._graphs.get(key)
-            if graph is None or not graph.fits(clouds):
-                total = sum(c.shape[0] for c in clouds)
-                with self._graph_lock:  # one capture at a time; a larger stack than the graph was captured for replaces it
-                    graph = PyramidGraph(max(total, graph.capacity if graph is not None and graph.B == len(clouds) else 0), len(clouds),
-                                         b.num_stages, b.init_voxel_size, b.init_radius, self.pipeline.neighbor_limits, self.device)
-                self._graphs[key] = graph
-            plan = graph.launch(clouds)
-            event = torch.cuda.Event()
-            event.record(stream)
-            return job, plan, plan.pts[0], event
         points = stack_clouds(clouds, self.device)
         # (a torch.tensor(..., device=...) from a Python list is a pageable host-to-device copy: it would block the host until the
         # stream has drained, i.e. until the previous stack's forward is done -- pinned + non_blocking keeps the host running ahead)
@@ -245,18 +214,6 @@ class ConcurrentRegistration:
         job, plan, points, _ = begun
         model = self.pipeline.model
         data = plan.finish()
-        if self.pyramid_graphs:
-            # the graph's buffers are overwritten by this lane's next stack: what outlives the forward -- the point arrays the output
-            # dicts are views of (and, for the tests' return_pyramid, every table) -- is copied out; the forward reads the copies
-            S, fine = len(data['points']), model.backbone.fine_stage
-            keep = range(S) if self.return_pyramid else (0, fine, S - 1)
-            data['points'] = [t.clone() if i in keep else t for i, t in enumerate(data['points'])]
-            data['lengths'] = [t.clone() for t in data['lengths']]  # tiny; read by the forward and by anyone who keeps the dict
-            if self.return_pyramid:  # the only way `data` escapes this lane (out['_stack_pyramid']): then NOTHING in it may alias the graph
-                for key in ('neighbors', 'subsampling', 'upsampling', '_order'):
-                    if data.get(key) is not None:
-                        data[key] = [t.clone() for t in data[key]]
-                data['_overflow'] = data['_overflow'].clone()
         data['features'] = torch.ones((points.shape[0], 1), dtype=torch.float32, device=points.device)
         data['batch_size'] = len(job)
         if model._native is None:
@@ -362,8 +319,7 @@ class ConcurrentRegistration:
                         index, ref, src, sink, _ = job[0]
                         sink(index, self.pipeline(ref, src))
                     else:
-                        outs = self.pipeline.register_batch([(ref, src) for _, ref, src, _, _ in job],
-                                                            pyramid_stream=self.pyramid_streams[lane], return_pyramid=self.return_pyramid)
+                        outs = self.pipeline.register_batch([(ref, src) for _, ref, src, _, _ in job], return_pyramid=self.return_pyramid)
                         if self.return_pyramid:
                             outs, data = outs
                             for out in outs:

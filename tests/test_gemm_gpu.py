@@ -316,64 +316,6 @@ def test_residual_tail_without_the_apply_pass_is_bitwise_the_apply_pass(mid, c_i
     assert torch.equal(got, want)
 
 
-_BREG_CHILD = r'''
-import hashlib, json, sys
-sys.path.insert(0, {root!r})
-import torch
-from geotransformer_amd import kernels
-kernels.set_precision('fp32')
-out = {{}}
-def digest(*ts):
-    h = hashlib.sha256()
-    for t in ts:
-        h.update(t.detach().cpu().numpy().tobytes())
-    return h.hexdigest()[:16]
-# (M, N, K): 128- / 64- / 32-wide tiles, shallow and deep, split-K launches (2900 x 128 x 1920, 560 x 256 x 3840), the three-slot deep
-# launches of the 64-wide tile (9956 x 1024 x 512: GEOTR_GEMM_BREG=2 replaces those as well), ragged row and column counts
-for M, N, K in [(3000, 256, 32), (5000, 512, 128), (1500, 256, 384), (4096, 64, 960), (40000, 32, 480), (2900, 128, 1920), (560, 256, 3840),
-                (1024, 96, 64), (9956, 1024, 512), (43826, 512, 512), (1031, 200, 96), (70000, 128, 64)]:
-    g = torch.Generator().manual_seed(M + N + K)
-    a = torch.randn(M, K, generator=g).cuda()
-    w = torch.randn(N, K, generator=g).cuda()
-    bias = torch.randn(N, generator=g).cuda()
-    res = torch.randn(M, N, generator=g).cuda()
-    div = torch.randint(0, 5, (M,), generator=g, dtype=torch.int32).cuda()
-    packed = kernels.gemm_pack(w)
-    full = kernels.gemm_packed(a, packed, N, bias=bias, row_div=div, residual=res, act='leaky')
-    plain = kernels.gemm_packed(a, packed, N, split_k=False)
-    out[f'{{M}}x{{N}}x{{K}}'] = digest(full, plain)
-# the statistics epilogue over row segments (records + output)
-for N, K, segs in [(128, 32, [5000, 3333, 129, 128, 1, 77]), (256, 128, [40000]), (64, 64, [1500, 1500, 700])]:
-    g = torch.Generator().manual_seed(N * 1000 + K)
-    a = torch.randn(sum(segs), K, generator=g).cuda()
-    w = torch.randn(N, K, generator=g).cuda()
-    bias = torch.randn(N, generator=g).cuda()
-    y, stats, rpr = kernels.linear_gn(a, w, bias, seg_rows=segs)
-    out[f'stats {{N}}x{{K}}'] = digest(y, stats)
-torch.cuda.synchronize()
-print('RESULT ' + json.dumps(out))
-'''
-
-
-def test_weight_fragments_from_l2_form_is_bitwise_the_lds_form():
-    """GEOTR_GEMM_BREG=1 / 2 (round 4, opt-in): the exact-fp32 packed GEMM with its weight fragments loaded straight from L2 into registers
-    (activation-only LDS ring, 8-row epilogue slabs, three blocks per CU) writes the same bits as the shipped LDS form: same operand
-    values, same MFMA order, same epilogue row order.  The switch is read once per process: three children."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    got = {}
-    for mode in ('0', '1', '2'):
-        env = dict(os.environ, GEOTR_GEMM_BREG=mode)
-        res = subprocess.run([sys.executable, '-c', _BREG_CHILD.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
-        assert res.returncode == 0, res.stderr[-2000:]
-        got[mode] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('RESULT ')][-1][7:])
-    assert len(got['0']) == 15
-    assert got['0'] == got['1'] == got['2'], got
-
-
 def test_packed_weight_format_is_checked_against_the_arithmetic_mode():
     """ADVICE r4: the two pack layouts have the same size; a buffer packed for one arithmetic must not be consumed by the other.  The
     library records the layout per buffer address (geotr_gemm_pack_format) and every packed entry point refuses a mismatch."""

@@ -80,8 +80,8 @@ def test_stacked_pairs_match_single_pair_runs():
         assert torch.equal(one[k], want[0][k]), k
 
 
-@pytest.mark.parametrize('lanes,graph', [(1, False), (3, False), (2, True)])
-def test_pipelined_lanes_match_the_synchronous_stack_call(lanes, graph, monkeypatch):
+@pytest.mark.parametrize('lanes', [1, 3])
+def test_pipelined_lanes_match_the_synchronous_stack_call(lanes):
     """Round 3: a lane enqueues the next stack's pyramid -- no host read (build_pyramid_async) -- behind the forward it has just launched
     and waits on the host once per stack.  Outputs, pyramid tables included, must be bitwise those of the synchronous
     register_batch call on the same stack; a bad input in the middle of the queue surfaces in drain() and leaves the lanes usable."""
@@ -89,8 +89,6 @@ def test_pipelined_lanes_match_the_synchronous_stack_call(lanes, graph, monkeypa
     from geotransformer_amd.config import make_cfg
     from geotransformer_amd.pipeline import ConcurrentRegistration, RegistrationPipeline
     from geotransformer_amd.synthetic import make_pair
-    if graph:  # the pyramid's launch sequence replayed from a captured hipGraph (native.PyramidGraph); stacks of different sizes: the
-        monkeypatch.setenv('GEOTR_PYRAMID_GRAPH', '1')  # graph is re-captured when a larger stack arrives
     cfg = make_cfg('3dmatch', {'backbone.init_dim': 16, 'backbone.group_norm': 4, 'backbone.output_dim': 64,
                                'geotransformer.input_dim': 256, 'geotransformer.hidden_dim': 64, 'geotransformer.output_dim': 64})
     torch.manual_seed(cfg.seed)
@@ -112,7 +110,7 @@ def test_pipelined_lanes_match_the_synchronous_stack_call(lanes, graph, monkeypa
             assert torch.equal(ta, tb), key
     torch.cuda.synchronize()
     runner = ConcurrentRegistration(pipe, lanes=lanes, stack=3, return_pyramid=True)
-    assert runner.pipelined and runner.pyramid_graphs == graph
+    assert runner.pipelined
     got = {}
     flat = [pr for st in stacks for pr in st]
     for rep in range(2):  # two submissions without a join in between: 10 stacks queued
