@@ -320,8 +320,9 @@ WORKLOADS = {
 }
 
 # (lanes, pairs stacked per launch sequence) per configuration: measured in profiles/r02_ab_runs.md and r02_other_configs.md
-# (round 4: kitti 3 lanes -- 144.0 vs 137.3 pairs/s with 2, 118.1 with 1; profiles/r04_ab_runs.md section 7)
-LAUNCH_SHAPE = {'3dmatch': (4, 16), 'lomatch': (4, 16), 'modelnet': (4, 16), 'kitti': (3, 4)}
+# (round 4: kitti 3 lanes -- 144.0 vs 137.3 pairs/s with 2, 118.1 with 1; profiles/r04_ab_runs.md section 7;
+#  round 5: 3 x 6 147.5, 3 x 4 144.7, 4 x 4 144.8, 2 x 4 135.7, 4 x 2 134.4, 6 x 2 134.9; profiles/r05_ab_runs.md)
+LAUNCH_SHAPE = {'3dmatch': (4, 16), 'lomatch': (4, 16), 'modelnet': (4, 16), 'kitti': (3, 6)}
 
 
 def build_pair(seed, config, n_points):

@@ -54,7 +54,8 @@ struct FVec<4> {
 // (gemm.hip: four steps of an 8-deep group per 16-byte fragment) -- the reference's own arithmetic end to end (round 4).
 // MULTI: the layer has several channel blocks (c_total = NH C, NH > 1); false: c_total == C and the block loop is a single pass at
 // compile time (phase 2's accumulators are then not live across phase 1: the register allocation of the C_in = 32 / 64 layers is unchanged).
-template <int C, int WAVES, int TERMS, bool MULTI>
+// CTW: 32-column output tiles per wave (1: C_out <= 32 WAVES; 2: C_out = 64 WAVES -- the 512-wide layers of the 5-stage backbone).
+template <int C, int WAVES, int TERMS, bool MULTI, int CTW = 1>
 __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
                                                                   const float* __restrict__ sp, const int64_t* __restrict__ nb,
                                                                   const float* __restrict__ kp, const unsigned char* __restrict__ pos,
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   const float kx = kp_ok ? kp[3 * n16] : 0.f, ky = kp_ok ? kp[3 * n16 + 1] : 0.f, kz = kp_ok ? kp[3 * n16 + 2] : 0.f;
   const int steps = (H + 3) >> 2;
   const int CT = c_out >> 5;            // 32-column tiles of the output
-  const int KPARTS = WAVES / CT;        // K ranges of phase 2
-  const int ct = wave % CT, kpart = wave / CT;
+  const int CTP = CT / CTW;             // column tiles taken side by side by the waves (tile s of a wave: ct + s CTP)
+  const int KPARTS = WAVES / CTP;       // K ranges of phase 2
+  const int ct = wave % CTP, kpart = wave / CTP;
   const int nkk = F32 ? K / 8 : K / 16;  // 16-deep steps of phase 2 (K % 32 == 0); fp32: 8-deep groups of four 32x32x2 steps
   // channel blocks (c_total = NH C): steps of a block's LOCAL contraction index -> steps of the packed weight, whose rows are k c_total + c
   const int NH = MULTI ? c_total / C : 1;
@@ -116,9 +118,11 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
     const int64_t m0 = tile * kFusedRows;
     const int rows_nxt = tile + 1 < tile_end ? load_rows(tile + 1) : 0;  // in flight under this tile's work
     if (lane < PPW) row_s[wave * PPW + lane] = rows_cur;                 // read by the epilogue, three barriers later
-    f32x16 acc2;  // phase 2's accumulators: kept across the channel blocks
+    f32x16 acc2[CTW];  // phase 2's accumulators: kept across the channel blocks
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    for (int s = 0; s < CTW; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[s][r] = 0.f;
     for (int hb = 0; hb < NH; ++hb) {  // ---- channel block hb: channels C hb .. C hb + C - 1 of every neighbour row
     // ------------------------------------------------------------------ phase 1: g = w . f per point, software-pipelined over the wave's points
     // Three dependent global round trips lead to a point's first MFMA (neighbour index -> support position -> feature row); done
@@ -239,38 +243,48 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
     if constexpr (F32) {
       // group q: lane (fr, fk) holds A[fr][8 q + 4 fk + e] and W[8 q + 4 fk + e][32 ct + fr], e = 0 .. 3 = its operands of four steps
       const float* a32 = A_32 + (lane & 31) * RS32 + 4 * (lane >> 5);
-      const int ctc = min(ct, NT - 1);
-      const float* b32 = reinterpret_cast<const float*>(Bhi) + ((int64_t)ctc * 2 * KS * 64 + lane) * 4;
+      const float* b32[CTW];
+#pragma unroll
+      for (int s = 0; s < CTW; ++s)
+        b32[s] = reinterpret_cast<const float*>(Bhi) + ((int64_t)min(ct + s * CTP, NT - 1) * 2 * KS * 64 + lane) * 4;
 #pragma unroll 2
       for (int q = kk0; q < kk1; ++q) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(a32 + 8 * q);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(b32 + (int64_t)wstep(q) * 256);
+        f32x4 bv[CTW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc2, 0, 0, 0);
+        for (int s = 0; s < CTW; ++s) bv[s] = *reinterpret_cast<const f32x4*>(b32[s] + (int64_t)wstep(q) * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int s = 0; s < CTW; ++s) acc2[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[s][e], acc2[s], 0, 0, 0);
       }
     } else {
       const unsigned short* a_hi = A_hi + (lane & 31) * RS + 8 * (lane >> 5);
       const unsigned short* a_lo = A_lo + (lane & 31) * RS + 8 * (lane >> 5);
-      const int ctc = min(ct, NT - 1);
-      const unsigned short* b_hi = Bhi + ((int64_t)ctc * KS * 64 + lane) * 8;
-      const unsigned short* b_lo = Blo + ((int64_t)ctc * KS * 64 + lane) * 8;
 #pragma unroll 2
       for (int kk = kk0; kk < kk1; ++kk) {
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_hi + 16 * kk);
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_hi + (int64_t)wstep(kk) * 512);
-        if constexpr (TERMS == 3) {
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(a_lo + 16 * kk);
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_lo + (int64_t)wstep(kk) * 512);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
+        bf16x8 al;
+        if constexpr (TERMS == 3) al = *reinterpret_cast<const bf16x8*>(a_lo + 16 * kk);
+#pragma unroll
+        for (int s = 0; s < CTW; ++s) {
+          const int64_t off = ((int64_t)min(ct + s * CTP, NT - 1) * KS * 64 + lane) * 8 + (int64_t)wstep(kk) * 512;
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bhi + off);
+          if constexpr (TERMS == 3) {
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Blo + off);
+            acc2[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2[s], 0, 0, 0);
+            acc2[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2[s], 0, 0, 0);
+          }
+          acc2[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2[s], 0, 0, 0);
         }
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2, 0, 0, 0);
       }
     }
     __syncthreads();  // every wave has read its A fragments: the tile's memory takes the next channel block / the K partials
     }  // channel blocks
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[(wave * 16 + r) * 64 + lane] = acc2[r];
+    for (int s = 0; s < CTW; ++s)  // tile ct + s CTP of K range kpart lives at partial index kpart CT + ct + s CTP (CTW = 1: the wave index)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[((kpart * CT + ct + s * CTP) * 16 + r) * 64 + lane] = acc2[s][r];
     __syncthreads();
     // ------------------------------------------------------------------ epilogue: sum the K partials, / count + bias, whole rows out
     for (int e = tid; e < kFusedRows * c_out; e += 64 * WAVES) {
@@ -396,6 +410,7 @@ int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h) {
   if (!(c_in == 32 || (c_in >= 64 && c_in % 64 == 0 && c_in <= 4096)) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 4 * kMaxSteps) return 0;
   const int waves = 8;
   const int64_t ct = c_out / 32;
+  if (ct == 2 * waves) return c_in > 64;  // two column tiles per wave: the multi-block kernel only (C_in >= 128)
   return ct <= waves && waves % ct == 0;
 }
 
@@ -441,12 +456,12 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
   const int64_t tiles = (m + kFusedRows - 1) / kFusedRows;
   // persistent: a few tiles per resident workgroup; a multiple of 8 blocks, one share of the tile range per XCD
   const unsigned grid = (unsigned)((std::min<int64_t>(tiles, 256 * (c_in == 32 ? 8 : 4)) + 7) / 8 * 8);
-#define GEOTR_KPF(CC, WW, TT, MM)                                                                                                  \
+#define GEOTR_KPF(CC, WW, TT, MM, ...)                                                                                                  \
   do {                                                                                                                             \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<CC, WW, TT, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<CC, WW, TT, MM, ##__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)lds) != hipSuccess)                                                                               \
       return fail(GEOTR_E_LAUNCH, "kpconv_fused: cannot reserve %zu B of LDS", lds);                                               \
-    kpconv_fused_kernel<CC, WW, TT, MM><<<dim3(grid), dim3(64 * WW), lds, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points,  \
+    kpconv_fused_kernel<CC, WW, TT, MM, ##__VA_ARGS__><<<dim3(grid), dim3(64 * WW), lds, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points,  \
                                                                                pos_flag, m, ns, (int)h, sigma, (int)c_in, (int)c_out, KS, NT, bhi, \
                                                                                blo, bias, order, out);                             \
   } while (0)
@@ -459,10 +474,14 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
     if (bf16_operands == 2) GEOTR_KPF(64, 8, 0, false);
     else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1, false);
     else GEOTR_KPF(64, 8, 3, false);
-  } else {  // several channel blocks of 64
+  } else if (c_out <= 32 * waves) {  // several channel blocks of 64
     if (bf16_operands == 2) GEOTR_KPF(64, 8, 0, true);
     else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1, true);
     else GEOTR_KPF(64, 8, 3, true);
+  } else {  // ... and two column tiles per wave (C_out = 512)
+    if (bf16_operands == 2) GEOTR_KPF(64, 8, 0, true, 2);
+    else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1, true, 2);
+    else GEOTR_KPF(64, 8, 3, true, 2);
   }
 #undef GEOTR_KPF
   GEOTR_CHECK_LAUNCH("kpconv_fused");
