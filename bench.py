@@ -532,6 +532,7 @@ def main():
     ap.add_argument('--no-numa-bind', action='store_true', help="do not bind the process to the GPU's NUMA node (A/B runs)")
     ap.add_argument('--no-sibling-mode', '--no-fp32-mode', dest='no_sibling_mode', action='store_true',
                     help='skip the split-bf16 sibling block (the same workload re-timed in the narrower arithmetic of rounds 1-3)')
+    ap.add_argument('--detail', default=None, metavar='PATH', help='where the full record goes (default: bench_detail.json next to bench.py)')
     ap.add_argument('--dry-run', action='store_true',
                     help='no devices: rehearse the N-rank launcher path, rank bring-up decisions, sharding and collectives over gloo (CPU test)')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16', 'fp32-unpacked'],
@@ -731,7 +732,7 @@ def main():
 
     if rank == 0:
         D = cfg.geotransformer.hidden_dim
-        detail_path = os.path.join(ROOT, 'bench_detail.json')
+        detail_path = args.detail or os.path.join(ROOT, 'bench_detail.json')
         line = {
             'metric': {'3dmatch': 'registration pairs/sec (20k-pt synthetic 3DMatch pair)',
                        'kitti': 'registration pairs/sec (120k-pt synthetic KITTI-shape pair)',

@@ -2,9 +2,9 @@
 # Round artifacts on the GPU box: full GPU suite, bench line (fp32 headline + split-bf16 sibling, CPU baseline, 4-pair parity), rocprofv3
 # kernel stats of the same command (4 lanes and 1 lane), PMC passes (HBM traffic, fp32), per-instantiation GEMM traffic table,
 # the other BASELINE configurations.
-# usage (from the repo root, via gpurun): bash scripts/refresh_artifacts.sh r04   (SUITE=0 skips the GPU test suite, OTHERS=0 the other configs)
+# usage (from the repo root, via gpurun): bash scripts/refresh_artifacts.sh r05   (SUITE=0 skips the GPU test suite, OTHERS=0 the other configs)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/artifacts_$TAG
 mkdir -p $OUT
@@ -41,10 +41,7 @@ except Exception as e: print('$name FAILED', e)" | tee -a $OUT/ab_runs.txt; }
 if [ "${AB:-1}" = "1" ]; then
   EXTRA="" ab default X=1
   EXTRA="--precision bf16x3" ab split_bf16 X=1
-  EXTRA="--precision fp32-unpacked" ab fp32_unpacked X=1
-  EXTRA="" ab fp32_round3_tiling GEOTR_F32_PLAN=0
-  EXTRA="" ab rg_tile_kernel GEOTR_RG_TILE=1
-  EXTRA="--lanes 1" ab one_lane X=1
+  EXTRA="" ab kpconv_two_kernel GEOTR_KPCONV_FUSED=0
   EXTRA="--lanes 2" ab two_lanes X=1
   EXTRA="--lanes 6" ab six_lanes X=1
   EXTRA="" ab default_again X=1
