@@ -17,13 +17,20 @@ def main():
             continue
         c, p, b = d['config'], d.get('parity') or {}, d.get('cpu_baseline') or {}
         shape = f"{c['lanes_per_gpu']} x {c['pairs_stacked_per_launch_sequence']}"
-        reports = p.get('reports') or ([p] if p else [])  # round 4: several pairs of the last timed step; rounds 1-3: pair 0 only
-        mse = max((r.get(k) or 0.0) for r in reports for k in ('mse_ref_feats_c', 'mse_src_feats_c', 'mse_ref_feats_f', 'mse_src_feats_f')) if p else None
-        bound = reports[0].get('feature_mse_bound') if reports else None
-        dT = [r.get('transform_max_abs_diff') for r in reports if r.get('transform_max_abs_diff') is not None]
+        if 'pairs_checked' in p:  # round 5: the compact line (per-pair reports live in the run's --detail file)
+            npairs, mse, bound, dmax = p['pairs_checked'], p.get('max_feature_mse'), None, p.get('max_transform_abs_diff')
+            extra = f"; pyramids {p.get('pyramids_identical')}/{p.get('pyramids_checked')} identical; RRE {p.get('max_rre_deg'):.2e} deg, RTE {p.get('max_rte_m'):.2e} m" \
+                if p.get('max_rre_deg') is not None else ''
+        else:
+            reports = p.get('reports') or ([p] if p else [])  # round 4: several pairs of the last timed step; rounds 1-3: pair 0 only
+            npairs = len(reports)
+            mse = max((r.get(k) or 0.0) for r in reports for k in ('mse_ref_feats_c', 'mse_src_feats_c', 'mse_ref_feats_f', 'mse_src_feats_f')) if p else None
+            bound = reports[0].get('feature_mse_bound') if reports else None
+            dT = [r.get('transform_max_abs_diff') for r in reports if r.get('transform_max_abs_diff') is not None]
+            dmax, extra = (max(dT) if dT else None), ''
         rows.append(f"| {name} | {d['value']} | {d['ms_per_step']} | {shape} | {c['matrix_precision']} | "
-                    f"{'ok' if p.get('ok') else ('-' if not p else 'NOT ok')} ({len(reports)} pair(s); max feature MSE {mse:.2e}, bound {bound}; "
-                    f"max pose |d| {max(dT) if dT else None}) | {b.get('value', '-')} |" if p else
+                    f"{'ok' if p.get('ok') else ('-' if not p else 'NOT ok')} ({npairs} pair(s); max feature MSE {mse:.2e}"
+                    f"{'' if bound is None else f', bound {bound}'}; max pose |d| {dmax}{extra}) | {b.get('value', '-')} |" if p else
                     f"| {name} | {d['value']} | {d['ms_per_step']} | {shape} | {c['matrix_precision']} | not run | - |")
         p = {k: v for k, v in p.items() if k != 'reports'}
         details.append(f"### {name}\n\n`{c['workload']}`\n\n```json\n{json.dumps({'parity': p, 'cpu_baseline': b, 'roofline': {k: v for k, v in (d.get('roofline') or {}).items() if k in ('kernel', 'achieved', 'peak', 'frac', 'executed_tflops', 'avg_launch_us', 'launches')}}, indent=1)}\n```\n")

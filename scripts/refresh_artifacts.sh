@@ -5,6 +5,7 @@
 # usage (from the repo root, via gpurun): bash scripts/refresh_artifacts.sh r05   (SUITE=0 skips the GPU test suite, OTHERS=0 the other configs)
 set -u
 TAG=${1:-r05}
+export ROUND=${TAG#r}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/artifacts_$TAG
 mkdir -p $OUT
@@ -15,7 +16,7 @@ if [ "${SUITE:-1}" = "1" ]; then
   tail -4 $OUT/gputests.log
 fi
 cd /tmp && export TMPDIR=/tmp
-timeout 600 python $ROOT/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+timeout 600 python $ROOT/bench.py --detail $OUT/bench_n1_detail.json > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 echo "bench rc=$?"; head -c 200 $OUT/bench_n1.json; echo
 B="--no-cpu-baseline --no-sibling-mode"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 $B > $OUT/bench_under_rocprof.json 2>/dev/null
@@ -50,9 +51,9 @@ fi
 cd $ROOT && python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt
 cd /tmp
 if [ "${OTHERS:-1}" = "1" ]; then
-  timeout 400 python $ROOT/bench.py --config lomatch --precision bf16 > $OUT/bench_lomatch_bf16.json 2> $OUT/bench_lomatch_bf16.err; echo "lomatch bf16 rc=$?"
-  timeout 300 python $ROOT/bench.py --config modelnet > $OUT/bench_modelnet.json 2> $OUT/bench_modelnet.err; echo "modelnet rc=$?"
-  timeout 400 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 8 > $OUT/bench_kitti.json 2> $OUT/bench_kitti.err; echo "kitti rc=$?"
+  timeout 400 python $ROOT/bench.py --config lomatch --precision bf16 --detail $OUT/bench_lomatch_bf16_detail.json > $OUT/bench_lomatch_bf16.json 2> $OUT/bench_lomatch_bf16.err; echo "lomatch bf16 rc=$?"
+  timeout 300 python $ROOT/bench.py --config modelnet --detail $OUT/bench_modelnet_detail.json > $OUT/bench_modelnet.json 2> $OUT/bench_modelnet.err; echo "modelnet rc=$?"
+  timeout 400 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 8 --detail $OUT/bench_kitti_detail.json > $OUT/bench_kitti.json 2> $OUT/bench_kitti.err; echo "kitti rc=$?"
   KARG=""; [ -s $OUT/bench_kitti.json ] && KARG="kitti=$OUT/bench_kitti.json"
   python $ROOT/scripts/other_configs_summary.py $OUT/other_configs.md modelnet=$OUT/bench_modelnet.json $KARG lomatch_bf16=$OUT/bench_lomatch_bf16.json
   head -12 $OUT/other_configs.md
