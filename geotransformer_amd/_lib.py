@@ -17,7 +17,7 @@ c_ptr = ctypes.c_void_p
 c_size = ctypes.c_size_t
 c_int = ctypes.c_int
 
-ABI_VERSION = 5  # geotr_abi_version() of the library this package's ctypes mirrors (native.py, kernels.py) were written against
+ABI_VERSION = 6  # geotr_abi_version() of the library this package's ctypes mirrors (native.py, kernels.py) were written against
 
 # name -> (restype, argtypes); must list every symbol include/geotr.h declares (tests check this)
 SIGNATURES = {
@@ -116,6 +116,14 @@ SIGNATURES = {
     'geotr_gse_knn_clouds': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geotr_gse_embed_table': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                       c_f32, c_f32, c_ptr, c_ptr]),
+    'geotr_gse_embed_table_ex': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                         c_f32, c_f32, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'geotr_attn_softmax_grouped_pos': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_ptr]),
+    'geotr_attn_softmax_ex': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_i64,
+                                      c_ptr, c_i64, c_ptr]),
+    'geotr_lgr_ex_workspace_bytes': (c_size, [c_i64, c_i64, c_i64, c_i64]),
+    'geotr_lgr_ex': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_int, c_f32, c_i64,
+                             c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'geotr_stack_clouds': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geotr_apply_transform': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'geotr_pairwise_distance': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),

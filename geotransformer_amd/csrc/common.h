@@ -63,7 +63,8 @@ int lgr_launch(const float* ref_knn_points, const float* src_knn_points, const u
                const float* score_mat, int64_t ld_patch, int64_t ld_row, int64_t p, int64_t k, int64_t topk, float confidence_threshold,
                int mutual, float acceptance_radius, int64_t correspondence_threshold, int64_t num_refinement_steps, const int32_t* p_count,
                float* ref_corr_points, float* src_corr_points, float* corr_scores, int32_t* num_corr, float* estimated_transform, void* ws,
-               size_t ws_bytes, void* stream, int batch, const LgrBatch& bs);
+               size_t ws_bytes, void* stream, int batch, const LgrBatch& bs, const float* global_scores = nullptr,
+               int64_t correspondence_limit = 0);
 
 int sinkhorn_launch(int batch, const float* const* ref_feats, const int64_t* nr, const float* const* src_feats, const int64_t* ns, int64_t c,
                     const int64_t* ref_knn_indices, const int64_t* src_knn_indices, const uint8_t* ref_knn_masks,

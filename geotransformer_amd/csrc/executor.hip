@@ -414,12 +414,24 @@ static void move_rows(Ctx& c, const float* src, float* dst, int64_t C, const Row
   if (hipGetLastError() != hipSuccess) c.check(fail(GEOTR_E_LAUNCH, "model_forward: move_rows launch failed"));
 }
 
+// qt[:, h, :] = q_h W_p[h], qb[:, h] = q_h . b_p[h] for the query rows of ALL groups at once: proj_p collapsed into the queries
+// (rpe_transformer.py:54-56)
+static void positional_queries(Ctx& c, int H, int64_t C, const float* q, int64_t ldq, int64_t rows, const geotr_linear* proj_p, float* qt,
+                               float* qb) {
+  const int64_t ch = C / H;
+  c.check(geotr_gemm(q, ldq, proj_p->w, C, 1, qt, H * C, rows, C, ch, H, ch, ch * C, C, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+  c.check(geotr_gemm(q, ldq, proj_p->b, 1, 1, qb, H, rows, 1, ch, H, ch, ch, 1, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+}
+
 // Attention cores of G (target, memory) cloud pairs in three grouped launches (+ two for the positional collapse):
 // q rows of group g start at q + qrow[g] * ldq (n[g] rows), k / v rows at k + krow[g] * ldkv (m[g] rows); hidden (rows, C) gets the
 // result at row qrow[g].  emb != nullptr (self-attention): emb[g] = (n[g], n[g], C) embedding, proj_p collapsed into qt / qb.
+// pos_pre / qb_pre (self-attention, optional): the positional term already computed by the embedding launch (geotr_gse_embed_table_ex;
+// same layout as the scores built here) and its q . b_p part -- then the embedding is not read at all.
 static void attention_groups(Ctx& c, int H, int64_t C, int G, const int64_t* n, const int64_t* m, const float* q, int64_t ldq,
                              const int64_t* qrow, int64_t q_rows_total, const float* k, const float* v, int64_t ldkv, const int64_t* krow,
-                             const float* const* emb, const geotr_linear* proj_p, float* hidden) {
+                             const float* const* emb, const geotr_linear* proj_p, float* hidden, const float* pos_pre = nullptr,
+                             const float* qb_pre = nullptr) {
   const int64_t ch = C / H;
   const size_t mk = c.mark();
   geotr_gemm_groups g1, g2;
@@ -444,16 +456,17 @@ static void attention_groups(Ctx& c, int H, int64_t C, int G, const int64_t* n, 
     total += (int64_t)H * n[g] * mp;
   }
   float* scores = c.alloc<float>((size_t)total);
-  float* qt = emb ? c.alloc<float>((size_t)q_rows_total * H * C) : nullptr;
-  float* qb = emb ? c.alloc<float>((size_t)q_rows_total * H) : nullptr;
+  const bool own_pos = emb && !pos_pre;
+  float* qt = own_pos ? c.alloc<float>((size_t)q_rows_total * H * C) : nullptr;
+  float* qb = own_pos ? c.alloc<float>((size_t)q_rows_total * H) : nullptr;
   if (c.live()) {
     c.check(geotr_gemm_grouped(q, k, 0, scores, &g1, H, 1.0f, c.stream));
-    if (emb) {  // qt[:, h, :] = q_h W_p[h], qb[:, h] = q_h . b_p[h] for the rows of ALL groups at once
-      c.check(geotr_gemm(q, ldq, proj_p->w, C, 1, qt, H * C, q_rows_total, C, ch, H, ch, ch * C, C, nullptr, nullptr, nullptr, 0, 1.0f, 0,
-                         c.stream));
-      c.check(geotr_gemm(q, ldq, proj_p->b, 1, 1, qb, H, q_rows_total, 1, ch, H, ch, ch, 1, nullptr, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+    if (pos_pre) {
+      c.check(geotr_attn_softmax_grouped_pos(scores, &ga, pos_pre, qb_pre, H, 1.0f / sqrtf((float)ch), c.stream));
+    } else {
+      if (emb) positional_queries(c, H, C, q, ldq, q_rows_total, proj_p, qt, qb);
+      c.check(geotr_attn_softmax_grouped(scores, &ga, qt, qb, C, H, 1.0f / sqrtf((float)ch), c.stream));
     }
-    c.check(geotr_attn_softmax_grouped(scores, &ga, qt, qb, C, H, 1.0f / sqrtf((float)ch), c.stream));
     c.check(geotr_gemm_grouped(scores, v, 1, hidden, &g2, H, 1.0f, c.stream));
   }
   c.release(mk);
@@ -483,17 +496,58 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
     to_work.src0[q] = stack0[q], to_work.dst0[q] = work0[q], to_work.rows[q] = cloud_n[q];
     to_stack.src0[q] = work0[q], to_stack.dst0[q] = stack0[q], to_stack.rows[q] = cloud_n[q];
   }
+  float* xin = c.alloc<float>((size_t)N * c_dim);
+  move_rows(c, feats_bb, xin, c_dim, to_work);
+  const float* x = linear(c, t.in_proj, xin, c_dim, N, 0);
+  // q / k / v of a self-attention layer: one fused (N, C) x (C, 3C) GEMM where the descriptor carries the concatenated weight
+  auto project_qkv = [&](const geotr_attn_layer& L, const float* xl, const float*& q, const float*& k, const float*& v, int64_t& ld) {
+    if (L.qkv_w) {
+      float* qkv = c.alloc<float>((size_t)N * 3 * C);
+      if (use_packed(L.qkv_packed, xl, C, N, C))
+        c.check(packed_gemm(c, xl, C, L.qkv_packed, qkv, 3 * C, N, 3 * C, C, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+      else if (c.live())
+        c.check(geotr_gemm(xl, C, L.qkv_w, C, 0, qkv, 3 * C, N, 3 * C, C, 1, 0, 0, 0, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
+      q = qkv, k = qkv + C, v = qkv + 2 * C, ld = 3 * C;
+    } else {
+      q = linear(c, L.q, xl, C, N, 0), k = linear(c, L.k, xl, C, N, 0), v = linear(c, L.v, xl, C, N, 0), ld = C;
+    }
+  };
+  // Round 5: the FIRST self-attention layer's positional scores come out of the embedding launch (gse_embed_table_kernel<.., POS>): its
+  // queries are projected before the embedding exists, W_p is collapsed into them, and the table kernel contracts every e[i, j, :] with
+  // qt[i, h, :] while it holds the row in registers -- that layer's softmax then never streams the (n, n, D) tensor.
+  static const bool pos_fused_enabled = [] {
+    const char* e = std::getenv("GEOTR_GSE_POS_FUSED");  // A/B switch for measurements: 0 = every self layer reads the embedding
+    return !(e && e[0] == '0');
+  }();
+  const bool pos_fused = pos_fused_enabled && t.gse_precision == 5 && t.proj_d.out == 256 && C == 256 && H == 4 && t.num_layers > 0 &&
+                         t.layers[0].is_self;
+  const float *q0 = nullptr, *k0 = nullptr, *v0 = nullptr, *pos0 = nullptr, *qb0 = nullptr;
+  int64_t ld0 = 0;
   // geometric structure embeddings, one (n, n, D) tensor per cloud
   const float* emb[2 * GEOTR_MAX_PAIRS];
   if (t.gse_precision == 5) {  // by table: all clouds of the stack in one ragged launch (+ one for the k nearest superpoints)
     geotr_gse_clouds gc;
-    std::memset(&gc, 0, sizeof(gc));
+    geotr_gse_pos gp;
+    std::memset(&gc, 0, sizeof(gc)), std::memset(&gp, 0, sizeof(gp));
     gc.count = 2 * B;
-    int64_t tot = 0, sq = 0;
+    int64_t tot = 0, sq = 0, pos_tot = 0;
     for (int q = 0; q < 2 * B; ++q) {
       gc.n[q] = (int32_t)cloud_n[q], gc.row0[q] = (int32_t)stack0[q], gc.emb_off[q] = tot;
       tot += cloud_n[q] * cloud_n[q] * t.proj_d.out;
       sq += cloud_n[q] * cloud_n[q];
+      const int64_t mp = (cloud_n[q] + 3) / 4 * 4;  // = the score layout attention_groups builds for the self layers
+      gp.q_row0[q] = (int32_t)work0[q], gp.ld[q] = (int32_t)mp, gp.pos_off[q] = pos_tot;
+      pos_tot += (int64_t)H * cloud_n[q] * mp;
+    }
+    float* qt_first = nullptr;
+    float* pos_first = nullptr;
+    if (pos_fused) {
+      project_qkv(t.layers[0], x, q0, k0, v0, ld0);
+      qt_first = c.alloc<float>((size_t)N * H * C);
+      float* qb_first = c.alloc<float>((size_t)N * H);
+      pos_first = c.alloc<float>((size_t)pos_tot);
+      if (c.live()) positional_queries(c, H, C, q0, ld0, N, &t.layers[0].p, qt_first, qb_first);
+      pos0 = pos_first, qb0 = qb_first;
     }
     float* emb_all = c.alloc<float>((size_t)tot);
     int32_t* knn = c.alloc<int32_t>((size_t)N * t.angle_k);
@@ -501,8 +555,9 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
     if (c.live()) {
       c.check(geotr_gse_knn_clouds(pts_c, &gc, t.angle_k, knn, c.stream));
       ProfScope prof(c.stream);
-      c.check(geotr_gse_embed_table(pts_c, knn, &gc, t.angle_k, t.proj_d.out, t.gse_table_d, t.gse_points_d, t.gse_table_a, t.gse_points_a,
-                                    t.proj_d.w, t.proj_d.b, t.proj_a.w, t.proj_a.b, t.div_term, t.sigma_d, t.sigma_a, emb_all, c.stream));
+      c.check(geotr_gse_embed_table_ex(pts_c, knn, &gc, t.angle_k, t.proj_d.out, t.gse_table_d, t.gse_points_d, t.gse_table_a, t.gse_points_a,
+                                       t.proj_d.w, t.proj_d.b, t.proj_a.w, t.proj_a.b, t.div_term, t.sigma_d, t.sigma_a, t.reduction_a,
+                                       qt_first, pos_fused ? &gp : nullptr, pos_first, emb_all, c.stream));
       prof.done(-sq);
     }
   } else {  // fused sinusoid -> MFMA kernels, one launch per cloud, shared split-weight workspace
@@ -510,27 +565,18 @@ static void transformer_stack(Ctx& c, const geotr_transformer& t, int B, const i
     for (int q = 0; q < 2 * B; ++q) emb[q] = gse(c, t, pts_c + 3 * stack0[q], cloud_n[q], gws, q == 0);
   }
 
-  float* xin = c.alloc<float>((size_t)N * c_dim);
-  move_rows(c, feats_bb, xin, c_dim, to_work);
-  const float* x = linear(c, t.in_proj, xin, c_dim, N, 0);
   for (int l = 0; l < t.num_layers; ++l) {
     const geotr_attn_layer& L = t.layers[l];
     float* y = c.alloc<float>((size_t)N * C);
     if (L.is_self) {
       const float *q, *k, *v;
       int64_t ld;
-      if (L.qkv_w) {
-        float* qkv = c.alloc<float>((size_t)N * 3 * C);
-        if (use_packed(L.qkv_packed, x, C, N, C))
-          c.check(packed_gemm(c, x, C, L.qkv_packed, qkv, 3 * C, N, 3 * C, C, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-        else if (c.live())
-          c.check(geotr_gemm(x, C, L.qkv_w, C, 0, qkv, 3 * C, N, 3 * C, C, 1, 0, 0, 0, L.qkv_b, nullptr, nullptr, 0, 1.0f, 0, c.stream));
-        q = qkv, k = qkv + C, v = qkv + 2 * C, ld = 3 * C;
-      } else {
-        q = linear(c, L.q, x, C, N, 0), k = linear(c, L.k, x, C, N, 0), v = linear(c, L.v, x, C, N, 0), ld = C;
-      }
+      const bool first_fused = l == 0 && pos_fused;
+      if (first_fused) q = q0, k = k0, v = v0, ld = ld0;
+      else project_qkv(L, x, q, k, v, ld);
       float* hidden = c.alloc<float>((size_t)N * C);
-      attention_groups(c, H, C, 2 * B, cloud_n, cloud_n, q, ld, work0, N, k, v, ld, work0, emb, &L.p, hidden);
+      attention_groups(c, H, C, 2 * B, cloud_n, cloud_n, q, ld, work0, N, k, v, ld, work0, emb, &L.p, hidden, first_fused ? pos0 : nullptr,
+                       first_fused ? qb0 : nullptr);
       attn_tail(c, L, hidden, x, N, C, y);
     } else {
       // sequential cross-attention (conditional_transformer.py:110-111): refs attend to the sources, then the sources to the
@@ -778,6 +824,8 @@ static int validate(const geotr_model* net, const geotr_pyramid* pyr) {
   GEOTR_CHECK_ARG(S >= 3 && S <= GEOTR_MAX_STAGES && pyr->num_stages == S, "model_forward: %d stages (pyramid has %d)", S, pyr->num_stages);
   GEOTR_CHECK_ARG(net->backbone.num_blocks == 2 + 3 * (S - 1), "model_forward: backbone block count does not match the depth");
   GEOTR_CHECK_ARG(net->transformer.num_layers >= 1 && net->transformer.num_layers <= 8, "model_forward: 1..8 transformer layers");
+  GEOTR_CHECK_ARG(net->transformer.reduction_a == 0 || (net->transformer.reduction_a == 1 && net->transformer.gse_precision == 5),
+                  "model_forward: reduction_a must be 0 (max) or 1 (mean; with the table embedding, gse_precision 5, only)");
   GEOTR_CHECK_ARG(pyr->num_pairs >= 1 && pyr->num_pairs <= GEOTR_MAX_PAIRS, "model_forward: 1..%d stacked pairs", GEOTR_MAX_PAIRS);
   for (int s = 0; s < S; ++s) {
     int64_t tot = 0;

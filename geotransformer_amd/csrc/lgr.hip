@@ -173,7 +173,8 @@ __device__ __forceinline__ T* lgr_shift(T* p, int64_t bytes) {
 __global__ __launch_bounds__(256) void lgr_corr_kernel(const float* __restrict__ score, int64_t ld_patch, int ld_row, int K, int topk,
                                                        float thr, int mutual, const unsigned char* __restrict__ rmask,
                                                        const unsigned char* __restrict__ smask, int cap, const int* __restrict__ p_count,
-                                                       int* __restrict__ cnt, int* __restrict__ stage_ij, float* __restrict__ stage_score, LgrBatch bs) {
+                                                       int* __restrict__ cnt, int* __restrict__ stage_ij, float* __restrict__ stage_score, LgrBatch bs,
+                                                       const float* __restrict__ gscore) {
   score = lgr_shift(score, bs.score);
   rmask = lgr_shift(rmask, bs.knn_mask);
   smask = lgr_shift(smask, bs.knn_mask);
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void lgr_corr_kernel(const float* __restrict__
     const int pos = base_s + block_exclusive_scan<256>(flag, sm, tot);
     if (flag && pos < cap) {
       stage_ij[(int64_t)p * cap + pos] = (i << 16) | j;
-      stage_score[(int64_t)p * cap + pos] = v;
+      stage_score[(int64_t)p * cap + pos] = gscore ? v * gscore[p] : v;  // use_global_score (local_global_registration.py:225-226)
     }
     __syncthreads();
     if (tid == 0) base_s += tot;
@@ -284,6 +285,75 @@ __global__ __launch_bounds__(256) void lgr_gather_kernel(const float* __restrict
     }
     scores[off + e] = stage_score[(int64_t)p * cap + e];
   }
+}
+
+// (2b) correspondence_limit (local_global_registration.py:145-148): the VERIFICATION set -- what the hypotheses are scored on and the pose is
+// refined on -- is the `limit` best-scoring correspondences when there are more.  One workgroup: the threshold value by a radix select over
+// the float bits (scores are positive: exp(.) above a positive confidence threshold, times a positive global score), then an ordered
+// compaction: everything above the threshold, and entries equal to it in index order until the set is full.  The set is kept in INDEX order
+// (torch.topk lists it by descending score; the weighted sums it feeds are accumulated in fp64, so the order is immaterial).
+__global__ __launch_bounds__(1024) void lgr_limit_kernel(const float* __restrict__ ref_corr, const float* __restrict__ src_corr,
+                                                         const float* __restrict__ scores, const int* __restrict__ total, int limit,
+                                                         float* __restrict__ vref, float* __restrict__ vsrc, float* __restrict__ vscore,
+                                                         int* __restrict__ vtotal) {
+  __shared__ int hist[256];
+  __shared__ int sm[17];
+  __shared__ unsigned prefix_s;
+  __shared__ int want_s, base_s, eq_base_s;
+  const int tid = threadIdx.x, C = *total;
+  if (C <= limit) {
+    for (int i = tid; i < C; i += 1024) {
+      for (int d = 0; d < 3; ++d) vref[3 * (int64_t)i + d] = ref_corr[3 * (int64_t)i + d], vsrc[3 * (int64_t)i + d] = src_corr[3 * (int64_t)i + d];
+      vscore[i] = scores[i];
+    }
+    if (tid == 0) *vtotal = C;
+    return;
+  }
+  if (tid == 0) prefix_s = 0u, want_s = limit;
+  __syncthreads();
+  for (int shift = 24; shift >= 0; shift -= 8) {  // byte by byte from the top: the bucket that holds the limit-th largest value
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = prefix_s;
+    const unsigned high_mask = shift == 24 ? 0u : ~((1u << (shift + 8)) - 1u);
+    for (int i = tid; i < C; i += 1024) {
+      const unsigned b = __float_as_uint(scores[i]);
+      if ((b & high_mask) == prefix) atomicAdd(&hist[(b >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int want = want_s, bucket = 255;
+      for (; bucket > 0; --bucket) {
+        if (hist[bucket] >= want) break;
+        want -= hist[bucket];
+      }
+      prefix_s = prefix | ((unsigned)bucket << shift);
+      want_s = want;  // how many entries of the chosen bucket still belong to the set
+    }
+    __syncthreads();
+  }
+  const unsigned thr = prefix_s;  // bits of the limit-th largest score; want_s of the entries equal to it are taken
+  const int take_eq = want_s;
+  if (tid == 0) base_s = 0, eq_base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < C; i0 += 1024) {
+    const int i = i0 + tid;
+    unsigned b = 0;
+    if (i < C) b = __float_as_uint(scores[i]);
+    const int is_eq = i < C && b == thr;
+    int eq_tot, tot;
+    const int eq_rank = eq_base_s + block_exclusive_scan<1024>(is_eq, sm, eq_tot);
+    const int flag = i < C && (b > thr || (is_eq && eq_rank < take_eq));
+    const int pos = base_s + block_exclusive_scan<1024>(flag, sm, tot);
+    if (flag) {
+      for (int d = 0; d < 3; ++d) vref[3 * (int64_t)pos + d] = ref_corr[3 * (int64_t)i + d], vsrc[3 * (int64_t)pos + d] = src_corr[3 * (int64_t)i + d];
+      vscore[pos] = scores[i];
+    }
+    __syncthreads();
+    if (tid == 0) base_s += tot, eq_base_s += eq_tot;
+    __syncthreads();
+  }
+  if (tid == 0) *vtotal = base_s;
 }
 
 // (3) one hypothesis per patch pair with >= min_corr correspondences (local registration, :165-171)
@@ -413,12 +483,14 @@ int lgr_launch(const float* ref_knn_points, const float* src_knn_points, const u
               int64_t topk, float confidence_threshold, int mutual, float acceptance_radius, int64_t correspondence_threshold,
               int64_t num_refinement_steps, const int32_t* p_count, float* ref_corr_points, float* src_corr_points,
               float* corr_scores, int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream_, int batch,
-               const LgrBatch& bs) {
+               const LgrBatch& bs, const float* global_scores, int64_t correspondence_limit) {
   GEOTR_CHECK_ARG(p >= 1 && k >= 1 && k <= 256 && topk >= 1 && topk <= 4, "lgr: bad sizes (k <= 256, topk <= 4)");
   GEOTR_CHECK_ARG(num_refinement_steps >= 1, "lgr: num_refinement_steps must be >= 1");
   GEOTR_CHECK_ARG(ref_knn_points && src_knn_points && ref_knn_masks && src_knn_masks && score_mat && ref_corr_points &&
                       src_corr_points && corr_scores && num_corr && estimated_transform && ws, "lgr: null pointer");
-  if (ws_bytes < geotr_lgr_workspace_bytes(p, k, topk)) return fail(GEOTR_E_WORKSPACE, "lgr: workspace too small");
+  const bool limited = correspondence_limit > 0;
+  GEOTR_CHECK_ARG(!limited || (batch == 1 && correspondence_limit < (1ll << 30)), "lgr: correspondence_limit is a single-pair option");
+  if (ws_bytes < geotr_lgr_ex_workspace_bytes(p, k, topk, correspondence_limit)) return fail(GEOTR_E_WORKSPACE, "lgr: workspace too small");
   hipStream_t stream = (hipStream_t)stream_;
   const int cap = (int)(k * topk);
   Carver c(ws);
@@ -429,22 +501,36 @@ int lgr_launch(const float* ref_knn_points, const float* src_knn_points, const u
   int* valid = c.take<int>((size_t)p);
   int* inliers = c.take<int>((size_t)p);
   float* T_all = c.take<float>((size_t)p * 16);
+  // verification set of correspondence_limit (at most min(limit, p * cap) rows)
+  const size_t vrows = limited ? (size_t)std::min<int64_t>(correspondence_limit, p * (int64_t)cap) : 0;
+  float* vref = limited ? c.take<float>(vrows * 3) : nullptr;
+  float* vsrc = limited ? c.take<float>(vrows * 3) : nullptr;
+  float* vscore = limited ? c.take<float>(vrows) : nullptr;
+  int* vtotal = limited ? c.take<int>(1) : nullptr;
   const size_t lds = sizeof(float) * ((size_t)k * (k + 1) + 2 * (size_t)k);
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(&lgr_corr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(GEOTR_E_LAUNCH, "lgr: cannot reserve LDS");
   lgr_corr_kernel<<<dim3((unsigned)p, (unsigned)batch), dim3(256), lds, stream>>>(score_mat, ld_patch, (int)ld_row, (int)k, (int)topk,
                                                                  confidence_threshold, mutual, ref_knn_masks, src_knn_masks, cap, p_count,
-                                                                 cnt, stage_ij, stage_score, bs);
+                                                                 cnt, stage_ij, stage_score, bs, global_scores);
   lgr_gather_kernel<<<dim3((unsigned)p, (unsigned)batch), dim3(256), 0, stream>>>(ref_knn_points, src_knn_points, (int)k, (int)p, cap, cnt, stage_ij,
                                                                  stage_score, ref_corr_points, src_corr_points, corr_scores, offsets,
                                                                  num_corr, bs);
   lgr_local_kernel<<<dim3((unsigned)p, (unsigned)batch), dim3(64), 0, stream>>>(ref_corr_points, src_corr_points, corr_scores, cnt, offsets,
                                                                (int)correspondence_threshold, T_all, valid, bs);
-  lgr_score_kernel<<<dim3((unsigned)p, (unsigned)batch), dim3(256), 0, stream>>>(ref_corr_points, src_corr_points, num_corr, T_all, valid,
-                                                                acceptance_radius, inliers, bs);
-  lgr_refine_kernel<<<dim3(1, (unsigned)batch), dim3(1024), 0, stream>>>(ref_corr_points, src_corr_points, corr_scores, num_corr, T_all, inliers,
-                                                        (int)p, acceptance_radius, (int)num_refinement_steps, estimated_transform, bs);
+  // hypotheses are scored, and the pose refined, on the verification set: all correspondences, or the best `limit` of them (:145-152)
+  const float *ver_ref = ref_corr_points, *ver_src = src_corr_points, *ver_score = corr_scores;
+  const int* ver_total = num_corr;
+  if (limited) {
+    lgr_limit_kernel<<<dim3(1), dim3(1024), 0, stream>>>(ref_corr_points, src_corr_points, corr_scores, num_corr, (int)vrows, vref, vsrc, vscore,
+                                                         vtotal);
+    ver_ref = vref, ver_src = vsrc, ver_score = vscore, ver_total = vtotal;
+  }
+  lgr_score_kernel<<<dim3((unsigned)p, (unsigned)batch), dim3(256), 0, stream>>>(ver_ref, ver_src, ver_total, T_all, valid, acceptance_radius,
+                                                                inliers, bs);
+  lgr_refine_kernel<<<dim3(1, (unsigned)batch), dim3(1024), 0, stream>>>(ver_ref, ver_src, ver_score, ver_total, T_all, inliers, (int)p,
+                                                        acceptance_radius, (int)num_refinement_steps, estimated_transform, bs);
   GEOTR_CHECK_LAUNCH("lgr");
   return GEOTR_OK;
 }
@@ -467,6 +553,15 @@ size_t geotr_lgr_workspace_bytes(int64_t p, int64_t k, int64_t topk) {
   return align_up(P * cap * 4) * 2 + align_up(P * 4) * 4 + align_up(P * 64);
 }
 
+size_t geotr_lgr_ex_workspace_bytes(int64_t p, int64_t k, int64_t topk, int64_t correspondence_limit) {
+  size_t bytes = geotr_lgr_workspace_bytes(p, k, topk);
+  if (correspondence_limit > 0) {
+    const size_t rows = (size_t)std::min<int64_t>(correspondence_limit, std::max<int64_t>(p, 1) * k * topk);
+    bytes += align_up(rows * 12) * 2 + align_up(rows * 4) + align_up(4);
+  }
+  return bytes;
+}
+
 int geotr_lgr(const float* ref_knn_points, const float* src_knn_points, const uint8_t* ref_knn_masks,
               const uint8_t* src_knn_masks, const float* score_mat, int64_t ld_patch, int64_t ld_row, int64_t p, int64_t k,
               int64_t topk, float confidence_threshold, int mutual, float acceptance_radius, int64_t correspondence_threshold,
@@ -477,6 +572,19 @@ int geotr_lgr(const float* ref_knn_points, const float* src_knn_points, const ui
   return lgr_launch(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, ld_patch, ld_row, p, k, topk,
                     confidence_threshold, mutual, acceptance_radius, correspondence_threshold, num_refinement_steps, p_count,
                     ref_corr_points, src_corr_points, corr_scores, num_corr, estimated_transform, ws, ws_bytes, stream_, 1, bs);
+}
+
+int geotr_lgr_ex(const float* ref_knn_points, const float* src_knn_points, const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks,
+                 const float* score_mat, int64_t ld_patch, int64_t ld_row, int64_t p, int64_t k, int64_t topk, float confidence_threshold,
+                 int mutual, float acceptance_radius, int64_t correspondence_threshold, int64_t num_refinement_steps, const int32_t* p_count,
+                 const float* global_scores, int64_t correspondence_limit, float* ref_corr_points, float* src_corr_points, float* corr_scores,
+                 int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream_) {
+  LgrBatch bs;
+  std::memset(&bs, 0, sizeof(bs));
+  return lgr_launch(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, ld_patch, ld_row, p, k, topk,
+                    confidence_threshold, mutual, acceptance_radius, correspondence_threshold, num_refinement_steps, p_count,
+                    ref_corr_points, src_corr_points, corr_scores, num_corr, estimated_transform, ws, ws_bytes, stream_, 1, bs, global_scores,
+                    correspondence_limit > 0 ? correspondence_limit : 0);
 }
 
 }  // extern "C"

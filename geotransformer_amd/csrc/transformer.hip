@@ -11,6 +11,7 @@
 //                        (transformer/rpe_transformer.py:51-62).  With emb == NULL it is the plain
 //                        scaled softmax of transformer/vanilla_transformer.py:55-63.
 #include <algorithm>
+#include <cstring>
 
 #include "common.h"
 
@@ -543,14 +544,28 @@ __device__ __forceinline__ bool gse_in_table(float x, int points) { return x * (
 // the wave walks its 64 pairs with lanes <-> channels (V = D / 64 per lane, 16-byte accesses at D = 256): every table row and
 // every output row is one contiguous wave-wide access.  All clouds of a stack in ONE ragged launch (blockIdx.x -> cloud by the
 // chunk prefix table).
-template <int D, int S>
-__global__ __launch_bounds__(256) void gse_embed_table_kernel(const float* __restrict__ pts_all, const int* __restrict__ knn_all,
+// MEAN: reduction_a = 'mean' (geotransformer.py:66-69): the k angular slots are summed in slot order and divided by k instead of the max.
+// POS (round 5, D = 256, 4 heads): the positional attention term of the FIRST self-attention layer out of the same pass
+// (rpe_transformer.py:51-58 consumes embed_qk right after it exists): pos[h, i, j] = e[i, j, :] . qt[i, h, :] with qt = W_p[h]^T q_h of
+// that layer (computed before this launch) while e[i, j, :] is still in registers -- 16 FMAs per lane, a transposing butterfly over the
+// wave (7 exchanges for the 4 heads), the 4 x 64 results of a wave's pairs staged in LDS and stored as coalesced row segments.  That
+// layer's softmax then reads (heads, n, n) scalars instead of streaming the (n, n, D) embedding: one of its three 0.2 GB reads per pair
+// is gone (geotr_attn_softmax_grouped_pos).
+struct GsePos {
+  int q_row0[2 * GEOTR_MAX_PAIRS];     // first row of cloud q in qt (rows, 4, D)
+  int ld[2 * GEOTR_MAX_PAIRS];         // row stride of cloud q's (4, n, ld) block of pos
+  int64_t pos_off[2 * GEOTR_MAX_PAIRS];  // its first element
+};
+template <int D, int S, bool MEAN = false, bool POS = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void gse_embed_table_kernel(const float* __restrict__ pts_all, const int* __restrict__ knn_all,
                                                               GseClouds cl, const float* __restrict__ tab_d, int points_d,
                                                               const float* __restrict__ tab_a, int points_a,
                                                               const float* __restrict__ Wd, const float* __restrict__ bd,
                                                               const float* __restrict__ Wa, const float* __restrict__ ba,
                                                               const float* __restrict__ div_term, float inv_sigma_d, float factor_a,
-                                                              float* __restrict__ out_all) {
+                                                              float* __restrict__ out_all, const float* __restrict__ qt,
+                                                              float* __restrict__ pos_all, GsePos pp) {
+  static_assert(!POS || D == 256, "the positional by-product is written for D = 256 (every lane owns 4 channels), 4 heads");
   constexpr int V = D >= 256 ? 4 : (D >= 128 ? 2 : 1);
   constexpr int ACTIVE = D / V;  // lanes that own channels (64, or D when D < 64)
   int q = 0;
@@ -568,10 +583,12 @@ __global__ __launch_bounds__(256) void gse_embed_table_kernel(const float* __res
   float vals[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) vals[s] = 0.f;
+  int my_i = 0, my_j = 0;  // the lane's own pair (POS: query row / key of its positional scores)
   {
     const int64_t p = p0 + lane;
     if (p < total) {
       const int i = (int)(p / n), j = (int)(p - (int64_t)i * n);
+      my_i = i, my_j = j;
       const float pi[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
       const float pj[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
       vals[0] = sqrtf(expanded_sqdist(pi, pj)) * inv_sigma_d;
@@ -598,6 +615,48 @@ __global__ __launch_bounds__(256) void gse_embed_table_kernel(const float* __res
     for (int c = 0; c < V; ++c) bias[c] = b1[c] + b2[c];
   }
   const int count = (int)min((int64_t)64, total - p0);
+  // ---- POS: qt[i, h, c0 .. c0 + 3] of the current query row in registers (reloaded when the wave's pairs move on to the next row) ----
+  __shared__ float pos_s[POS ? 4 : 1][4][64];
+  // qt[i, h, c0 .. c0 + 3] of the current query row is parked in LDS (each lane reads back only what it wrote): held in registers it
+  // added 16 VGPRs to the table-row loads' peak and cost two of the five waves per SIMD (132 vs 89 VGPRs)
+  __shared__ float4 qt_s[POS ? 4 : 1][4][64];
+  int cur_i = -1;
+  auto emit_pos = [&](int e, const float (&r)[V]) {  // every lane of the wave is here (D = 256: all 64 own channels)
+    if constexpr (POS) {
+      __builtin_amdgcn_sched_barrier(0);  // nothing of this block is hoisted into the table-row loads above (their 64 registers are the peak)
+      const int ie = __builtin_amdgcn_readlane(my_i, e);  // wave-uniform
+      if (ie != cur_i) {
+        cur_i = ie;
+        const float* row = qt + ((int64_t)(pp.q_row0[q] + ie) * 4) * D + c0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) qt_s[wave][h][lane] = *reinterpret_cast<const float4*>(row + h * D);
+      }
+      float qtv[4][4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const float4 w4 = qt_s[wave][h][lane];
+        qtv[h][0] = w4.x, qtv[h][1] = w4.y, qtv[h][2] = w4.z, qtv[h][3] = w4.w;
+      }
+      float part[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) part[h] = fmaf(r[3], qtv[h][3], fmaf(r[2], qtv[h][2], fmaf(r[1], qtv[h][1], r[0] * qtv[h][0])));
+      // transposing butterfly: after the exchange over 32 the lower half-wave carries heads 0, 1 and the upper one heads 2, 3; after the
+      // one over 16 every 16-lane group carries ONE head (group g: head g); four more steps sum inside the group
+      const bool up = lane >= 32, odd = (lane & 16) != 0;
+      float a0 = up ? part[2] : part[0], a1 = up ? part[3] : part[1];
+      const float s0 = up ? part[0] : part[2], s1 = up ? part[1] : part[3];
+      a0 += __shfl_xor(s0, 32, 64);
+      a1 += __shfl_xor(s1, 32, 64);
+      float keep = odd ? a1 : a0;
+      const float send = odd ? a0 : a1;
+      keep += __shfl_xor(send, 16, 64);
+      keep += __shfl_xor(keep, 8, 64);
+      keep += __shfl_xor(keep, 4, 64);
+      keep += __shfl_xor(keep, 2, 64);
+      keep += __shfl_xor(keep, 1, 64);
+      if ((lane & 15) == 0) pos_s[wave][lane >> 4][e] = keep;
+    }
+  };
   unsigned long long slow = 0;  // pairs with an index beyond its table (or NaN): wave-uniform mask, handled after the main loop
   for (int e = 0; e < count; ++e) {
     float x[S];
@@ -623,12 +682,13 @@ __global__ __launch_bounds__(256) void gse_embed_table_kernel(const float* __res
       float a[V];
       rows[s].eval(a);
 #pragma unroll
-      for (int c = 0; c < V; ++c) m[c] = fmaxf(m[c], a[c]);
+      for (int c = 0; c < V; ++c) m[c] = MEAN ? m[c] + a[c] : fmaxf(m[c], a[c]);
     }
     float r[V];
 #pragma unroll
-    for (int c = 0; c < V; ++c) r[c] = (d[c] + m[c]) + bias[c];
+    for (int c = 0; c < V; ++c) r[c] = (d[c] + (MEAN ? __fdiv_rn(m[c], (float)(S - 1)) : m[c])) + bias[c];
     *reinterpret_cast<typename GseVec<V>::T*>(out + (p0 + e) * D + c0) = *reinterpret_cast<const typename GseVec<V>::T*>(r);
+    emit_pos(e, r);
   }
   while (slow) {  // exact direct evaluation (rare)
     const int e = __builtin_ctzll(slow);
@@ -641,7 +701,7 @@ __global__ __launch_bounds__(256) void gse_embed_table_kernel(const float* __res
     if (lane >= ACTIVE) continue;
     float d[V], m[V];
 #pragma unroll
-    for (int c = 0; c < V; ++c) d[c] = 0.f, m[c] = -3.4e38f;
+    for (int c = 0; c < V; ++c) d[c] = 0.f, m[c] = MEAN ? 0.f : -3.4e38f;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const float x = xs[s];
@@ -658,13 +718,25 @@ __global__ __launch_bounds__(256) void gse_embed_table_kernel(const float* __res
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         if (s == 0) d[c] = a[c];
-        else m[c] = fmaxf(m[c], a[c]);
+        else m[c] = MEAN ? m[c] + a[c] : fmaxf(m[c], a[c]);
       }
     }
     float r[V];
 #pragma unroll
-    for (int c = 0; c < V; ++c) r[c] = (d[c] + m[c]) + bias[c];
+    for (int c = 0; c < V; ++c) r[c] = (d[c] + (MEAN ? __fdiv_rn(m[c], (float)(S - 1)) : m[c])) + bias[c];
     *reinterpret_cast<typename GseVec<V>::T*>(out + (p0 + e) * D + c0) = *reinterpret_cast<const typename GseVec<V>::T*>(r);
+    emit_pos(e, r);
+  }
+  if constexpr (POS) {  // the wave's 4 x 64 positional scores: lane <-> its own pair, one coalesced row segment per head
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < count) {
+      float* pos = pos_all + pp.pos_off[q];
+      const int ld = pp.ld[q];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) pos[((int64_t)h * n + my_i) * ld + my_j] = pos_s[wave][h][lane];
+    }
   }
 }
 
@@ -731,6 +803,23 @@ __global__ __launch_bounds__(256) void attn_pos_kernel(float* __restrict__ score
 // query's qt row sits in LDS and is read as broadcasts.  The (n, n, C) embedding is read exactly once per layer -- this kernel
 // is its only consumer -- so it is bound by that stream.
 // Ragged groups (one per cloud of a stack): blockIdx.y = group, blockIdx.x = query row (rows past the group's n exit).
+// Optional modifiers of the scaled scores, in the reference's order (rpe_transformer.py:59-64, vanilla_transformer.py:57-64):
+//   v = factors[i, j] * v;  v = v * key_weights[j];  key_masks[j] -> -inf;  masks[i, j] -> -inf   (a fully masked row is NaN, as torch)
+struct AttnExtras {
+  const float* key_weights;   // (m) or null
+  const uint8_t* key_masks;   // (m), nonzero = ignored, or null
+  const float* factors;       // (n, m) row stride ld_f, or null
+  const uint8_t* masks;       // (n, m) row stride ld_m, nonzero = ignored, or null
+  int64_t ld_f, ld_m;
+};
+__device__ __forceinline__ float attn_apply_extras(float v, int i, int j, const AttnExtras& ex) {
+  if (ex.factors) v = ex.factors[(int64_t)i * ex.ld_f + j] * v;
+  if (ex.key_weights) v = v * ex.key_weights[j];
+  if (ex.key_masks && ex.key_masks[j]) v = -__builtin_inff();
+  if (ex.masks && ex.masks[(int64_t)i * ex.ld_m + j]) v = -__builtin_inff();
+  return v;
+}
+
 struct AttnGroups {
   int count;
   int n[GEOTR_MAX_GROUPS], m[GEOTR_MAX_GROUPS], ld[GEOTR_MAX_GROUPS];
@@ -738,10 +827,10 @@ struct AttnGroups {
   const float* emb[GEOTR_MAX_GROUPS];
 };
 
-template <int H, bool GROUPED>
+template <int H, bool GROUPED, bool EXTRAS = false>
 __device__ __forceinline__ void attn_pos_softmax_body(float* __restrict__ scores, const float* __restrict__ emb,
                                                       const float* __restrict__ qt, const float* __restrict__ qb, int n, int m, int ld,
-                                                      int C, float scale, const AttnGroups* gr) {
+                                                      int C, float scale, const AttnGroups* gr, const AttnExtras* ex = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (GROUPED) {
     const int g = blockIdx.y;
@@ -793,7 +882,11 @@ __device__ __forceinline__ void attn_pos_softmax_body(float* __restrict__ scores
     }
     if (kl == 0) {
 #pragma unroll
-      for (int h = 0; h < H; ++h) sc_s[h * m + j] = (scores[((int64_t)h * n + i) * ld + j] + (acc[h] + qbv[h])) * scale;
+      for (int h = 0; h < H; ++h) {
+        float v = (scores[((int64_t)h * n + i) * ld + j] + (acc[h] + qbv[h])) * scale;
+        if constexpr (EXTRAS) v = attn_apply_extras(v, i, j, *ex);
+        sc_s[h * m + j] = v;
+      }
     }
   }
   __syncthreads();
@@ -825,20 +918,41 @@ __global__ __launch_bounds__(256) void attn_pos_softmax_grouped_kernel(float* __
                                                                        const float* __restrict__ qb, int C, float scale, AttnGroups gr) {
   attn_pos_softmax_body<H, true>(scores, nullptr, qt, qb, 0, 0, 0, C, scale, &gr);
 }
+template <int H>
+__global__ __launch_bounds__(256) void attn_pos_softmax_extras_kernel(float* __restrict__ scores, const float* __restrict__ emb,
+                                                                      const float* __restrict__ qt, const float* __restrict__ qb, int n, int m,
+                                                                      int ld, int C, float scale, AttnExtras ex) {
+  attn_pos_softmax_body<H, false, true>(scores, emb, qt, qb, n, m, ld, C, scale, nullptr, &ex);
+}
 
 // softmax over the keys of one query row, all heads: scores <- softmax(scores * scale)
-template <bool GROUPED>
-__device__ __forceinline__ void attn_softmax_body(float* __restrict__ scores, int n, int m, int ld, int H, float scale, const AttnGroups* gr) {
+// MODE 0: as stated.  MODE 1 (grouped launches): the positional term comes precomputed -- pos (same layout as scores, written by
+// gse_embed_table_kernel<.., POS>) and qb (rows, H): scores <- softmax((scores + (pos + qb)) * scale), the association of
+// attn_pos_softmax_body.  MODE 2 (one cloud): scaled scores modified by AttnExtras before the softmax.
+template <bool GROUPED, int MODE = 0>
+__device__ __forceinline__ void attn_softmax_body(float* __restrict__ scores, int n, int m, int ld, int H, float scale, const AttnGroups* gr,
+                                                  const float* __restrict__ pos = nullptr, const float* __restrict__ qb = nullptr,
+                                                  const AttnExtras* ex = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float sc_s[];  // [H][m]
+  int64_t q_off = 0;
   if (GROUPED) {
     const int g = blockIdx.y;
     n = gr->n[g], m = gr->m[g], ld = gr->ld[g];
     if ((int)blockIdx.x >= n) return;
     scores += gr->sc_off[g];
+    if (MODE == 1) pos += gr->sc_off[g], q_off = gr->q_off[g];
   }
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < H * m; e += 256) sc_s[e] = scores[((int64_t)(e / m) * n + i) * ld + (e % m)];
+  for (int e = tid; e < H * m; e += 256) {
+    const int h = e / m, j = e % m;
+    const int64_t at = ((int64_t)h * n + i) * ld + j;
+    float v = scores[at];
+    if (MODE == 1) v = (v + (pos[at] + qb[(q_off + i) * H + h])) * scale;
+    if (MODE == 2) v = attn_apply_extras(v * scale, i, j, *ex);
+    sc_s[e] = v;
+  }
   __syncthreads();
+  if (MODE != 0) scale = 1.0f;  // (already applied)
   for (int h = wave; h < H; h += 4) {  // wave per head
     float mx = -3.4e38f;
     for (int j = lane; j < m; j += 64) mx = fmaxf(mx, sc_s[h * m + j] * scale);
@@ -860,6 +974,14 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ s
 }
 __global__ __launch_bounds__(256) void attn_softmax_grouped_kernel(float* __restrict__ scores, int H, float scale, AttnGroups gr) {
   attn_softmax_body<true>(scores, 0, 0, 0, H, scale, &gr);
+}
+__global__ __launch_bounds__(256) void attn_softmax_grouped_pos_kernel(float* __restrict__ scores, const float* __restrict__ pos,
+                                                                       const float* __restrict__ qb, int H, float scale, AttnGroups gr) {
+  attn_softmax_body<true, 1>(scores, 0, 0, 0, H, scale, &gr, pos, qb);
+}
+__global__ __launch_bounds__(256) void attn_softmax_extras_kernel(float* __restrict__ scores, int n, int m, int ld, int H, float scale,
+                                                                  AttnExtras ex) {
+  attn_softmax_body<false, 2>(scores, n, m, ld, H, scale, nullptr, nullptr, nullptr, &ex);
 }
 
 }  // namespace geotr
@@ -1027,10 +1149,10 @@ int geotr_gse_table_build(const float* div_term, const float* w, int64_t d, int6
   return geotr_gemm(basis, d, w, d, 0, table, d, points * 4, d, d, 1, 0, 0, 0, nullptr, nullptr, nullptr, 0, 1.0f, 0, stream_);
 }
 
-int geotr_gse_embed_table(const float* points, const int32_t* knn, const geotr_gse_clouds* clouds, int64_t k, int64_t d,
-                          const float* table_d, int64_t points_d, const float* table_a, int64_t points_a, const float* w_d,
-                          const float* b_d, const float* w_a, const float* b_a, const float* div_term, float sigma_d, float sigma_a,
-                          float* out, void* stream_) {
+int geotr_gse_embed_table_ex(const float* points, const int32_t* knn, const geotr_gse_clouds* clouds, int64_t k, int64_t d,
+                             const float* table_d, int64_t points_d, const float* table_a, int64_t points_a, const float* w_d,
+                             const float* b_d, const float* w_a, const float* b_a, const float* div_term, float sigma_d, float sigma_a,
+                             int reduction_a, const float* qt, const geotr_gse_pos* pos_layout, float* pos, float* out, void* stream_) {
   GEOTR_CHECK_ARG(k >= 1 && k <= kMaxK, "gse_embed_table: angle_k must be in [1, %d]", kMaxK);
   GEOTR_CHECK_ARG(d == 32 || d == 64 || d == 128 || d == 256, "gse_embed_table: hidden_dim must be 32, 64, 128 or 256 (got %lld)", (long long)d);
   GEOTR_CHECK_ARG(points && knn && table_d && table_a && w_d && b_d && w_a && b_a && div_term && out, "gse_embed_table: null pointer");
@@ -1038,35 +1160,70 @@ int geotr_gse_embed_table(const float* points, const int32_t* knn, const geotr_g
   GEOTR_CHECK_ARG(((reinterpret_cast<uintptr_t>(table_d) | reinterpret_cast<uintptr_t>(table_a) | reinterpret_cast<uintptr_t>(out) |
                     reinterpret_cast<uintptr_t>(b_d) | reinterpret_cast<uintptr_t>(b_a)) & 15) == 0,
                   "gse_embed_table: tables, biases and output must be 16-byte aligned");
+  GEOTR_CHECK_ARG(reduction_a == 0 || reduction_a == 1, "gse_embed_table: reduction_a must be 0 (max) or 1 (mean)");
+  const bool with_pos = pos != nullptr;
+  GEOTR_CHECK_ARG(!with_pos || (qt && pos_layout && d == 256 && (reinterpret_cast<uintptr_t>(qt) & 15) == 0),
+                  "gse_embed_table: the positional by-product needs qt (16-byte aligned), its layout, and hidden_dim 256 (4 heads)");
   GseClouds cl;
   int max_n;
   const int rc = gse_clouds(clouds, k, cl, max_n);
   if (rc != GEOTR_OK) return rc;
   for (int q = 0; q < cl.count; ++q) GEOTR_CHECK_ARG(cl.emb_off[q] % 4 == 0, "gse_embed_table: embedding offsets must be multiples of 4 floats");
+  GsePos pp;
+  std::memset(&pp, 0, sizeof(pp));
+  if (with_pos)
+    for (int q = 0; q < cl.count; ++q) {
+      GEOTR_CHECK_ARG(pos_layout->q_row0[q] >= 0 && pos_layout->ld[q] >= cl.n[q] && pos_layout->pos_off[q] >= 0,
+                      "gse_embed_table: bad positional layout of cloud %d", q);
+      pp.q_row0[q] = pos_layout->q_row0[q], pp.ld[q] = pos_layout->ld[q], pp.pos_off[q] = pos_layout->pos_off[q];
+    }
   hipStream_t stream = (hipStream_t)stream_;
   const float inv_sigma_d = 1.0f / sigma_d;
   const float factor_a = (float)(180.0 / ((double)sigma_a * 3.14159265358979323846));  // geotransformer.py:14
   const dim3 grid((unsigned)cl.chunk0[cl.count]);
-#define GEOTR_GSE_TAB(DD, SS)                                                                                                        \
-  gse_embed_table_kernel<DD, SS><<<grid, dim3(256), 0, stream>>>(points, knn, cl, table_d, (int)points_d, table_a, (int)points_a, w_d, b_d, \
-                                                                 w_a, b_a, div_term, inv_sigma_d, factor_a, out)
-#define GEOTR_GSE_TAB_D(DD)             \
-  switch ((int)k) {                     \
-    case 1: GEOTR_GSE_TAB(DD, 2); break; \
-    case 2: GEOTR_GSE_TAB(DD, 3); break; \
-    case 3: GEOTR_GSE_TAB(DD, 4); break; \
-    default: GEOTR_GSE_TAB(DD, 5); break; \
+#define GEOTR_GSE_TAB(DD, SS, MM, PP)                                                                                                     \
+  gse_embed_table_kernel<DD, SS, MM, PP><<<grid, dim3(256), 0, stream>>>(points, knn, cl, table_d, (int)points_d, table_a, (int)points_a, w_d, \
+                                                                         b_d, w_a, b_a, div_term, inv_sigma_d, factor_a, out, qt, pos, pp)
+#define GEOTR_GSE_TAB_S(DD, MM, PP)             \
+  switch ((int)k) {                             \
+    case 1: GEOTR_GSE_TAB(DD, 2, MM, PP); break; \
+    case 2: GEOTR_GSE_TAB(DD, 3, MM, PP); break; \
+    case 3: GEOTR_GSE_TAB(DD, 4, MM, PP); break; \
+    default: GEOTR_GSE_TAB(DD, 5, MM, PP); break; \
   }
-  switch (d) {
-    case 32: GEOTR_GSE_TAB_D(32); break;
-    case 64: GEOTR_GSE_TAB_D(64); break;
-    case 128: GEOTR_GSE_TAB_D(128); break;
-    default: GEOTR_GSE_TAB_D(256); break;
+#define GEOTR_GSE_TAB_D(DD)                       \
+  if (reduction_a == 1) {                         \
+    GEOTR_GSE_TAB_S(DD, true, false)              \
+  } else {                                        \
+    GEOTR_GSE_TAB_S(DD, false, false)             \
+  }
+  if (with_pos) {  // (d == 256)
+    if (reduction_a == 1) {
+      GEOTR_GSE_TAB_S(256, true, true)
+    } else {
+      GEOTR_GSE_TAB_S(256, false, true)
+    }
+  } else {
+    switch (d) {
+      case 32: GEOTR_GSE_TAB_D(32); break;
+      case 64: GEOTR_GSE_TAB_D(64); break;
+      case 128: GEOTR_GSE_TAB_D(128); break;
+      default: GEOTR_GSE_TAB_D(256); break;
+    }
   }
 #undef GEOTR_GSE_TAB_D
+#undef GEOTR_GSE_TAB_S
 #undef GEOTR_GSE_TAB
   GEOTR_CHECK_LAUNCH("gse_embed_table");
   return GEOTR_OK;
+}
+
+int geotr_gse_embed_table(const float* points, const int32_t* knn, const geotr_gse_clouds* clouds, int64_t k, int64_t d,
+                          const float* table_d, int64_t points_d, const float* table_a, int64_t points_a, const float* w_d,
+                          const float* b_d, const float* w_a, const float* b_a, const float* div_term, float sigma_d, float sigma_a,
+                          float* out, void* stream_) {
+  return geotr_gse_embed_table_ex(points, knn, clouds, k, d, table_d, points_d, table_a, points_a, w_d, b_d, w_a, b_a, div_term, sigma_d,
+                                  sigma_a, 0, nullptr, nullptr, nullptr, out, stream_);
 }
 
 int geotr_attn_softmax(float* scores, int64_t ld, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m,
@@ -1156,6 +1313,70 @@ int geotr_attn_softmax_grouped(float* scores, const geotr_attn_groups* groups, c
   else rc = go(attn_pos_softmax_grouped_kernel<8>, scores, qt, qb, (int)c, scale, gr);
   if (rc != GEOTR_OK) return rc;
   GEOTR_CHECK_LAUNCH("attn_softmax_grouped");
+  return GEOTR_OK;
+}
+
+int geotr_attn_softmax_grouped_pos(float* scores, const geotr_attn_groups* groups, const float* pos, const float* qb, int64_t heads,
+                                   float scale, void* stream_) {
+  GEOTR_CHECK_ARG(scores && groups && pos && qb && groups->count >= 1 && groups->count <= GEOTR_MAX_GROUPS,
+                  "attn_softmax_grouped_pos: null pointer or not 1..%d groups", GEOTR_MAX_GROUPS);
+  GEOTR_CHECK_ARG(heads >= 1 && heads <= 8, "attn_softmax_grouped_pos: heads must be 1..8");
+  AttnGroups gr;
+  gr.count = groups->count;
+  int maxn = 0, maxm = 0;
+  for (int i = 0; i < GEOTR_MAX_GROUPS; ++i) {
+    const bool on = i < groups->count;
+    gr.n[i] = on ? (int)groups->n[i] : 0, gr.m[i] = on ? (int)groups->m[i] : 0, gr.ld[i] = on ? (int)groups->ld[i] : 0;
+    gr.sc_off[i] = on ? groups->scores_off[i] : 0, gr.q_off[i] = on ? groups->q_row0[i] : 0;
+    gr.emb[i] = nullptr;
+    if (on) {
+      GEOTR_CHECK_ARG(gr.n[i] >= 1 && gr.m[i] >= 1 && gr.ld[i] >= gr.m[i], "attn_softmax_grouped_pos: bad group %d", i);
+      maxn = std::max(maxn, gr.n[i]), maxm = std::max(maxm, gr.m[i]);
+    }
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t lds = sizeof(float) * (size_t)(heads * maxm);
+  if (lds > 160 * 1024) return fail(GEOTR_E_CAPACITY, "attn_softmax_grouped_pos: %d keys need %zu B of LDS", maxm, lds);
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_softmax_grouped_pos_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(GEOTR_E_LAUNCH, "attn_softmax_grouped_pos: cannot reserve %zu B of LDS", lds);
+  attn_softmax_grouped_pos_kernel<<<dim3((unsigned)maxn, (unsigned)groups->count), dim3(256), lds, stream>>>(scores, pos, qb, (int)heads, scale, gr);
+  GEOTR_CHECK_LAUNCH("attn_softmax_grouped_pos");
+  return GEOTR_OK;
+}
+
+int geotr_attn_softmax_ex(float* scores, int64_t ld, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m, int64_t c,
+                          int64_t heads, float scale, const float* key_weights, const uint8_t* key_masks, const float* attention_factors,
+                          int64_t ld_factors, const uint8_t* attention_masks, int64_t ld_masks, void* stream_) {
+  if (!key_weights && !key_masks && !attention_factors && !attention_masks)
+    return geotr_attn_softmax(scores, ld, emb, qt, qb, n, m, c, heads, scale, stream_);
+  GEOTR_CHECK_ARG(n >= 0 && m >= 1 && ld >= m && heads >= 1 && heads <= 8, "attn_softmax_ex: bad sizes (heads <= 8)");
+  if (n == 0) return GEOTR_OK;
+  GEOTR_CHECK_ARG(scores && (!emb || (qt && qb)), "attn_softmax_ex: null pointer");
+  GEOTR_CHECK_ARG((!attention_factors || ld_factors >= m) && (!attention_masks || ld_masks >= m), "attn_softmax_ex: bad leading dimensions");
+  GEOTR_CHECK_ARG(!emb || (c % 32 == 0 && c <= 512 && (heads == 1 || heads == 2 || heads == 4 || heads == 8)),
+                  "attn_softmax_ex: the positional term needs c %% 32 == 0, c <= 512 and 1, 2, 4 or 8 heads");
+  AttnExtras ex;
+  ex.key_weights = key_weights, ex.key_masks = key_masks, ex.factors = attention_factors, ex.masks = attention_masks;
+  ex.ld_f = ld_factors, ex.ld_m = ld_masks;
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t lds = sizeof(float) * (size_t)((emb ? c * heads : 0) + heads * m);
+  if (lds > 160 * 1024) return fail(GEOTR_E_CAPACITY, "attn_softmax_ex: %lld keys need %zu B of LDS", (long long)m, lds);
+  auto go = [&](auto kern, auto... args) -> int {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(GEOTR_E_LAUNCH, "attn_softmax_ex: cannot reserve %zu B of LDS", lds);
+    kern<<<dim3((unsigned)n), dim3(256), lds, stream>>>(args...);
+    return GEOTR_OK;
+  };
+  int rc;
+  if (!emb) rc = go(attn_softmax_extras_kernel, scores, (int)n, (int)m, (int)ld, (int)heads, scale, ex);
+  else if (heads == 1) rc = go(attn_pos_softmax_extras_kernel<1>, scores, emb, qt, qb, (int)n, (int)m, (int)ld, (int)c, scale, ex);
+  else if (heads == 2) rc = go(attn_pos_softmax_extras_kernel<2>, scores, emb, qt, qb, (int)n, (int)m, (int)ld, (int)c, scale, ex);
+  else if (heads == 4) rc = go(attn_pos_softmax_extras_kernel<4>, scores, emb, qt, qb, (int)n, (int)m, (int)ld, (int)c, scale, ex);
+  else rc = go(attn_pos_softmax_extras_kernel<8>, scores, emb, qt, qb, (int)n, (int)m, (int)ld, (int)c, scale, ex);
+  if (rc != GEOTR_OK) return rc;
+  GEOTR_CHECK_LAUNCH("attn_softmax_ex");
   return GEOTR_OK;
 }
 

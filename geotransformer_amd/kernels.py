@@ -492,6 +492,16 @@ class GseClouds(ctypes.Structure):  # geotr_gse_clouds
     _fields_ = [('count', ctypes.c_int32), ('n', ctypes.c_int32 * 32), ('row0', ctypes.c_int32 * 32), ('emb_off', ctypes.c_int64 * 32)]
 
 
+class AttnGroups(ctypes.Structure):  # geotr_attn_groups
+    _fields_ = [('count', ctypes.c_int32), ('pad_', ctypes.c_int32), ('n', ctypes.c_int64 * 32), ('m', ctypes.c_int64 * 32),
+                ('ld', ctypes.c_int64 * 32), ('scores_off', ctypes.c_int64 * 32), ('q_row0', ctypes.c_int64 * 32),
+                ('emb', ctypes.c_void_p * 32)]
+
+
+class GsePos(ctypes.Structure):  # geotr_gse_pos
+    _fields_ = [('q_row0', ctypes.c_int32 * 32), ('ld', ctypes.c_int32 * 32), ('pos_off', ctypes.c_int64 * 32)]
+
+
 GSE_TABLE_SPAN = 64.0  # the distance table covers d / sigma_d <= 64 (12.8 m at the 3DMatch sigma_d); beyond: direct evaluation in-kernel
 GSE_TABLE_DENSITY = 16  # grid points per unit index (kGseTabInv in csrc/transformer.hip)
 
@@ -516,8 +526,11 @@ def gse_tables(div_term, w_d, w_a, sigma_a):
     return gse_table(div_term, w_d, GSE_TABLE_SPAN), gse_table(div_term, w_a, 180.0 / float(sigma_a))
 
 
-def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, precision=None, tables=None):
-    """(n, n, D) geometric structure embedding of one cloud (n, 3).  `tables` (precision 5): a cached `gse_tables` result."""
+def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, precision=None, tables=None, reduction_a='max', qt=None):
+    """(n, n, D) geometric structure embedding of one cloud (n, 3).  `tables` (precision 5): a cached `gse_tables` result.
+    `reduction_a`: 'max' (every reference config) or 'mean' over the angular slots (geotransformer.py:65-68; table form only).
+    `qt` (n, 4, 256), table form only: additionally returns pos (4, n, ld) with pos[h, i, j] = emb[i, j, :] . qt[i, h, :] -- the positional
+    attention term of the first self-attention layer out of the same pass (geotr_gse_embed_table_ex)."""
     lib = _lib.load()
     points = _f32c(points)
     n, d = points.shape[0], w_d.shape[0]
@@ -527,16 +540,31 @@ def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, preci
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
     precision = GSE_PRECISION if precision is None else int(precision)
+    if reduction_a not in ('max', 'mean'):
+        raise ValueError(f'Unsupported reduction mode: {reduction_a}.')
+    pos = None
     if precision == 5:
         tab_d, tab_a = tables if tables is not None else gse_tables(div_term, w_d, w_a, sigma_a)
         cl = GseClouds()
         cl.count, cl.n[0], cl.row0[0], cl.emb_off[0] = 1, n, 0, 0
+        pl = GsePos()
+        if qt is not None:
+            qt = _f32c(qt)
+            assert qt.shape == (n, 4, d) and d == 256, 'the positional by-product is built for 4 heads of a 256-wide model'
+            ld = (n + 3) // 4 * 4
+            pos = torch.empty((4, n, ld), dtype=torch.float32, device=points.device)
+            pl.q_row0[0], pl.ld[0], pl.pos_off[0] = 0, ld, 0
         if n > 0:
-            _lib.check(lib.geotr_gse_embed_table(_lib.ptr(points), _lib.ptr(knn), ctypes.byref(cl), knn.shape[1], d, _lib.ptr(tab_d),
-                                                 tab_d.shape[0], _lib.ptr(tab_a), tab_a.shape[0], _lib.ptr(_f32c(w_d)), _lib.ptr(_f32c(b_d)),
-                                                 _lib.ptr(_f32c(w_a)), _lib.ptr(_f32c(b_a)), _lib.ptr(_f32c(div_term)), float(sigma_d),
-                                                 float(sigma_a), _lib.ptr(out), _lib.stream_ptr()), 'geotr_gse_embed_table')
+            _lib.check(lib.geotr_gse_embed_table_ex(_lib.ptr(points), _lib.ptr(knn), ctypes.byref(cl), knn.shape[1], d, _lib.ptr(tab_d),
+                                                    tab_d.shape[0], _lib.ptr(tab_a), tab_a.shape[0], _lib.ptr(_f32c(w_d)), _lib.ptr(_f32c(b_d)),
+                                                    _lib.ptr(_f32c(w_a)), _lib.ptr(_f32c(b_a)), _lib.ptr(_f32c(div_term)), float(sigma_d),
+                                                    float(sigma_a), int(reduction_a == 'mean'), _lib.ptr(qt),
+                                                    ctypes.byref(pl) if qt is not None else None, _lib.ptr(pos), _lib.ptr(out),
+                                                    _lib.stream_ptr()), 'geotr_gse_embed_table_ex')
     else:
+        if reduction_a != 'max' or qt is not None:
+            raise NotImplementedError("reduction_a='mean' and the positional by-product exist in the table form of the embedding only "
+                                      "(set_precision(..., gse='table'))")
         ws = _lib.workspace(lib.geotr_gse_embed_workspace_bytes(d, precision), points.device)
         _lib.check(lib.geotr_gse_embed(_lib.ptr(points), _lib.ptr(knn), n, knn.shape[1], d, _lib.ptr(_f32c(div_term)),
                                        _lib.ptr(_f32c(w_d)), _lib.ptr(b_d), _lib.ptr(_f32c(w_a)), _lib.ptr(b_a), float(sigma_d),
@@ -545,21 +573,42 @@ def gse_embed(points, knn, div_term, w_d, b_d, w_a, b_a, sigma_d, sigma_a, preci
     if prof is not None:
         end.record()
         prof.append((start, end, n))
-    return out
+    return out if qt is None else (out, pos[:, :, :n])
 
 
-def attn_softmax(scores, scale, emb=None, qt=None, qb=None):
-    """In-place softmax over the last dim of scores (H, n, m); with `emb` adds the relative-position term first."""
+def attn_softmax(scores, scale, emb=None, qt=None, qb=None, key_weights=None, key_masks=None, attention_factors=None, attention_masks=None,
+                 pos=None):
+    """In-place softmax over the last dim of scores (H, n, m); with `emb` adds the relative-position term first.
+    key_weights (m), key_masks (m) bool, attention_factors (n, m), attention_masks (n, m) bool: the optional modifiers of the reference's
+    attention layers (rpe_transformer.py:59-64, vanilla_transformer.py:57-64), applied to the scaled scores in the reference's order.
+    `pos` (H, n, ld) + qb: the positional term precomputed by gse_embed(..., qt=...) instead of `emb` / `qt`."""
     lib = _lib.load()
     H, n, m = scores.shape
     ld = scores.stride(1)
     assert scores.stride(2) == 1 and scores.stride(0) == n * ld, 'scores must be (H, n, m) rows with a common leading dimension'
     c = 0
+    if pos is not None:
+        assert emb is None and pos.shape == scores.shape and pos.stride() == scores.stride() and key_weights is None and key_masks is None \
+            and attention_factors is None and attention_masks is None
+        g = AttnGroups()
+        g.count, g.n[0], g.m[0], g.ld[0], g.scores_off[0], g.q_row0[0] = 1, n, m, ld, 0, 0
+        _lib.check(lib.geotr_attn_softmax_grouped_pos(_lib.ptr(scores), ctypes.byref(g), _lib.ptr(pos), _lib.ptr(_f32c(qb)), H, float(scale),
+                                                      _lib.stream_ptr()), 'geotr_attn_softmax_grouped_pos')
+        return scores
     if emb is not None:
         emb, qt, qb = _f32c(emb), _f32c(qt), _f32c(qb)
         c = emb.shape[-1]
-    _lib.check(lib.geotr_attn_softmax(_lib.ptr(scores), ld, _lib.ptr(emb), _lib.ptr(qt), _lib.ptr(qb), n, m, c, H, float(scale),
-                                      _lib.stream_ptr()), 'geotr_attn_softmax')
+    if key_weights is None and key_masks is None and attention_factors is None and attention_masks is None:
+        _lib.check(lib.geotr_attn_softmax(_lib.ptr(scores), ld, _lib.ptr(emb), _lib.ptr(qt), _lib.ptr(qb), n, m, c, H, float(scale),
+                                          _lib.stream_ptr()), 'geotr_attn_softmax')
+        return scores
+    kw = None if key_weights is None else _f32c(key_weights).reshape(m)
+    km = None if key_masks is None else key_masks.reshape(m).to(torch.uint8).contiguous()
+    af = None if attention_factors is None else _f32c(attention_factors).reshape(n, m)
+    am = None if attention_masks is None else attention_masks.reshape(n, m).to(torch.uint8).contiguous()
+    _lib.check(lib.geotr_attn_softmax_ex(_lib.ptr(scores), ld, _lib.ptr(emb), _lib.ptr(qt), _lib.ptr(qb), n, m, c, H, float(scale),
+                                         _lib.ptr(kw), _lib.ptr(km), _lib.ptr(af), m, _lib.ptr(am), m, _lib.stream_ptr()),
+               'geotr_attn_softmax_ex')
     return scores
 
 
@@ -637,8 +686,9 @@ def weighted_procrustes(src_points, ref_points, weights=None):
 
 
 def lgr(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, topk, confidence_threshold, mutual,
-        acceptance_radius, correspondence_threshold, num_refinement_steps):
+        acceptance_radius, correspondence_threshold, num_refinement_steps, global_scores=None, correspondence_limit=None):
     """Local-to-global registration.  score_mat (P, R, R) with R >= K: the leading (K, K) block is used (drops dustbins).
+    global_scores (P,): use_global_score; correspondence_limit: size of the verification set (local_global_registration.py:145-152, 225-226).
     Returns (ref_corr (cap,3), src_corr (cap,3), scores (cap,), num_corr (1,) int32 device, transform (4,4))."""
     lib = _lib.load()
     ref_knn_points, src_knn_points = _f32c(ref_knn_points), _f32c(src_knn_points)
@@ -651,13 +701,17 @@ def lgr(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat,
     scores = torch.empty(cap, dtype=torch.float32, device=dev)
     num = torch.zeros(1, dtype=torch.int32, device=dev)
     T = torch.empty((4, 4), dtype=torch.float32, device=dev)
-    ws = _lib.workspace(lib.geotr_lgr_workspace_bytes(P, K, int(topk)), dev)
-    _lib.check(lib.geotr_lgr(_lib.ptr(ref_knn_points), _lib.ptr(src_knn_points), _lib.ptr(ref_knn_masks.contiguous()),
-                             _lib.ptr(src_knn_masks.contiguous()), _lib.ptr(score_mat), score_mat.stride(0), score_mat.stride(1),
-                             P, K, int(topk), float(confidence_threshold), int(bool(mutual)), float(acceptance_radius),
-                             int(correspondence_threshold), int(num_refinement_steps), None, _lib.ptr(ref_corr), _lib.ptr(src_corr),
-                             _lib.ptr(scores), _lib.ptr(num), _lib.ptr(T), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
-               'geotr_lgr')
+    limit = 0 if correspondence_limit is None else int(correspondence_limit)
+    if correspondence_limit is not None and limit < 1:
+        raise ValueError('correspondence_limit must be a positive integer')
+    gs = None if global_scores is None else _f32c(global_scores).reshape(P)
+    ws = _lib.workspace(lib.geotr_lgr_ex_workspace_bytes(P, K, int(topk), limit), dev)
+    _lib.check(lib.geotr_lgr_ex(_lib.ptr(ref_knn_points), _lib.ptr(src_knn_points), _lib.ptr(ref_knn_masks.contiguous()),
+                                _lib.ptr(src_knn_masks.contiguous()), _lib.ptr(score_mat), score_mat.stride(0), score_mat.stride(1),
+                                P, K, int(topk), float(confidence_threshold), int(bool(mutual)), float(acceptance_radius),
+                                int(correspondence_threshold), int(num_refinement_steps), None, _lib.ptr(gs), limit, _lib.ptr(ref_corr),
+                                _lib.ptr(src_corr), _lib.ptr(scores), _lib.ptr(num), _lib.ptr(T), _lib.ptr(ws), ws.numel(),
+                                _lib.stream_ptr()), 'geotr_lgr_ex')
     return ref_corr, src_corr, scores, num, T
 
 

@@ -45,6 +45,9 @@ class GeoTransformer(nn.Module):
         # True: the whole forward runs in the native executor (one C-ABI call, csrc/executor.hip); False: the same kernels
         # driven module by module from Python (the drop-in module API; used by the parity tests of the individual modules)
         self.use_native = True
+        # options no reference config sets exist at the module level only (C ABI: geotr_lgr_ex): such a model runs module by module
+        if self.fine_matching.use_global_score or self.fine_matching.correspondence_limit is not None:
+            self.use_native = False
         self._native = None
 
     def _ground_truth_node_correspondences(self, data_dict, out, ref_part=None, src_part=None):

@@ -9,9 +9,7 @@ from ..transformer import RPEConditionalTransformer, SinusoidalPositionalEmbeddi
 class GeometricStructureEmbedding(nn.Module):
     def __init__(self, hidden_dim, sigma_d, sigma_a, angle_k, reduction_a='max'):
         super().__init__()
-        if reduction_a != 'max':
-            if reduction_a == 'mean':
-                raise NotImplementedError("reduction_a='mean' is not used by any reference config; the fused kernel implements 'max'")
+        if reduction_a not in ['max', 'mean']:
             raise ValueError(f'Unsupported reduction mode: {reduction_a}.')
         self.sigma_d = sigma_d
         self.sigma_a = sigma_a
@@ -31,14 +29,14 @@ class GeometricStructureEmbedding(nn.Module):
         return self._tables[1]
 
     def forward(self, points):
-        """points (1, N, 3) -> embeddings (1, N, N, D): proj_d(sin/cos(d)) + max_k proj_a(sin/cos(angle_k))."""
+        """points (1, N, 3) -> embeddings (1, N, N, D): proj_d(sin/cos(d)) + max_k (or mean_k) proj_a(sin/cos(angle_k))."""
         if points.shape[0] != 1:
             raise NotImplementedError('batch size 1 (one cloud per call), as in the reference model')
         pts = points[0]
         knn = kernels.gse_knn(pts, self.angle_k)
         emb = kernels.gse_embed(pts, knn, self.embedding.div_term, self.proj_d.weight, self.proj_d.bias,
                                 self.proj_a.weight, self.proj_a.bias, self.sigma_d, self.sigma_a,
-                                tables=self.tables() if kernels.GSE_PRECISION == 5 else None)
+                                tables=self.tables() if kernels.GSE_PRECISION == 5 else None, reduction_a=self.reduction_a)
         return emb.unsqueeze(0)
 
 

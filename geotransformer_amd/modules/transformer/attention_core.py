@@ -2,10 +2,13 @@
 from ... import kernels
 
 
-def _check_unsupported(**kwargs):
-    for name, value in kwargs.items():
-        if value is not None:
-            raise NotImplementedError(f'{name} is not used by the registration hot path and is not implemented')
+def _one(t):
+    """(1, ...) option tensor of the reference signature -> the single cloud's slice (or None)."""
+    if t is None:
+        return None
+    if t.shape[0] != 1:
+        raise NotImplementedError('batch size 1 (one cloud per call), as in the reference model')
+    return t[0]
 
 
 class FusedProjection:
@@ -33,8 +36,11 @@ class FusedProjection:
         return outs
 
 
-def multi_head_attention(q, k, v, num_heads, emb=None, w_p=None, b_p=None):
+def multi_head_attention(q, k, v, num_heads, emb=None, w_p=None, b_p=None, key_weights=None, key_masks=None, attention_factors=None,
+                         attention_masks=None):
     """q (n, C), k/v (m, C) already projected.  Returns (hidden (n, C), probabilities (H, n, m)).
+    key_weights (m), key_masks (m) bool, attention_factors (n, m), attention_masks (n, m) bool: the reference's optional score modifiers
+    (rpe_transformer.py:59-64, vanilla_transformer.py:57-64), applied inside the softmax kernel.
 
     scores = softmax((q_h k_h^T + q_h . (W_p e + b_p)_h) / sqrt(C/H)); the second term is evaluated as
     e . (W_p[h]^T q_h) + q_h . b_p[h] (exact algebra), so `proj_p` over the (n, m, C)
@@ -53,9 +59,11 @@ def multi_head_attention(q, k, v, num_heads, emb=None, w_p=None, b_p=None):
         kernels.gemm(q3, w_p.view(H, ch, C), b_is_kn=True, out=qt.permute(1, 0, 2))  # qt[:, h, :] = q_h W_p[h]
         qb = q.new_empty((n, H))
         kernels.gemm(q3, b_p.view(H, ch, 1), b_is_kn=True, out=qb.t().unsqueeze(2))   # qb[:, h] = q_h . b_p[h]
-        kernels.attn_softmax(scores, 1.0 / ch ** 0.5, emb=emb, qt=qt, qb=qb)
+        kernels.attn_softmax(scores, 1.0 / ch ** 0.5, emb=emb, qt=qt, qb=qb, key_weights=key_weights, key_masks=key_masks,
+                             attention_factors=attention_factors, attention_masks=attention_masks)
     else:
-        kernels.attn_softmax(scores, 1.0 / ch ** 0.5)
+        kernels.attn_softmax(scores, 1.0 / ch ** 0.5, key_weights=key_weights, key_masks=key_masks, attention_factors=attention_factors,
+                             attention_masks=attention_masks)
     hidden = q.new_empty((n, C))
     kernels.gemm(scores, v3, b_is_kn=True, out=hidden.view(n, H, ch).permute(1, 0, 2))
     return hidden, scores

@@ -22,21 +22,19 @@ class RPEConditionalTransformer(nn.Module):
         self.parallel = parallel
 
     def forward(self, feats0, feats1, embeddings0, embeddings1, masks0=None, masks1=None):
-        if masks0 is not None or masks1 is not None:
-            raise NotImplementedError('superpoint masks are not passed by the registration model')
         attention_scores = []
-        for i, block in enumerate(self.blocks):
+        for i, block in enumerate(self.blocks):  # masks: True = superpoint ignored as a key (conditional_transformer.py:100-111)
             layer = self.layers[i]
             if block == 'self':
-                feats0, scores0 = layer(feats0, feats0, embeddings0)
-                feats1, scores1 = layer(feats1, feats1, embeddings1)
+                feats0, scores0 = layer(feats0, feats0, embeddings0, memory_masks=masks0)
+                feats1, scores1 = layer(feats1, feats1, embeddings1, memory_masks=masks1)
             elif self.parallel:
-                new0, scores0 = layer(feats0, feats1)
-                new1, scores1 = layer(feats1, feats0)
+                new0, scores0 = layer(feats0, feats1, memory_masks=masks1)
+                new1, scores1 = layer(feats1, feats0, memory_masks=masks0)
                 feats0, feats1 = new0, new1
             else:  # sequential: the source attends to the already-updated reference
-                feats0, scores0 = layer(feats0, feats1)
-                feats1, scores1 = layer(feats1, feats0)
+                feats0, scores0 = layer(feats0, feats1, memory_masks=masks1)
+                feats1, scores1 = layer(feats1, feats0, memory_masks=masks0)
             if self.return_attention_scores:
                 attention_scores.append([scores0, scores1])
         if self.return_attention_scores:

@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from ... import kernels
-from .attention_core import FusedProjection, _check_unsupported, multi_head_attention
+from .attention_core import FusedProjection, _one, multi_head_attention
 from .output_layer import AttentionOutput
 
 
@@ -25,7 +25,6 @@ class RPEMultiHeadAttention(nn.Module):
 
     def forward(self, input_q, input_k, input_v, embed_qk, key_weights=None, key_masks=None, attention_factors=None):
         """input_* (1, N|M, C), embed_qk (1, N, M, C) -> hidden (1, N, C), attention scores (1, H, N, M)."""
-        _check_unsupported(key_weights=key_weights, key_masks=key_masks, attention_factors=attention_factors)
         if input_q.shape[0] != 1:
             raise NotImplementedError('batch size 1 (one cloud per call), as in the reference model')
         if input_q is input_k and input_k is input_v:  # self-attention: one (N, C) x (C, 3C) GEMM
@@ -38,7 +37,8 @@ class RPEMultiHeadAttention(nn.Module):
                 k = kernels.linear(input_k[0], self.proj_k.weight, self.proj_k.bias)
                 v = kernels.linear(input_v[0], self.proj_v.weight, self.proj_v.bias)
         hidden, probs = multi_head_attention(q, k, v, self.num_heads, emb=embed_qk[0], w_p=self.proj_p.weight,
-                                             b_p=self.proj_p.bias)
+                                             b_p=self.proj_p.bias, key_weights=_one(key_weights), key_masks=_one(key_masks),
+                                             attention_factors=_one(attention_factors))
         return hidden.unsqueeze(0), probs.unsqueeze(0)
 
 

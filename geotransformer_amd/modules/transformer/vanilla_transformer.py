@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from ... import kernels
-from .attention_core import FusedProjection, _check_unsupported, multi_head_attention
+from .attention_core import FusedProjection, _one, multi_head_attention
 from .output_layer import AttentionOutput
 
 
@@ -23,8 +23,6 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, input_q, input_k, input_v, key_weights=None, key_masks=None, attention_factors=None,
                 attention_masks=None):
-        _check_unsupported(key_weights=key_weights, key_masks=key_masks, attention_factors=attention_factors,
-                           attention_masks=attention_masks)
         if input_q.shape[0] != 1:
             raise NotImplementedError('batch size 1 (one cloud per call), as in the reference model')
         q = kernels.linear(input_q[0], self.proj_q.weight, self.proj_q.bias)
@@ -33,7 +31,8 @@ class MultiHeadAttention(nn.Module):
         else:
             k = kernels.linear(input_k[0], self.proj_k.weight, self.proj_k.bias)
             v = kernels.linear(input_v[0], self.proj_v.weight, self.proj_v.bias)
-        hidden, probs = multi_head_attention(q, k, v, self.num_heads)
+        hidden, probs = multi_head_attention(q, k, v, self.num_heads, key_weights=_one(key_weights), key_masks=_one(key_masks),
+                                             attention_factors=_one(attention_factors), attention_masks=_one(attention_masks))
         return hidden.unsqueeze(0), probs.unsqueeze(0)
 
 

@@ -81,7 +81,7 @@ class AttnLayer(ctypes.Structure):
 
 
 class Transformer(ctypes.Structure):
-    _fields_ = [('num_layers', I32), ('num_heads', I32), ('angle_k', I32), ('pad_', I32), ('sigma_d', F32), ('sigma_a', F32),
+    _fields_ = [('num_layers', I32), ('num_heads', I32), ('angle_k', I32), ('reduction_a', I32), ('sigma_d', F32), ('sigma_a', F32),
                 ('gse_precision', I32), ('pad2_', I32), ('gse_table_d', P_F32), ('gse_table_a', P_F32), ('gse_points_d', I64),
                 ('gse_points_a', I64), ('div_term', P_F32), ('proj_d', Linear), ('proj_a', Linear), ('in_proj', Linear), ('out_proj', Linear),
                 ('layers', AttnLayer * 8)]
@@ -218,6 +218,7 @@ class NativeModel:
         t.num_layers, t.num_heads = len(layers), layers[0].attention.attention.num_heads
         t.angle_k, t.sigma_d, t.sigma_a = tr.embedding.angle_k, float(tr.embedding.sigma_d), float(tr.embedding.sigma_a)
         t.gse_precision = int(kernels.GSE_PRECISION)
+        t.reduction_a = int(tr.embedding.reduction_a == 'mean')  # (the executor refuses 'mean' with the MFMA forms of the embedding)
         if t.gse_precision == 5:  # lookup tables of proj_d / proj_a, built once per weight set (kept alive with the descriptor)
             tab_d, tab_a = tr.embedding.tables()
             self._keep += [tab_d, tab_a]
@@ -257,6 +258,9 @@ class NativeModel:
         d.num_sinkhorn_iterations = m.optimal_transport.num_iterations
         d.dual_normalization = int(m.coarse_matching.dual_normalization)
         f = m.fine_matching
+        if f.use_global_score or f.correspondence_limit is not None:
+            raise NotImplementedError('use_global_score / correspondence_limit are module-level options (geotr_lgr_ex); the native executor '
+                                      'carries the settings of the reference configs -- run this model with use_native = False')
         d.topk, d.mutual, d.correspondence_threshold = f.k, int(f.mutual), f.correspondence_threshold
         d.num_refinement_steps = f.num_refinement_steps
         d.gemm_mode = kernels.gemm_mode()

@@ -34,7 +34,7 @@ extern "C" {
 const char* geotr_last_error(void);
 /* ABI version of this header; bumped on any signature change.  A host compares the macro it was compiled against with what the
  * loaded library reports. */
-#define GEOTR_ABI_VERSION 5
+#define GEOTR_ABI_VERSION 6
 int geotr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -344,6 +344,21 @@ int geotr_gse_embed_table(const float* points, const int32_t* knn, const geotr_g
                           const float* table_d, int64_t points_d, const float* table_a, int64_t points_a, const float* w_d,
                           const float* b_d, const float* w_a, const float* b_a, const float* div_term, float sigma_d, float sigma_a,
                           float* out, void* stream);
+/* geotr_gse_embed_table_ex (ABI 6): the same launch with
+ *   reduction_a : 0 = max over the k angular slots (every reference config), 1 = mean (sum in slot order / k)
+ *                                              geotransformer/modules/geotransformer/geotransformer.py:20-23,65-68
+ *   pos != NULL : additionally pos[h, i, j] = out[i, j, :] . qt[q_row0 + i, h, :] for 4 heads, d = 256 -- the positional attention
+ *                 term of the FIRST self-attention layer (rpe_transformer.py:51-58) while the embedding row is in registers; cloud q's
+ *                 block is (4, n, ld[q]) floats at pos + pos_off[q], its query rows start at row q_row0[q] of qt (rows, 4, d).
+ *                 geotr_attn_softmax_grouped_pos consumes it, so that layer never reads the (n, n, d) embedding. */
+typedef struct geotr_gse_pos {
+  int32_t q_row0[32], ld[32];
+  int64_t pos_off[32];
+} geotr_gse_pos;
+int geotr_gse_embed_table_ex(const float* points, const int32_t* knn, const geotr_gse_clouds* clouds, int64_t k, int64_t d,
+                             const float* table_d, int64_t points_d, const float* table_a, int64_t points_a, const float* w_d,
+                             const float* b_d, const float* w_a, const float* b_a, const float* div_term, float sigma_d, float sigma_a,
+                             int reduction_a, const float* qt, const geotr_gse_pos* pos_layout, float* pos, float* out, void* stream);
 
 /* The same over ragged groups (one per cloud of a stack) in one launch: group i has n[i] query rows, m[i] keys, score rows of leading
  * dimension ld[i] starting at scores + scores_off[i] (head stride n[i]*ld[i]), embedding emb[i] (all NULL: plain scaled softmax) and
@@ -355,6 +370,17 @@ typedef struct geotr_attn_groups {
 } geotr_attn_groups;
 int geotr_attn_softmax_grouped(float* scores, const geotr_attn_groups* groups, const float* qt, const float* qb, int64_t c, int64_t heads,
                                float scale, void* stream);
+/* (ABI 6) ... with the positional term precomputed by geotr_gse_embed_table_ex: pos has the layout of scores (same offsets, leading
+ * dimensions and head strides); scores <- softmax((scores + (pos + qb[q_row0 + i, h])) * scale).  groups->emb is ignored. */
+int geotr_attn_softmax_grouped_pos(float* scores, const geotr_attn_groups* groups, const float* pos, const float* qb, int64_t heads,
+                                   float scale, void* stream);
+/* (ABI 6) geotr_attn_softmax with the optional modifiers of the reference's attention layers, applied to the scaled scores in the
+ * reference's order: v = attention_factors[i, j] * v; v = v * key_weights[j]; key_masks[j] != 0 -> -inf; attention_masks[i, j] != 0 ->
+ * -inf; then the softmax (a fully masked row is NaN, as torch.softmax gives).  All four NULL: exactly geotr_attn_softmax.
+ *                       transformer/rpe_transformer.py:35,59-64, vanilla_transformer.py:36-64 */
+int geotr_attn_softmax_ex(float* scores, int64_t ld, const float* emb, const float* qt, const float* qb, int64_t n, int64_t m, int64_t c,
+                          int64_t heads, float scale, const float* key_weights, const uint8_t* key_masks, const float* attention_factors,
+                          int64_t ld_factors, const uint8_t* attention_masks, int64_t ld_masks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * P1/M1/S1/S2  matching heads
@@ -433,6 +459,20 @@ int geotr_lgr(const float* ref_knn_points, const float* src_knn_points, const ui
               int64_t topk, float confidence_threshold, int mutual, float acceptance_radius, int64_t correspondence_threshold,
               int64_t num_refinement_steps, const int32_t* p_count, float* ref_corr_points, float* src_corr_points,
               float* corr_scores, int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream);
+/* (ABI 6) geotr_lgr with the two remaining options of the reference module (one pair per call):
+ *   global_scores (p) or NULL : use_global_score -- the correspondence scores of patch pair b are exp(score) * global_scores[b]
+ *                               (the selection thresholds see the unscaled exp(score))          local_global_registration.py:225-226
+ *   correspondence_limit > 0  : when more correspondences exist, hypotheses are scored and the pose is refined on the `limit`
+ *                               best-scoring ones (ties at the limit-th score: lower index first); the returned lists stay complete
+ *                                                                                               local_global_registration.py:145-152
+ * use_dustbin is not offered: the reference's own branch (local_global_registration.py:78, `corr_mat[:, -1:, -1]`) yields a (B, 1)
+ * matrix that cannot be combined with the (B, K, K) masks -- there is no behaviour to mirror. */
+size_t geotr_lgr_ex_workspace_bytes(int64_t p, int64_t k, int64_t topk, int64_t correspondence_limit);
+int geotr_lgr_ex(const float* ref_knn_points, const float* src_knn_points, const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks,
+                 const float* score_mat, int64_t ld_patch, int64_t ld_row, int64_t p, int64_t k, int64_t topk, float confidence_threshold,
+                 int mutual, float acceptance_radius, int64_t correspondence_threshold, int64_t num_refinement_steps, const int32_t* p_count,
+                 const float* global_scores, int64_t correspondence_limit, float* ref_corr_points, float* src_corr_points, float* corr_scores,
+                 int32_t* num_corr, float* estimated_transform, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Native executor: the whole inference forward of experiments/<exp>/model.py:69-212 (minus the ground-truth
@@ -493,7 +533,8 @@ typedef struct geotr_attn_layer {                                    /* RPETrans
   const void* qkv_packed; const void* kv_packed;                     /* optional geotr_gemm_pack of the fused weights (stacked pairs) */
 } geotr_attn_layer;
 typedef struct geotr_transformer {                                   /* GeometricTransformer, modules/geotransformer/geotransformer.py:75-155 */
-  int32_t num_layers, num_heads, angle_k, pad_;
+  int32_t num_layers, num_heads, angle_k;
+  int32_t reduction_a;                                               /* 0: max over the angular slots, 1: mean (gse_precision 5 only; ABI 6, was padding) */
   float sigma_d, sigma_a;
   int32_t gse_precision, pad2_;                                      /* 0: fp32 MFMA, 1: split-bf16 MFMA, 3: bf16 MFMA (geotr_gse_embed); 5: by table */
   const float* gse_table_d; const float* gse_table_a;                /* gse_precision 5: geotr_gse_table_build of proj_d / proj_a */

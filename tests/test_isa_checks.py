@@ -50,6 +50,7 @@ def test_no_instruction_touches_an_in_flight_lds_fragment(tmp_path, source, pref
 # vectoriser); everything else must come out of the compiler as scalar fp32 VALU code
 EXPLICIT_PACKED = ('kpconv_gather_kernel', 'l2_normalize_kernel', 'lgr_score_kernel', 'nc_overlap_kernel', 'patch_sinkhorn_kernel',
                    'attn_softmax_kernel', 'attn_softmax_grouped_kernel', 'attn_pos_softmax_kernel', 'attn_pos_softmax_grouped_kernel',
+                   'attn_softmax_grouped_pos_kernel', 'attn_softmax_extras_kernel', 'attn_pos_softmax_extras_kernel',  # (round 5: the same bodies)
                    'gse_embed_table_kernelILi128E')
 LANE_HALF_SHUFFLES = ('kpconv_gather_kernel',)  # op_sel'd broadcasts of one neighbour weight over a channel pair, written by hand
 
