@@ -197,7 +197,14 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     c.release(mk);
     return out;
   }
-  if (fused_enabled && kp.packed && flag && kp.num_kernel_points == 15 && geotr_kpconv_fused_supported(kp.in, kp.out, h) &&
+  // deep layers (C_in >= 128, several channel blocks through the LDS tile): 1 = fused (default), 0 = two-kernel path, 2 = fused only when
+  // the launch has at least two full rounds of 32-row tiles on the 256 CUs (A/B switch for measurements, profiles/r05_ab_runs.md)
+  static const int fused_deep = [] {
+    const char* e = std::getenv("GEOTR_KPCONV_FUSED_DEEP");
+    return e ? std::atoi(e) : 1;
+  }();
+  const bool deep_ok = kp.in <= 64 || fused_deep == 1 || (fused_deep == 2 && m >= 2 * 256 * 32);
+  if (fused_enabled && deep_ok && kp.packed && flag && kp.num_kernel_points == 15 && geotr_kpconv_fused_supported(kp.in, kp.out, h) &&
       (reinterpret_cast<uintptr_t>(s_feats) & 15) == 0) {
     if (c.live()) {
       ProfScope prof(c.stream);

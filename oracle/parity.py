@@ -24,8 +24,15 @@ Tolerances (BASELINE.json north_star: neighbour indices bit-exact, feature MSE <
   transform                 asserted for EVERY pair whose patches all align: the oracle's local-to-global registration
                             (oracle/model_oracle.py) is re-run on the oracle's own matching scores listed in the HIP side's patch
                             and point order (hypotheses with equal inlier counts are ranked by position, so the pose is a function
-                            of that order), and |d| <= 5e-3 per entry is required against it; the plain difference to the
-                            oracle's pose in its own order, rotation / translation errors are reported as well
+                            of that order), and |d| <= 5 % of the head's acceptance radius per entry is required against it
+                            (3DMatch / ModelNet: 0.1 m -> 5e-3; KITTI: 0.6 m -> 3e-2 -- round 5: under random weights a KITTI pair
+                            can keep a handful of correspondences (6 in one of the four pairs of profiles/r05_other_configs.md), and a
+                            Procrustes fit on 6 points with 50 m lever arms turns the 1e-5 differences of the matching scores into
+                            1 cm / 0.05 degrees: the tolerance is tied to the scale the head itself works at, the other three pairs of
+                            that run agree to 3e-3 / 2e-5 / 3e-5); in addition (round 5, every mode) the oracle's head re-run on THIS
+                            side's own matching scores must reproduce this side's pose to the same tolerance -- the head is held
+                            to account separately from the scores it is fed; the plain difference to the oracle's pose in its own
+                            order, rotation / translation errors (fp64) are reported as well
 """
 import numpy as np
 import torch
@@ -199,8 +206,18 @@ BF16_TOLERANCES = dict(feature_mse_bound=1e-4, score_tie_rtol=5e-2, score_atol=0
                        pose_gate=(POSE_GATE_RRE_DEG, POSE_GATE_RTE_M), head_on_own_scores_atol=5e-3)
 
 
+REFERENCE_RADIUS = 0.1  # acceptance radius of the 3DMatch / ModelNet heads: TRANSFORM_ATOL is 5 % of it
+
+
+def pose_tolerance(fine_cfg):
+    """Entry-wise pose tolerance of the fp32-grade modes: TRANSFORM_ATOL at the 3DMatch / ModelNet acceptance radius (0.1 m), scaled with
+    the head's acceptance radius above it (KITTI: 0.6 m -> 3e-2); never below TRANSFORM_ATOL."""
+    radius = float((fine_cfg or {}).get('acceptance_radius', REFERENCE_RADIUS))
+    return TRANSFORM_ATOL * max(1.0, radius / REFERENCE_RADIUS)
+
+
 def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, score_tie_rtol=SCORE_TIE_RTOL, score_atol=SCORE_ATOL,
-                 transform_atol=TRANSFORM_ATOL, pose_gate=None, head_on_own_scores_atol=None):
+                 transform_atol=None, pose_gate=None, head_on_own_scores_atol=None):
     """Returns a JSON-able report; report['ok'] is the verdict under the tolerances in this file's header.
     `feature_mse_bound`: the default is for the fp32-grade modes; plain-bf16 operands are held to the north-star bound (1e-4).
     `score_tie_rtol`: how close two oracle coarse scores must be for a rank swap to count as a tie (plain-bf16 features carry 2^-9
@@ -217,7 +234,11 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, 
     is asserted for every pair whose patches align."""
     fine_cfg = fine_cfg or want.get('_fine_cfg')
     head_cfg = want.get('_head_cfg')
-    rep = {'feature_mse_bound': feature_mse_bound}
+    if transform_atol is None:  # fp32-grade modes: 5 % of the head's acceptance radius, and the head is checked on this side's own scores too
+        transform_atol = pose_tolerance(fine_cfg)
+        if head_on_own_scores_atol is None:
+            head_on_own_scores_atol = transform_atol
+    rep = {'feature_mse_bound': feature_mse_bound, 'transform_atol': transform_atol}
     ok = True
     for k in ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f'):
         g, w = got[k].detach().cpu(), want[k]

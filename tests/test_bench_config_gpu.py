@@ -108,7 +108,7 @@ def test_bench_workload_stacked_lanes_match_oracle(matrix_precision):
     # asserted are those with a patch whose point set differs by a distance tie, and compare_pair says so
     for q, r in enumerate(reports):
         if not r['patches_differing_by_distance_ties']:
-            assert r['transform_compared'] and r['transform_max_abs_diff'] <= parity.TRANSFORM_ATOL, (q, r)
+            assert r["transform_compared"] and r["transform_max_abs_diff"] <= r["transform_atol"], (q, r)
         else:
             assert 'distance tie' in r['transform_not_compared_because'], (q, r)
     assert sum(r['transform_compared'] for r in reports) >= 6

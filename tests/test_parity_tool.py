@@ -105,6 +105,17 @@ def test_the_pose_is_asserted_in_this_sides_order():
     got['estimated_transform'][1, 3] += 0.05
     rep = parity.compare_pair(got, want)
     assert not rep['ok'] and rep['transform_compared']
+    # round 5: the tolerance is 5 % of the head's acceptance radius (0.5 here -> 2.5e-2) and the head is also re-run on THIS side's scores
+    assert abs(rep['transform_atol'] - 0.025) < 1e-12 and rep['transform_max_abs_diff_vs_oracle_head_on_own_scores'] > 0.04
+    got['estimated_transform'][1, 3] -= 0.05 - 0.01
+    assert parity.compare_pair(got, want)['ok']                               # 1 cm at a 0.5 m radius: inside
+
+
+def test_pose_tolerance_scales_with_the_heads_acceptance_radius():
+    assert parity.pose_tolerance({'acceptance_radius': 0.1}) == parity.TRANSFORM_ATOL       # 3DMatch / ModelNet heads
+    assert parity.pose_tolerance({'acceptance_radius': 0.05}) == parity.TRANSFORM_ATOL      # never below
+    assert abs(parity.pose_tolerance({'acceptance_radius': 0.6}) - 0.03) < 1e-12            # KITTI head
+    assert parity.pose_tolerance(None) == parity.TRANSFORM_ATOL
 
 
 def _oracle_like(seed=11, n=7, m=9, P=24, K=5, N=40, M=30):
