@@ -41,10 +41,8 @@ try:
 except Exception as e: print('$name FAILED', e)" | tee -a $OUT/ab_runs.txt; }
 if [ "${AB:-1}" = "1" ]; then
   EXTRA="" ab default X=1
-  EXTRA="--precision bf16x3" ab split_bf16 X=1
-  EXTRA="" ab kpconv_two_kernel GEOTR_KPCONV_FUSED=0
-  EXTRA="--lanes 2" ab two_lanes X=1
-  EXTRA="--lanes 6" ab six_lanes X=1
+  EXTRA="" ab deep_kpconv_fused GEOTR_KPCONV_FUSED_DEEP=1
+  EXTRA="" ab pos_unfused GEOTR_GSE_POS_FUSED=0
   EXTRA="" ab default_again X=1
 fi
 # the driver's smoke entry point
@@ -54,6 +52,13 @@ if [ "${OTHERS:-1}" = "1" ]; then
   timeout 400 python $ROOT/bench.py --config lomatch --precision bf16 --detail $OUT/bench_lomatch_bf16_detail.json > $OUT/bench_lomatch_bf16.json 2> $OUT/bench_lomatch_bf16.err; echo "lomatch bf16 rc=$?"
   timeout 300 python $ROOT/bench.py --config modelnet --detail $OUT/bench_modelnet_detail.json > $OUT/bench_modelnet.json 2> $OUT/bench_modelnet.err; echo "modelnet rc=$?"
   timeout 400 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 8 --detail $OUT/bench_kitti_detail.json > $OUT/bench_kitti.json 2> $OUT/bench_kitti.err; echo "kitti rc=$?"
+  timeout 200 env GEOTR_KPCONV_FUSED_DEEP=1 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 8 $B > $OUT/ab_kitti_deep_fused.json 2> $OUT/ab_kitti_deep_fused.err
+  timeout 200 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 8 $B > $OUT/ab_kitti_default.json 2> $OUT/ab_kitti_default.err
+  python -c "
+import json
+for n in ('default', 'deep_fused'):
+    try: d = json.load(open('$OUT/ab_kitti_%s.json' % n)); print('kitti', n, d['value'], 'pairs/s')
+    except Exception as e: print('kitti', n, 'FAILED', e)" | tee -a $OUT/ab_runs.txt
   KARG=""; [ -s $OUT/bench_kitti.json ] && KARG="kitti=$OUT/bench_kitti.json"
   python $ROOT/scripts/other_configs_summary.py $OUT/other_configs.md modelnet=$OUT/bench_modelnet.json $KARG lomatch_bf16=$OUT/bench_lomatch_bf16.json
   head -12 $OUT/other_configs.md
