@@ -218,7 +218,7 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     c.release(mk);
     return out;
   }
-  // two-kernel path (shapes the fused kernel does not take): the (m, 15 c_in) operand is written once and read by the GEMM.  (Bounding
+  // two-kernel path (the deep layers, and shapes the fused kernel does not take): the (m, 15 c_in) operand is written once and read by the GEMM.  (Bounding
   // it to an Infinity-Cache-sized chunk per round was measured not to pay -- profiles/r02_ab_runs.md -- and the switch is gone.)
   float* weighted = c.alloc<float>((size_t)m * kdim);
   int32_t* nnum = c.alloc<int32_t>((size_t)m);

@@ -24,6 +24,9 @@
 // 64 h .. 64 h + 63 of every neighbour row through phase 1 into the SAME LDS tile and phase 2 adds its 15 x 64 slice of the contraction
 // (rows k C_in + 64 h + c of the packed weight) to the accumulators it keeps across the blocks -- the (M, 15 C_in) operand of those
 // layers (207 + 128 MB per 8-pair stack, profiles/r04_pmc_hbm_traffic_fp32.md) never exists, and LDS stays at the 64-channel size.
+// MEASURED (profiles/r05_ab_runs.md section 3): 3.7 % SLOWER end to end than gather -> split-K packed GEMM (those layers are matrix-bound,
+// phase 2 streams the weight from L2 once per 32-row tile, 280 tiles on 256 CUs quantise to two rounds), so the model executor keeps the
+// two-kernel path for them (GEOTR_KPCONV_FUSED_DEEP=1 switches); the instantiations stay for the C ABI and their tests.
 // Supported: C_in = 32 or a multiple of 64, C_out a multiple of 32 with C_out / 32 dividing the wave count (32 .. 256), H <= 40.
 // Everything else stays on the two-kernel path.
 #include <cstdlib>
