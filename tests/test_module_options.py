@@ -47,3 +47,32 @@ def test_attention_signatures_mirror_the_reference():
         'input_q', 'input_k', 'input_v', 'embed_qk', 'key_weights', 'key_masks', 'attention_factors']  # rpe_transformer.py:35
     assert list(inspect.signature(MultiHeadAttention.forward).parameters)[1:] == [
         'input_q', 'input_k', 'input_v', 'key_weights', 'key_masks', 'attention_factors', 'attention_masks']  # vanilla_transformer.py:36-38
+
+
+def test_new_entry_points_validate_their_arguments_before_touching_the_device():
+    """ABI 6 entry points: argument checks run on the host before any launch (no GPU needed), with the error text in geotr_last_error."""
+    from geotransformer_amd import _lib
+    lib = _lib.load()
+
+    def err():
+        lib.geotr_last_error.restype = ctypes.c_char_p
+        return lib.geotr_last_error().decode()
+
+    # the verification set of correspondence_limit needs room in the workspace, bounded by the number of correspondences that can exist
+    base = lib.geotr_lgr_workspace_bytes(256, 64, 3)
+    assert lib.geotr_lgr_ex_workspace_bytes(256, 64, 3, 0) == base
+    assert base < lib.geotr_lgr_ex_workspace_bytes(256, 64, 3, 1000) < lib.geotr_lgr_ex_workspace_bytes(256, 64, 3, 10 ** 9)
+    assert lib.geotr_lgr_ex_workspace_bytes(256, 64, 3, 10 ** 9) == lib.geotr_lgr_ex_workspace_bytes(256, 64, 3, 256 * 64 * 3)
+    null = ctypes.c_void_p(0)
+    rc = lib.geotr_gse_embed_table_ex(null, null, null, 9, 256, null, 2, null, 2, null, null, null, null, null, 0.2, 15.0, 0, null, null, null, null, null)
+    assert rc != 0 and 'angle_k' in err()
+    rc = lib.geotr_gse_embed_table_ex(null, null, null, 3, 100, null, 2, null, 2, null, null, null, null, null, 0.2, 15.0, 0, null, null, null, null, null)
+    assert rc != 0 and 'hidden_dim' in err()
+    rc = lib.geotr_attn_softmax_grouped_pos(null, null, null, null, 4, 0.125, null)
+    assert rc != 0 and 'attn_softmax_grouped_pos' in err()
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.geotr_attn_softmax_ex(p, 2, null, null, null, 2, 4, 0, 2, 0.5, p, null, null, 0, null, 0, null)  # ld < m
+    assert rc != 0 and 'bad sizes' in err()
+    rc = lib.geotr_attn_softmax_ex(p, 4, null, null, null, 2, 4, 0, 2, 0.5, null, null, p, 2, null, 0, null)  # factors' leading dimension < m
+    assert rc != 0 and 'leading dimensions' in err()
