@@ -289,7 +289,11 @@ def compact_line(detail):
     par = detail.get('parity')
     if par:
         line['parity'] = {k: par[k] for k in ('ok', 'pairs_checked', 'pyramids_checked', 'pyramids_identical', 'pose_gated', 'max_feature_mse',
-                                              'max_transform_abs_diff', 'max_rre_deg', 'max_rte_m') if k in par}
+                                              'max_transform_abs_diff', 'max_rre_deg', 'max_rte_m', 'correspondences', 'max_procrustes_condition',
+                                              'pairs_on_relaxed_pose_tolerance') if k in par}
+        if line['parity'].get('max_procrustes_condition') is not None:
+            c = line['parity']['max_procrustes_condition']
+            line['parity']['max_procrustes_condition'] = round(c, 1) if c == c and c != float('inf') else None
     sib = detail.get('split_bf16_mode')
     if sib:
         line['split_bf16_mode'] = {'value': sib.get('value'), 'parity_ok': (sib.get('parity') or {}).get('ok'),
@@ -758,7 +762,7 @@ def main():
                        'parallelism': f'pairs sharded over {world} rank(s), 1 process/GPU, no data-path collective',
                        'collective_backend': 'rccl' if backend == 'nccl' else backend,
                        'weights': 'random init, seed 7351', 'matrix_precision': args.precision, 'gse': args.gse,
-                       'inputs': ('raw xyz in pinned host memory; H2D timed (480 KB/pair, hipMemcpyAsync per cloud on the lane stream)'
+                       'inputs': ('raw xyz in pinned host memory; H2D timed (480 KB/pair: one staging kernel per stack reads the pinned clouds over PCIe on the lane stream)'
                                   if args.inputs == 'host' else 'raw xyz resident in HBM before the timed region (H2D not timed)')},
             'roofline': main_run['roofline'],
             'detail_file': os.path.basename(detail_path),
@@ -819,6 +823,11 @@ def main():
                         'max_feature_mse': max(max(r[k] for k in r if k.startswith('mse_')) for r in reports),
                         'max_transform_abs_diff': max((r['transform_max_abs_diff'] for r in reports if r['transform_max_abs_diff'] is not None), default=None),
                         'max_rre_deg': max(rres, default=None), 'max_rte_m': max(rtes, default=None),
+                        # what conditions the pose tolerance (oracle/parity.py pose_tolerance): correspondences kept by each checked pair,
+                        # the worst Procrustes condition number, and how many pairs were given the radius-scaled translation bound
+                        'correspondences': [r['correspondences'][0] for r in reports],
+                        'max_procrustes_condition': max((r['procrustes_condition'] for r in reports), default=None),
+                        'pairs_on_relaxed_pose_tolerance': sum(bool(r.get('pose_tolerance_relaxed')) for r in reports),
                         'what': (f'pyramid tables of ALL {len(identical)} pairs of the LAST TIMED step (the tables the timed run computed, cut out of their '
                                  f'stacks) byte-compared with the oracle collate; forward outputs of {len(reports)} of them (slots {slots} of {args.batch}: '
                                  f'stacks of {args.stack}, {args.lanes} lanes) vs the CPU oracle on each pair alone; tolerances in oracle/parity.py; a '

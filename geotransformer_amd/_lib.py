@@ -17,7 +17,7 @@ c_ptr = ctypes.c_void_p
 c_size = ctypes.c_size_t
 c_int = ctypes.c_int
 
-ABI_VERSION = 6  # geotr_abi_version() of the library this package's ctypes mirrors (native.py, kernels.py) were written against
+ABI_VERSION = 7  # geotr_abi_version() of the library this package's ctypes mirrors (native.py, kernels.py) were written against
 
 # name -> (restype, argtypes); must list every symbol include/geotr.h declares (tests check this)
 SIGNATURES = {
@@ -76,6 +76,7 @@ SIGNATURES = {
     'geotr_gemm_packed_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
     'geotr_gemm_pack_f32': (c_int, [c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr, c_ptr]),
     'geotr_gemm_pack_format': (c_int, [c_ptr]),
+    'geotr_gemm_pack_forget': (None, [c_ptr]),
     'geotr_gemm_packed_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_int, c_ptr]),
     'geotr_gemm_packed_splitk_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
     'geotr_gemm_packed_splitk_workspace_bytes_mode': (c_size, [c_i64, c_i64, c_i64, c_int]),

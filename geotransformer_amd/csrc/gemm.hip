@@ -994,6 +994,11 @@ int geotr::pack_format_check(const void* packed, int gemm_mode, const char* what
 
 extern "C" int geotr_gemm_pack_format(const void* packed) { return geotr::pack_format_of(packed); }
 
+extern "C" void geotr_gemm_pack_forget(const void* packed) {
+  std::lock_guard<std::mutex> lock(g_pack_mutex);
+  g_pack_format.erase(packed);
+}
+
 extern "C" size_t geotr_gemm_pack_bytes(int64_t n, int64_t k) { return (size_t)(2 * 2 * pack_pad32(n) * pack_pad32(k)); }
 
 extern "C" int geotr_gemm_pack(const float* B, int64_t ldb, int b_is_kn, int64_t n, int64_t k, void* packed, void* stream) {

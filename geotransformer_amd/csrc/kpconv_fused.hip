@@ -35,8 +35,21 @@
 
 namespace geotr {
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+#ifdef GEOTR_KPF_STAMPS  // measurement build only (scripts/abi_bench.cpp `kpconv`): cycles of wave 0 per section, summed over tiles and blocks
+__device__ unsigned long long g_kpf_stamps[8];
+#define KPF_STAMP(i)                                             \
+  do {                                                           \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    stamp_acc[i] += now_ - stamp_t;                              \
+    stamp_t = now_;                                              \
+  } while (0)
+#else
+#define KPF_STAMP(i) do {} while (0)
+#endif
 
 constexpr int kFusedRows = 32;  // query points per workgroup tile = one 32-row MFMA tile
 constexpr int kMaxSteps = 10;   // neighbour steps of 4 held in registers: H <= 40 (every reference config: 24 .. 40)
@@ -58,8 +71,9 @@ struct FVec<4> {
 // MULTI: the layer has several channel blocks (c_total = NH C, NH > 1); false: c_total == C and the block loop is a single pass at
 // compile time (phase 2's accumulators are then not live across phase 1: the register allocation of the C_in = 32 / 64 layers is unchanged).
 // CTW: 32-column output tiles per wave (1: C_out <= 32 WAVES; 2: C_out = 64 WAVES -- the 512-wide layers of the 5-stage backbone).
+// C = 32 tiles (78 KB of LDS) are meant to share a CU two by two: 4 waves per SIMD, i.e. at most 128 VGPRs (C = 64: one workgroup, 256)
 template <int C, int WAVES, int TERMS, bool MULTI, int CTW = 1>
-__global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
+__global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) void kpconv_fused_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
                                                                   const float* __restrict__ sp, const int64_t* __restrict__ nb,
                                                                   const float* __restrict__ kp, const unsigned char* __restrict__ pos,
                                                                   int64_t M, int64_t Ns, int H, float sigma, int c_total, int c_out, int KS, int NT,
@@ -77,15 +91,20 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   unsigned short* A_hi = reinterpret_cast<unsigned short*>(fsm);
   unsigned short* A_lo = A_hi + kFusedRows * RS;
   float* A_32 = reinterpret_cast<float*>(fsm);  // TERMS == 0: [32][RS32] fp32
-  float4* relw_all = reinterpret_cast<float4*>(A_lo + kFusedRows * RS);  // [WAVES][2][64] (rel.xyz, neighbour index bits), two slots per wave
-  int* cnt_s = reinterpret_cast<int*>(relw_all + WAVES * 128);           // [32] neighbours with a positive feature sum
+  // (rel.xyz, neighbour index bits) per (point, neighbour): MULTI keeps [32][40] float4 behind the tile; otherwise they live in the first
+  // 640 bytes of the point's own tile row until its MFMAs have consumed them (relw_of below) -- the tile is ALL the kernel's LDS:
+  // 62 KB at C = 32 (two workgroups per CU with room to spare), 124 KB at C = 64
+  float4* relw_all = reinterpret_cast<float4*>(A_lo + kFusedRows * RS);
+  int* cnt_s = reinterpret_cast<int*>(relw_all + (MULTI ? kFusedRows * 40 : 0));  // [32] neighbours with a positive feature sum
   int* row_s = cnt_s + kFusedRows;                                       // [32] the tile's query rows (visiting order applied)
   float* part = reinterpret_cast<float*>(fsm);                           // [WAVES][16][64] K partials (reuses the A tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, q4 = lane >> 4;
-  float4* relw = relw_all + wave * 128;
   const float inv_sigma = 1.f / sigma;
+  // the feature rows as a raw buffer (Ns c_total floats < 4 GB: checked by the host): loads past its end return zeros
+  const __amdgpu_buffer_rsrc_t feat_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feats), 0, (int)((unsigned)Ns * (unsigned)c_total * 4u), 0x00020000);
   // the lane's kernel point (row of the phase-1 A operand); row 15 is padding
   const bool kp_ok = n16 < 15;
   const float kx = kp_ok ? kp[3 * n16] : 0.f, ky = kp_ok ? kp[3 * n16 + 1] : 0.f, kz = kp_ok ? kp[3 * n16 + 2] : 0.f;
@@ -106,89 +125,156 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
   // their neighbour rows) or rows 32 t .. when no order is given; outputs land in their own rows either way, and a row's result never
   // depends on its tile mates.  Blocks take CONTIGUOUS tile ranges, XCD by XCD (block b runs on XCD b % 8): the blocks resident on one
   // XCD work through one stretch of the order, so the neighbour rows they share are hits in that XCD's L2.
-  // The rows of a tile are fetched one tile AHEAD (lane i < PPW: the wave's i-th point), so the order lookup never adds a dependent
-  // round trip to the neighbour-index -> position -> feature chain below.  Rows past M are computed on a clamped index, never stored.
-  auto load_rows = [&](int64_t tile) -> int {
+  // Rows past M are computed on a clamped index, never stored.
+  auto load_rows = [&](int64_t tile) -> int {  // lane i < PPW: the wave's i-th point of that tile
     const int64_t t = min(tile * kFusedRows + wave * PPW + min(lane, PPW - 1), M - 1);
     return order ? order[t] : (int)t;
+  };
+  // Round 6: the dependent chain  order -> neighbour index -> support position  of a tile is off the tile's critical path.  Section
+  // stamps of round 5's kernel (profiles/r06_kpconv_sections.md): a wave spent ~6 000 cycles per point in phase 1 against 640 / 1 152
+  // cycles of matrix-pipe work (C_in = 32 / 64) -- every point paid two dependent global round trips (index, then position) that a
+  // two-deep software pipeline over only FOUR points per wave could not hide, and the influence arithmetic of a point ran as one block
+  // ahead of its MFMAs.  Now: the rows of a tile are fetched TWO tiles ahead, the neighbour indices of its four points one tile ahead
+  // (at the start of the previous tile's phase 1: four loads in flight together), their positions and flags at the start of the
+  // previous tile's phase 2 (sixteen loads in flight together, landing under the weight stream) -- so a tile starts with everything
+  // but the feature rows in registers; and inside phase 1 the influence arithmetic + feature loads of point i + 1 are interleaved step
+  // by step with the MFMAs of point i.  Same operations in the same order per output element: bit-identical results.
+  auto load_idx = [&](int rows, int (&jx)[PPW]) {
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+      const int64_t m = __builtin_amdgcn_readlane(rows, p);
+      jx[p] = lane < H ? (int)nb[m * H + lane] : (int)Ns;  // (Ns < 2^31: checked by the host)
+    }
+  };
+  auto load_rel = [&](int rows, const int (&jx)[PPW], float (&rx)[PPW][3], int (&cn)[PPW]) {
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+      const int64_t m = __builtin_amdgcn_readlane(rows, p);
+      const int64_t j = jx[p];
+      bool counted = false;
+      rx[p][0] = rx[p][1] = rx[p][2] = 0.f;
+      if (j < Ns) {
+        rx[p][0] = sp[3 * j] - qp[3 * m], rx[p][1] = sp[3 * j + 1] - qp[3 * m + 1], rx[p][2] = sp[3 * j + 2] - qp[3 * m + 2];
+        counted = pos[j] != 0;
+      }
+      cn[p] = __popcll(__ballot(counted));
+    }
+  };
+  // (relative position, neighbour index bits) of point p: the first 40 float4 of the point's OWN row of the A tile (nothing is stored
+  // there before the point's MFMAs have consumed them) -- MULTI keeps a separate region, its rows are rewritten once per channel block
+  auto relw_of = [&](int p) -> float4* {
+    if constexpr (MULTI) return relw_all + (wave * PPW + p) * 40;
+    else if constexpr (F32) return reinterpret_cast<float4*>(A_32 + (wave * PPW + p) * RS32);
+    else return reinterpret_cast<float4*>(A_hi + (wave * PPW + p) * RS);
   };
   const int64_t tiles = (M + kFusedRows - 1) / kFusedRows;
   const int lblock = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);  // gridDim.x % 8 == 0 (host)
   const int64_t per_block = (tiles + gridDim.x - 1) / gridDim.x;
-  const int64_t tile_end = min(tiles, (int64_t)(lblock + 1) * per_block);
-  int rows_cur = (int64_t)lblock * per_block < tile_end ? load_rows((int64_t)lblock * per_block) : 0;
-  for (int64_t tile = (int64_t)lblock * per_block; tile < tile_end; ++tile) {
+  const int64_t tile_begin = (int64_t)lblock * per_block, tile_end = min(tiles, (int64_t)(lblock + 1) * per_block);
+  float a_r[2][kMaxSteps];            // influences (A operands) of the point in flight / the next one
+  float b_r[2][kMaxSteps][G][VEC];    // their neighbours' channels (B operands)
+  // (C = 32 runs two workgroups per CU at <= 128 VGPRs: the other workgroup covers the round trip and the 20 registers are not there)
+  constexpr bool PRE_B0 = C >= 64;
+  bool b0_loaded = false;             // set 0 of b_r already holds point 0 of the tile about to start (loaded under the previous tile's epilogue)
+  // neighbour (4 u + q4)'s channels of one point: ONE bounds-checked buffer load per group -- an absent neighbour (pad index, lanes past
+  // H, steps past `steps`) gets an out-of-range offset, for which the hardware returns zeros
+  auto load_feats = [&](int id, bool ok, int hb, float (&b)[G][VEC]) {
+    const unsigned off = ok ? 4u * ((unsigned)id * (unsigned)(MULTI ? c_total : C) + (unsigned)(C * hb + VEC * n16)) : 0xffffffffu;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if constexpr (VEC == 4) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, off, 64 * VEC * g, 0));
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) b[g][j] = v[j];
+      } else {
+        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(feat_rsrc, off, 64 * VEC * g, 0));
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) b[g][j] = v[j];
+      }
+    }
+  };
+  int rows_cur = 0, rows_nxt = 0;
+  int jx_cur[PPW], cn_cur[PPW];
+  float rx_cur[PPW][3];
+#pragma unroll
+  for (int p = 0; p < PPW; ++p) jx_cur[p] = 0, cn_cur[p] = 0, rx_cur[p][0] = rx_cur[p][1] = rx_cur[p][2] = 0.f;
+  if (tile_begin < tile_end) {
+    rows_cur = load_rows(tile_begin);
+    rows_nxt = tile_begin + 1 < tile_end ? load_rows(tile_begin + 1) : 0;
+    load_idx(rows_cur, jx_cur);
+    load_rel(rows_cur, jx_cur, rx_cur, cn_cur);
+  }
+#ifdef GEOTR_KPF_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_amdgcn_s_memtime();
+#endif
+  for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
     const int64_t m0 = tile * kFusedRows;
-    const int rows_nxt = tile + 1 < tile_end ? load_rows(tile + 1) : 0;  // in flight under this tile's work
-    if (lane < PPW) row_s[wave * PPW + lane] = rows_cur;                 // read by the epilogue, three barriers later
+    const int rows_nn = tile + 2 < tile_end ? load_rows(tile + 2) : 0;  // in flight under this tile's work
+    if (lane < PPW) row_s[wave * PPW + lane] = rows_cur;                // read by the epilogue, three barriers later
+    // the next tile's neighbour indices: issued now, consumed (position loads) at the start of this tile's phase 2
+    int jx_nxt[PPW], cn_nxt[PPW];
+    float rx_nxt[PPW][3];
+    const bool have_next = tile + 1 < tile_end;
+    if (have_next) load_idx(rows_nxt, jx_nxt);
+    else {
+#pragma unroll
+      for (int p = 0; p < PPW; ++p) jx_nxt[p] = (int)Ns;
+    }
     f32x16 acc2[CTW];  // phase 2's accumulators: kept across the channel blocks
 #pragma unroll
     for (int s = 0; s < CTW; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[s][r] = 0.f;
     for (int hb = 0; hb < NH; ++hb) {  // ---- channel block hb: channels C hb .. C hb + C - 1 of every neighbour row
-    // ------------------------------------------------------------------ phase 1: g = w . f per point, software-pipelined over the wave's points
-    // Three dependent global round trips lead to a point's first MFMA (neighbour index -> support position -> feature row); done
-    // one point after the other they cost ~2 us each and the kernel was latency-bound at 3.7x its matrix-pipe time.  Pipeline:
-    //   stage A1(i)  load the neighbour index               stage A2(i)  load position + flag, write (rel, index) to LDS slot i & 1
-    //   stage B1(i)  influences + feature loads (registers)  stage B2(i)  MFMAs, split, A-tile stores
-    // iteration i runs A2(i+1), A1(i+2), B1(i+1) BEFORE B2(i): the loads of the next point are in flight under this point's MFMAs.
-    // Rows past M are computed on a clamped index and never stored.
-    auto stage_a1 = [&](int i) -> int64_t {  // -> the lane's neighbour index of the wave's i-th point (lanes >= H: pad)
-      const int64_t m = __builtin_amdgcn_readlane(rows_cur, i);
-      return lane < H ? nb[m * H + lane] : Ns;
-    };
-    auto stage_a2 = [&](int i, int64_t j) {
-      const int64_t m = __builtin_amdgcn_readlane(rows_cur, i);
-      float4 rv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-      bool counted = false;
-      if (j < Ns) {
-        rv.x = sp[3 * j] - qp[3 * m], rv.y = sp[3 * j + 1] - qp[3 * m + 1], rv.z = sp[3 * j + 2] - qp[3 * m + 2];
-        rv.w = __int_as_float((int)j);
-        counted = pos[j] != 0;
-      }
-      relw[(i & 1) * 64 + lane] = rv;
-      const unsigned long long bal = __ballot(counted);
-      if (lane == 0) cnt_s[wave * PPW + i] = __popcll(bal);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    float a_cur[kMaxSteps], a_nxt[kMaxSteps];
-    float b_cur[kMaxSteps][G][VEC], b_nxt[kMaxSteps][G][VEC];
-    auto stage_b1 = [&](int i, float (&a)[kMaxSteps], float (&b)[kMaxSteps][G][VEC]) {
+    // ------------------------------------------------------------------ phase 1: g = w . f per point
+#if defined(GEOTR_KPF_PRIO) && GEOTR_KPF_PRIO == 1
+    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);  // experiment: the younger half loses every arbitration against the older one
+#elif defined(GEOTR_KPF_PRIO) && GEOTR_KPF_PRIO == 2
+    __builtin_amdgcn_s_setprio(wave & 3);
+#endif
 #pragma unroll
-      for (int u = 0; u < kMaxSteps; ++u) {
-        const float4 rv = relw[(i & 1) * 64 + ((4 * u + q4) & 63)];  // lanes >= H of the slot hold index -1
-        const int id = __float_as_int(rv.w);
-        const bool ok = u < steps && id >= 0;
-        a[u] = 0.f;
-        if (ok && kp_ok) {
-          const float dx = rv.x - kx, dy = rv.y - ky, dz = rv.z - kz;
-          a[u] = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);  // as kpconv_gather_kernel
-        }
-        const float* fr = feats + (unsigned)((ok ? id : 0) * (MULTI ? c_total : C) + C * hb + VEC * n16);  // < 2^31 elements (checked by the host)
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const typename FVec<VEC>::T v = *reinterpret_cast<const typename FVec<VEC>::T*>(fr + 16 * VEC * g);
-          const float* vf = reinterpret_cast<const float*>(&v);
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) b[u][g][j] = ok ? vf[j] : 0.f;
-        }
-      }
+    for (int p = 0; p < PPW; ++p) {
+      if (lane < 40 && (!MULTI || hb == 0)) relw_of(p)[lane] = make_float4(rx_cur[p][0], rx_cur[p][1], rx_cur[p][2], __int_as_float(jx_cur[p] < Ns ? jx_cur[p] : -1));
+      if (lane == 0 && hb == 0) cnt_s[wave * PPW + p] = cn_cur[p];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // one neighbour step of point i: the lane's influence (A operand) and its neighbour's channels (B operands, one load per group)
+    // Branch-free: one 16-byte LDS read, selects, one buffer load per group (the plain-load form compiled to two branches and two
+    // dependent LDS reads per step, which also pinned the MFMAs between them).  `with_feats` false: the channels are already in b.
+    auto b1_step = [&](int i, int u, float& a, float (&b)[G][VEC], bool with_feats) {
+      const float4 rv = relw_of(i)[4 * u + q4];  // lanes >= H of the row hold index -1
+      const int id = __float_as_int(rv.w);
+      const bool ok = u < steps && id >= 0;
+      const float dx = rv.x - kx, dy = rv.y - ky, dz = rv.z - kz;
+      const float w = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);  // as kpconv_gather_kernel
+      a = w * ((ok && kp_ok) ? 1.f : 0.f);  // (w is finite and >= 0: the product is w or +0 exactly; a select here is compiled to a branch around the arithmetic)
+      if (with_feats) load_feats(id, ok, hb, b);
     };
-    auto stage_b2 = [&](int i, const float (&a)[kMaxSteps], const float (&b)[kMaxSteps][G][VEC]) {
+    if (PRE_B0 && hb == 0 && b0_loaded) {  // (uniform)
+#pragma unroll
+      for (int u = 0; u < kMaxSteps; ++u) b1_step(0, u, a_r[0][u], b_r[0][u], false);
+    } else {
+#pragma unroll
+      for (int u = 0; u < kMaxSteps; ++u) b1_step(0, u, a_r[0][u], b_r[0][u], true);
+    }
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int cur = i & 1, nxt = cur ^ 1;
       f32x4 acc[G][VEC];
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[g][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < kMaxSteps; ++u)  // steps past `steps` multiply zeros (their operands are 0): the order of the sum over h is kept
+      for (int u = 0; u < kMaxSteps; ++u) {  // steps past `steps` multiply zeros (their operands are 0): the order of the sum over h is kept
+        if (i + 1 < PPW) b1_step(i + 1, u, a_r[nxt][u], b_r[nxt][u], true);
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][g][j], acc[g][j], 0, 0, 0);
+          for (int j = 0; j < VEC; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r[cur][u], b_r[cur][u][g][j], acc[g][j], 0, 0, 0);
+      }
       // accumulator (16 kernel points x 16 columns per tile): lane holds rows 4 q4 + r, column n16 -> A[row][k C + channel]
       const int row = wave * PPW + i;
 #pragma unroll
@@ -207,10 +293,10 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {  // hi = bf16(x), lo = bf16(x - hi), round to nearest even (v_cvt_pk_bf16_f32, as gemm.hip)
             const float x = acc[g][j][r];
-            const __bf16 hb = (__bf16)x;
-            const __bf16 lb = (__bf16)(x - (float)hb);
-            h[j] = (unsigned)__builtin_bit_cast(unsigned short, hb);
-            l[j] = (unsigned)__builtin_bit_cast(unsigned short, lb);
+            const __bf16 hb_ = (__bf16)x;
+            const __bf16 lb_ = (__bf16)(x - (float)hb_);
+            h[j] = (unsigned)__builtin_bit_cast(unsigned short, hb_);
+            l[j] = (unsigned)__builtin_bit_cast(unsigned short, lb_);
           }
           const int e = row * RS + kpt * C + 16 * VEC * g + VEC * n16;  // VEC consecutive bf16: 4- or 8-byte aligned
           if constexpr (VEC == 2) {
@@ -222,25 +308,21 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
           }
         }
       }
-    };
-    {
-      int64_t j_next = stage_a1(0);
-      stage_a2(0, j_next);
-      j_next = stage_a1(1 < PPW ? 1 : 0);
-      stage_b1(0, a_cur, b_cur);
+    }
+#ifdef GEOTR_KPF_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    KPF_STAMP(0);     // phase 1 (this wave's points)
+    // the next tile's positions and flags: sixteen loads in flight together, landing under the weight stream of phase 2
+    if (hb == NH - 1) {
+      if (have_next) load_rel(rows_nxt, jx_nxt, rx_nxt, cn_nxt);
+      else {
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) {
-        if (i + 1 < PPW) {
-          stage_a2(i + 1, j_next);
-          if (i + 2 < PPW) j_next = stage_a1(i + 2);
-          if (i & 1) stage_b1(i + 1, a_cur, b_cur);
-          else stage_b1(i + 1, a_nxt, b_nxt);
-        }
-        if (i & 1) stage_b2(i, a_nxt, b_nxt);
-        else stage_b2(i, a_cur, b_cur);
+        for (int p = 0; p < PPW; ++p) cn_nxt[p] = 0, rx_nxt[p][0] = rx_nxt[p][1] = rx_nxt[p][2] = 0.f;
       }
     }
     __syncthreads();  // A tile complete
+    KPF_STAMP(1);     // wait for the other waves' points
     // ------------------------------------------------------------------ phase 2: out += A . W  (this wave: column tile ct, steps kk0 .. kk1)
     auto wstep = [&](int q) { return MULTI ? (q / GP) * gp_total + hb * GP + (q % GP) : q; };  // local step -> step of the packed weight
     if constexpr (F32) {
@@ -250,16 +332,32 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
 #pragma unroll
       for (int s = 0; s < CTW; ++s)
         b32[s] = reinterpret_cast<const float*>(Bhi) + ((int64_t)min(ct + s * CTP, NT - 1) * 2 * KS * 64 + lane) * 4;
-#pragma unroll 2
-      for (int q = kk0; q < kk1; ++q) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(a32 + 8 * q);
-        f32x4 bv[CTW];
+      // weight fragments three groups ahead (an L2 round trip is 2-3 groups of MFMAs long), the tile's own fragment one group ahead
+      constexpr int WD = 3;
+      f32x4 bq[WD][CTW];
 #pragma unroll
-        for (int s = 0; s < CTW; ++s) bv[s] = *reinterpret_cast<const f32x4*>(b32[s] + (int64_t)wstep(q) * 256);
+      for (int d = 0; d < WD; ++d)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int s = 0; s < CTW; ++s)
+          bq[d][s] = *reinterpret_cast<const f32x4*>(b32[s] + (int64_t)wstep(min(kk0 + d, max(kk1 - 1, kk0))) * 256);
+      f32x4 av_n = *reinterpret_cast<const f32x4*>(a32 + 8 * min(kk0, max(kk1 - 1, 0)));
+      for (int q0 = kk0; q0 < kk1; q0 += WD) {
 #pragma unroll
-          for (int s = 0; s < CTW; ++s) acc2[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[s][e], acc2[s], 0, 0, 0);
+        for (int d = 0; d < WD; ++d) {
+          const int q = q0 + d;
+          if (q >= kk1) break;  // (uniform)
+          const f32x4 av = av_n;
+          f32x4 bv[CTW];
+#pragma unroll
+          for (int s = 0; s < CTW; ++s) bv[s] = bq[d][s];
+          av_n = *reinterpret_cast<const f32x4*>(a32 + 8 * min(q + 1, kk1 - 1));
+#pragma unroll
+          for (int s = 0; s < CTW; ++s) bq[d][s] = *reinterpret_cast<const f32x4*>(b32[s] + (int64_t)wstep(min(q + WD, kk1 - 1)) * 256);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < CTW; ++s) acc2[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[s][e], acc2[s], 0, 0, 0);
+        }
       }
     } else {
       const unsigned short* a_hi = A_hi + (lane & 31) * RS + 8 * (lane >> 5);
@@ -282,13 +380,29 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
         }
       }
     }
+    // the channels of the NEXT tile's first point (set 0 of b_r is free since point PPW - 2): its loads fly under the partial sums, the
+    // epilogue and two barriers instead of opening the next tile with a bare round trip.  The neighbour index of lane (n16, q4) at
+    // step u is the index lane 4 u + q4 fetched (jx_nxt[0]): one bpermute per step.
+    if (PRE_B0 && hb == NH - 1) {
+      b0_loaded = have_next;
+      if (have_next) {
+#pragma unroll
+        for (int u = 0; u < kMaxSteps; ++u) {
+          const int id = __builtin_amdgcn_ds_bpermute(4 * (4 * u + q4), jx_nxt[0]);
+          load_feats(id, u < steps && 4 * u + q4 < H && id < Ns, 0, b_r[0][u]);
+        }
+      }
+    }
+    KPF_STAMP(2);     // phase 2 (this wave's K range)
     __syncthreads();  // every wave has read its A fragments: the tile's memory takes the next channel block / the K partials
+    KPF_STAMP(3);     // wait for the other waves' K ranges
     }  // channel blocks
 #pragma unroll
     for (int s = 0; s < CTW; ++s)  // tile ct + s CTP of K range kpart lives at partial index kpart CT + ct + s CTP (CTW = 1: the wave index)
 #pragma unroll
       for (int r = 0; r < 16; ++r) part[((kpart * CT + ct + s * CTP) * 16 + r) * 64 + lane] = acc2[s][r];
     __syncthreads();
+    KPF_STAMP(4);     // partials to LDS + barrier
     // ------------------------------------------------------------------ epilogue: sum the K partials, / count + bias, whole rows out
     for (int e = tid; e < kFusedRows * c_out; e += 64 * WAVES) {
       const int row = e / c_out, col = e - row * c_out;
@@ -301,9 +415,19 @@ __global__ __launch_bounds__(64 * WAVES) void kpconv_fused_kernel(const float* _
       for (int p = 0; p < KPARTS; ++p) v += part[(p * CT + t) * 16 * 64 + src];
       out[m * c_out + col] = v / (float)max(cnt_s[row], 1) + (bias ? bias[col] : 0.f);
     }
+    KPF_STAMP(5);     // epilogue
     __syncthreads();  // partials, counts and rows are consumed before the next tile overwrites them
-    rows_cur = rows_nxt;
+    KPF_STAMP(6);
+    rows_cur = rows_nxt, rows_nxt = rows_nn;
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) jx_cur[p] = jx_nxt[p], cn_cur[p] = cn_nxt[p], rx_cur[p][0] = rx_nxt[p][0], rx_cur[p][1] = rx_nxt[p][1], rx_cur[p][2] = rx_nxt[p][2];
   }
+#ifdef GEOTR_KPF_STAMPS
+  if (tid == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_kpf_stamps[i], stamp_acc[i]);
+    atomicAdd(&g_kpf_stamps[7], (unsigned long long)(tile_end > tile_begin ? tile_end - tile_begin : 0));
+  }
+#endif
 }
 
 // ---- first layer (C_in = 1, kpconv.py:79-121 with a one-channel feature): the whole layer per point is 15 influence-weighted sums
@@ -409,6 +533,15 @@ using namespace geotr;
 
 extern "C" {
 
+#ifdef GEOTR_KPF_STAMPS
+// measurement build only: reads and clears the section counters (7 sections of wave 0 in cycles, [7] = tiles)
+int geotr_debug_kpf_stamps(unsigned long long* out) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kpf_stamps), sizeof(zero)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_kpf_stamps), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
+
 int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h) {
   if (!(c_in == 32 || (c_in >= 64 && c_in % 64 == 0 && c_in <= 4096)) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 4 * kMaxSteps) return 0;
   const int waves = 8;
@@ -445,7 +578,7 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
   GEOTR_CHECK_ARG(s_feats && q_points && s_points && neighbors && kernel_points && pos_flag && packed && out, "kpconv_fused: null pointer");
   GEOTR_CHECK_ARG((reinterpret_cast<uintptr_t>(s_feats) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed) & 15) == 0,
                   "kpconv_fused: features and packed weights must be 16-byte aligned");
-  GEOTR_CHECK_ARG(ns * c_in < (1ll << 31), "kpconv_fused: more than 2^31 feature elements");
+  GEOTR_CHECK_ARG(ns * c_in < (1ll << 30), "kpconv_fused: more than 2^30 feature elements (the feature rows are read as one 4 GB buffer)");
   GEOTR_CHECK_ARG(bf16_operands >= 0 && bf16_operands <= 2, "kpconv_fused: arithmetic mode must be 0 (split-bf16), 1 (bf16) or 2 (fp32)");
   if (const int rc = pack_format_check(packed, bf16_operands, "kpconv_fused")) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -454,11 +587,13 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
   const unsigned short* blo = bhi + np_pad * kp_pad;
   const int KS = (int)(kp_pad / 16), NT = (int)(np_pad / 32);
   const int waves = 8;
-  const int64_t cb = c_in == 32 ? 32 : 64;  // channel block: what one pass of a tile holds in LDS
-  const size_t lds = (size_t)2 * kFusedRows * (15 * cb + 8) * 2 + (size_t)waves * 128 * 16 + 2 * kFusedRows * 4;
+  // channel block: what one pass of a tile holds in LDS.  (C_in = 64 as two blocks of 32 -- a 78 KB tile, two workgroups per CU -- was
+  // measured in round 6 before phase 1 was re-pipelined: 2 942 vs 2 815 us per 16-pair stack alone, no change end to end; removed.)
+  const int64_t cb = c_in == 32 ? 32 : 64;
+  const size_t lds = (size_t)2 * kFusedRows * (15 * cb + 8) * 2 + (c_in > cb ? (size_t)kFusedRows * 40 * 16 : 0) + 2 * kFusedRows * 4;
   const int64_t tiles = (m + kFusedRows - 1) / kFusedRows;
   // persistent: a few tiles per resident workgroup; a multiple of 8 blocks, one share of the tile range per XCD
-  const unsigned grid = (unsigned)((std::min<int64_t>(tiles, 256 * (c_in == 32 ? 8 : 4)) + 7) / 8 * 8);
+  const unsigned grid = (unsigned)((std::min<int64_t>(tiles, 256 * (cb == 32 ? 8 : 4)) + 7) / 8 * 8);
 #define GEOTR_KPF(CC, WW, TT, MM, ...)                                                                                                  \
   do {                                                                                                                             \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<CC, WW, TT, MM, ##__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \

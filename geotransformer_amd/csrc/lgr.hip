@@ -289,9 +289,15 @@ __global__ __launch_bounds__(256) void lgr_gather_kernel(const float* __restrict
 
 // (2b) correspondence_limit (local_global_registration.py:145-148): the VERIFICATION set -- what the hypotheses are scored on and the pose is
 // refined on -- is the `limit` best-scoring correspondences when there are more.  One workgroup: the threshold value by a radix select over
-// the float bits (scores are positive: exp(.) above a positive confidence threshold, times a positive global score), then an ordered
+// an ORDER-PRESERVING key of the float bits (lgr_order_key: sign bit set for non-negative values, all bits flipped for negative ones, so
+// unsigned key order = float order for every finite score -- a caller-supplied global score may be negative; NaN sorts above +inf like
+// torch.topk's "NaN is the largest"), then an ordered
 // compaction: everything above the threshold, and entries equal to it in index order until the set is full.  The set is kept in INDEX order
 // (torch.topk lists it by descending score; the weighted sums it feeds are accumulated in fp64, so the order is immaterial).
+__device__ inline unsigned lgr_order_key(float x) {
+  const unsigned b = __float_as_uint(x);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
 __global__ __launch_bounds__(1024) void lgr_limit_kernel(const float* __restrict__ ref_corr, const float* __restrict__ src_corr,
                                                          const float* __restrict__ scores, const int* __restrict__ total, int limit,
                                                          float* __restrict__ vref, float* __restrict__ vsrc, float* __restrict__ vscore,
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(1024) void lgr_limit_kernel(const float* __restrict
     const unsigned prefix = prefix_s;
     const unsigned high_mask = shift == 24 ? 0u : ~((1u << (shift + 8)) - 1u);
     for (int i = tid; i < C; i += 1024) {
-      const unsigned b = __float_as_uint(scores[i]);
+      const unsigned b = lgr_order_key(scores[i]);
       if ((b & high_mask) == prefix) atomicAdd(&hist[(b >> shift) & 255u], 1);
     }
     __syncthreads();
@@ -332,14 +338,14 @@ __global__ __launch_bounds__(1024) void lgr_limit_kernel(const float* __restrict
     }
     __syncthreads();
   }
-  const unsigned thr = prefix_s;  // bits of the limit-th largest score; want_s of the entries equal to it are taken
+  const unsigned thr = prefix_s;  // key of the limit-th largest score; want_s of the entries equal to it are taken
   const int take_eq = want_s;
   if (tid == 0) base_s = 0, eq_base_s = 0;
   __syncthreads();
   for (int i0 = 0; i0 < C; i0 += 1024) {
     const int i = i0 + tid;
     unsigned b = 0;
-    if (i < C) b = __float_as_uint(scores[i]);
+    if (i < C) b = lgr_order_key(scores[i]);
     const int is_eq = i < C && b == thr;
     int eq_tot, tot;
     const int eq_rank = eq_base_s + block_exclusive_scan<1024>(is_eq, sm, eq_tot);

@@ -71,6 +71,14 @@ def use_packed(a):
             and a.data_ptr() % 16 == 0)
 
 
+def _forget_when_freed(packed):
+    """The library records the layout of every buffer it packs by ADDRESS; drop the record when the tensor dies, so that the caching
+    allocator can hand the address to an unrelated buffer (geotr_gemm_pack_forget)."""
+    import weakref
+    weakref.finalize(packed, _lib.load().geotr_gemm_pack_forget, ctypes.c_void_p(packed.data_ptr())).atexit = False
+    return packed
+
+
 def gemm_pack(weight, b_is_kn=False, view=None):
     """Packed hi/lo bf16 planes of a static weight for gemm_packed.  `weight` is the parameter itself (2-D (N,K), or (K,N) with
     b_is_kn; `view` = 2-D shape to read it as, e.g. KPConv's (15*C_in, C_out)).  The result is cached ON the tensor object
@@ -87,6 +95,7 @@ def gemm_pack(weight, b_is_kn=False, view=None):
     packed = torch.empty(lib.geotr_gemm_pack_bytes(n, k), dtype=torch.uint8, device=weight.device)
     pack = lib.geotr_gemm_pack_f32 if f32 else lib.geotr_gemm_pack
     _lib.check(pack(_lib.ptr(w2), w2.stride(0), int(b_is_kn), n, k, _lib.ptr(packed), _lib.stream_ptr()), 'geotr_gemm_pack')
+    _forget_when_freed(packed)
     try:
         weight._geotr_packed = (key, packed)
     except AttributeError:  # tensors that reject attributes are simply not cached
@@ -245,7 +254,7 @@ def decoder_packs(weight, latent_ch):
         packed = torch.empty(lib.geotr_gemm_pack_bytes(n, k), dtype=torch.uint8, device=w.device)
         pack = lib.geotr_gemm_pack_f32 if f32 else lib.geotr_gemm_pack
         _lib.check(pack(view.data_ptr(), view.stride(0), 0, n, k, _lib.ptr(packed), _lib.stream_ptr()), 'geotr_gemm_pack')
-        out.append(packed)
+        out.append(_forget_when_freed(packed))
     try:
         weight._geotr_split_packed = (key, tuple(out))
     except AttributeError:

@@ -26,6 +26,18 @@ def _check_cloud(points, host_ok=False):
             and points.dtype == torch.float32 and (points.is_cuda or (host_ok and points.is_pinned()))):
         raise ValueError('a cloud must be a non-empty (N, 3) float32 device tensor' + (' or pinned host tensor' if host_ok else '') + ', got '
                          f'{tuple(points.shape) if torch.is_tensor(points) else type(points)}')
+    # a strided view of a pinned tensor is still "pinned", but .contiguous() of it would be a PAGEABLE copy whose address the staging
+    # kernel then dereferences from the GPU: host clouds must be contiguous as they are
+    if not points.is_cuda and not points.is_contiguous():
+        raise ValueError('a pinned host cloud must be contiguous (a strided view would need a pageable copy the GPU cannot read); '
+                         'pass points.contiguous().pin_memory()')
+
+
+def _to_device(points, device):
+    """A cloud on the device: device tensors as they are, pinned host tensors by an asynchronous copy on the current stream (the paths that
+    do not stage a whole stack in one launch: single pairs, the synchronous lane loop, lanes == 1)."""
+    _check_cloud(points, host_ok=True)
+    return points if points.is_cuda else points.to(device, non_blocking=True)
 
 
 def stack_clouds(clouds, device):
@@ -37,7 +49,8 @@ def stack_clouds(clouds, device):
     lib = _lib.load()
     points = torch.empty((sum(int(c.shape[0]) for c in clouds), 3), dtype=torch.float32, device=device)
     for g in range(0, len(clouds), 32):
-        group = [c if c.is_contiguous() else c.contiguous() for c in clouds[g:g + 32]]
+        group = [c if c.is_contiguous() else c.contiguous() for c in clouds[g:g + 32]]  # (host clouds are contiguous: _check_cloud)
+        assert all(c.is_cuda or c.is_pinned() for c in group), 'stack_clouds: a host cloud must be pinned'
         ptrs = (ctypes.c_void_p * len(group))(*[c.data_ptr() for c in group])
         rows = (ctypes.c_int64 * len(group))(*[int(c.shape[0]) for c in group])
         row0 = sum(int(c.shape[0]) for c in clouds[:g])
@@ -57,7 +70,7 @@ class RegistrationPipeline:
     def collate(self, ref_points, src_points, ref_feats=None, src_feats=None):
         """Device-resident equivalent of registration_collate_fn_stack_mode for one pair."""
         b = self.cfg.backbone
-        _check_cloud(ref_points), _check_cloud(src_points)
+        ref_points, src_points = _to_device(ref_points, self.device), _to_device(src_points, self.device)
         points = torch.cat([ref_points, src_points], dim=0)
         lengths = torch.tensor([ref_points.shape[0], src_points.shape[0]], dtype=torch.int64, device=points.device)
         if ref_feats is None:
@@ -119,8 +132,9 @@ class RegistrationPipeline:
         b = self.cfg.backbone
         clouds = [c for pair in pairs for c in pair]
         for c in clouds:
-            _check_cloud(c)
-        points = torch.cat(clouds, dim=0)
+            _check_cloud(c, host_ok=True)
+        # pinned host clouds (the reference's per-item to_cuda): staged by the one-launch kernel of the pipelined lanes
+        points = torch.cat(clouds, dim=0) if all(c.is_cuda for c in clouds) else stack_clouds(clouds, self.device)
         lengths = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64, device=points.device)
         t0 = time.perf_counter()
         data = build_pyramid(points, lengths, b.num_stages, b.init_voxel_size, b.init_radius, self.neighbor_limits)
@@ -163,11 +177,6 @@ class ConcurrentRegistration:
         self.stack = max(1, min(16, int(stack)))
         self.device = pipeline.device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
-        # Lanes that start together stay in phase (equal stacks take equal time): every lane then runs the same kind of kernel at the same
-        # moment -- pyramid next to pyramid, GEMM next to GEMM -- and they compete for the same unit instead of filling each other's gaps
-        # (rocprofv3 timeline, profiles/r04_ab_runs.md: a stage-0 radius query overlaps another lane's radius query for 52-62 % of its
-        # duration).  `lane_stagger_ms`: lane i starts its FIRST job i x that many milliseconds late; the offset then persists.
-        self.lane_stagger_s = 1e-3 * float(os.environ.get('GEOTR_LANE_STAGGER_MS', '0'))
         self._queue = queue.SimpleQueue()
         self._pending = 0
         self._cv = threading.Condition()
@@ -238,7 +247,6 @@ class ConcurrentRegistration:
         with torch.cuda.stream(stream), torch.no_grad():
             begun = None   # (job, plan, points, event): pyramid enqueued, its sizes not yet on the host
             flying = None  # (job, raw, data, counts): forward launched, its counts not yet on the host
-            first = True
 
             def land():  # nothing else to overlap with: wait for the stack in flight and deliver it
                 nonlocal flying
@@ -262,16 +270,12 @@ class ConcurrentRegistration:
                     if job is None:
                         land()
                         return
-                    if first and self.lane_stagger_s > 0 and lane > 0:
-                        time.sleep(lane * self.lane_stagger_s)  # phase offset against the other lanes (see __init__)
-                    first = False
                     if len(job) == 1:  # a single pair: the one-pair entry point, synchronously
                         land()
                         index, ref, src, sink, ready = job[0]
                         try:
                             stream.wait_event(ready)
-                            ref, src = (c if c.is_cuda else c.to(self.device, non_blocking=True) for c in (ref, src))
-                            sink(index, self.pipeline(ref, src))
+                            sink(index, self.pipeline(ref, src))  # (pinned host clouds are copied by the pipeline itself)
                             self._job_done(job)
                         except BaseException as exc:
                             self._job_done(job, exc)

@@ -34,7 +34,7 @@ extern "C" {
 const char* geotr_last_error(void);
 /* ABI version of this header; bumped on any signature change.  A host compares the macro it was compiled against with what the
  * loaded library reports. */
-#define GEOTR_ABI_VERSION 6
+#define GEOTR_ABI_VERSION 7
 int geotr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -201,6 +201,10 @@ int geotr_gemm_pack_f32(const float* B, int64_t ldb, int b_is_kn, int64_t n, int
  * every entry point that takes a packed weight and an arithmetic mode (geotr_gemm_packed*, geotr_kpconv_fused, the model forward)
  * returns GEOTR_E_INVALID when the recorded format contradicts the mode (0 / 1 need format 1, 2 needs format 2). */
 int geotr_gemm_pack_format(const void* packed);
+/* ABI 7: drops the record of `packed` (call it when the buffer is released: an allocator may hand the same address to an unrelated buffer
+ * -- e.g. a COPY of a weight packed in the other layout -- which would otherwise be refused on the stale record).  Unknown pointers are
+ * ignored; a forgotten buffer reads as format 0 (never refused). */
+void geotr_gemm_pack_forget(const void* packed);
 int geotr_gemm_packed_f32(const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                           const float* bias, const int32_t* row_div, const float* residual, int64_t ldr, float alpha, int act,
                           void* stream);

@@ -24,14 +24,16 @@ Tolerances (BASELINE.json north_star: neighbour indices bit-exact, feature MSE <
   transform                 asserted for EVERY pair whose patches all align: the oracle's local-to-global registration
                             (oracle/model_oracle.py) is re-run on the oracle's own matching scores listed in the HIP side's patch
                             and point order (hypotheses with equal inlier counts are ranked by position, so the pose is a function
-                            of that order), and |d| <= 5 % of the head's acceptance radius per entry is required against it
-                            (3DMatch / ModelNet: 0.1 m -> 5e-3; KITTI: 0.6 m -> 3e-2 -- round 5: under random weights a KITTI pair
-                            can keep a handful of correspondences (6 in one of the four pairs of profiles/r05_other_configs.md), and a
-                            Procrustes fit on 6 points with 50 m lever arms turns the 1e-5 differences of the matching scores into
-                            1 cm / 0.05 degrees: the tolerance is tied to the scale the head itself works at, the other three pairs of
-                            that run agree to 3e-3 / 2e-5 / 3e-5); in addition (round 5, every mode) the oracle's head re-run on THIS
-                            side's own matching scores must reproduce this side's pose to the same tolerance -- the head is held
-                            to account separately from the scores it is fed; the plain difference to the oracle's pose in its own
+                            of that order), and |d| <= 5e-3 per entry is required against it.  Round 6 (VERDICT r5 weak 1 / ADVICE): the
+                            bound is CONDITIONED, not scaled: the rotation block is always held to 5e-3; the translation column is held
+                            to 5e-3 whenever the pair keeps >= 30 correspondences (MIN_WELL_POSED_CORRESPONDENCES) and only below that
+                            to 5 % of the head's acceptance radius (KITTI: 0.6 m -> 3e-2) -- under random weights a KITTI pair can keep
+                            a handful of correspondences (6 in one of the four pairs of profiles/r05_other_configs.md), and a Procrustes
+                            fit on 6 points with 50 m lever arms turns the 1e-5 differences of the matching scores into 1 cm.  The
+                            report carries `correspondences`, `procrustes_condition` (sigma_1 / sigma_3 of the weighted cross-covariance
+                            of this side's correspondence set) and `pose_tolerance_relaxed`; in addition (every mode) the oracle's head
+                            re-run on THIS side's own matching scores must reproduce this side's pose under the same rule -- the head is
+                            held to account separately from the scores it is fed; the plain difference to the oracle's pose in its own
                             order, rotation / translation errors (fp64) are reported as well
 """
 import numpy as np
@@ -207,13 +209,37 @@ BF16_TOLERANCES = dict(feature_mse_bound=1e-4, score_tie_rtol=5e-2, score_atol=0
 
 
 REFERENCE_RADIUS = 0.1  # acceptance radius of the 3DMatch / ModelNet heads: TRANSFORM_ATOL is 5 % of it
+MIN_WELL_POSED_CORRESPONDENCES = 30  # below this a weighted Procrustes fit is ill-conditioned enough to amplify 1e-5 score differences
 
 
-def pose_tolerance(fine_cfg):
-    """Entry-wise pose tolerance of the fp32-grade modes: TRANSFORM_ATOL at the 3DMatch / ModelNet acceptance radius (0.1 m), scaled with
-    the head's acceptance radius above it (KITTI: 0.6 m -> 3e-2); never below TRANSFORM_ATOL."""
+def pose_tolerance(fine_cfg, correspondences=None):
+    """Entry-wise tolerance of the TRANSLATION column in the fp32-grade modes (the rotation block is always held to TRANSFORM_ATOL):
+    TRANSFORM_ATOL when the pair keeps at least MIN_WELL_POSED_CORRESPONDENCES correspondences (or the count is unknown and the head works
+    at the reference radius); only a pair with fewer is given 5 % of the head's acceptance radius (KITTI: 0.6 m -> 3e-2), never below
+    TRANSFORM_ATOL.  `correspondences=None` returns the relaxed bound of the head (what a badly conditioned pair would get)."""
     radius = float((fine_cfg or {}).get('acceptance_radius', REFERENCE_RADIUS))
-    return TRANSFORM_ATOL * max(1.0, radius / REFERENCE_RADIUS)
+    relaxed = TRANSFORM_ATOL * max(1.0, radius / REFERENCE_RADIUS)
+    if correspondences is not None and correspondences >= MIN_WELL_POSED_CORRESPONDENCES:
+        return TRANSFORM_ATOL
+    return relaxed
+
+
+def procrustes_condition(got):
+    """sigma_1 / sigma_3 of the weighted cross-covariance of this side's final correspondence set (what the last weighted Procrustes of the
+    head decomposes): large = the rotation about one axis is barely determined.  inf for fewer than 3 correspondences / a planar set."""
+    if not all(k in got for k in ('ref_corr_points', 'src_corr_points', 'corr_scores')) or int(got['corr_scores'].shape[0]) < 3:
+        return float('inf')
+    r, s = got['ref_corr_points'].detach().cpu().double().numpy(), got['src_corr_points'].detach().cpu().double().numpy()
+    w = got['corr_scores'].detach().cpu().double().numpy()
+    w = w / max(w.sum(), 1e-30)
+    rc, sc = (w[:, None] * r).sum(0), (w[:, None] * s).sum(0)
+    sv = np.linalg.svd((s - sc).T @ (w[:, None] * (r - rc)), compute_uv=False)
+    return float(sv[0] / sv[2]) if sv[2] > 0 else float('inf')
+
+
+def _pose_entries_within(T, Tref, rot_atol, trans_atol):
+    d = np.abs(np.asarray(T, dtype=np.float64) - np.asarray(Tref, dtype=np.float64))
+    return bool(d[:3, :3].max() <= rot_atol and d[:3, 3].max() <= trans_atol and d[3].max() <= rot_atol)
 
 
 def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, score_tie_rtol=SCORE_TIE_RTOL, score_atol=SCORE_ATOL,
@@ -234,11 +260,16 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, 
     is asserted for every pair whose patches align."""
     fine_cfg = fine_cfg or want.get('_fine_cfg')
     head_cfg = want.get('_head_cfg')
-    if transform_atol is None:  # fp32-grade modes: 5 % of the head's acceptance radius, and the head is checked on this side's own scores too
-        transform_atol = pose_tolerance(fine_cfg)
+    n_corr = int(got['corr_scores'].shape[0]) if 'corr_scores' in got else None
+    rot_atol = transform_atol
+    if transform_atol is None:  # fp32-grade modes: conditioned on the correspondence count (pose_tolerance); the head is checked on this side's own scores too
+        transform_atol = pose_tolerance(fine_cfg, n_corr)
+        rot_atol = TRANSFORM_ATOL
         if head_on_own_scores_atol is None:
             head_on_own_scores_atol = transform_atol
-    rep = {'feature_mse_bound': feature_mse_bound, 'transform_atol': transform_atol}
+    rep = {'feature_mse_bound': feature_mse_bound, 'transform_atol': transform_atol, 'rotation_atol': rot_atol,
+           'pose_tolerance_relaxed': bool(np.isfinite(transform_atol) and transform_atol > TRANSFORM_ATOL and rot_atol == TRANSFORM_ATOL),
+           'procrustes_condition': procrustes_condition(got)}
     ok = True
     for k in ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f'):
         g, w = got[k].detach().cpu(), want[k]
@@ -376,11 +407,13 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, 
                                                        got['ref_node_corr_knn_masks'].cpu(), got['src_node_corr_knn_masks'].cpu(), scores, fine_cfg)
             rep['transform_max_abs_diff'] = float(np.abs(T - Tc.numpy()).max())
             rep['transform_compared'] = True
+            pose_ok = _pose_entries_within(T, Tc.numpy(), rot_atol, transform_atol)
         elif rep['coarse_identical'] and rep['patches_in_identical_point_order'] == 1.0:
             rep['transform_max_abs_diff'] = rep['transform_max_abs_diff_vs_oracle_order']
             rep['transform_compared'] = True
+            pose_ok = _pose_entries_within(T, Tw, rot_atol, transform_atol)
         if rep['transform_compared']:
-            ok &= rep['transform_max_abs_diff'] <= transform_atol
+            ok &= pose_ok
         else:  # never silently: say why the pose of an accepted pair could not be asserted
             rep['transform_not_compared_because'] = (
                 f'{tie_patches} patch(es) hold another point set, each explained by a distance tie ({tie_points} points moved)' if tie_patches and not unexplained
@@ -405,6 +438,6 @@ def compare_pair(got, want, feature_mse_bound=FEATURE_MSE_BOUND, fine_cfg=None, 
         _, _, _, Th = mo.local_global_registration(got['ref_node_corr_knn_points'].cpu(), got['src_node_corr_knn_points'].cpu(),
                                                    got['ref_node_corr_knn_masks'].cpu(), got['src_node_corr_knn_masks'].cpu(), own, fine_cfg)
         rep['transform_max_abs_diff_vs_oracle_head_on_own_scores'] = float(np.abs(got['estimated_transform'].cpu().numpy() - Th.numpy()).max())
-        ok &= rep['transform_max_abs_diff_vs_oracle_head_on_own_scores'] <= head_on_own_scores_atol
+        ok &= _pose_entries_within(got['estimated_transform'].cpu().numpy(), Th.numpy(), min(rot_atol, head_on_own_scores_atol), head_on_own_scores_atol)
     rep['ok'] = bool(ok)
     return rep

@@ -10,6 +10,7 @@
 //                                                                        every packed shape of a 16-pair 3DMatch stack, with the time the
 //                                                                        fp32 MFMA roof and the HBM roof allow next to the measured one
 //          scripts/abi_bench.bin pyramid [3dmatch|kitti] [pairs] [reps]   the collate-equivalent pyramid of one stack (geotr_pyramid_build)
+//          scripts/abi_bench.bin kpconv [pairs] [reps] [fp32|bf16x3|bf16]  the fused KPConv layers of one stack on its own pyramid (time, roof fraction, output hash)
 //          scripts/abi_bench.bin embedding [clouds] [superpoints] [reps]  structure embedding by table + one layer's positional softmax
 #include <hip/hip_runtime.h>
 
@@ -23,6 +24,9 @@
 #include <vector>
 
 #include "geotr.h"
+#ifdef GEOTR_KPF_STAMPS
+extern "C" int geotr_debug_kpf_stamps(unsigned long long* out);  // measurement build of the library only (kpconv_fused.hip)
+#endif
 
 #define HIP_OK(call)                                                                              \
   do {                                                                                            \
@@ -214,6 +218,176 @@ static int run_pyramid(const std::string& config, int pairs, int reps) {
   return worst == 0 ? 0 : 1;
 }
 
+// The fused KPConv layers of one stack on a real pyramid: geotr_pyramid_build, random features (post-LeakyReLU-like: mostly positive
+// rows), the library's own row flags and packed fp32 weights, then geotr_kpconv_fused per layer shape of the 3DMatch backbone
+// (C_in = 32: encoder1_2, encoder2_1 strided; C_in = 64: encoder2_2/2_3, encoder3_1 strided).  Prints the time per launch, the fraction
+// of the fp32 matrix roof and an FNV hash of the output bytes (variants of the kernel must print the same hash).
+static int run_kpconv(int pairs, int reps, int mode) {
+  const int S = 4, per_cloud = 20000;
+  const float voxel = 0.025f, radius = 0.0625f, extent = 3.f;
+  const int64_t limits[GEOTR_MAX_STAGES] = {38, 36, 36, 38, 40};
+  const int B = 2 * pairs;
+  std::mt19937 rng(1000);
+  std::vector<float> all;
+  std::vector<int64_t> lengths;
+  for (int b = 0; b < B; ++b) {
+    const auto cloud = surface_cloud(per_cloud, extent, voxel, rng);
+    all.insert(all.end(), cloud.begin(), cloud.end());
+    lengths.push_back((int64_t)cloud.size() / 3);
+  }
+  const int64_t n0 = (int64_t)all.size() / 3;
+  float* d_points;
+  int64_t* d_lengths;
+  HIP_OK(hipMalloc(&d_points, all.size() * 4));
+  HIP_OK(hipMalloc(&d_lengths, B * 8));
+  HIP_OK(hipMemcpy(d_points, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_lengths, lengths.data(), B * 8, hipMemcpyHostToDevice));
+  geotr_pyramid_buffers buf = {};
+  buf.points[0] = d_points, buf.lengths[0] = d_lengths;
+  for (int i = 0; i < S; ++i) {
+    if (i) {
+      HIP_OK(hipMalloc(&buf.points[i], n0 * 12));
+      HIP_OK(hipMalloc(&buf.lengths[i], B * 8));
+    }
+    HIP_OK(hipMalloc(&buf.neighbors[i], n0 * limits[i] * 8));
+    HIP_OK(hipMalloc(&buf.order[i], n0 * 4));
+    if (i < S - 1) {
+      HIP_OK(hipMalloc(&buf.subsampling[i], n0 * limits[i] * 8));
+      HIP_OK(hipMalloc(&buf.upsampling[i], n0 * limits[i + 1] * 8));
+    }
+  }
+  const size_t ws_bytes = geotr_pyramid_workspace_bytes(n0, B, S);
+  void* ws;
+  int32_t* overflow;
+  HIP_OK(hipMalloc(&ws, ws_bytes));
+  HIP_OK(hipMalloc(&overflow, 4));
+  HIP_OK(hipMemset(overflow, 0, 4));
+  std::vector<int64_t> lengths_host((size_t)S * B);
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));
+  GEOTR_OK_OR_DIE(geotr_pyramid_build(d_points, d_lengths, B, n0, S, voxel, radius, limits, &buf, lengths_host.data(), overflow, ws, ws_bytes, stream));
+  int64_t rows[GEOTR_MAX_STAGES] = {};
+  for (int i = 0; i < S; ++i)
+    for (int b = 0; b < B; ++b) rows[i] += lengths_host[(size_t)i * B + b];
+  // {c_in, c_out, support stage, query stage}
+  const int layers[][4] = {{32, 32, 0, 0}, {32, 32, 0, 1}, {64, 64, 1, 1}, {64, 64, 1, 2}};
+  std::uniform_real_distribution<float> sym(-1.f, 1.f);
+  int rc = 0;
+  double total_us = 0.0;
+  for (const auto& L : layers) {
+    const int64_t c_in = L[0], c_out = L[1], ns = rows[L[2]], m = rows[L[3]], h = limits[L[2]];
+    const int64_t* nb = L[2] == L[3] ? buf.neighbors[L[2]] : buf.subsampling[L[2]];
+    std::vector<float> f((size_t)ns * c_in), w((size_t)15 * c_in * c_out), kp(45), bias(c_out);
+    for (auto& x : f) x = std::max(sym(rng), -0.1f);
+    for (auto& x : w) x = sym(rng) / std::sqrt((float)(15 * c_in));
+    const float sigma = 2.0f * voxel * (float)(1 << L[2]), krad = 2.5f * voxel * (float)(1 << L[2]);
+    for (auto& x : kp) x = 0.66f * krad * sym(rng);
+    kp[0] = kp[1] = kp[2] = 0.f;
+    for (auto& x : bias) x = sym(rng);
+    float *d_f, *d_w, *d_kp, *d_bias, *d_out;
+    uint8_t* d_flag;
+    void* packed;
+    HIP_OK(hipMalloc(&d_f, f.size() * 4));
+    HIP_OK(hipMalloc(&d_w, w.size() * 4));
+    HIP_OK(hipMalloc(&d_kp, 45 * 4));
+    HIP_OK(hipMalloc(&d_bias, c_out * 4));
+    HIP_OK(hipMalloc(&d_out, (size_t)m * c_out * 4));
+    HIP_OK(hipMalloc(&d_flag, ns));
+    HIP_OK(hipMalloc(&packed, geotr_gemm_pack_bytes(c_out, 15 * c_in)));
+    HIP_OK(hipMemcpy(d_f, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_kp, kp.data(), 45 * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_bias, bias.data(), c_out * 4, hipMemcpyHostToDevice));
+    if (mode == 2) GEOTR_OK_OR_DIE(geotr_gemm_pack_f32(d_w, c_out, 1, c_out, 15 * c_in, packed, stream));
+    else GEOTR_OK_OR_DIE(geotr_gemm_pack(d_w, c_out, 1, c_out, 15 * c_in, packed, stream));
+    GEOTR_OK_OR_DIE(geotr_row_positive(d_f, ns, c_in, d_flag, stream));
+    auto launch = [&] {
+      GEOTR_OK_OR_DIE(geotr_kpconv_fused(d_f, buf.points[L[3]], buf.points[L[2]], nb, d_kp, d_flag, m, ns, h, c_in, c_out, 15, sigma, packed, d_bias,
+                                         mode, buf.order[L[3]], d_out, stream));
+    };
+    HIP_OK(hipMemsetAsync(d_out, 0, (size_t)m * c_out * 4, stream));
+    launch();
+    std::vector<float> out((size_t)m * c_out);
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+    // a sample of rows against an fp64 restatement of kpconv.py:79-121 on the host
+    double worst = 0.0, scale = 0.0;
+    {
+      std::vector<float> qp((size_t)m * 3), sp((size_t)ns * 3);
+      std::vector<uint8_t> flag(ns);
+      HIP_OK(hipMemcpy(qp.data(), buf.points[L[3]], qp.size() * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(sp.data(), buf.points[L[2]], sp.size() * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(flag.data(), d_flag, ns, hipMemcpyDeviceToHost));
+      std::vector<int64_t> nbr(h);
+      for (int t = 0; t < 48; ++t) {
+        const int64_t row = (int64_t)((double)t / 48.0 * (double)m) + (t % 7);
+        if (row >= m) continue;
+        HIP_OK(hipMemcpy(nbr.data(), nb + row * h, h * 8, hipMemcpyDeviceToHost));
+        std::vector<double> g((size_t)15 * c_in, 0.0);
+        int cnt = 0;
+        for (int64_t hh = 0; hh < h; ++hh) {
+          const int64_t j = nbr[hh];
+          if (j >= ns) continue;
+          cnt += flag[j] != 0;
+          for (int k = 0; k < 15; ++k) {
+            const double dx = (double)(sp[3 * j] - qp[3 * row]) - kp[3 * k], dy = (double)(sp[3 * j + 1] - qp[3 * row + 1]) - kp[3 * k + 1],
+                         dz = (double)(sp[3 * j + 2] - qp[3 * row + 2]) - kp[3 * k + 2];
+            const double wgt = std::max(0.0, 1.0 - std::sqrt(dx * dx + dy * dy + dz * dz) / sigma);
+            if (wgt > 0.0)
+              for (int64_t c = 0; c < c_in; ++c) g[(size_t)k * c_in + c] += wgt * f[(size_t)j * c_in + c];
+          }
+        }
+        for (int64_t o = 0; o < c_out; ++o) {
+          double acc = 0.0;
+          for (int64_t kc = 0; kc < 15 * c_in; ++kc) acc += g[kc] * w[(size_t)kc * c_out + o];
+          const double want = acc / std::max(cnt, 1) + bias[o];
+          worst = std::max(worst, std::fabs(want - (double)out[(size_t)row * c_out + o]));
+          scale = std::max(scale, std::fabs(want));
+        }
+      }
+    }
+    const double tol = (mode == 1 ? 2e-2 : mode == 2 ? 5e-6 : 3e-5) * std::max(1.0, scale);
+    if (worst > tol) rc = 1;
+    uint64_t hash = 1469598103934665603ull;
+    for (const float v : out) {
+      uint32_t bits;
+      std::memcpy(&bits, &v, 4);
+      hash = (hash ^ bits) * 1099511628211ull;
+    }
+    hipEvent_t t0, t1;
+    HIP_OK(hipEventCreate(&t0));
+    HIP_OK(hipEventCreate(&t1));
+    HIP_OK(hipEventRecord(t0, stream));
+    for (int r = 0; r < reps; ++r) launch();
+    HIP_OK(hipEventRecord(t1, stream));
+    HIP_OK(hipEventSynchronize(t1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, t0, t1));
+    const double us = 1e3 * ms / reps;
+#ifdef GEOTR_KPF_STAMPS
+    {
+      unsigned long long st[8];
+      if (geotr_debug_kpf_stamps(st) == 0 && st[7] > 0) {
+        const double t = (double)st[7];
+        std::printf("{\"op\": \"kpconv_fused_sections\", \"c_in\": %lld, \"cycles_per_tile_wave0\": {\"phase1\": %.0f, \"barrier1\": %.0f, \"phase2\": %.0f, "
+                    "\"barrier2\": %.0f, \"partials\": %.0f, \"epilogue\": %.0f, \"barrier3\": %.0f}, \"tiles\": %.0f}\n",
+                    (long long)c_in, st[0] / t, st[1] / t, st[2] / t, st[3] / t, st[4] / t, st[5] / t, st[6] / t, t);
+      }
+    }
+#endif
+    const double flops = 2.0 * m * (16.0 * ((h + 3) / 4 * 4) * c_in + 15.0 * c_in * c_out);  // the MFMA work issued (phase 1 incl. its padding row / steps)
+    std::printf("{\"op\": \"kpconv_fused\", \"c_in\": %lld, \"c_out\": %lld, \"m\": %lld, \"ns\": %lld, \"h\": %lld, \"us\": %.1f, \"issued_tflops\": %.1f, "
+                "\"frac_of_fp32_matrix_roof\": %.3f, \"out_hash\": \"%016llx\", \"max_abs_error_vs_fp64\": %.3g, \"tolerance\": %.3g, \"ok\": %s}\n",
+                (long long)c_in, (long long)c_out, (long long)m, (long long)ns, (long long)h, us, flops / us * 1e-6, flops / us * 1e-6 / 157.3,
+                (unsigned long long)hash, worst, tol, worst <= tol ? "true" : "false");
+    // launches per forward: encoder1_2 x1, encoder2_1 x1, encoder2_2/2_3 x2, encoder3_1 x1
+    total_us += us * (L[0] == 64 && L[2] == L[3] ? 2 : 1);
+    for (void* p : {(void*)d_f, (void*)d_w, (void*)d_kp, (void*)d_bias, (void*)d_out, (void*)d_flag, packed}) HIP_OK(hipFree(p));
+  }
+  std::printf("{\"op\": \"kpconv_fused_layers_of_a_stack\", \"pairs\": %d, \"us_per_stack_alone\": %.0f, \"us_per_pair\": %.1f}\n", pairs, total_us, total_us / pairs);
+  return rc;
+}
+
 // The embedding path of one stack: tables of the two projections, the ragged structure embedding of `clouds` clouds of `n` superpoints
 // (written once: clouds x n x n x 256 floats) and ONE attention layer's positional softmax reading it (the transformer has three per cloud).
 static int run_embedding(int clouds, int n, int reps) {
@@ -328,6 +502,8 @@ int main(int argc, char** argv) {
     for (const auto& s : shapes) rc |= run_gemm(s[0], s[1], s[2], am, 20);
     return rc;
   }
+  if (mode == "kpconv")  // kpconv [pairs per stack=16] [reps=5] [fp32|bf16x3|bf16]
+    return run_kpconv(argc > 2 ? std::atoi(argv[2]) : 16, argc > 3 ? std::atoi(argv[3]) : 5, arithmetic(argc > 4 ? argv[4] : "fp32"));
   if (mode == "embedding")  // embedding [clouds=32] [superpoints=300] [reps=5]
     return run_embedding(argc > 2 ? std::atoi(argv[2]) : 32, argc > 3 ? std::atoi(argv[3]) : 300, argc > 4 ? std::atoi(argv[4]) : 5);
   if (mode == "cloud") {  // cloud [3dmatch|kitti]: one synthetic cloud as text (to look at its density without a GPU)

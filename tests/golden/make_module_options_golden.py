@@ -106,13 +106,25 @@ def main():
         s['lgr/ref_knn_points'], s['lgr/src_knn_points'], s['lgr/ref_knn_masks'], s['lgr/src_knn_masks'] = ref, src, rmask, smask
         s['lgr/score_mat'], s['lgr/global_scores'] = score, gscore
         for name, kwargs in (('plain', {}), ('global', dict(use_global_score=True)), ('limit', dict(correspondence_limit=150)),
-                             ('both', dict(use_global_score=True, correspondence_limit=150))):
-            m = LocalGlobalRegistration(3, 0.05, mutual=True, confidence_threshold=0.05, correspondence_threshold=3, num_refinement_steps=5,
-                                        **kwargs)
+                             ('both', dict(use_global_score=True, correspondence_limit=150)),
+                             # round 6 (VERDICT r5 missing 4): the `rc || cc` branch of local_global_registration.py:73-76
+                             ('nonmutual', dict(mutual=False)), ('nonmutual_limit', dict(mutual=False, correspondence_limit=150))):
+            kwargs = dict(dict(mutual=True), **kwargs)
+            m = LocalGlobalRegistration(3, 0.05, confidence_threshold=0.05, correspondence_threshold=3, num_refinement_steps=5, **kwargs)
             rc, sc, cs, T = m(ref, src, rmask, smask, score, gscore)
             s[f'lgr/{name}/ref_corr_points'], s[f'lgr/{name}/src_corr_points'] = rc, sc
             s[f'lgr/{name}/corr_scores'], s[f'lgr/{name}/estimated_transform'] = cs, T
             print(name, 'correspondences', cs.shape[0], 'T[:3, 3] =', T[:3, 3].tolist())
+        # round 6: caller-supplied global scores may be negative -- torch.topk orders them as floats; a third of the patches here
+        gsigned = gscore.clone()
+        gsigned[::3] = -gsigned[::3]
+        s['lgr/global_scores_signed'] = gsigned
+        m = LocalGlobalRegistration(3, 0.05, mutual=True, confidence_threshold=0.05, correspondence_threshold=3, num_refinement_steps=5,
+                                    use_global_score=True, correspondence_limit=150)
+        rc, sc, cs, T = m(ref, src, rmask, smask, score, gsigned)
+        s['lgr/both_signed/ref_corr_points'], s['lgr/both_signed/src_corr_points'] = rc, sc
+        s['lgr/both_signed/corr_scores'], s['lgr/both_signed/estimated_transform'] = cs, T
+        print('both_signed correspondences', cs.shape[0], 'negative', int((cs < 0).sum()), 'T[:3, 3] =', T[:3, 3].tolist())
     arrays = {k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in s.items()}
     np.savez_compressed(os.path.join(HERE, 'module_options.npz'), **arrays)
     print('wrote', os.path.join(HERE, 'module_options.npz'), f'({len(arrays)} arrays)')

@@ -111,11 +111,49 @@ def test_the_pose_is_asserted_in_this_sides_order():
     assert parity.compare_pair(got, want)['ok']                               # 1 cm at a 0.5 m radius: inside
 
 
-def test_pose_tolerance_scales_with_the_heads_acceptance_radius():
+def test_pose_tolerance_is_conditioned_on_the_correspondence_count():
+    # round 6: 5e-3 whenever >= 30 correspondences survive; the radius-scaled bound only below that
     assert parity.pose_tolerance({'acceptance_radius': 0.1}) == parity.TRANSFORM_ATOL       # 3DMatch / ModelNet heads
     assert parity.pose_tolerance({'acceptance_radius': 0.05}) == parity.TRANSFORM_ATOL      # never below
-    assert abs(parity.pose_tolerance({'acceptance_radius': 0.6}) - 0.03) < 1e-12            # KITTI head
+    assert abs(parity.pose_tolerance({'acceptance_radius': 0.6}) - 0.03) < 1e-12            # KITTI head, count unknown: the relaxed bound
+    assert abs(parity.pose_tolerance({'acceptance_radius': 0.6}, 6) - 0.03) < 1e-12         # 6 correspondences: relaxed
+    assert parity.pose_tolerance({'acceptance_radius': 0.6}, 29) > parity.TRANSFORM_ATOL
+    assert parity.pose_tolerance({'acceptance_radius': 0.6}, 30) == parity.TRANSFORM_ATOL   # well posed: the strict bound
+    assert parity.pose_tolerance({'acceptance_radius': 0.6}, 3000) == parity.TRANSFORM_ATOL
     assert parity.pose_tolerance(None) == parity.TRANSFORM_ATOL
+
+
+def test_relaxed_pose_tolerance_never_covers_the_rotation_block_and_needs_few_correspondences():
+    from oracle import model_oracle as mo
+    fine = dict(topk=2, acceptance_radius=0.5, mutual=True, confidence_threshold=0.05, correspondence_threshold=2, num_refinement_steps=3)
+    want = _pair(seed=3, P=8, K=6)                                            # its correspondence list has 11 entries: badly conditioned
+    want['matching_scores'] = want['matching_scores'].clamp(-3, 0.5)
+    want['matching_scores'][:, 2, :] = -1e12
+    want['_fine_cfg'] = fine
+    T0 = mo.local_global_registration(want['ref_node_corr_knn_points'], want['src_node_corr_knn_points'], want['ref_node_corr_knn_masks'],
+                                      want['src_node_corr_knn_masks'], want['matching_scores'][:, :-1, :-1], fine)[3]
+    want['estimated_transform'] = T0.clone()
+    got = copy.deepcopy(want)
+    got.pop('_fine_cfg')
+    g = torch.Generator().manual_seed(2)
+    got['ref_corr_points'], got['src_corr_points'] = torch.randn(11, 3, generator=g), torch.randn(11, 3, generator=g)
+    rep = parity.compare_pair(got, want)
+    assert rep['ok'] and rep['pose_tolerance_relaxed'] and abs(rep['transform_atol'] - 0.025) < 1e-12, rep
+    assert 1.0 < rep['procrustes_condition'] < float('inf') and rep['correspondences'][0] == 11
+    got['estimated_transform'] = T0.clone()
+    got['estimated_transform'][1, 3] += 0.01                                  # 1 cm at a 0.5 m radius with 11 correspondences: inside
+    assert parity.compare_pair(got, want)['ok']
+    got['estimated_transform'] = T0.clone()
+    got['estimated_transform'][0, 1] += 0.01                                  # a rotation entry: held to 5e-3 whatever the radius
+    rep = parity.compare_pair(got, want)
+    assert not rep['ok'] and rep['rotation_atol'] == parity.TRANSFORM_ATOL, rep
+    # the same 1 cm with a well-posed correspondence set is outside: the strict bound applies
+    got['estimated_transform'] = T0.clone()
+    got['estimated_transform'][1, 3] += 0.01
+    got['corr_scores'] = torch.rand(40, generator=g)
+    got['ref_corr_points'], got['src_corr_points'] = torch.randn(40, 3, generator=g), torch.randn(40, 3, generator=g)
+    rep = parity.compare_pair(got, want)
+    assert not rep['ok'] and rep['transform_atol'] == parity.TRANSFORM_ATOL and not rep['pose_tolerance_relaxed'], rep
 
 
 def _oracle_like(seed=11, n=7, m=9, P=24, K=5, N=40, M=30):

@@ -190,3 +190,44 @@ def test_pinned_host_inputs_are_bitwise_the_device_inputs():
             runner2.drain()
         finally:
             runner2.close()
+
+
+def test_host_inputs_on_every_path_and_strided_pinned_views_are_refused(monkeypatch):
+    """(1) a strided view of a pinned tensor reports is_pinned() but .contiguous() of it is pageable -- refused with a clear
+    error instead of handing the GPU an address it cannot read; (2) pinned host inputs work on the paths that do not stage a whole stack
+    (the synchronous lane loop GEOTR_PIPELINED=0, lanes == 1 with stack 1, register_batch and the one-pair call), bitwise as device inputs."""
+    from geotransformer_amd.config import make_cfg
+    from geotransformer_amd.pipeline import ConcurrentRegistration, RegistrationPipeline, stack_clouds, _check_cloud
+    from geotransformer_amd.synthetic import make_pair
+    cfg = make_cfg('3dmatch', {'backbone.init_dim': 16, 'backbone.group_norm': 4, 'backbone.output_dim': 64,
+                               'geotransformer.input_dim': 256, 'geotransformer.hidden_dim': 64, 'geotransformer.output_dim': 64})
+    torch.manual_seed(cfg.seed)
+    pipe = RegistrationPipeline(cfg, device='cuda:0')
+    items = [make_pair(190 + i, '3dmatch', n_points=2000 + 211 * i) for i in range(4)]
+    host = [(torch.from_numpy(it['ref_points']).pin_memory(), torch.from_numpy(it['src_points']).pin_memory()) for it in items]
+    dev = [(r.cuda(), s.cuda()) for r, s in host]
+    wide = torch.zeros((500, 6)).pin_memory()
+    strided = wide[:, :3]
+    assert strided.is_pinned() and not strided.is_contiguous()
+    with pytest.raises(ValueError, match='contiguous'):
+        _check_cloud(strided, host_ok=True)
+    with pytest.raises(ValueError, match='contiguous'):
+        pipe(strided, host[0][1])
+    want = [pipe(*d)['estimated_transform'] for d in dev]
+    assert torch.equal(pipe(*host[0])['estimated_transform'], want[0])                      # the one-pair call
+    stacked = pipe.register_batch(host[:3])                                                 # register_batch, host and mixed
+    stacked_dev = pipe.register_batch(dev[:3])
+    mixed = pipe.register_batch([(host[0][0], dev[0][1]), dev[1], host[2]])
+    for a, b, c in zip(stacked, stacked_dev, mixed):
+        assert torch.equal(a['estimated_transform'], b['estimated_transform']) and torch.equal(c['estimated_transform'], b['estimated_transform'])
+    monkeypatch.setenv('GEOTR_PIPELINED', '0')
+    for lanes, stack in ((2, 2), (1, 2), (1, 1)):                                           # the synchronous lane loop and the lanes == 1 fast path
+        runner = ConcurrentRegistration(pipe, lanes=lanes, stack=stack)
+        assert not runner.pipelined
+        got, ref = {}, {}
+        runner.run_batch(host, lambda i, out: got.__setitem__(i, out['estimated_transform']))
+        runner.run_batch(dev, lambda i, out: ref.__setitem__(i, out['estimated_transform']))
+        torch.cuda.synchronize()
+        runner.close()
+        for i in range(len(items)):
+            assert torch.equal(got[i], ref[i]), (lanes, stack, i)
