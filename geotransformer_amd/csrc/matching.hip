@@ -16,6 +16,7 @@
 namespace geotr {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ float sqn3(const float* p) { return (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]; }
 // ops/pairwise_distance.py:23-30: x2 - 2xy + y2, clamped at 0.  The reference's xy is a BLAS product over k = 3: an x86 sgemm micro-kernel
@@ -753,6 +754,247 @@ __global__ __launch_bounds__(K == 128 ? 1024 : 512) void patch_sinkhorn_kernel(c
   }
 }
 
+// ---- round 6: ONE WAVE per patch pair (K = 32 / 64), the sweeps without a transcendental per matrix entry ----------------------------
+// The block kernel above spends its time in v_exp_f32: 2 x 65 x 68 quarter-rate exponentials per sweep and patch pair, 3.5 G per 16-pair
+// stack = 352 us of the chip's whole transcendental rate, ~1 100 us measured (profiles/r05_kernel_trace.md: 69 us per pair alone).  The
+// log-sum-exp of a sweep factors:   LSE_j(S_ij + v_j) = a_i + log( sum_j exp(S_ij - a_i) exp(v_j) ),  a_i = max_j S_ij.
+// E_ij = exp(S_ij - a_i) in [0, 1] never changes, so it is computed ONCE; a half-sweep is then the 65 x 65 matrix-vector product
+// E . exp(v) -- 65 FMAs per lane -- plus one log and one exp per row.  Lane i owns row i AND column i of E in registers (130 VGPRs), the
+// dustbin row / column (index K) is spread over the lanes and summed with DPP adds; exp(u), exp(v) travel through 65 floats of
+// wave-private LDS (broadcast 16-byte reads).  No block barrier: a wave is a patch pair, four to a block.
+// The factorisation is exact algebra, not the reference's rounding sequence: the sums differ from max-shifted ones by ~1e-6 relative
+// (tests: <= 2e-3 absolute on the log scores, measured ~1e-5).  exp(v) can leave fp32's range where the max-shifted form cannot (scores of
+// magnitude ~100): every half-sweep checks its sums (1e-30 < s < 1e30, NaN fails) and a wave that fails re-does THAT half-sweep in the
+// max-shifted form from S, u, v (the reference's formula; test_sinkhorn_wave_fallback forces it).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+}
+// sum over the 64 lanes, returned wave-uniform (quad swaps, row mirrors, row broadcasts: no LDS crossbar)
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  x = dpp_add<0xB1, 0xf>(x);   // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E, 0xf>(x);   // quad_perm [2,3,0,1]
+  x = dpp_add<0x141, 0xf>(x);  // row_half_mirror
+  x = dpp_add<0x140, 0xf>(x);  // row_mirror: every lane holds its 16-lane row's sum
+  x = dpp_add<0x142, 0xa>(x);  // row_bcast:15 into rows 1, 3
+  x = dpp_add<0x143, 0xc>(x);  // row_bcast:31 into rows 2, 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ float wave_max_all(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+  return x;
+}
+#define GEOTR_WAVE_SYNC()                                     \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
+
+constexpr int kSinkWavesPerBlock = 4;
+template <int K>
+constexpr int sink_wave_floats() {  // LDS floats per wave: S (aliasing the two gathered feature blocks) + u, v, exp(u), exp(v)
+  return ((((K + 1) * (K + 1) > 2 * K * 33 ? (K + 1) * (K + 1) : 2 * K * 33) + 3) / 4 * 4) + 4 * ((K + 1 + 3) / 4 * 4);
+}
+
+template <int K>  // points per patch: 32 or 64 (K + 1 <= 65: lane i <-> row i and column i; index K = the dustbin)
+__global__ __launch_bounds__(64 * kSinkWavesPerBlock, 2) void patch_sinkhorn_wave_kernel(
+    const float* __restrict__ ref_feats, int64_t nr, const float* __restrict__ src_feats, int64_t ns, int C, const int64_t* __restrict__ ref_idx,
+    const int64_t* __restrict__ src_idx, const unsigned char* __restrict__ ref_mask, const unsigned char* __restrict__ src_mask,
+    const float* __restrict__ alpha_p, int iters, const float* __restrict__ scores_in, const int* __restrict__ p_count, float* __restrict__ out,
+    int P, int force_exact, SinkhornBatch sb) {
+  if (sb.count > 0) {
+    const int b = blockIdx.y;
+    ref_feats = sb.ref_feats[b], src_feats = sb.src_feats[b], nr = sb.nr[b], ns = sb.ns[b];
+    ref_idx += b * sb.idx_stride, src_idx += b * sb.idx_stride;
+    ref_mask += b * sb.mask_stride, src_mask += b * sb.mask_stride;
+    if (p_count) p_count += b * sb.pcount_stride;
+    out += b * sb.out_stride;
+  }
+  constexpr int K1 = K + 1, T = K / 32;
+  constexpr int VP = (K1 + 3) / 4 * 4;
+  constexpr int R0 = sink_wave_floats<K>() - 4 * VP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * kSinkWavesPerBlock + wave;
+  if (p >= P || (p_count && p >= *p_count)) return;  // wave-uniform; the kernel has no block barrier
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* S = smem + wave * sink_wave_floats<K>();  // [K1][K1]
+  float* A_s = S;                                  // [K][33]  (dead before S is written)
+  float* B_s = S + K * 33;                         // [K][33]
+  float* u = S + R0;                               // [VP] each
+  float* v = u + VP;
+  float* eu = v + VP;
+  float* ev = eu + VP;
+  const int64_t* ri = ref_idx + (int64_t)p * K;
+  const int64_t* si = src_idx + (int64_t)p * K;
+  const bool active = lane < K;
+  const int li = active ? lane : 0;
+  const bool rm_l = active && ref_mask[(int64_t)p * K + li] != 0, sm_l = active && src_mask[(int64_t)p * K + li] != 0;
+  const unsigned long long rbits = __ballot(rm_l), sbits = __ballot(sm_l);
+  const int fr = lane & 31, fk = lane >> 5;
+
+  if (!scores_in) {
+    // ---- scores on the matrix cores: the wave's T x T tiles of 32 x 32, channels in chunks of 32 through LDS ----
+    f32x16 acc[T * T];
+#pragma unroll
+    for (int t = 0; t < T * T; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    constexpr int NL = 2 * K * 8 / 64;  // 16-byte loads per lane and chunk: loads 0 .. NL/2-1 reference rows, the rest source rows
+    // the feature rows as raw buffers (< 2^30 elements each: checked by the host): a pad index or a channel past C gets an offset
+    // outside the buffer, for which the hardware returns zeros -- no branch around any load
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ref_feats), 0, (int)((unsigned)nr * (unsigned)C * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src_feats), 0, (int)((unsigned)ns * (unsigned)C * 4u), 0x00020000);
+    unsigned rowoff[NL];
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+      const int e = lane + 64 * t;
+      const int r = (e / 8) % K, kq = (e % 8) * 4;
+      const int64_t row = t < NL / 2 ? ri[r] : si[r];
+      rowoff[t] = row < (t < NL / 2 ? nr : ns) ? 4u * ((unsigned)row * (unsigned)C + (unsigned)kq) : 0xffffffffu;  // pad index -> zero row
+    }
+    for (int k0 = 0; k0 < C; k0 += 32) {
+      f32x4 val[NL];
+#pragma unroll
+      for (int t = 0; t < NL; ++t) {
+        const int kq = ((lane + 64 * t) % 8) * 4;
+        const unsigned off = k0 + kq < C ? rowoff[t] : 0xffffffffu;
+        val[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(t < NL / 2 ? rsrc_r : rsrc_s, off, 4 * k0, 0));
+      }
+      GEOTR_WAVE_SYNC();  // the previous chunk's fragment reads are done
+#pragma unroll
+      for (int t = 0; t < NL; ++t) {
+        const int e = lane + 64 * t;
+        const int side = e / (K * 8), r = (e / 8) % K, kq = (e % 8) * 4;
+        float* d = (side == 0 ? A_s : B_s) + r * 33 + kq;
+        d[0] = val[t][0], d[1] = val[t][1], d[2] = val[t][2], d[3] = val[t][3];
+      }
+      GEOTR_WAVE_SYNC();
+#pragma unroll
+      for (int t = 0; t < T * T; ++t) {
+        const int tr = t / T, tc = t % T;
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+          const float a = A_s[(32 * tr + fr) * 33 + 2 * ks + fk];
+          const float b = B_s[(32 * tc + fr) * 33 + 2 * ks + fk];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    GEOTR_WAVE_SYNC();  // S takes the feature blocks' memory
+    const float inv = sqrtf((float)C);
+#pragma unroll
+    for (int t = 0; t < T * T; ++t) {
+      const int tr = t / T, tc = t % T;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = 32 * tr + (q & 3) + 8 * (q >> 2) + 4 * fk, j = 32 * tc + fr;
+        S[i * K1 + j] = (((rbits >> i) & 1) && ((sbits >> j) & 1)) ? acc[t][q] / inv : -kSinkInf;  // model.py:188
+      }
+    }
+  } else {  // stand-alone optimal transport: scores were computed by the caller (learnable_sinkhorn.py:20)
+    const float* sp = scores_in + (int64_t)p * K * K;
+    for (int e = lane; e < K * K; e += 64) {
+      const int i = e / K, j = e % K;
+      S[i * K1 + j] = (((rbits >> i) & 1) && ((sbits >> j) & 1)) ? sp[e] : -kSinkInf;
+    }
+  }
+  // dustbin row / column (learnable_sinkhorn.py:41-48) and marginals (:50-62)
+  const float alpha = *alpha_p;
+  if (active) {
+    S[lane * K1 + K] = rm_l ? alpha : -kSinkInf;
+    S[K * K1 + lane] = sm_l ? alpha : -kSinkInf;
+  }
+  if (lane == 0) S[K * K1 + K] = alpha;
+  const float nvr = (float)__popcll(rbits), nvc = (float)__popcll(sbits);
+  const float norm = -logf(nvr + nvc);
+  const float lmu = rm_l ? norm : -kSinkInf, lnu = sm_l ? norm : -kSinkInf;
+  const float lmu_d = logf(nvc) + norm, lnu_d = logf(nvr) + norm;
+  GEOTR_WAVE_SYNC();
+  // ---- E: lane i's row and column of exp(S - max), the dustbin row / column one entry per lane ----
+  float Erow[K1], Ecol[K1];
+  float rmax = -3.4e38f, cmax = -3.4e38f;
+#pragma unroll
+  for (int j = 0; j < K1; ++j) {
+    Erow[j] = S[li * K1 + j], Ecol[j] = S[j * K1 + li];
+    rmax = fmaxf(rmax, Erow[j]), cmax = fmaxf(cmax, Ecol[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < K1; ++j) Erow[j] = __expf(Erow[j] - rmax), Ecol[j] = __expf(Ecol[j] - cmax);
+  const float corner = alpha;
+  const float dr = active ? S[K * K1 + li] : -3.4e38f, dc = active ? S[li * K1 + K] : -3.4e38f;
+  const float drmax = fmaxf(wave_max_all(dr), corner), dcmax = fmaxf(wave_max_all(dc), corner);
+  const float Edr = active ? __expf(dr - drmax) : 0.f, Edc = active ? __expf(dc - dcmax) : 0.f;
+  const float Edr_c = __expf(corner - drmax), Edc_c = __expf(corner - dcmax);
+  // ---- 100 x { u = log_mu - LSE_j(S + v);  v = log_nu - LSE_i(S + u) }  (:13-18) ----
+  float my_u = 0.f, my_v = 0.f, u_d = 0.f, v_d = 0.f;      // the lane's own entries and the dustbin's (uniform)
+  float my_eu = 1.f, my_ev = 1.f, eu_d = 1.f, ev_d = 1.f;  // their exponentials
+  if (lane < VP) eu[lane] = lane < K1 ? 1.f : 0.f, ev[lane] = lane < K1 ? 1.f : 0.f;
+  if (VP > 64 && lane < VP - 64) eu[64 + lane] = 64 + lane < K1 ? 1.f : 0.f, ev[64 + lane] = 64 + lane < K1 ? 1.f : 0.f;
+  GEOTR_WAVE_SYNC();
+  // one half-sweep: `E` = the lane's row (half 0) or column (half 1) of E, `eo` = exp of the other potential in LDS
+  auto half_sweep = [&](const float (&E)[K1], float emax, float Ed, float Ed_c, float dmax, const float* eo, float my_eo, float eo_d,
+                        float* raw_o, float my_raw_o, float raw_o_d, bool rows, float lm, float lm_d, float& mine, float& mine_d) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < VP / 4; ++q) {
+      const float4 o = *reinterpret_cast<const float4*>(eo + 4 * q);
+      if (4 * q < K1) s0 = fmaf(E[4 * q], o.x, s0);
+      if (4 * q + 1 < K1) s1 = fmaf(E[4 * q + 1 < K1 ? 4 * q + 1 : 0], o.y, s1);
+      if (4 * q + 2 < K1) s0 = fmaf(E[4 * q + 2 < K1 ? 4 * q + 2 : 0], o.z, s0);
+      if (4 * q + 3 < K1) s1 = fmaf(E[4 * q + 3 < K1 ? 4 * q + 3 : 0], o.w, s1);
+    }
+    const float s = s0 + s1;
+    const float sd = wave_sum_dpp(Ed * my_eo) + Ed_c * eo_d;
+    float lse = emax + __logf(s), lse_d = dmax + __logf(sd);
+    const bool bad = (active && !(s > 1e-30f && s < 1e30f)) || !(sd > 1e-30f && sd < 1e30f);
+    if (__any(bad) || force_exact) {  // (wave-uniform) the max-shifted form of the reference for this half-sweep
+      if (active) raw_o[lane] = my_raw_o;
+      if (lane == 0) raw_o[K] = raw_o_d;
+      GEOTR_WAVE_SYNC();
+      float mx = -3.4e38f, sum = 0.f;
+      for (int j = 0; j < K1; ++j) {
+        const float x = (rows ? S[li * K1 + j] : S[j * K1 + li]) + raw_o[j];
+        if (x > mx) {
+          sum = sum * __expf(mx - x) + 1.f;
+          mx = x;
+        } else {
+          sum += __expf(x - mx);
+        }
+      }
+      lse = mx + __logf(sum);
+      const float xd = active ? (rows ? S[K * K1 + li] : S[li * K1 + K]) + my_raw_o : -3.4e38f;
+      const float xc = corner + raw_o_d;
+      const float md = fmaxf(wave_max_all(xd), xc);
+      const float sde = wave_sum_dpp(active ? __expf(xd - md) : 0.f) + __expf(xc - md);
+      lse_d = md + __logf(sde);
+    }
+    mine = lm - lse;
+    mine_d = lm_d - lse_d;
+  };
+  for (int it = 0; it < iters; ++it) {
+    half_sweep(Erow, rmax, Edr, Edr_c, drmax, ev, my_ev, ev_d, v, my_v, v_d, true, lmu, lmu_d, my_u, u_d);
+    my_eu = __expf(my_u), eu_d = __expf(u_d);
+    if (active) eu[lane] = my_eu;
+    if (lane == 0) eu[K] = eu_d;
+    GEOTR_WAVE_SYNC();
+    half_sweep(Ecol, cmax, Edc, Edc_c, dcmax, eu, my_eu, eu_d, u, my_u, u_d, false, lnu, lnu_d, my_v, v_d);
+    my_ev = __expf(my_v), ev_d = __expf(v_d);
+    if (active) ev[lane] = my_ev;
+    if (lane == 0) ev[K] = ev_d;
+    GEOTR_WAVE_SYNC();
+  }
+  if (active) u[lane] = my_u, v[lane] = my_v;
+  if (lane == 0) u[K] = u_d, v[K] = v_d;
+  GEOTR_WAVE_SYNC();
+  float* o = out + (int64_t)p * K1 * K1;
+  for (int e = lane; e < K1 * K1; e += 64) {
+    const int i = e / K1, j = e - i * K1;
+    o[e] = ((S[e] + u[i]) + v[j]) - norm;
+  }
+}
+
 // patches of the selected superpoint pairs (experiments/.../model.py:169-174): row p of the outputs = row corr_idx[p] of
 // the per-node tables; grid (P, 2): blockIdx.y = 0 reference side, 1 source side
 template <bool AGENT>
@@ -943,9 +1185,35 @@ static int sinkhorn_launch_impl(const float* ref_feats, int64_t nr, const float*
                                                                             src_knn_indices, ref_knn_masks, src_knn_masks, alpha, \
                                                                             (int)num_iterations, scores_in, p_count, matching_scores, sb); \
   } while (0)
-  if (k == 32) LAUNCH(32);
+  // K = 32 / 64: one wave per patch pair, sweeps as matrix-vector products (patch_sinkhorn_wave_kernel).  GEOTR_SINKHORN_FORM (measurement
+  // switch): "block" = the round-2 block kernel, "wave-exact" = the wave kernel with every half-sweep in the max-shifted form
+  static const int form = [] {
+    const char* e = std::getenv("GEOTR_SINKHORN_FORM");
+    if (e && std::strcmp(e, "block") == 0) return 0;
+    if (e && std::strcmp(e, "wave-exact") == 0) return 2;
+    return 1;
+  }();
+#define LAUNCH_WAVE(KK)                                                                                                          \
+  do {                                                                                                                           \
+    const size_t wlds = sizeof(float) * kSinkWavesPerBlock * sink_wave_floats<KK>();                                              \
+    if (wlds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sinkhorn_wave_kernel<KK>),                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds) != hipSuccess)            \
+      return fail(GEOTR_E_LAUNCH, "patch_sinkhorn: cannot reserve %zu B of LDS", wlds);                                           \
+    patch_sinkhorn_wave_kernel<KK><<<dim3((unsigned)((p + kSinkWavesPerBlock - 1) / kSinkWavesPerBlock), (unsigned)(sb.count > 0 ? sb.count : 1)), \
+                                     dim3(64 * kSinkWavesPerBlock), wlds, stream>>>(ref_feats, nr, src_feats, ns, (int)c, ref_knn_indices, \
+                                                                                    src_knn_indices, ref_knn_masks, src_knn_masks, alpha,   \
+                                                                                    (int)num_iterations, scores_in, p_count, matching_scores, \
+                                                                                    (int)p, form == 2 ? 1 : 0, sb);                          \
+  } while (0)
+  // (the wave kernel reads the feature rows as 4 GB raw buffers)
+  bool wave_ok = form != 0 && (scores_in || (nr * c < (1ll << 30) && ns * c < (1ll << 30)));
+  for (int b = 0; b < sb.count; ++b) wave_ok = wave_ok && sb.nr[b] * c < (1ll << 30) && sb.ns[b] * c < (1ll << 30);
+  if (k == 32 && wave_ok) LAUNCH_WAVE(32);
+  else if (k == 64 && wave_ok) LAUNCH_WAVE(64);
+  else if (k == 32) LAUNCH(32);
   else if (k == 64) LAUNCH(64);
   else LAUNCH(128);
+#undef LAUNCH_WAVE
 #undef LAUNCH
   GEOTR_CHECK_LAUNCH("patch_sinkhorn");
   return GEOTR_OK;

@@ -462,6 +462,73 @@ static int run_embedding(int clouds, int n, int reps) {
   return 0;
 }
 
+// S1 + S2 of one stack: `patches` patch pairs of k points, c channels (16 pairs x 256 coarse matches at the bench workload), 100 sweeps.
+// Prints the time per launch and a checksum of the output (to compare the kernel forms: GEOTR_SINKHORN_FORM=block | wave-exact | default).
+static int run_sinkhorn(int patches, int k, int c, int reps) {
+  std::mt19937 rng(9);
+  std::normal_distribution<float> nrm(0.f, 1.f);
+  std::uniform_real_distribution<float> u01(0.f, 1.f);
+  const int64_t n = 40000;
+  std::vector<float> rf((size_t)n * c), sf((size_t)n * c);
+  for (auto* f : {&rf, &sf})  // unit rows, as the model's fine features
+    for (int64_t i = 0; i < n; ++i) {
+      double ss = 0;
+      for (int j = 0; j < c; ++j) (*f)[i * c + j] = nrm(rng), ss += (double)(*f)[i * c + j] * (*f)[i * c + j];
+      for (int j = 0; j < c; ++j) (*f)[i * c + j] /= (float)std::sqrt(ss);
+    }
+  std::vector<int64_t> ri((size_t)patches * k), si((size_t)patches * k);
+  std::vector<uint8_t> rm((size_t)patches * k), sm((size_t)patches * k);
+  for (size_t e = 0; e < ri.size(); ++e) {
+    rm[e] = u01(rng) < 0.9f, sm[e] = u01(rng) < 0.9f;
+    ri[e] = rm[e] ? (int64_t)(u01(rng) * (n - 1)) : n, si[e] = sm[e] ? (int64_t)(u01(rng) * (n - 1)) : n;
+  }
+  float *drf, *dsf, *dalpha, *dout;
+  int64_t *dri, *dsi;
+  uint8_t *drm, *dsm;
+  const float alpha = 1.0f;
+  const size_t out_floats = (size_t)patches * (k + 1) * (k + 1);
+  HIP_OK(hipMalloc(&drf, rf.size() * 4));
+  HIP_OK(hipMalloc(&dsf, sf.size() * 4));
+  HIP_OK(hipMalloc(&dri, ri.size() * 8));
+  HIP_OK(hipMalloc(&dsi, si.size() * 8));
+  HIP_OK(hipMalloc(&drm, rm.size()));
+  HIP_OK(hipMalloc(&dsm, sm.size()));
+  HIP_OK(hipMalloc(&dalpha, 4));
+  HIP_OK(hipMalloc(&dout, out_floats * 4));
+  HIP_OK(hipMemcpy(drf, rf.data(), rf.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dsf, sf.data(), sf.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dri, ri.data(), ri.size() * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dsi, si.data(), si.size() * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(drm, rm.data(), rm.size(), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dsm, sm.data(), sm.size(), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dalpha, &alpha, 4, hipMemcpyHostToDevice));
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));
+  auto fn = [&] {
+    GEOTR_OK_OR_DIE(geotr_patch_sinkhorn(drf, n, dsf, n, c, dri, dsi, drm, dsm, patches, k, dalpha, 100, nullptr, nullptr, dout, stream));
+  };
+  fn();
+  hipEvent_t t0, t1;
+  HIP_OK(hipEventCreate(&t0));
+  HIP_OK(hipEventCreate(&t1));
+  HIP_OK(hipEventRecord(t0, stream));
+  for (int r = 0; r < reps; ++r) fn();
+  HIP_OK(hipEventRecord(t1, stream));
+  HIP_OK(hipEventSynchronize(t1));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, t0, t1));
+  std::vector<float> out(out_floats);
+  HIP_OK(hipMemcpy(out.data(), dout, out_floats * 4, hipMemcpyDeviceToHost));
+  double sum = 0, sum_abs = 0;
+  for (float x : out)
+    if (x > -1e6f) sum += x, sum_abs += std::fabs(x);
+  const char* form = std::getenv("GEOTR_SINKHORN_FORM");
+  std::printf("{\"op\": \"patch_sinkhorn\", \"form\": \"%s\", \"patches\": %d, \"k\": %d, \"c\": %d, \"us\": %.1f, \"us_per_pair_of_256\": %.1f, "
+              "\"finite_sum\": %.6f, \"finite_abs_sum\": %.6f}\n",
+              form ? form : "wave", patches, k, c, 1e3 * ms / reps, 1e3 * ms / reps * 256.0 / patches, sum, sum_abs);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (geotr_abi_version() != GEOTR_ABI_VERSION) {
     std::fprintf(stderr, "library ABI %d, header ABI %d\n", geotr_abi_version(), GEOTR_ABI_VERSION);
@@ -506,6 +573,9 @@ int main(int argc, char** argv) {
     return run_kpconv(argc > 2 ? std::atoi(argv[2]) : 16, argc > 3 ? std::atoi(argv[3]) : 5, arithmetic(argc > 4 ? argv[4] : "fp32"));
   if (mode == "embedding")  // embedding [clouds=32] [superpoints=300] [reps=5]
     return run_embedding(argc > 2 ? std::atoi(argv[2]) : 32, argc > 3 ? std::atoi(argv[3]) : 300, argc > 4 ? std::atoi(argv[4]) : 5);
+  if (mode == "sinkhorn")  // sinkhorn [patches=4096] [k=64] [c=256] [reps=5]
+    return run_sinkhorn(argc > 2 ? std::atoi(argv[2]) : 4096, argc > 3 ? std::atoi(argv[3]) : 64, argc > 4 ? std::atoi(argv[4]) : 256,
+                        argc > 5 ? std::atoi(argv[5]) : 5);
   if (mode == "cloud") {  // cloud [3dmatch|kitti]: one synthetic cloud as text (to look at its density without a GPU)
     const bool kitti = argc > 2 && std::string(argv[2]) == "kitti";
     std::mt19937 rng(1000);
@@ -517,6 +587,6 @@ int main(int argc, char** argv) {
     const std::string config = argc > 2 ? argv[2] : "3dmatch";
     return run_pyramid(config, argc > 3 ? std::atoi(argv[3]) : (config == "kitti" ? 4 : 16), argc > 4 ? std::atoi(argv[4]) : 5);
   }
-  std::fprintf(stderr, "usage: %s gemm M N K [fp32|bf16x3|bf16] [reps] | shapes [fp32|bf16x3|bf16] [all] | pyramid [3dmatch|kitti] [pairs] [reps] | embedding [clouds] [superpoints] [reps]\n", argv[0]);
+  std::fprintf(stderr, "usage: %s gemm M N K [fp32|bf16x3|bf16] [reps] | shapes [fp32|bf16x3|bf16] [all] | pyramid [3dmatch|kitti] [pairs] [reps] | embedding [clouds] [superpoints] [reps] | sinkhorn [patches] [k] [c] [reps]\n", argv[0]);
   return 64;
 }

@@ -121,6 +121,34 @@ def test_sinkhorn_matches_oracle(K, C):
     assert torch.isfinite(got[valid]).all() and float(e.sum()) > 0
 
 
+@pytest.mark.parametrize('K', [32, 64])
+@pytest.mark.parametrize('scale', [1.0, 40.0, 400.0])
+def test_sinkhorn_wave_fallback(K, scale):
+    """The one-wave-per-patch kernel (K = 32 / 64) runs its sweeps as E . exp(v) products; scores whose potentials leave fp32's exp range
+    (scale 40: some half-sweeps, scale 400: all of them) must take the max-shifted form of learnable_sinkhorn.py:13-18 instead."""
+    from geotransformer_amd.modules.sinkhorn import LearnableLogOptimalTransport
+    from oracle import model_oracle as mo
+    g = torch.Generator().manual_seed(100 + K)
+    P = 7
+    scores = scale * torch.randn(P, K, K, generator=g)
+    rmask = torch.rand(P, K, generator=g) > 0.2
+    smask = torch.rand(P, K, generator=g) > 0.3
+    smask[2] = False  # no valid source point
+    rmask[4] = True
+    smask[4] = True   # a full patch
+    ot = LearnableLogOptimalTransport(100)
+    with torch.no_grad():
+        ot.alpha.fill_(0.7)
+    want = mo.optimal_transport(scores, rmask, smask, ot.alpha.detach(), 100)
+    got = ot.cuda()(scores.cuda(), rmask.cuda(), smask.cuda()).cpu()
+    valid = torch.ones(P, dtype=torch.bool)
+    valid[2] = False
+    assert torch.isfinite(got[valid]).all()
+    # entries of masked rows / columns are ~ -1e12 on both sides; compare relative to the magnitude
+    err = ((got[valid] - want[valid]).abs() / (1.0 + want[valid].abs())).max()
+    assert float(err) < 2e-3 * max(1.0, scale / 40.0), float(err)
+
+
 def test_weighted_procrustes_matches_oracle():
     from geotransformer_amd.modules.registration import weighted_procrustes
     from oracle import model_oracle as mo
