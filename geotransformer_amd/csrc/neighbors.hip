@@ -240,6 +240,7 @@ __global__ void rg_scatter_kernel(const float* __restrict__ s, int batch, const 
 // into an LDS row with ballot + popcount, then ranked (keys are distinct) and written out.
 // The number of queries and the pad index are read on the device (the lengths / the support clouds' headers): a pyramid stage whose size
 // only the device knows needs no host read (round 3).  nq_cap = row capacity of the query array.
+constexpr int kRgAhead = 4;  // candidate steps in flight per wave (rg_query_kernel, rg_query_quad_kernel)
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
                                                        const float4* __restrict__ sorted, const float* __restrict__ q,
@@ -285,35 +286,44 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
     }
     const int inc = wave_inclusive_scan(seg_len);
     const int total = __shfl(inc, 8, 64);
-    int pre[9], st[9];
+    // flat candidate index t -> sorted row t + off[k], k = the last run that starts at or before t (empty runs share their successor's start)
+    int pre[9], off[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       pre[k] = __shfl(inc - seg_len, k, 64);
-      st[k] = __shfl(seg_start, k, 64);
+      off[k] = __shfl(seg_start, k, 64) - pre[k];
     }
 
+    // Round 6: kRgAhead steps of 64 candidates are LOADED before the first is judged -- the loop was one dependent L2 / MALL round trip per
+    // step (KITTI's dense searches: 10-16 steps per query, 30 % of that configuration's kernel time); same candidates in the same order.
     int base = 0;
-    for (int t0 = 0; t0 < total; t0 += 64) {
-      const int t = t0 + lane;
-      bool accept = false;
-      unsigned long long key = 0;
-      if (t < total) {
-        int k = 0;
+    for (int t0 = 0; t0 < total; t0 += 64 * kRgAhead) {
+      float4 pc[kRgAhead];
 #pragma unroll
-        for (int j = 1; j < 9; ++j) k = (t >= pre[j]) ? j : k;
-        const float4 p = sorted[st[k] + (t - pre[k])];
+      for (int u = 0; u < kRgAhead; ++u) {
+        const int t = t0 + 64 * u + lane;
+        int o = off[0];
+#pragma unroll
+        for (int j = 1; j < 9; ++j) o = (t >= pre[j]) ? off[j] : o;
+        pc[u] = sorted[t < total ? t + o : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < kRgAhead; ++u) {
+        if (t0 + 64 * u >= total) break;  // (uniform)
+        const int t = t0 + 64 * u + lane;
+        const float4 p = pc[u];
         // L2_Simple_Adaptor::evalMetric (nanoflann.hpp:432-440): ((dx*dx) + dy*dy) + dz*dz, no FMA
         const float dx = __fsub_rn(qx, p.x), dy = __fsub_rn(qy, p.y), dz = __fsub_rn(qz, p.z);
         const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        accept = d < r2;  // strict (nanoflann.hpp:249-253)
-        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+        const bool accept = t < total && d < r2;  // strict (nanoflann.hpp:249-253)
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+        const unsigned long long ballot = __ballot(accept);
+        if (!COUNT_ONLY) {
+          const int rank = base + __popcll(ballot & ((1ull << lane) - 1ull));
+          if (accept && rank < cap) keys[rank] = key;
+        }
+        base += __popcll(ballot);
       }
-      const unsigned long long ballot = __ballot(accept);
-      if (!COUNT_ONLY) {
-        const int rank = base + __popcll(ballot & ((1ull << lane) - 1ull));
-        if (accept && rank < cap) keys[rank] = key;
-      }
-      base += __popcll(ballot);
     }
     int count = base;
     if (COUNT_ONLY) {
@@ -413,38 +423,41 @@ __global__ __launch_bounds__(256, 5) void rg_query_quad_kernel(const CloudGrid* 
       if (l >= o) inc += t;
     }
     const int total = __shfl(inc, 8, 16);
-    int pre[9], st[9];
+    int pre[9], off[9];  // flat candidate index t -> sorted row t + off[k] (see rg_query_kernel)
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       pre[k] = __shfl(inc - seg_len, k, 16);
-      st[k] = __shfl(seg_start, k, 16);
+      off[k] = __shfl(seg_start, k, 16) - pre[k];
     }
     int most = total;  // the longest candidate list of the four
     most = max(most, __shfl_xor(most, 16, 64));
     most = max(most, __shfl_xor(most, 32, 64));
     int base = 0;
-    for (int t0 = 0; t0 < most; t0 += 16) {
-      const int t = t0 + l;
-      bool accept = false;
-      unsigned long long key = 0;
-      if (t < total) {
-        int k = 0;
+    for (int t0 = 0; t0 < most; t0 += 16 * kRgAhead) {  // kRgAhead steps of 16 candidates per group loaded before the first is judged
+      float4 pc[kRgAhead];
 #pragma unroll
-        for (int j = 1; j < 9; ++j) k = (t >= pre[j]) ? j : k;
-        int pk = pre[0], sk = st[0];
+      for (int u = 0; u < kRgAhead; ++u) {
+        const int t = t0 + 16 * u + l;
+        int o = off[0];
 #pragma unroll
-        for (int j = 1; j < 9; ++j) pk = (k == j) ? pre[j] : pk, sk = (k == j) ? st[j] : sk;
-        const float4 p = sorted[sk + (t - pk)];
+        for (int j = 1; j < 9; ++j) o = (t >= pre[j]) ? off[j] : o;
+        pc[u] = sorted[t < total ? t + o : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < kRgAhead; ++u) {
+        if (t0 + 16 * u >= most) break;  // (uniform)
+        const int t = t0 + 16 * u + l;
+        const float4 p = pc[u];
         // L2_Simple_Adaptor::evalMetric (nanoflann.hpp:432-440): ((dx*dx) + dy*dy) + dz*dz, no FMA
         const float dx = __fsub_rn(qx, p.x), dy = __fsub_rn(qy, p.y), dz = __fsub_rn(qz, p.z);
         const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        accept = d < r2;  // strict (nanoflann.hpp:249-253)
-        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+        const bool accept = t < total && d < r2;  // strict (nanoflann.hpp:249-253)
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+        const unsigned field = (unsigned)(__ballot(accept) >> (16 * grp)) & 0xffffu;  // this group's 16 lanes
+        const int rank = base + __popc(field & ((1u << l) - 1u));
+        if (accept && rank < kQuadKeys) keys[rank] = key;
+        base += __popc(field);
       }
-      const unsigned field = (unsigned)(__ballot(accept) >> (16 * grp)) & 0xffffu;  // this group's 16 lanes
-      const int rank = base + __popc(field & ((1u << l) - 1u));
-      if (accept && rank < kQuadKeys) keys[rank] = key;
-      base += __popc(field);
     }
     const int count = base;
     const bool dense = has_q && count > kQuadKeys;
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(256, 5) void rg_query_quad_kernel(const CloudGrid* 
       const long long s_start1 = __shfl((long long)g.s_start, lead, 64);
       int pre1[9], st1[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) pre1[k] = __shfl(pre[k], lead, 64), st1[k] = __shfl(st[k], lead, 64);
+      for (int k = 0; k < 9; ++k) pre1[k] = __shfl(pre[k], lead, 64), st1[k] = __shfl(off[k], lead, 64) + pre1[k];
       int cnt1 = 0;
       for (int t0 = 0; t0 < tot1; t0 += 64) {
         const int t = t0 + lane;

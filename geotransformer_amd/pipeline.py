@@ -50,7 +50,7 @@ def stack_clouds(clouds, device):
     points = torch.empty((sum(int(c.shape[0]) for c in clouds), 3), dtype=torch.float32, device=device)
     for g in range(0, len(clouds), 32):
         group = [c if c.is_contiguous() else c.contiguous() for c in clouds[g:g + 32]]  # (host clouds are contiguous: _check_cloud)
-        assert all(c.is_cuda or c.is_pinned() for c in group), 'stack_clouds: a host cloud must be pinned'
+        assert all(c.is_cuda or c.is_pinned() or c.shape[0] == 0 for c in group), 'stack_clouds: a host cloud must be pinned'  # (an empty cloud is never read)
         ptrs = (ctypes.c_void_p * len(group))(*[c.data_ptr() for c in group])
         rows = (ctypes.c_int64 * len(group))(*[int(c.shape[0]) for c in group])
         row0 = sum(int(c.shape[0]) for c in clouds[:g])

@@ -341,11 +341,11 @@ def weighted_procrustes(src_points, ref_points, weights, eps=1e-5):
     Hm = (src_points - src_c).permute(0, 2, 1) @ (weights * (ref_points - ref_c))
     U, _, V = torch.svd(Hm)
     Ut = U.transpose(1, 2)
-    eye = torch.eye(3).unsqueeze(0).repeat(B, 1, 1)
+    eye = torch.eye(3, dtype=Hm.dtype).unsqueeze(0).repeat(B, 1, 1)
     eye[:, -1, -1] = torch.sign(torch.det(V @ Ut))
     R = V @ eye @ Ut
     t = (ref_c.permute(0, 2, 1) - R @ src_c.permute(0, 2, 1)).squeeze(2)
-    T = torch.eye(4).unsqueeze(0).repeat(B, 1, 1)
+    T = torch.eye(4, dtype=Hm.dtype).unsqueeze(0).repeat(B, 1, 1)
     T[:, :3, :3] = R
     T[:, :3, 3] = t
     return T.squeeze(0) if squeeze else T
@@ -368,9 +368,16 @@ def correspondence_matrix(score_mat, ref_knn_masks, src_knn_masks, k, threshold,
     return torch.logical_and(corr, mask_mat)
 
 
-def local_global_registration(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, cfg):
+def local_global_registration(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, score_mat, cfg, near_tie_slack=None,
+                              procrustes_dtype=None):
     """LocalGlobalRegistration.forward (local_global_registration.py:196-235) with
-    local_to_global_registration (:137-194); use_dustbin=False, use_global_score=False, no correspondence_limit."""
+    local_to_global_registration (:137-194); use_dustbin=False, use_global_score=False, no correspondence_limit.
+    `near_tie_slack` (parity tooling only; None = the reference's behaviour): also returns, as a fifth value, [(support, refined pose)] of
+    every hypothesis whose inlier count is within that many of the best one's, best first -- the poses the head would have produced had a
+    borderline inlier (residual within rounding of the acceptance radius) tipped the argmax of :171 the other way.
+    `procrustes_dtype` (parity tooling only): the correspondences are selected in fp32 as the reference does, everything after
+    (per-patch Procrustes, inlier counts, refinement) runs in that dtype -- torch.float64 shows whether the reference's own fp32 head is
+    numerically stable on an input."""
     score_mat = torch.exp(score_mat)
     corr_mat = correspondence_matrix(score_mat, ref_knn_masks, src_knn_masks, cfg['topk'], cfg['confidence_threshold'],
                                      cfg.get('mutual', True))
@@ -379,6 +386,8 @@ def local_global_registration(ref_knn_points, src_knn_points, ref_knn_masks, src
     ref_corr = ref_knn_points[bidx, ridx]
     src_corr = src_knn_points[bidx, sidx]
     scores = score_mat[bidx, ridx, sidx]
+    if procrustes_dtype is not None:
+        ref_corr, src_corr, scores = ref_corr.to(procrustes_dtype), src_corr.to(procrustes_dtype), scores.to(procrustes_dtype)
     radius = cfg['acceptance_radius']
     # chunks of consecutive correspondences per patch pair with >= correspondence_threshold entries (:153-163)
     counts = torch.bincount(bidx, minlength=score_mat.shape[0])
@@ -386,9 +395,9 @@ def local_global_registration(ref_knn_points, src_knn_points, ref_knn_masks, src
     chunks = [(int(s), int(s + c)) for s, c in zip(starts, counts) if c >= cfg['correspondence_threshold']]
     if len(chunks) > 0:
         mc = max(y - x for x, y in chunks)
-        br = torch.zeros(len(chunks), mc, 3)
-        bs = torch.zeros(len(chunks), mc, 3)
-        bw = torch.zeros(len(chunks), mc)
+        br = torch.zeros(len(chunks), mc, 3, dtype=scores.dtype)
+        bs = torch.zeros(len(chunks), mc, 3, dtype=scores.dtype)
+        bw = torch.zeros(len(chunks), mc, dtype=scores.dtype)
         for i, (x, y) in enumerate(chunks):  # convert_to_batch (:86-128): zero padded
             br[i, : y - x], bs[i, : y - x], bw[i, : y - x] = ref_corr[x:y], src_corr[x:y], scores[x:y]
         T = weighted_procrustes(bs, br, bw)
@@ -396,17 +405,31 @@ def local_global_registration(ref_knn_points, src_knn_points, ref_knn_masks, src
         residuals = torch.linalg.norm(ref_corr.unsqueeze(0) - aligned, dim=2)
         inliers = torch.lt(residuals, radius)
         best = inliers.sum(dim=1).argmax()
-        cur = scores * inliers[best].float()
+        cur = scores * inliers[best].to(scores.dtype)
     else:  # degenerate branch (:179-184)
         T0 = weighted_procrustes(src_corr, ref_corr, scores)
         res = torch.linalg.norm(ref_corr - apply_transform(src_corr, T0), dim=1)
         cur = scores * torch.lt(res, radius).float()
-    T = weighted_procrustes(src_corr, ref_corr, cur)
-    for _ in range(cfg['num_refinement_steps'] - 1):
-        res = torch.linalg.norm(ref_corr - apply_transform(src_corr, T), dim=1)
-        cur = scores * torch.lt(res, radius).float()
+    def refine(cur):
         T = weighted_procrustes(src_corr, ref_corr, cur)
-    return ref_corr, src_corr, scores, T
+        for _ in range(cfg['num_refinement_steps'] - 1):
+            res = torch.linalg.norm(ref_corr - apply_transform(src_corr, T), dim=1)
+            cur = scores * torch.lt(res, radius).to(scores.dtype)
+            T = weighted_procrustes(src_corr, ref_corr, cur)
+        return T
+
+    T = refine(cur)
+    if near_tie_slack is None:
+        return ref_corr, src_corr, scores, T
+    near = []
+    if len(chunks) > 0:
+        support = inliers.sum(dim=1)
+        order = torch.argsort(-support, stable=True)
+        for h in order.tolist():
+            if int(support[h]) < int(support[best]) - int(near_tie_slack):
+                break
+            near.append((int(support[h]), refine(scores * inliers[h].to(scores.dtype))))
+    return ref_corr, src_corr, scores, T, near
 
 
 # ---------------------------------------------------------------------------------------------
