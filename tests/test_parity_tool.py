@@ -118,7 +118,14 @@ def test_head_on_own_scores_accepts_only_the_fp64_head_or_a_support_near_tie():
     from oracle import model_oracle as mo
     fine = dict(topk=2, acceptance_radius=0.5, mutual=True, confidence_threshold=0.05, correspondence_threshold=2, num_refinement_steps=3)
     want = _pair(seed=3, P=8, K=6)
-    want['matching_scores'] = want['matching_scores'].clamp(-3, 0.5)
+    # a real registration: the source patches are the reference patches moved rigidly (patch 5 by another motion: a weaker hypothesis),
+    # the scores favour the true matches
+    g = torch.Generator().manual_seed(11)
+    Rm = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    Rm = Rm * torch.sign(torch.det(Rm))
+    want['src_node_corr_knn_points'] = (want['ref_node_corr_knn_points'] - torch.tensor([0.3, -0.2, 0.1])) @ Rm
+    want['src_node_corr_knn_points'][5] = want['ref_node_corr_knn_points'][5].flip(1) + 0.7
+    want['matching_scores'] = torch.full((8, 7, 7), -6.0) + 5.5 * torch.eye(7) + 0.05 * torch.randn(8, 7, 7, generator=g)
     want['matching_scores'][:, 2, :] = -1e12
     want['node_corr_scores'] = torch.full((8,), 0.25)
     want['_fine_cfg'] = fine
