@@ -451,14 +451,39 @@ static int run_embedding(int clouds, int n, int reps) {
     HIP_OK(hipEventElapsedTime(&ms, t0, t1));
     return 1e3 * ms / reps;
   };
-  const double us_embed = time_of([&] {
-    GEOTR_OK_OR_DIE(geotr_gse_embed_table(pts, knn, &gc, k, d, tab_d, points_d, tab_a, points_a, w_d, b_d, w_a, b_a, div_term, sigma_d, sigma_a, emb, stream));
-  });
   const double us_softmax = time_of([&] { GEOTR_OK_OR_DIE(geotr_attn_softmax_grouped(scores, &ag, qt, qb, d, heads, 0.125f, stream)); });
   const double emb_bytes = 4.0 * emb_floats;
-  std::printf("{\"op\": \"embedding\", \"clouds\": %d, \"superpoints\": %d, \"embedding_mb\": %.0f, \"gse_embed_table_us\": %.1f, "
-              "\"gse_written_gbps\": %.0f, \"attn_pos_softmax_us\": %.1f, \"attn_read_gbps\": %.0f}\n",
-              clouds, n, emb_bytes * 1e-6, us_embed, emb_bytes / us_embed * 1e-3, us_softmax, emb_bytes / us_softmax * 1e-3);
+  // the embedding launch in its two forms (GEOTR_GSE_SLICED is read per call), without and with the first layer's positional scores
+  geotr_gse_pos pl = {};
+  int64_t pos_floats = 0;
+  for (int q = 0; q < clouds; ++q) {
+    const int ld = (n + 3) / 4 * 4;
+    pl.q_row0[q] = q * n, pl.ld[q] = ld, pl.pos_off[q] = pos_floats;
+    pos_floats += (int64_t)heads * n * ld;
+  }
+  float* pos;
+  HIP_OK(hipMalloc(&pos, pos_floats * 4));
+  std::vector<float> host(1 << 20);
+  for (const char* form : {"0", "1", "0", "1"}) {
+    setenv("GEOTR_GSE_SLICED", form, 1);
+    const double us_plain = time_of([&] {
+      GEOTR_OK_OR_DIE(geotr_gse_embed_table(pts, knn, &gc, k, d, tab_d, points_d, tab_a, points_a, w_d, b_d, w_a, b_a, div_term, sigma_d, sigma_a, emb, stream));
+    });
+    const double us_pos = time_of([&] {
+      GEOTR_OK_OR_DIE(geotr_gse_embed_table_ex(pts, knn, &gc, k, d, tab_d, points_d, tab_a, points_a, w_d, b_d, w_a, b_a, div_term, sigma_d, sigma_a, 0,
+                                               qt, &pl, pos, emb, stream));
+    });
+    HIP_OK(hipMemcpy(host.data(), emb + emb_floats / 3, host.size() * 4, hipMemcpyDeviceToHost));
+    double cs = 0;
+    for (float x : host) cs += x;
+    HIP_OK(hipMemcpy(host.data(), pos + pos_floats / 3, std::min<size_t>(host.size(), pos_floats / 2) * 4, hipMemcpyDeviceToHost));
+    double cp = 0;
+    for (size_t i = 0; i < std::min<size_t>(host.size(), pos_floats / 2); ++i) cp += host[i];
+    std::printf("{\"op\": \"embedding\", \"form\": \"%s\", \"clouds\": %d, \"superpoints\": %d, \"embedding_mb\": %.0f, \"gse_embed_table_us\": %.1f, "
+                "\"gse_written_gbps\": %.0f, \"with_pos_us\": %.1f, \"emb_checksum\": %.6f, \"pos_checksum\": %.6f, \"attn_pos_softmax_us\": %.1f, \"attn_read_gbps\": %.0f}\n",
+                form[0] == '1' ? "sliced" : "classic", clouds, n, emb_bytes * 1e-6, us_plain, emb_bytes / us_plain * 1e-3, us_pos, cs, cp, us_softmax,
+                emb_bytes / us_softmax * 1e-3);
+  }
   return 0;
 }
 
