@@ -551,6 +551,10 @@ __device__ __forceinline__ bool gse_in_table(float x, int points) { return x * (
 // wave (7 exchanges for the 4 heads), the 4 x 64 results of a wave's pairs staged in LDS and stored as coalesced row segments.  That
 // layer's softmax then reads (heads, n, n) scalars instead of streaming the (n, n, D) embedding: one of its three 0.2 GB reads per pair
 // is gone (geotr_attn_softmax_grouped_pos).
+// Round 6 measured the alternative of walking the pairs once per 32-channel slice with the angular table's slice resident in LDS (commit
+// 6769f2a, profiles/r06_ab_runs.md): bit-identical embedding, 1 261-1 419 vs 1 739 us per 16-pair stack WITHOUT the positional by-product,
+// but 1 822-1 859 vs 1 740 us with it -- every slice pass has to reduce and accumulate its own partial of e . qt (8x the reductions and a
+// read-modify-write of pos per pass), and the model always takes the by-product.  Removed.
 struct GsePos {
   int q_row0[2 * GEOTR_MAX_PAIRS];     // first row of cloud q in qt (rows, 4, D)
   int ld[2 * GEOTR_MAX_PAIRS];         // row stride of cloud q's (4, n, ld) block of pos
@@ -736,283 +740,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void g
       const int ld = pp.ld[q];
 #pragma unroll
       for (int h = 0; h < 4; ++h) pos[((int64_t)h * n + my_i) * ld + my_j] = pos_s[wave][h][lane];
-    }
-  }
-}
-
-// ---- round 6: the same embedding in CHANNEL SLICES, the angular table resident in LDS -------------------------------------------------
-// gse_embed_table_kernel above moves (1 + k) x 4 KB of table rows through the vector L1 per (i, j) to produce 1 KB of output: 47 GB per
-// 16-pair stack in 1 756 us = 26.8 TB/s, i.e. it sits on the L1 / L2 delivery rate (64 B/clk/CU; L2 ~34 TB/s), not on HBM (0.23 of the
-// write roof; profiles/r05_kernel_trace.md).  The k angular lookups are three quarters of that traffic and their table is small
-// (194 x 4 KB at sigma_a = 15): a 32-channel slice of it is 99 KB -- it fits in LDS, whose read rate is ~5x the L1's.  So:
-//   * a workgroup owns a contiguous range of 64-pair tasks and walks it ONCE PER SLICE (8 slices of 32 channels): it stages the angular
-//     table's slice in LDS, then every wave takes 8 pairs per step -- lane = (pair slot, 4 channels) -- reading the angular coefficients
-//     with ds_read_b128 and only the distance coefficients (4 x 128-byte lines per pair) through L1;
-//   * every output row is written as eight full 128-byte lines, one per slice pass; the embedding's bits are those of the kernel above
-//     (same table rows, same Horner chains, same max / mean / bias order);
-//   * POS: the slice's 32-channel partial of e[i, j, :] . qt[i, h, :] is summed over the slot's 8 lanes (three DPP adds) and accumulated
-//     into pos[h, i, j] by the SAME lane in every pass (pass 0 stores, passes 1-7 add: a fixed order, no atomics); qt rows of the task's
-//     one or two query rows are parked in LDS per wave (n >= 64: checked by the host).
-// Indices are recomputed per pass (one atan2 triple per lane and 64 pairs: ~5 % of the pass).
-constexpr int kGseSlice = 32;
-template <int CTRL>
-__device__ __forceinline__ float gse_dpp_add(float x) {
-  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
-}
-template <int S, bool MEAN, bool POS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void gse_embed_sliced_kernel(const float* __restrict__ pts_all, const int* __restrict__ knn_all, GseClouds cl,
-                                                                      const float* __restrict__ tab_d, int points_d,
-                                                                      const float* __restrict__ tab_a, int points_a,
-                                                                      const float* __restrict__ Wd, const float* __restrict__ bd,
-                                                                      const float* __restrict__ Wa, const float* __restrict__ ba,
-                                                                      const float* __restrict__ div_term, float inv_sigma_d, float factor_a,
-                                                                      float* __restrict__ out_all, const float* __restrict__ qt,
-                                                                      float* __restrict__ pos_all, GsePos pp, int tasks_per_block) {
-  constexpr int D = 256;
-  extern __shared__ __attribute__((aligned(16))) float gsm[];
-  float* tab_s = gsm;                                           // [points_a][4][32]: row (g, k) at 4 g + (k ^ (g & 1)) -- see the reads
-  float* qt_s = tab_s + (size_t)points_a * 4 * kGseSlice;       // [WAVES][2 query rows][4 heads][32]
-  float* pos_s = qt_s + (POS ? WAVES * 2 * 4 * kGseSlice : 0);  // [WAVES][4 heads][64 pairs]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = lane >> 3, cq = lane & 7;
-  const int total_tasks = 4 * cl.chunk0[cl.count];
-  const int t_begin = (int)blockIdx.x * tasks_per_block, t_end = min(total_tasks, t_begin + tasks_per_block);
-  auto wave_sync = [] {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  for (int slice = 0; slice < D / kGseSlice; ++slice) {
-    __syncthreads();  // the previous pass has read its slice
-    for (int e = tid; e < points_a * 4 * 8; e += 64 * WAVES) {
-      const int row = e >> 3, c4 = e & 7, g = row >> 2, k = row & 3;
-      const float4 v = *reinterpret_cast<const float4*>(tab_a + (int64_t)row * D + slice * kGseSlice + 4 * c4);
-      *reinterpret_cast<float4*>(tab_s + (4 * g + (k ^ (g & 1))) * kGseSlice + 4 * c4) = v;
-    }
-    __syncthreads();
-    const int c0 = slice * kGseSlice + 4 * cq;
-    float bias[4];
-    {
-      const float4 b1 = *reinterpret_cast<const float4*>(bd + c0), b2 = *reinterpret_cast<const float4*>(ba + c0);
-      bias[0] = b1.x + b2.x, bias[1] = b1.y + b2.y, bias[2] = b1.z + b2.z, bias[3] = b1.w + b2.w;
-    }
-    // task t = 64 consecutive pairs of one cloud; its parameters are needed one task ahead (the next task's qt rows are fetched under
-    // this task's work)
-    struct Task {
-      int q, n, i_first, row_switch, count;
-      int64_t p0;
-      bool live;
-    };
-    auto task_of = [&](int t) -> Task {
-      Task k;
-      k.live = t < t_end;
-      const int chunk = min(t, total_tasks - 1) >> 2;
-      int q = 0;
-      while (q + 1 < cl.count && chunk >= cl.chunk0[q + 1]) ++q;
-      k.q = q, k.n = cl.n[q];
-      const int64_t total = (int64_t)k.n * k.n;
-      k.p0 = ((int64_t)(chunk - cl.chunk0[q]) * 4 + (t & 3)) * 64;
-      k.live = k.live && k.p0 < total;
-      k.count = k.live ? (int)min((int64_t)64, total - k.p0) : 0;
-      k.i_first = k.live ? (int)(k.p0 / k.n) : 0;
-      k.row_switch = (int)((int64_t)(k.i_first + 1) * k.n - k.p0);  // pairs e >= row_switch sit in query row i_first + 1
-      return k;
-    };
-    // qt[i_first + r, h, slice] of a task's (at most two) query rows: lane = (r, h, 4 channels)
-    auto qt_fetch = [&](const Task& k) -> float4 {
-      if (!POS || !k.live) return make_float4(0.f, 0.f, 0.f, 0.f);
-      const int r = lane >> 5, h = (lane >> 3) & 3;
-      const int row = min(k.i_first + r, k.n - 1);
-      return *reinterpret_cast<const float4*>(qt + ((int64_t)(pp.q_row0[k.q] + row) * 4 + h) * D + c0);
-    };
-    auto qt_park = [&](const float4& v) {
-      const int r = lane >> 5, h = (lane >> 3) & 3;
-      *reinterpret_cast<float4*>(qt_s + ((wave * 2 + r) * 4 + h) * kGseSlice + 4 * cq) = v;
-    };
-    Task cur = task_of(t_begin + wave);
-    if constexpr (POS) {
-      qt_park(qt_fetch(cur));
-      wave_sync();
-    }
-    for (int t = t_begin + wave; t < t_end; t += WAVES) {
-      const Task nxt = task_of(t + WAVES);
-      const float4 qt_nxt = qt_fetch(nxt);  // in flight under this task
-      if (!cur.live) {
-        if constexpr (POS) {
-          qt_park(qt_nxt);
-          wave_sync();
-        }
-        cur = nxt;
-        continue;
-      }
-      const int q = cur.q, n = cur.n, count = cur.count, row_switch = cur.row_switch;
-      const int64_t p0 = cur.p0, total = (int64_t)n * n;
-      const float* pts = pts_all + 3 * (int64_t)cl.row0[q];
-      const int* knn = knn_all + (int64_t)cl.row0[q] * (S - 1);
-      float* out = out_all + cl.emb_off[q];
-      // ---- embedding indices of the lane's pair (geotransformer.py:36-53): as gse_embed_table_kernel ----
-      float vals[S];
-#pragma unroll
-      for (int s = 0; s < S; ++s) vals[s] = 0.f;
-      int my_i = 0, my_j = 0;
-      {
-        const int64_t p = p0 + lane;
-        if (p < total) {
-          const int i = (int)(p / n), j = (int)(p - (int64_t)i * n);
-          my_i = i, my_j = j;
-          const float pi[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
-          const float pj[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
-          vals[0] = sqrtf(expanded_sqdist(pi, pj)) * inv_sigma_d;
-          const float ax = pj[0] - pi[0], ay = pj[1] - pi[1], az = pj[2] - pi[2];  // anchor vector
-#pragma unroll
-          for (int x = 0; x < S - 1; ++x) {
-            const int r = knn[i * (S - 1) + x];
-            const float rx = pts[3 * r] - pi[0], ry = pts[3 * r + 1] - pi[1], rz = pts[3 * r + 2] - pi[2];
-            const float cx = ry * az - rz * ay, cy = rz * ax - rx * az, cz = rx * ay - ry * ax;
-            const float sinv = sqrtf((cx * cx + cy * cy) + cz * cz);
-            const float cosv = ((rx * ax + ry * ay) + rz * az) + 0.0f;  // +0: see gse_embed_kernel (atan2(+0, -0) trap)
-            vals[1 + x] = atan2f(sinv, cosv) * factor_a;
-          }
-        }
-      }
-      // POS: the scores accumulated by the earlier passes, fetched now and added at the end of the task (no exposed round trip)
-      float pos_old[4] = {0.f, 0.f, 0.f, 0.f};
-      float* pos_dst = nullptr;
-      int64_t pos_hs = 0;
-      if constexpr (POS) {
-        pos_dst = pos_all + pp.pos_off[q] + (int64_t)my_i * pp.ld[q] + my_j;
-        pos_hs = (int64_t)n * pp.ld[q];
-        if (slice > 0 && lane < count) {
-#pragma unroll
-          for (int h = 0; h < 4; ++h) pos_old[h] = pos_dst[h * pos_hs];
-        }
-      }
-      // pair e of the task is finished with r[]: the output line, and the slot's positional partial into pos_s
-      auto finish = [&](int e, const float (&r)[4]) {
-        *reinterpret_cast<float4*>(out + (p0 + e) * D + c0) = make_float4(r[0], r[1], r[2], r[3]);
-        if constexpr (POS) {
-          const float* qrow = qt_s + ((wave * 2 + (e >= row_switch ? 1 : 0)) * 4) * kGseSlice + 4 * cq;
-          float part[4];
-#pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            const float4 w4 = *reinterpret_cast<const float4*>(qrow + h * kGseSlice);
-            part[h] = fmaf(r[3], w4.w, fmaf(r[2], w4.z, fmaf(r[1], w4.y, r[0] * w4.x)));
-            part[h] = gse_dpp_add<0xB1>(part[h]);   // quad_perm [1,0,3,2]
-            part[h] = gse_dpp_add<0x4E>(part[h]);   // quad_perm [2,3,0,1]
-            part[h] = gse_dpp_add<0x141>(part[h]);  // row_half_mirror: every lane of the slot holds the 32-channel sum
-          }
-          const float mine = cq == 0 ? part[0] : (cq == 1 ? part[1] : (cq == 2 ? part[2] : part[3]));
-          if (cq < 4) pos_s[(wave * 4 + cq) * 64 + e] = mine;
-        }
-      };
-      // the distance row of a step through L1 (four 128-byte lines per pair), issued one step ahead of its use
-      struct DistRow {
-        float a[4][4];
-        float x, delta;
-        bool fast;
-      };
-      auto dist_load = [&](int st) -> DistRow {
-        DistRow dr;
-        const int e = 8 * st + slot;
-        dr.x = __shfl(vals[0], e, 64);
-        dr.fast = e < count && gse_in_table(dr.x, points_d);
-        const int g = dr.fast ? (int)(dr.x * (float)kGseTabInv + 0.5f) : 0;
-        dr.delta = dr.x - (float)g * (1.0f / (float)kGseTabInv);
-        const float* row = tab_d + (int64_t)g * 4 * D + c0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 v = *reinterpret_cast<const float4*>(row + k * D);
-          dr.a[k][0] = v.x, dr.a[k][1] = v.y, dr.a[k][2] = v.z, dr.a[k][3] = v.w;
-        }
-        return dr;
-      };
-      unsigned slow = 0;  // steps whose pair has an index beyond its table (or NaN): the slot's 8 lanes agree
-      DistRow dcur = dist_load(0);
-#ifndef GEOTR_GSE_SL_UNROLL
-#define GEOTR_GSE_SL_UNROLL 2
-#endif
-#pragma unroll GEOTR_GSE_SL_UNROLL
-      for (int st = 0; st < 8; ++st) {
-        const int e = 8 * st + slot;
-        const DistRow dn = dist_load(min(st + 1, 7));
-        bool fast = dcur.fast;
-        float xa[S];
-#pragma unroll
-        for (int s = 1; s < S; ++s) {
-          xa[s] = __shfl(vals[s], e, 64);
-          fast = fast && gse_in_table(xa[s], points_a);
-        }
-        if (e < count && !fast) slow |= 1u << st;
-        float d[4], m[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          d[c] = fmaf(fmaf(fmaf(dcur.a[3][c], dcur.delta, dcur.a[2][c]), dcur.delta, dcur.a[1][c]), dcur.delta, dcur.a[0][c]);
-#pragma unroll
-        for (int s = 1; s < S; ++s) {  // the angular rows from LDS, one slot at a time
-          const int g = fast ? (int)(xa[s] * (float)kGseTabInv + 0.5f) : 0;
-          const float delta = xa[s] - (float)g * (1.0f / (float)kGseTabInv);
-          // rows of odd g hold their coefficients in swapped pairs: the bank half a lane group reads depends on (g + k), not on k alone,
-          // so two slots served in one LDS cycle collide half as often
-          float4 a[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const float4*>(tab_s + (4 * g + (k ^ (g & 1))) * kGseSlice + 4 * cq);
-          const float ev[4] = {fmaf(fmaf(fmaf(a[3].x, delta, a[2].x), delta, a[1].x), delta, a[0].x),
-                               fmaf(fmaf(fmaf(a[3].y, delta, a[2].y), delta, a[1].y), delta, a[0].y),
-                               fmaf(fmaf(fmaf(a[3].z, delta, a[2].z), delta, a[1].z), delta, a[0].z),
-                               fmaf(fmaf(fmaf(a[3].w, delta, a[2].w), delta, a[1].w), delta, a[0].w)};
-#pragma unroll
-          for (int c = 0; c < 4; ++c) m[c] = s == 1 ? ev[c] : (MEAN ? m[c] + ev[c] : fmaxf(m[c], ev[c]));
-        }
-        dcur = dn;
-        if (!fast) continue;
-        float r[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) r[c] = (d[c] + (MEAN ? __fdiv_rn(m[c], (float)(S - 1)) : m[c])) + bias[c];
-        finish(e, r);
-      }
-      for (int st = 0; st < 8; ++st) {  // exact direct evaluation (rare): as gse_embed_table_kernel's
-        if (!__any((slow >> st) & 1u)) continue;
-        const int e = 8 * st + slot;
-        float xs[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) xs[s] = __shfl(vals[s], e, 64);
-        if (!((slow >> st) & 1u)) continue;
-        float d[4], m[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) d[c] = 0.f, m[c] = MEAN ? 0.f : -3.4e38f;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-          float acc[4] = {0.f, 0.f, 0.f, 0.f};
-          const float* W = s == 0 ? Wd : Wa;
-          for (int tt = 0; tt < D / 2; ++tt) {
-            float sv, cv;
-            sincosf(xs[s] * div_term[tt], &sv, &cv);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = fmaf(W[(int64_t)(c0 + c) * D + 2 * tt + 1], cv, fmaf(W[(int64_t)(c0 + c) * D + 2 * tt], sv, acc[c]));
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (s == 0) d[c] = acc[c];
-            else m[c] = MEAN ? m[c] + acc[c] : fmaxf(m[c], acc[c]);
-          }
-        }
-        float r[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) r[c] = (d[c] + (MEAN ? __fdiv_rn(m[c], (float)(S - 1)) : m[c])) + bias[c];
-        finish(e, r);
-      }
-      if constexpr (POS) {  // the task's 4 x 64 partial scores: lane <-> its own pair; pass 0 stores, later passes add (fixed order)
-        wave_sync();
-        if (lane < count) {
-#pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            const float v = pos_s[(wave * 4 + h) * 64 + lane];
-            pos_dst[h * pos_hs] = slice == 0 ? v : pos_old[h] + v;
-          }
-        }
-        qt_park(qt_nxt);
-        wave_sync();  // pos_s is free and qt_s holds the next task's rows
-      }
-      cur = nxt;
     }
   }
 }
@@ -1457,57 +1184,6 @@ int geotr_gse_embed_table_ex(const float* points, const int32_t* knn, const geot
   hipStream_t stream = (hipStream_t)stream_;
   const float inv_sigma_d = 1.0f / sigma_d;
   const float factor_a = (float)(180.0 / ((double)sigma_a * 3.14159265358979323846));  // geotransformer.py:14
-  // Round 6: large launches at D = 256 take the channel-sliced kernel (angular table slice resident in LDS).  It re-stages 8 x 99 KB per
-  // workgroup whatever the launch size, so small launches (a single pair) keep the kernel above.  GEOTR_GSE_SLICED=0 switches it off,
-  // GEOTR_GSE_SLICED_MIN_PAIRS moves the threshold (measurement switches).
-  {
-    const int sliced = [] {
-      const char* e = std::getenv("GEOTR_GSE_SLICED");
-      return e ? std::atoi(e) : 1;
-    }();
-    const int64_t min_pairs = [] {
-      const char* e = std::getenv("GEOTR_GSE_SLICED_MIN_PAIRS");
-      return e ? (int64_t)std::atoll(e) : (int64_t)1000000;
-    }();
-#ifndef GEOTR_GSE_SL_WAVES
-#define GEOTR_GSE_SL_WAVES 12
-#endif
-    constexpr int kSlicedWaves = GEOTR_GSE_SL_WAVES;
-    int64_t all_pairs = 0;
-    bool rows_ok = true;
-    for (int q = 0; q < cl.count; ++q) all_pairs += (int64_t)cl.n[q] * cl.n[q], rows_ok = rows_ok && cl.n[q] >= 64;
-    const size_t lds = sizeof(float) * ((size_t)points_a * 4 * kGseSlice + (with_pos ? (size_t)kSlicedWaves * (2 * 4 * kGseSlice + 4 * 64) : 0));
-    if (sliced && d == 256 && k >= 1 && k <= 3 && rows_ok && all_pairs >= min_pairs && lds <= 150 * 1024 &&
-        ((reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(pos)) & 3) == 0) {
-      const int total_tasks = 4 * cl.chunk0[cl.count];
-      const int blocks = 256;
-      const int per = ((total_tasks + blocks - 1) / blocks + kSlicedWaves - 1) / kSlicedWaves * kSlicedWaves;
-      const dim3 sgrid((unsigned)((total_tasks + per - 1) / per));
-      auto go = [&](auto kern) -> int {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-          return fail(GEOTR_E_LAUNCH, "gse_embed_table: cannot reserve %zu B of LDS", lds);
-        kern<<<sgrid, dim3(64 * kSlicedWaves), lds, stream>>>(points, knn, cl, table_d, (int)points_d, table_a, (int)points_a, w_d, b_d, w_a, b_a,
-                                                              div_term, inv_sigma_d, factor_a, out, qt, pos, pp, per);
-        return GEOTR_OK;
-      };
-      int src = GEOTR_OK;
-#define GEOTR_GSE_SL(SS)                                                                              \
-  if (with_pos) {                                                                                     \
-    src = reduction_a == 1 ? go(gse_embed_sliced_kernel<SS, true, true, kSlicedWaves>) : go(gse_embed_sliced_kernel<SS, false, true, kSlicedWaves>); \
-  } else {                                                                                            \
-    src = reduction_a == 1 ? go(gse_embed_sliced_kernel<SS, true, false, kSlicedWaves>) : go(gse_embed_sliced_kernel<SS, false, false, kSlicedWaves>); \
-  }
-      switch ((int)k) {
-        case 1: GEOTR_GSE_SL(2) break;
-        case 2: GEOTR_GSE_SL(3) break;
-        default: GEOTR_GSE_SL(4) break;
-      }
-#undef GEOTR_GSE_SL
-      if (src != GEOTR_OK) return src;
-      GEOTR_CHECK_LAUNCH("gse_embed_table (sliced)");
-      return GEOTR_OK;
-    }
-  }
   const dim3 grid((unsigned)cl.chunk0[cl.count]);
 #define GEOTR_GSE_TAB(DD, SS, MM, PP)                                                                                                     \
   gse_embed_table_kernel<DD, SS, MM, PP><<<grid, dim3(256), 0, stream>>>(points, knn, cl, table_d, (int)points_d, table_a, (int)points_a, w_d, \

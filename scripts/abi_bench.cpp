@@ -453,7 +453,7 @@ static int run_embedding(int clouds, int n, int reps) {
   };
   const double us_softmax = time_of([&] { GEOTR_OK_OR_DIE(geotr_attn_softmax_grouped(scores, &ag, qt, qb, d, heads, 0.125f, stream)); });
   const double emb_bytes = 4.0 * emb_floats;
-  // the embedding launch in its two forms (GEOTR_GSE_SLICED is read per call), without and with the first layer's positional scores
+  // the embedding launch without and with the first layer's positional scores
   geotr_gse_pos pl = {};
   int64_t pos_floats = 0;
   for (int q = 0; q < clouds; ++q) {
@@ -464,8 +464,7 @@ static int run_embedding(int clouds, int n, int reps) {
   float* pos;
   HIP_OK(hipMalloc(&pos, pos_floats * 4));
   std::vector<float> host(1 << 20);
-  for (const char* form : {"0", "1", "0", "1"}) {
-    setenv("GEOTR_GSE_SLICED", form, 1);
+  for (int rep = 0; rep < 2; ++rep) {
     const double us_plain = time_of([&] {
       GEOTR_OK_OR_DIE(geotr_gse_embed_table(pts, knn, &gc, k, d, tab_d, points_d, tab_a, points_a, w_d, b_d, w_a, b_a, div_term, sigma_d, sigma_a, emb, stream));
     });
@@ -479,9 +478,9 @@ static int run_embedding(int clouds, int n, int reps) {
     HIP_OK(hipMemcpy(host.data(), pos + pos_floats / 3, std::min<size_t>(host.size(), pos_floats / 2) * 4, hipMemcpyDeviceToHost));
     double cp = 0;
     for (size_t i = 0; i < std::min<size_t>(host.size(), pos_floats / 2); ++i) cp += host[i];
-    std::printf("{\"op\": \"embedding\", \"form\": \"%s\", \"clouds\": %d, \"superpoints\": %d, \"embedding_mb\": %.0f, \"gse_embed_table_us\": %.1f, "
+    std::printf("{\"op\": \"embedding\", \"clouds\": %d, \"superpoints\": %d, \"embedding_mb\": %.0f, \"gse_embed_table_us\": %.1f, "
                 "\"gse_written_gbps\": %.0f, \"with_pos_us\": %.1f, \"emb_checksum\": %.6f, \"pos_checksum\": %.6f, \"attn_pos_softmax_us\": %.1f, \"attn_read_gbps\": %.0f}\n",
-                form[0] == '1' ? "sliced" : "classic", clouds, n, emb_bytes * 1e-6, us_plain, emb_bytes / us_plain * 1e-3, us_pos, cs, cp, us_softmax,
+                clouds, n, emb_bytes * 1e-6, us_plain, emb_bytes / us_plain * 1e-3, us_pos, cs, cp, us_softmax,
                 emb_bytes / us_softmax * 1e-3);
   }
   return 0;
