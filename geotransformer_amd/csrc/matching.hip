@@ -995,6 +995,208 @@ __global__ __launch_bounds__(64 * kSinkWavesPerBlock, 2) void patch_sinkhorn_wav
   }
 }
 
+// ---- the same factorisation at K = 128 (KITTI, ModelNet): one BLOCK of four waves per patch pair ----------------------------------------
+// 129 rows do not fit a wave: waves 0, 1 own the rows (lane <-> row 64 w + lane, its 129 entries of E in registers) and run the u
+// half-sweeps, waves 2, 3 own the columns and run the v half-sweeps; the dustbin row is summed by wave 0 (two entries per lane), the dustbin
+// column by wave 2, so a wave's fallback decision needs nobody else.  exp(u), exp(v) and the raw potentials (for the max-shifted fallback of
+// another wave) travel through LDS; two block barriers per sweep.  KITTI trace (profiles/r06_kernel_trace.md): the round-2 block kernel
+// (1 024 threads streaming S from LDS through 2 x 129 x 132 exponentials per sweep) took 4 640 us per 6-pair stack, 10 % of that
+// configuration's kernel time.
+template <int K>
+constexpr int sink_block_floats() {
+  return ((((K + 1) * (K + 1) > 2 * K * 33 ? (K + 1) * (K + 1) : 2 * K * 33) + 3) / 4 * 4) + 4 * ((K + 1 + 3) / 4 * 4) + 2 * K;
+}
+__global__ __launch_bounds__(256, 2) void patch_sinkhorn_block128_kernel(
+    const float* __restrict__ ref_feats, int64_t nr, const float* __restrict__ src_feats, int64_t ns, int C, const int64_t* __restrict__ ref_idx,
+    const int64_t* __restrict__ src_idx, const unsigned char* __restrict__ ref_mask, const unsigned char* __restrict__ src_mask,
+    const float* __restrict__ alpha_p, int iters, const float* __restrict__ scores_in, const int* __restrict__ p_count, float* __restrict__ out,
+    int force_exact, SinkhornBatch sb) {
+  if (sb.count > 0) {
+    const int b = blockIdx.y;
+    ref_feats = sb.ref_feats[b], src_feats = sb.src_feats[b], nr = sb.nr[b], ns = sb.ns[b];
+    ref_idx += b * sb.idx_stride, src_idx += b * sb.idx_stride;
+    ref_mask += b * sb.mask_stride, src_mask += b * sb.mask_stride;
+    if (p_count) p_count += b * sb.pcount_stride;
+    out += b * sb.out_stride;
+  }
+  const int p = blockIdx.x;
+  if (p_count && p >= *p_count) return;  // (block-uniform)
+  constexpr int K = 128, K1 = K + 1, T = K / 32, NT = 256;
+  constexpr int VP = (K1 + 3) / 4 * 4;
+  constexpr int R0 = sink_block_floats<K>() - 4 * VP - 2 * K;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* S = smem;            // [K1][K1]
+  float* A_s = S;             // [K][33]  (dead before S is written)
+  float* B_s = S + K * 33;    // [K][33]
+  float* u = S + R0;          // [VP] each
+  float* v = u + VP;
+  float* eu = v + VP;
+  float* ev = eu + VP;
+  int* rm_s = reinterpret_cast<int*>(ev + VP);  // [K] masks as ints
+  int* sm_s = rm_s + K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t* ri = ref_idx + (int64_t)p * K;
+  const int64_t* si = src_idx + (int64_t)p * K;
+  if (tid < K) rm_s[tid] = ref_mask[(int64_t)p * K + tid] != 0;
+  else sm_s[tid - K] = src_mask[(int64_t)p * K + tid - K] != 0;
+  const int fr = lane & 31, fk = lane >> 5;
+  if (!scores_in) {
+    // ---- scores on the matrix cores: wave w owns tiles w, w + 4, w + 8, w + 12 ----
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    constexpr int NL = 2 * K * 8 / NT;  // 16-byte loads per thread and chunk: loads 0 .. NL/2-1 reference rows, the rest source rows
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ref_feats), 0, (int)((unsigned)nr * (unsigned)C * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src_feats), 0, (int)((unsigned)ns * (unsigned)C * 4u), 0x00020000);
+    unsigned rowoff[NL];
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+      const int e = tid + NT * t;
+      const int r = (e / 8) % K, kq = (e % 8) * 4;
+      const int64_t row = t < NL / 2 ? ri[r] : si[r];
+      rowoff[t] = row < (t < NL / 2 ? nr : ns) ? 4u * ((unsigned)row * (unsigned)C + (unsigned)kq) : 0xffffffffu;  // pad index -> zero row
+    }
+    for (int k0 = 0; k0 < C; k0 += 32) {
+      f32x4 val[NL];
+#pragma unroll
+      for (int t = 0; t < NL; ++t) {
+        const int kq = ((tid + NT * t) % 8) * 4;
+        const unsigned off = k0 + kq < C ? rowoff[t] : 0xffffffffu;
+        val[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(t < NL / 2 ? rsrc_r : rsrc_s, off, 4 * k0, 0));
+      }
+      __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+      for (int t = 0; t < NL; ++t) {
+        const int e = tid + NT * t;
+        const int r = (e / 8) % K, kq = (e % 8) * 4;
+        float* d = (t < NL / 2 ? A_s : B_s) + r * 33 + kq;
+        d[0] = val[t][0], d[1] = val[t][1], d[2] = val[t][2], d[3] = val[t][3];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int tile = wave + 4 * t, tr = tile / T, tc = tile % T;
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+          const float a = A_s[(32 * tr + fr) * 33 + 2 * ks + fk];
+          const float b = B_s[(32 * tc + fr) * 33 + 2 * ks + fk];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // S takes the feature blocks' memory
+    const float inv = sqrtf((float)C);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int tile = wave + 4 * t, tr = tile / T, tc = tile % T;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = 32 * tr + (q & 3) + 8 * (q >> 2) + 4 * fk, j = 32 * tc + fr;
+        S[i * K1 + j] = (rm_s[i] && sm_s[j]) ? acc[t][q] / inv : -kSinkInf;  // model.py:188
+      }
+    }
+  } else {  // stand-alone optimal transport: scores were computed by the caller (learnable_sinkhorn.py:20)
+    __syncthreads();
+    const float* sp = scores_in + (int64_t)p * K * K;
+    for (int e = tid; e < K * K; e += NT) {
+      const int i = e / K, j = e % K;
+      S[i * K1 + j] = (rm_s[i] && sm_s[j]) ? sp[e] : -kSinkInf;
+    }
+  }
+  // dustbin row / column (learnable_sinkhorn.py:41-48) and marginals (:50-62)
+  const float alpha = *alpha_p;
+  if (tid < K) S[tid * K1 + K] = rm_s[tid] ? alpha : -kSinkInf;
+  else S[K * K1 + tid - K] = sm_s[tid - K] ? alpha : -kSinkInf;
+  if (tid == 0) S[K * K1 + K] = alpha;
+  int nvr_i = 0, nvc_i = 0;
+  for (int e = 0; e < K; e += 64) nvr_i += __popcll(__ballot(rm_s[e + lane] != 0)), nvc_i += __popcll(__ballot(sm_s[e + lane] != 0));
+  const float nvr = (float)nvr_i, nvc = (float)nvc_i;
+  const float norm = -logf(nvr + nvc);
+  // this thread's line: waves 0, 1 -> row idx, waves 2, 3 -> column idx
+  const bool rows = wave < 2;
+  const int idx = 64 * (wave & 1) + lane;
+  const float lm = (rows ? rm_s[idx] : sm_s[idx]) ? norm : -kSinkInf;
+  const float lm_d = (rows ? logf(nvc) : logf(nvr)) + norm;  // the dustbin's marginal of this side
+  const bool dust_wave = (wave & 1) == 0;                    // wave 0: dustbin row, wave 2: dustbin column
+  for (int e = tid; e < VP; e += NT) u[e] = 0.f, v[e] = 0.f, eu[e] = e < K1 ? 1.f : 0.f, ev[e] = e < K1 ? 1.f : 0.f;
+  __syncthreads();
+  // ---- E: the thread's row / column of exp(S - max); the dustbin line two entries per lane of its wave ----
+  float E[K1];
+  float emax = -3.4e38f;
+#pragma unroll
+  for (int j = 0; j < K1; ++j) {
+    E[j] = rows ? S[idx * K1 + j] : S[j * K1 + idx];
+    emax = fmaxf(emax, E[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < K1; ++j) E[j] = __expf(E[j] - emax);
+  const float corner = alpha;
+  const float d0 = rows ? S[K * K1 + lane] : S[lane * K1 + K], d1 = rows ? S[K * K1 + 64 + lane] : S[(64 + lane) * K1 + K];
+  const float dmax = fmaxf(wave_max_all(fmaxf(d0, d1)), corner);
+  const float Ed0 = __expf(d0 - dmax), Ed1 = __expf(d1 - dmax), Ed_c = __expf(corner - dmax);
+  // ---- 100 x { u = log_mu - LSE_j(S + v);  v = log_nu - LSE_i(S + u) }  (:13-18) ----
+  float* mine_raw = rows ? u : v;
+  float* mine_exp = rows ? eu : ev;
+  float* other_raw = rows ? v : u;
+  const float* other_exp = rows ? ev : eu;
+  for (int it = 0; it < 2 * iters; ++it) {
+    if (((it & 1) == 0) == rows) {  // (wave-uniform) this wave's half-sweep
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < VP / 4; ++q) {
+        const float4 o = *reinterpret_cast<const float4*>(other_exp + 4 * q);
+        if (4 * q < K1) s0 = fmaf(E[4 * q], o.x, s0);
+        if (4 * q + 1 < K1) s1 = fmaf(E[4 * q + 1 < K1 ? 4 * q + 1 : 0], o.y, s1);
+        if (4 * q + 2 < K1) s0 = fmaf(E[4 * q + 2 < K1 ? 4 * q + 2 : 0], o.z, s0);
+        if (4 * q + 3 < K1) s1 = fmaf(E[4 * q + 3 < K1 ? 4 * q + 3 : 0], o.w, s1);
+      }
+      const float s = s0 + s1;
+      float lse = emax + __logf(s), lse_d = 0.f;
+      bool bad = !(s > 1e-30f && s < 1e30f);
+      if (dust_wave) {
+        const float sd = wave_sum_dpp(fmaf(Ed1, other_exp[64 + lane], Ed0 * other_exp[lane])) + Ed_c * other_exp[K];
+        lse_d = dmax + __logf(sd);
+        bad = bad || !(sd > 1e-30f && sd < 1e30f);
+      }
+      if (__any(bad) || force_exact) {  // (wave-uniform) the max-shifted form of the reference for this wave's lines
+        float mx = -3.4e38f, sum = 0.f;
+        for (int j = 0; j < K1; ++j) {
+          const float x = (rows ? S[idx * K1 + j] : S[j * K1 + idx]) + other_raw[j];
+          if (x > mx) {
+            sum = sum * __expf(mx - x) + 1.f;
+            mx = x;
+          } else {
+            sum += __expf(x - mx);
+          }
+        }
+        lse = mx + __logf(sum);
+        if (dust_wave) {
+          const float x0 = d0 + other_raw[lane], x1 = d1 + other_raw[64 + lane], xc = corner + other_raw[K];
+          const float md = fmaxf(wave_max_all(fmaxf(x0, x1)), xc);
+          const float sde = wave_sum_dpp(__expf(x0 - md) + __expf(x1 - md)) + __expf(xc - md);
+          lse_d = md + __logf(sde);
+        }
+      }
+      const float mine = lm - lse;
+      mine_raw[idx] = mine;
+      mine_exp[idx] = __expf(mine);
+      if (dust_wave && lane == 0) {
+        const float md = lm_d - lse_d;
+        mine_raw[K] = md;
+        mine_exp[K] = __expf(md);
+      }
+    }
+    __syncthreads();
+  }
+  float* o = out + (int64_t)p * K1 * K1;
+  for (int e = tid; e < K1 * K1; e += NT) {
+    const int i = e / K1, j = e - i * K1;
+    o[e] = ((S[e] + u[i]) + v[j]) - norm;
+  }
+}
+
 // patches of the selected superpoint pairs (experiments/.../model.py:169-174): row p of the outputs = row corr_idx[p] of
 // the per-node tables; grid (P, 2): blockIdx.y = 0 reference side, 1 source side
 template <bool AGENT>
@@ -1210,6 +1412,15 @@ static int sinkhorn_launch_impl(const float* ref_feats, int64_t nr, const float*
   for (int b = 0; b < sb.count; ++b) wave_ok = wave_ok && sb.nr[b] * c < (1ll << 30) && sb.ns[b] * c < (1ll << 30);
   if (k == 32 && wave_ok) LAUNCH_WAVE(32);
   else if (k == 64 && wave_ok) LAUNCH_WAVE(64);
+  else if (k == 128 && wave_ok) {
+    const size_t blds = sizeof(float) * sink_block_floats<128>();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sinkhorn_block128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds) !=
+        hipSuccess)
+      return fail(GEOTR_E_LAUNCH, "patch_sinkhorn: cannot reserve %zu B of LDS", blds);
+    patch_sinkhorn_block128_kernel<<<dim3((unsigned)p, (unsigned)(sb.count > 0 ? sb.count : 1)), dim3(256), blds, stream>>>(
+        ref_feats, nr, src_feats, ns, (int)c, ref_knn_indices, src_knn_indices, ref_knn_masks, src_knn_masks, alpha, (int)num_iterations, scores_in,
+        p_count, matching_scores, form == 2 ? 1 : 0, sb);
+  }
   else if (k == 32) LAUNCH(32);
   else if (k == 64) LAUNCH(64);
   else LAUNCH(128);

@@ -121,10 +121,10 @@ def test_sinkhorn_matches_oracle(K, C):
     assert torch.isfinite(got[valid]).all() and float(e.sum()) > 0
 
 
-@pytest.mark.parametrize('K', [32, 64])
+@pytest.mark.parametrize('K', [32, 64, 128])
 @pytest.mark.parametrize('scale', [1.0, 40.0, 400.0])
 def test_sinkhorn_wave_fallback(K, scale):
-    """The one-wave-per-patch kernel (K = 32 / 64) runs its sweeps as E . exp(v) products; scores whose potentials leave fp32's exp range
+    """The one-wave-per-patch kernels (K = 32 / 64; K = 128: four waves per patch) run their sweeps as E . exp(v) products; scores whose potentials leave fp32's exp range
     (scale 40: some half-sweeps, scale 400: all of them) must take the max-shifted form of learnable_sinkhorn.py:13-18 instead."""
     from geotransformer_amd.modules.sinkhorn import LearnableLogOptimalTransport
     from oracle import model_oracle as mo
