@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
                                                        const int64_t* __restrict__ q_len, int batch, int64_t nq_cap,
                                                        float r2, int width, int cap,
                                                        int64_t* __restrict__ out, int* __restrict__ counts,
-                                                       int* __restrict__ max_count, int* __restrict__ overflow) {
+                                                       int* __restrict__ max_count, int* __restrict__ overflow,
+                                                       const int* __restrict__ q_order) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t ns_total = rg_rows(hdr, batch);
@@ -260,7 +261,12 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
   // a query's ~8 000 cycles -- rocprofv3 SQ counters, profiles/r03_rg_query_counters.md -- and an empty wave paid all 32).
   int cloud_end = 0x7fffffff;
   if (batch <= 64) cloud_end = wave_inclusive_scan(lane < batch ? (int)q_len[lane] : 0);
-  for (int64_t qi = (int64_t)blockIdx.x * 4 + w; qi < nq_cap; qi += (int64_t)gridDim.x * 4) {
+  // q_order (round 6; batch <= 64): the queries are visited in the grid order of their own cloud -- the four waves of a block and the
+  // blocks resident on a CU then work on neighbouring queries, whose candidate cells are the same lines of L1 / L2 (KITTI's dense searches
+  // visited stage >= 1 rows in the hash order of the subsampling before)
+  const int64_t nq_total = (q_order && batch <= 64) ? (int64_t)__shfl(cloud_end, batch - 1, 64) : nq_cap;
+  for (int64_t pos = (int64_t)blockIdx.x * 4 + w; pos < nq_total; pos += (int64_t)gridDim.x * 4) {
+    const int64_t qi = (q_order && batch <= 64) ? (int64_t)q_order[pos] : pos;
     int b;
     if (batch <= 64) {
       b = __popcll(__ballot(lane < batch && qi >= (int64_t)cloud_end));
@@ -1258,9 +1264,13 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
     GEOTR_CHECK_LAUNCH("radius_query(tile)");
     return GEOTR_OK;
   }
+  static const bool dense_order = [] {
+    const char* e = std::getenv("GEOTR_RG_DENSE_ORDER");  // A/B switch: 0 = the one-query kernel visits rows in storage order
+    return !(e && e[0] == '0');
+  }();
   if (count_only) {
     rg_query_kernel<true><<<dim3(nb), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
-                                                             r2, 0, 0, nullptr, counts, max_count, nullptr);
+                                                             r2, 0, 0, nullptr, counts, max_count, nullptr, nullptr);
   } else {
     const size_t lds = (size_t)cap * 4 * sizeof(unsigned long long);
     if (lds > 64 * 1024) {
@@ -1270,7 +1280,7 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
     }
     rg_query_kernel<false><<<dim3(nb), dim3(256), lds, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
                                                                 r2, (int)width, (int)cap, out, nullptr,
-                                                                nullptr, overflow);
+                                                                nullptr, overflow, dense_order ? q_order : nullptr);
   }
   GEOTR_CHECK_LAUNCH("radius_query");
   return GEOTR_OK;
