@@ -133,7 +133,7 @@ def gemm_family_block(gemm, gemm_mode, lanes_note):
     return blk, top
 
 
-def roofline_blocks(events, cfg, args, pipe, out, kernels):
+def roofline_blocks(events, cfg, args, pipe, out, kernels, stage_rows=None):
     """Live roofline of the two heaviest kernel families from the executor's HIP events (recorded on the launch streams inside the
     timed region).  Returns the block of the family with the larger summed launch time (`roofline`), the other one under
     `roofline['other']`.  Work per launch (DESIGN.md section 3 states it per unit):
@@ -224,8 +224,34 @@ def roofline_blocks(events, cfg, args, pipe, out, kernels):
                         'mfma_frac_algorithmic': round(2.0 * m * n * kk / t_iso / 1e12 / (FP32_MATRIX_PEAK_TFLOPS if gemm_mode in (False, 'fp32') else BF16_MATRIX_PEAK_TFLOPS), 4),
                         'hbm_gbps': round(gemm_bytes(m, n, kk) / t_iso / 1e9, 1), 'hbm_frac': round(gemm_bytes(m, n, kk) / t_iso / 1e12 / HBM_PEAK_TBS, 4)})
         fam['gemm']['isolated'] = {'shapes': iso, 'note': 'the heaviest shapes re-run alone (random operands, bias-free epilogue), GPU otherwise idle'}
+    radius_blk = None
+    rad = [(sec, work) for sec, kind, work in events if kind == 'radius']
+    if rad and stage_rows:
+        # SURVEY 8(d) per unit: a query reads its own 12 B and writes `width` int64 indices; the support cloud's cell-sorted float4 copy is
+        # read at least once per search (every point is somebody's candidate); the 27-cell candidate re-reads are on-chip (L1 / L2) traffic
+        def rbytes(w):
+            qs, ss, width, _dense = w
+            return stage_rows[qs] * (12.0 + 8.0 * width) + stage_rows[ss] * 16.0
+        sec = sum(s_ for s_, _ in rad)
+        nbytes = sum(rbytes(w) for _, w in rad)
+        per = {}
+        for s_, w in rad:
+            d = per.setdefault(w, [0, 0.0])
+            d[0] += 1
+            d[1] += s_
+        radius_blk = {
+            'bound': 'hbm', 'kernel': 'rg_query_kernel (dense searches: one query per wave)' if any(w[3] for _, w in rad) else 'rg_query_quad_kernel (four queries per wave)',
+            'achieved': round(nbytes / sec / 1e9, 1), 'peak': HBM_PEAK_TBS * 1e3, 'unit': 'GB/s', 'frac': round(nbytes / sec / 1e12 / HBM_PEAK_TBS, 4),
+            'launches': len(rad), 'avg_launch_us': round(1e6 * sec / len(rad), 1), 'total_ms': round(1e3 * sec, 2),
+            'algorithmic_bytes_per_launch': round(nbytes / len(rad)),
+            'searches_in_flight': [{'query_stage': w[0], 'support_stage': w[1], 'width': w[2], 'launches': c_, 'avg_us': round(1e6 * t / c_, 1),
+                                    'algorithmic_mb': round(rbytes(w) / 1e6, 1)} for w, (c_, t) in sorted(per.items(), key=lambda kv: -kv[1][1])],
+            'note': 'algorithmic bytes of a search = query rows x (12 B + width x 8 B of int64 output) + support rows x 16 B (the cell-sorted copy once), '
+                    'rows = this run\'s own stage sizes per stack; the candidate re-reads of the 27-cell neighbourhoods are cache traffic; ' + lanes_note}
     order = sorted(fam, key=lambda f: -fam[f]['total_ms'])
     main = fam[order[0]]
+    if radius_blk:
+        main['radius'] = radius_blk
     if len(order) > 1:
         main['other'] = fam[order[1]]
     recorded = sum(fam[f]['launches'] for f in fam)
@@ -250,6 +276,19 @@ def pmc_traffic_bytes(kernel_substr, precision='fp32'):
         return None
     launches = sum(r['launches'] for r in hits)  # every instantiation of the family, weighted by its launches
     return round(sum(r['hbm_mb_per_launch'] * r['launches'] for r in hits) / launches * 1024 * 1024)
+
+
+def kernels_alone(workload_tag):
+    """us of kernel time per pair with ONE lane (no contention between lanes), from the latest committed one-lane rocprofv3 trace of this
+    command (profiles/r*_kernels_alone.json, written by scripts/kernel_trace_summary.py); None when the trace is of another workload."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernels_alone.json')))
+    if not found:
+        return None
+    rec = json.load(open(found[-1]))
+    if workload_tag and rec.get('workload') and str(rec['workload'])[:40] != str(workload_tag)[:40]:
+        return None
+    return {'us': rec.get('kernels_alone_us_per_pair'), 'file': os.path.basename(found[-1]), 'matrix_precision': rec.get('matrix_precision')}
 
 
 LINE_BUDGET_BYTES = 3072  # the driver keeps ~8 KB of stdout tail; round 4's 24.8 KB line was cut and could not be parsed
@@ -277,10 +316,16 @@ def compact_line(detail):
                                           'parallelism', 'collective_backend', 'matrix_precision', 'gse', 'inputs') if k in cfg}
     if detail.get('per_rank_pairs_per_s') is not None:
         line['per_rank_pairs_per_s'] = detail['per_rank_pairs_per_s']
+    if detail.get('kernels_alone_us_per_pair') is not None:
+        line['kernels_alone_us_per_pair'] = detail['kernels_alone_us_per_pair']
     line['roofline'] = _short_roofline(detail.get('roofline'))
     other = (detail.get('roofline') or {}).get('other')
     if other:
         line['roofline']['runner_up'] = {k: v for k, v in _short_roofline(other).items() if k in ('kernel', 'bound', 'frac', 'avg_launch_us')}
+    radius = (detail.get('roofline') or {}).get('radius')
+    if radius:
+        line['roofline']['radius_search'] = {k: radius[k] for k in ('kernel', 'bound', 'achieved', 'unit', 'frac', 'avg_launch_us', 'algorithmic_bytes_per_launch') if k in radius}
+        line['roofline']['radius_search']['kernel'] = str(radius.get('kernel', '')).split(' (')[0]
     base = detail.get('cpu_baseline')
     if base:
         line['cpu_baseline'] = {k: base[k] for k in ('value', 'unit', 'cores', 'kind', 'cpu_budget', 'nproc', 'collate_s', 'forward_s') if k in base}
@@ -710,13 +755,17 @@ def main():
         roof = None
         if rank == 0:
             assert torch.isfinite(gathered).all()
-            roof = roofline_blocks(events, cfg, args, pipe, out, kernels) if events else None  # (re-runs the heaviest shapes alone: still in this mode)
+            stage_rows = None  # rows per stage of ONE stack (the last step's stacks: every stack of the run has the same shape of workload)
+            pyr = [o['_stack_pyramid'] for _, o in last.values() if isinstance(o, dict) and '_stack_pyramid' in o]
+            if pyr:
+                stage_rows = [float(np.mean([sum(int(x) for x in p['lengths_host'][i]) for p in pyr])) for i in range(len(pyr[0]['lengths_host']))]
+            roof = roofline_blocks(events, cfg, args, pipe, out, kernels, stage_rows) if events else None  # (re-runs the heaviest shapes alone: still in this mode)
             if roof is not None:
                 name = 'gse_embed' if roof['kernel'].startswith('gse') else 'gemm_packed'
                 roof['traffic'] = pmc_traffic_bytes(name, precision)
                 roof['traffic_unit'] = ('HBM bytes/launch of this kernel family in this arithmetic mode (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes: '
                                         'read from the latest committed profiles/r*_pmc_hbm_traffic*.json -- bench.py cannot run under the counters itself; '
-                                        'collected with --lanes 1 --stack 8: a launch there covers 8 stacked pairs, half the rows of a 16-pair launch)')
+                                        'collected with --lanes 1 --stack 16 --batch 16: a launch there covers 16 stacked pairs, as in this run)')
         return {'precision': precision, 'elapsed': elapsed, 'last': dict(last), 'roofline': roof, 'host_cpus_busy': round(host_busy, 2),
                 'per_rank': [round(v, 1) for v in per_rank],
                 'value': args.steps * args.batch * world / elapsed, 'ms_per_step': 1e3 * elapsed / args.steps}
@@ -767,6 +816,11 @@ def main():
             'roofline': main_run['roofline'],
             'detail_file': os.path.basename(detail_path),
         }
+        alone = kernels_alone(f'BASELINE configs[{baseline_index}]') if args.precision == 'fp32' else None
+        if alone and alone.get('us') is not None and alone.get('matrix_precision') in (None, args.precision):
+            # (the figure of the committed ONE-LANE rocprofv3 trace of this command: kernel time per pair without contention between lanes)
+            line['kernels_alone_us_per_pair'] = alone['us']
+            line['config']['kernels_alone_source'] = f'profiles/{alone["file"]} (committed one-lane rocprofv3 trace of this command, not measured by this run)'
         if world == 1 and not args.no_cpu_baseline:
             os.sched_setaffinity(0, all_cpus)  # the CPU legs (child processes) may use every core the box allows
             # forward-parity sample: four slots of the LAST timed step, one per lane where the launch shape has four lanes, in different stack slots

@@ -66,6 +66,7 @@ static inline bool use_packed(const void* packed, const float* a, int64_t lda, i
 // decoder), 4 GroupNorm statistics records (bench.py gemm_bytes counts them as algorithmic bytes of the launch).
 constexpr int64_t kProfGemm = 1ll << 62;
 constexpr int64_t kProfResidual = 1ll << 50, kProfGather = 2ll << 50, kProfStats = 4ll << 50;
+constexpr int64_t kProfRadius = 1ll << 60;  // kProfRadius | query stage << 56 | support stage << 52 | table width << 20 | dense << 19 = a radius search of the pyramid
 constexpr int64_t kProfKpconv = 1ll << 61;  // kProfKpconv | h << 50 | m << 26 | c_out << 14 | 15 c_in = a fused KPConv layer (kpconv_fused.hip)
 struct ProfScope {
   int slot = -1;
@@ -954,15 +955,20 @@ static int pyramid_enqueue(const float* points, const int64_t* lengths, int64_t 
     GEOTR_CHECK_ARG(limits_host[i] >= 1 && limits_host[i] < (1 << 20), "pyramid_build: bad neighbour limit at stage %d", i);
     // (the visiting order of the QUERY rows -- their own stage's grid order -- selects the LDS-staged tile kernel: neighbours in that
     // order share their candidate cells)
-    int rc = radius_query_hinted(false, grids[i], pts[i], len[i], batch, n0, hint[i], n0, hint[i], r, limits_host[i], kRowCap, buf->neighbors[i],
-                                 nullptr, nullptr, overflow, stream, buf->order[i], sparse);
+    // (every search is one launch: bracketed for bench.py's live roofline of the radius family when the profiler is armed)
+    auto search = [&](int qs, int ss, const void* grid, float rad, int64_t width, int64_t* table) -> int {
+      ProfScope prof(stream);
+      const int rc = radius_query_hinted(false, grid, pts[qs], len[qs], batch, n0, hint[qs], n0, hint[ss], rad, width, kRowCap, table, nullptr, nullptr,
+                                         overflow, stream, buf->order[qs], sparse);
+      prof.done(kProfRadius | ((int64_t)qs << 56) | ((int64_t)ss << 52) | (width << 20) | ((int64_t)(sparse ? 0 : 1) << 19));
+      return rc;
+    };
+    int rc = search(i, i, grids[i], r, limits_host[i], buf->neighbors[i]);
     if (rc != GEOTR_OK) return rc;
     if (i < S - 1) {
-      rc = radius_query_hinted(false, grids[i], pts[i + 1], len[i + 1], batch, n0, hint[i + 1], n0, hint[i], r, limits_host[i], kRowCap,
-                               buf->subsampling[i], nullptr, nullptr, overflow, stream, buf->order[i + 1], sparse);
+      rc = search(i + 1, i, grids[i], r, limits_host[i], buf->subsampling[i]);
       if (rc != GEOTR_OK) return rc;
-      rc = radius_query_hinted(false, grids[i + 1], pts[i], len[i], batch, n0, hint[i], n0, hint[i + 1], 2.0f * r, limits_host[i + 1], kRowCap,
-                               buf->upsampling[i], nullptr, nullptr, overflow, stream, buf->order[i], sparse);
+      rc = search(i, i + 1, grids[i + 1], 2.0f * r, limits_host[i + 1], buf->upsampling[i]);
       if (rc != GEOTR_OK) return rc;
     }
     r *= 2.0f;

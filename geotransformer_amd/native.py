@@ -484,9 +484,10 @@ class KernelProfiler:
     Events are created here, handed to the library as raw handles and recorded by the executor on the launch stream; the first
     `capacity` such launches after arming are recorded.  `results()` -> [(seconds, kind, work)]: kind 'gse' with work = number of
     (i, j) superpoint pairs of the launch, kind 'gemm' with work = (m, n, k, epilogue flags: 1 residual read, 2 gathered coarse rows, 4 statistics records), or kind 'kpconv' (a fused KPConv layer) with
-    work = (m, c_out, 15 c_in, h)."""
+    work = (m, c_out, 15 c_in, h), or kind 'radius' (a radius search of the pyramid) with work = (query stage, support stage, table width, 1 = dense kernel)."""
     GEMM_TAG = 1 << 62
     KPCONV_TAG = 1 << 61
+    RADIUS_TAG = 1 << 60
 
     def __init__(self, capacity, stride=1):
         """`stride`: bracket every stride-th eligible launch only -- a timed event pair keeps its launch from overlapping its
@@ -522,6 +523,8 @@ class KernelProfiler:
                 out.append((sec, 'gemm', ((tag >> 26) & 0xffffff, (tag >> 14) & 0xfff, tag & 0x3fff, (tag >> 50) & 7)))  # (m, n, k, epilogue flags)
             elif tag & self.KPCONV_TAG and tag > 0:
                 out.append((sec, 'kpconv', ((tag >> 26) & 0xffffff, (tag >> 14) & 0xfff, tag & 0x3fff, (tag >> 50) & 0x7ff)))
+            elif tag & self.RADIUS_TAG and tag > 0:  # a radius search of the pyramid: (query stage, support stage, table width, dense kernel?)
+                out.append((sec, 'radius', ((tag >> 56) & 0xf, (tag >> 52) & 0xf, (tag >> 20) & 0xfffff, (tag >> 19) & 1)))
             elif tag != 0:
                 out.append((sec, 'gse', tag * tag if tag > 0 else -tag))
         return out

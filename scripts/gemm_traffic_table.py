@@ -3,7 +3,7 @@ the ALGORITHMIC bytes of the launches that ran on that instantiation in the same
 with its epilogue flags; bench.gemm_bytes counts A + C + W + residual / gathered rows / statistics records).  VERDICT r3 item 9.
 
 usage: gemm_traffic_table.py <pmc_hbm_traffic.json> <shapes.jsonl> <precision: fp32|bf16x3|bf16> <out.md>
-The shapes file must come from the SAME launch shape as the PMC passes (--lanes 1 --stack 8 --batch 8) with --profile-stride 1."""
+The shapes file must come from the SAME launch shape as the PMC passes (--lanes 1 --stack 16 --batch 16) with --profile-stride 1."""
 import ctypes
 import json
 import os
@@ -44,7 +44,7 @@ def main(pmc_json, shapes_jsonl, precision, out_md):
         mb = sum(r['hbm_mb_per_launch'] * r['launches'] for _, r in hits)
         rows.append((wm, wn, d, launches, mb))
     with open(out_md, 'w') as f:
-        f.write(f'# Packed-GEMM HBM traffic vs algorithmic bytes per instantiation ({precision}; `--lanes 1 --stack 8 --batch 8`: a launch covers 8 stacked pairs)\n\n')
+        f.write(f'# Packed-GEMM HBM traffic vs algorithmic bytes per instantiation ({precision}; `--lanes 1 --stack 16 --batch 16`: a launch covers 16 stacked pairs, as in the bench)\n\n')
         f.write('PMC = rocprofv3 FETCH_SIZE x2 + WRITE_SIZE summed over the traced launches (`scripts/pmc_summary.py`); algorithmic = '
                 '`bench.gemm_bytes` (A read + C written + packed W once each + residual / gathered coarse rows / statistics records the epilogue '
                 'really moves) summed over the launches of the timed region that map to the instantiation (tile width from the library\'s own plan); '

@@ -5,6 +5,23 @@ import json
 import sys
 
 
+def alone_record(stats_csv, bench_json):
+    """{kernels_alone_us_per_pair, pairs_traced, ...}: the one-lane trace's total kernel time per pair -- what bench.py quotes in its line
+    (profiles/rNN_kernels_alone.json)."""
+    d = json.load(open(bench_json))
+    all_rows = list(csv.DictReader(open(stats_csv)))
+    stacks = sum(int(r['Calls']) for r in all_rows if 'patch_sinkhorn' in r['Name'])
+    pairs = stacks * d['config']['pairs_stacked_per_launch_sequence']
+    rows = [r for r in all_rows if not r['Name'].startswith(('at::', '__amd_rocclr'))]
+    total = sum(float(r['TotalDurationNs']) for r in rows)
+    top = sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:8]
+    return {'kernels_alone_us_per_pair': round(total / 1e3 / pairs, 1), 'pairs_traced': pairs, 'lanes': d['config']['lanes_per_gpu'],
+            'workload': d['config'].get('workload'), 'matrix_precision': d['config'].get('matrix_precision'),
+            'pairs_per_s_under_the_profiler': d['value'],
+            'top': {r['Name'].split('(')[0].replace('void ', ''): round(float(r['TotalDurationNs']) / 1e3 / pairs, 1) for r in top},
+            'source': 'rocprofv3 --kernel-trace --stats -- python bench.py --lanes 1 --steps 6 --warmup 2 --no-cpu-baseline --no-sibling-mode'}
+
+
 def table(stats_csv, bench_json, top=32):
     d = json.load(open(bench_json))
     all_rows = list(csv.DictReader(open(stats_csv)))
@@ -60,6 +77,11 @@ def main():
                 'not been dispatched yet -- which a per-kernel duration excludes; under the profiler every dispatch is slower, which widens '
                 'that gap ' + plain + '.  The bench line\'s in-flight figure is the larger one, '
                 'i.e. its roofline fraction is the more conservative of the two; the one-lane pair is the like-for-like check.\n')
+
+
+    if out.endswith('_kernel_trace.md') or out.endswith('kernel_trace.md'):
+        with open(out[:-len('kernel_trace.md')] + 'kernels_alone.json', 'w') as f:
+            json.dump(alone_record(s1, b1), f, indent=1)
 
 
 if __name__ == '__main__':
