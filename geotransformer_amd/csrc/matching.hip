@@ -989,6 +989,7 @@ __global__ __launch_bounds__(64 * kSinkWavesPerBlock, 2) void patch_sinkhorn_wav
   if (lane == 0) u[K] = u_d, v[K] = v_d;
   GEOTR_WAVE_SYNC();
   float* o = out + (int64_t)p * K1 * K1;
+#pragma clang loop vectorize(disable) interleave(disable)  // (no compiler-made packed fp32: tests/test_isa_checks.py)
   for (int e = lane; e < K1 * K1; e += 64) {
     const int i = e / K1, j = e - i * K1;
     o[e] = ((S[e] + u[i]) + v[j]) - norm;
@@ -1191,6 +1192,7 @@ __global__ __launch_bounds__(256, 2) void patch_sinkhorn_block128_kernel(
     __syncthreads();
   }
   float* o = out + (int64_t)p * K1 * K1;
+#pragma clang loop vectorize(disable) interleave(disable)  // (no compiler-made packed fp32: tests/test_isa_checks.py)
   for (int e = tid; e < K1 * K1; e += NT) {
     const int i = e / K1, j = e - i * K1;
     o[e] = ((S[e] + u[i]) + v[j]) - norm;
