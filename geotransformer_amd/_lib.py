@@ -17,7 +17,7 @@ c_ptr = ctypes.c_void_p
 c_size = ctypes.c_size_t
 c_int = ctypes.c_int
 
-ABI_VERSION = 7  # geotr_abi_version() of the library this package's ctypes mirrors (native.py, kernels.py) were written against
+ABI_VERSION = 8  # geotr_abi_version() of the library this package's ctypes mirrors (native.py, kernels.py) were written against
 
 # name -> (restype, argtypes); must list every symbol include/geotr.h declares (tests check this)
 SIGNATURES = {

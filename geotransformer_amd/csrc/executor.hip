@@ -198,17 +198,8 @@ static float* kpconv(Ctx& c, const geotr_kpconv& kp, const float* s_feats, int64
     c.release(mk);
     return out;
   }
-  // Deep layers (C_in >= 128: several channel blocks through the fused kernel's LDS tile).  Measured in round 5 (profiles/r05_ab_runs.md
-  // section 3): the fused form removes the (M, 15 C_in) operand from HBM (207 + 128 MB per 8-pair stack) but LOSES to gather -> packed
-  // GEMM at these shapes -- 975 vs 1 011 pairs/s at four lanes, 755 vs 797 at one: its phase 2 streams the 1-4 MB weight from L2 once per
-  // 32-row tile where the packed GEMM shares it through the LDS ring, and 280 tiles on 256 CUs quantise to two rounds.  Default: the
-  // two-kernel path; GEOTR_KPCONV_FUSED_DEEP=1 fuses them all, =2 only launches of at least two full rounds of tiles.
-  static const int fused_deep = [] {
-    const char* e = std::getenv("GEOTR_KPCONV_FUSED_DEEP");
-    return e ? std::atoi(e) : 0;
-  }();
-  const bool deep_ok = kp.in <= 64 || fused_deep == 1 || (fused_deep == 2 && m >= 2 * 256 * 32);
-  if (fused_enabled && deep_ok && kp.packed && flag && kp.num_kernel_points == 15 && geotr_kpconv_fused_supported(kp.in, kp.out, h) &&
+  // (C_in <= 64 only: the deep layers are matrix-bound and lost 3.7 % fused -- profiles/r05_ab_runs.md section 3; that form was removed in round 6)
+  if (fused_enabled && kp.packed && flag && kp.num_kernel_points == 15 && geotr_kpconv_fused_supported(kp.in, kp.out, h) &&
       (reinterpret_cast<uintptr_t>(s_feats) & 15) == 0) {
     if (c.live()) {
       ProfScope prof(c.stream);

@@ -20,14 +20,10 @@
 //            per step (a_hi b_lo + a_lo b_hi + a_hi b_hi) against the SAME packed weight planes geotr_gemm_pack builds for the
 //            two-kernel path, streamed fragment by fragment from L2.  Waves split (column tile, K range); the K partials meet in
 //            LDS, the epilogue (/ count + bias) writes whole rows.
-// Wider layers (round 5: C_in = 128, 256, ... = NH channel blocks of 64) run the same tile NH times: block h takes channels
-// 64 h .. 64 h + 63 of every neighbour row through phase 1 into the SAME LDS tile and phase 2 adds its 15 x 64 slice of the contraction
-// (rows k C_in + 64 h + c of the packed weight) to the accumulators it keeps across the blocks -- the (M, 15 C_in) operand of those
-// layers (207 + 128 MB per 8-pair stack, profiles/r04_pmc_hbm_traffic_fp32.md) never exists, and LDS stays at the 64-channel size.
-// MEASURED (profiles/r05_ab_runs.md section 3): 3.7 % SLOWER end to end than gather -> split-K packed GEMM (those layers are matrix-bound,
-// phase 2 streams the weight from L2 once per 32-row tile, 280 tiles on 256 CUs quantise to two rounds), so the model executor keeps the
-// two-kernel path for them (GEOTR_KPCONV_FUSED_DEEP=1 switches); the instantiations stay for the C ABI and their tests.
-// Supported: C_in = 32 or a multiple of 64, C_out a multiple of 32 with C_out / 32 dividing the wave count (32 .. 256), H <= 40.
+// Wider layers (C_in >= 128) stay on the two-kernel path: round 5 built them as channel blocks of 64 through this tile and measured
+// 3.7 % SLOWER end to end (profiles/r05_ab_runs.md section 3: they are matrix-bound, phase 2 streams the 1-4 MB weight from L2 once per
+// 32-row tile); round 6 removed those instantiations (git: 2b000bd has them).
+// Supported: C_in = 32 or 64, C_out a multiple of 32 with C_out / 32 dividing the wave count (32 .. 256), H <= 40.
 // Everything else stays on the two-kernel path.
 #include <cstdlib>
 
@@ -68,15 +64,12 @@ struct FVec<4> {
 // C = C_in; WAVES = waves per workgroup; TERMS = 3 split-bf16 / 1 plain bf16 (hi planes only) / 0 exact fp32: the tile A stays fp32
 // in LDS (same bytes as its hi + lo halves) and phase 2 runs v_mfma_f32_32x32x2_f32 against the weight packed by geotr_gemm_pack_f32
 // (gemm.hip: four steps of an 8-deep group per 16-byte fragment) -- the reference's own arithmetic end to end (round 4).
-// MULTI: the layer has several channel blocks (c_total = NH C, NH > 1); false: c_total == C and the block loop is a single pass at
-// compile time (phase 2's accumulators are then not live across phase 1: the register allocation of the C_in = 32 / 64 layers is unchanged).
-// CTW: 32-column output tiles per wave (1: C_out <= 32 WAVES; 2: C_out = 64 WAVES -- the 512-wide layers of the 5-stage backbone).
 // C = 32 tiles (78 KB of LDS) are meant to share a CU two by two: 4 waves per SIMD, i.e. at most 128 VGPRs (C = 64: one workgroup, 256)
-template <int C, int WAVES, int TERMS, bool MULTI, int CTW = 1>
+template <int C, int WAVES, int TERMS>
 __global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) void kpconv_fused_kernel(const float* __restrict__ feats, const float* __restrict__ qp,
                                                                   const float* __restrict__ sp, const int64_t* __restrict__ nb,
                                                                   const float* __restrict__ kp, const unsigned char* __restrict__ pos,
-                                                                  int64_t M, int64_t Ns, int H, float sigma, int c_total, int c_out, int KS, int NT,
+                                                                  int64_t M, int64_t Ns, int H, float sigma, int c_out, int KS, int NT,
                                                                   const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo,
                                                                   const float* __restrict__ bias, const int* __restrict__ order,
                                                                   float* __restrict__ out) {
@@ -91,33 +84,27 @@ __global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) vo
   unsigned short* A_hi = reinterpret_cast<unsigned short*>(fsm);
   unsigned short* A_lo = A_hi + kFusedRows * RS;
   float* A_32 = reinterpret_cast<float*>(fsm);  // TERMS == 0: [32][RS32] fp32
-  // (rel.xyz, neighbour index bits) per (point, neighbour): MULTI keeps [32][40] float4 behind the tile; otherwise they live in the first
-  // 640 bytes of the point's own tile row until its MFMAs have consumed them (relw_of below) -- the tile is ALL the kernel's LDS:
-  // 62 KB at C = 32 (two workgroups per CU with room to spare), 124 KB at C = 64
-  float4* relw_all = reinterpret_cast<float4*>(A_lo + kFusedRows * RS);
-  int* cnt_s = reinterpret_cast<int*>(relw_all + (MULTI ? kFusedRows * 40 : 0));  // [32] neighbours with a positive feature sum
+  // (rel.xyz, neighbour index bits) per (point, neighbour) live in the first 640 bytes of the point's own tile row until its MFMAs have
+  // consumed them (relw_of below) -- the tile is ALL the kernel's LDS: 62 KB at C = 32 (two workgroups per CU with room to spare),
+  // 124 KB at C = 64
+  int* cnt_s = reinterpret_cast<int*>(A_lo + kFusedRows * RS);          // [32] neighbours with a positive feature sum
   int* row_s = cnt_s + kFusedRows;                                       // [32] the tile's query rows (visiting order applied)
   float* part = reinterpret_cast<float*>(fsm);                           // [WAVES][16][64] K partials (reuses the A tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, q4 = lane >> 4;
   const float inv_sigma = 1.f / sigma;
-  // the feature rows as a raw buffer (Ns c_total floats < 4 GB: checked by the host): loads past its end return zeros
+  // the feature rows as a raw buffer (Ns C floats < 4 GB: checked by the host): loads past its end return zeros
   const __amdgpu_buffer_rsrc_t feat_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feats), 0, (int)((unsigned)Ns * (unsigned)c_total * 4u), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feats), 0, (int)((unsigned)Ns * (unsigned)C * 4u), 0x00020000);
   // the lane's kernel point (row of the phase-1 A operand); row 15 is padding
   const bool kp_ok = n16 < 15;
   const float kx = kp_ok ? kp[3 * n16] : 0.f, ky = kp_ok ? kp[3 * n16 + 1] : 0.f, kz = kp_ok ? kp[3 * n16 + 2] : 0.f;
   const int steps = (H + 3) >> 2;
   const int CT = c_out >> 5;            // 32-column tiles of the output
-  const int CTP = CT / CTW;             // column tiles taken side by side by the waves (tile s of a wave: ct + s CTP)
-  const int KPARTS = WAVES / CTP;       // K ranges of phase 2
-  const int ct = wave % CTP, kpart = wave / CTP;
+  const int KPARTS = WAVES / CT;        // K ranges of phase 2
+  const int ct = wave % CT, kpart = wave / CT;
   const int nkk = F32 ? K / 8 : K / 16;  // 16-deep steps of phase 2 (K % 32 == 0); fp32: 8-deep groups of four 32x32x2 steps
-  // channel blocks (c_total = NH C): steps of a block's LOCAL contraction index -> steps of the packed weight, whose rows are k c_total + c
-  const int NH = MULTI ? c_total / C : 1;
-  constexpr int GP = F32 ? C / 8 : C / 16;           // steps per kernel point inside a block
-  const int gp_total = MULTI ? (F32 ? c_total / 8 : c_total / 16) : GP;  // steps per kernel point of the packed weight
   const int kk_per = (nkk + KPARTS - 1) / KPARTS;
   const int kk0 = kpart * kk_per, kk1 = min(nkk, kk0 + kk_per);
 
@@ -161,10 +148,9 @@ __global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) vo
     }
   };
   // (relative position, neighbour index bits) of point p: the first 40 float4 of the point's OWN row of the A tile (nothing is stored
-  // there before the point's MFMAs have consumed them) -- MULTI keeps a separate region, its rows are rewritten once per channel block
+  // there before the point's MFMAs have consumed them)
   auto relw_of = [&](int p) -> float4* {
-    if constexpr (MULTI) return relw_all + (wave * PPW + p) * 40;
-    else if constexpr (F32) return reinterpret_cast<float4*>(A_32 + (wave * PPW + p) * RS32);
+    if constexpr (F32) return reinterpret_cast<float4*>(A_32 + (wave * PPW + p) * RS32);
     else return reinterpret_cast<float4*>(A_hi + (wave * PPW + p) * RS);
   };
   const int64_t tiles = (M + kFusedRows - 1) / kFusedRows;
@@ -178,8 +164,8 @@ __global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) vo
   bool b0_loaded = false;             // set 0 of b_r already holds point 0 of the tile about to start (loaded under the previous tile's epilogue)
   // neighbour (4 u + q4)'s channels of one point: ONE bounds-checked buffer load per group -- an absent neighbour (pad index, lanes past
   // H, steps past `steps`) gets an out-of-range offset, for which the hardware returns zeros
-  auto load_feats = [&](int id, bool ok, int hb, float (&b)[G][VEC]) {
-    const unsigned off = ok ? 4u * ((unsigned)id * (unsigned)(MULTI ? c_total : C) + (unsigned)(C * hb + VEC * n16)) : 0xffffffffu;
+  auto load_feats = [&](int id, bool ok, float (&b)[G][VEC]) {
+    const unsigned off = ok ? 4u * ((unsigned)id * (unsigned)C + (unsigned)(VEC * n16)) : 0xffffffffu;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       if constexpr (VEC == 4) {
@@ -220,12 +206,9 @@ __global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) vo
 #pragma unroll
       for (int p = 0; p < PPW; ++p) jx_nxt[p] = (int)Ns;
     }
-    f32x16 acc2[CTW];  // phase 2's accumulators: kept across the channel blocks
+    f32x16 acc2;  // phase 2's accumulator
 #pragma unroll
-    for (int s = 0; s < CTW; ++s)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[s][r] = 0.f;
-    for (int hb = 0; hb < NH; ++hb) {  // ---- channel block hb: channels C hb .. C hb + C - 1 of every neighbour row
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
     // ------------------------------------------------------------------ phase 1: g = w . f per point
 #if defined(GEOTR_KPF_PRIO) && GEOTR_KPF_PRIO == 1
     if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);  // experiment: the younger half loses every arbitration against the older one
@@ -234,8 +217,8 @@ __global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) vo
 #endif
 #pragma unroll
     for (int p = 0; p < PPW; ++p) {
-      if (lane < 40 && (!MULTI || hb == 0)) relw_of(p)[lane] = make_float4(rx_cur[p][0], rx_cur[p][1], rx_cur[p][2], __int_as_float(jx_cur[p] < Ns ? jx_cur[p] : -1));
-      if (lane == 0 && hb == 0) cnt_s[wave * PPW + p] = cn_cur[p];
+      if (lane < 40) relw_of(p)[lane] = make_float4(rx_cur[p][0], rx_cur[p][1], rx_cur[p][2], __int_as_float(jx_cur[p] < Ns ? jx_cur[p] : -1));
+      if (lane == 0) cnt_s[wave * PPW + p] = cn_cur[p];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -250,9 +233,9 @@ __global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) vo
       const float dx = rv.x - kx, dy = rv.y - ky, dz = rv.z - kz;
       const float w = fmaxf(1.f - __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) * inv_sigma, 0.f);  // as kpconv_gather_kernel
       a = w * ((ok && kp_ok) ? 1.f : 0.f);  // (w is finite and >= 0: the product is w or +0 exactly; a select here is compiled to a branch around the arithmetic)
-      if (with_feats) load_feats(id, ok, hb, b);
+      if (with_feats) load_feats(id, ok, b);
     };
-    if (PRE_B0 && hb == 0 && b0_loaded) {  // (uniform)
+    if (PRE_B0 && b0_loaded) {  // (uniform)
 #pragma unroll
       for (int u = 0; u < kMaxSteps; ++u) b1_step(0, u, a_r[0][u], b_r[0][u], false);
     } else {
@@ -314,32 +297,23 @@ __global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) vo
 #endif
     KPF_STAMP(0);     // phase 1 (this wave's points)
     // the next tile's positions and flags: sixteen loads in flight together, landing under the weight stream of phase 2
-    if (hb == NH - 1) {
-      if (have_next) load_rel(rows_nxt, jx_nxt, rx_nxt, cn_nxt);
-      else {
+    if (have_next) load_rel(rows_nxt, jx_nxt, rx_nxt, cn_nxt);
+    else {
 #pragma unroll
-        for (int p = 0; p < PPW; ++p) cn_nxt[p] = 0, rx_nxt[p][0] = rx_nxt[p][1] = rx_nxt[p][2] = 0.f;
-      }
+      for (int p = 0; p < PPW; ++p) cn_nxt[p] = 0, rx_nxt[p][0] = rx_nxt[p][1] = rx_nxt[p][2] = 0.f;
     }
     __syncthreads();  // A tile complete
     KPF_STAMP(1);     // wait for the other waves' points
     // ------------------------------------------------------------------ phase 2: out += A . W  (this wave: column tile ct, steps kk0 .. kk1)
-    auto wstep = [&](int q) { return MULTI ? (q / GP) * gp_total + hb * GP + (q % GP) : q; };  // local step -> step of the packed weight
     if constexpr (F32) {
       // group q: lane (fr, fk) holds A[fr][8 q + 4 fk + e] and W[8 q + 4 fk + e][32 ct + fr], e = 0 .. 3 = its operands of four steps
       const float* a32 = A_32 + (lane & 31) * RS32 + 4 * (lane >> 5);
-      const float* b32[CTW];
-#pragma unroll
-      for (int s = 0; s < CTW; ++s)
-        b32[s] = reinterpret_cast<const float*>(Bhi) + ((int64_t)min(ct + s * CTP, NT - 1) * 2 * KS * 64 + lane) * 4;
+      const float* b32 = reinterpret_cast<const float*>(Bhi) + ((int64_t)min(ct, NT - 1) * 2 * KS * 64 + lane) * 4;
       // weight fragments three groups ahead (an L2 round trip is 2-3 groups of MFMAs long), the tile's own fragment one group ahead
       constexpr int WD = 3;
-      f32x4 bq[WD][CTW];
+      f32x4 bq[WD];
 #pragma unroll
-      for (int d = 0; d < WD; ++d)
-#pragma unroll
-        for (int s = 0; s < CTW; ++s)
-          bq[d][s] = *reinterpret_cast<const f32x4*>(b32[s] + (int64_t)wstep(min(kk0 + d, max(kk1 - 1, kk0))) * 256);
+      for (int d = 0; d < WD; ++d) bq[d] = *reinterpret_cast<const f32x4*>(b32 + (int64_t)min(kk0 + d, max(kk1 - 1, kk0)) * 256);
       f32x4 av_n = *reinterpret_cast<const f32x4*>(a32 + 8 * min(kk0, max(kk1 - 1, 0)));
       for (int q0 = kk0; q0 < kk1; q0 += WD) {
 #pragma unroll
@@ -347,16 +321,11 @@ __global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) vo
           const int q = q0 + d;
           if (q >= kk1) break;  // (uniform)
           const f32x4 av = av_n;
-          f32x4 bv[CTW];
-#pragma unroll
-          for (int s = 0; s < CTW; ++s) bv[s] = bq[d][s];
+          const f32x4 bv = bq[d];
           av_n = *reinterpret_cast<const f32x4*>(a32 + 8 * min(q + 1, kk1 - 1));
+          bq[d] = *reinterpret_cast<const f32x4*>(b32 + (int64_t)min(q + WD, kk1 - 1) * 256);
 #pragma unroll
-          for (int s = 0; s < CTW; ++s) bq[d][s] = *reinterpret_cast<const f32x4*>(b32[s] + (int64_t)wstep(min(q + WD, kk1 - 1)) * 256);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int s = 0; s < CTW; ++s) acc2[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[s][e], acc2[s], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc2, 0, 0, 0);
         }
       }
     } else {
@@ -367,40 +336,34 @@ __global__ __launch_bounds__(64 * WAVES, C == 32 ? 2 * WAVES / 4 : WAVES / 4) vo
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_hi + 16 * kk);
         bf16x8 al;
         if constexpr (TERMS == 3) al = *reinterpret_cast<const bf16x8*>(a_lo + 16 * kk);
-#pragma unroll
-        for (int s = 0; s < CTW; ++s) {
-          const int64_t off = ((int64_t)min(ct + s * CTP, NT - 1) * KS * 64 + lane) * 8 + (int64_t)wstep(kk) * 512;
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bhi + off);
-          if constexpr (TERMS == 3) {
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Blo + off);
-            acc2[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2[s], 0, 0, 0);
-            acc2[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2[s], 0, 0, 0);
-          }
-          acc2[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2[s], 0, 0, 0);
+        const int64_t off = ((int64_t)min(ct, NT - 1) * KS * 64 + lane) * 8 + (int64_t)kk * 512;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bhi + off);
+        if constexpr (TERMS == 3) {
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Blo + off);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
         }
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2, 0, 0, 0);
       }
     }
     // the channels of the NEXT tile's first point (set 0 of b_r is free since point PPW - 2): its loads fly under the partial sums, the
     // epilogue and two barriers instead of opening the next tile with a bare round trip.  The neighbour index of lane (n16, q4) at
     // step u is the index lane 4 u + q4 fetched (jx_nxt[0]): one bpermute per step.
-    if (PRE_B0 && hb == NH - 1) {
+    if (PRE_B0) {
       b0_loaded = have_next;
       if (have_next) {
 #pragma unroll
         for (int u = 0; u < kMaxSteps; ++u) {
           const int id = __builtin_amdgcn_ds_bpermute(4 * (4 * u + q4), jx_nxt[0]);
-          load_feats(id, u < steps && 4 * u + q4 < H && id < Ns, 0, b_r[0][u]);
+          load_feats(id, u < steps && 4 * u + q4 < H && id < Ns, b_r[0][u]);
         }
       }
     }
     KPF_STAMP(2);     // phase 2 (this wave's K range)
     __syncthreads();  // every wave has read its A fragments: the tile's memory takes the next channel block / the K partials
     KPF_STAMP(3);     // wait for the other waves' K ranges
-    }  // channel blocks
 #pragma unroll
-    for (int s = 0; s < CTW; ++s)  // tile ct + s CTP of K range kpart lives at partial index kpart CT + ct + s CTP (CTW = 1: the wave index)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) part[((kpart * CT + ct + s * CTP) * 16 + r) * 64 + lane] = acc2[s][r];
+    for (int r = 0; r < 16; ++r) part[(wave * 16 + r) * 64 + lane] = acc2[r];  // (tile ct of K range kpart = partial index kpart CT + ct = wave)
     __syncthreads();
     KPF_STAMP(4);     // partials to LDS + barrier
     // ------------------------------------------------------------------ epilogue: sum the K partials, / count + bias, whole rows out
@@ -543,10 +506,9 @@ int geotr_debug_kpf_stamps(unsigned long long* out) {
 #endif
 
 int geotr_kpconv_fused_supported(int64_t c_in, int64_t c_out, int64_t h) {
-  if (!(c_in == 32 || (c_in >= 64 && c_in % 64 == 0 && c_in <= 4096)) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 4 * kMaxSteps) return 0;
+  if (!(c_in == 32 || c_in == 64) || c_out < 32 || c_out % 32 != 0 || h < 1 || h > 4 * kMaxSteps) return 0;
   const int waves = 8;
   const int64_t ct = c_out / 32;
-  if (ct == 2 * waves) return c_in > 64;  // two column tiles per wave: the multi-block kernel only (C_in >= 128)
   return ct <= waves && waves % ct == 0;
 }
 
@@ -586,40 +548,28 @@ int geotr_kpconv_fused(const float* s_feats, const float* q_points, const float*
   const unsigned short* bhi = reinterpret_cast<const unsigned short*>(packed);
   const unsigned short* blo = bhi + np_pad * kp_pad;
   const int KS = (int)(kp_pad / 16), NT = (int)(np_pad / 32);
-  const int waves = 8;
-  // channel block: what one pass of a tile holds in LDS.  (C_in = 64 as two blocks of 32 -- a 78 KB tile, two workgroups per CU -- was
-  // measured in round 6 before phase 1 was re-pipelined: 2 942 vs 2 815 us per 16-pair stack alone, no change end to end; removed.)
-  const int64_t cb = c_in == 32 ? 32 : 64;
-  const size_t lds = (size_t)2 * kFusedRows * (15 * cb + 8) * 2 + (c_in > cb ? (size_t)kFusedRows * 40 * 16 : 0) + 2 * kFusedRows * 4;
+  // (C_in = 64 as two channel blocks of 32 -- a 78 KB tile, two workgroups per CU -- was measured in round 6: 2 942 vs 2 815 us per
+  // 16-pair stack alone, nothing end to end: profiles/r06_ab_runs.md section 1)
+  const size_t lds = (size_t)2 * kFusedRows * (15 * c_in + 8) * 2 + 2 * kFusedRows * 4;
   const int64_t tiles = (m + kFusedRows - 1) / kFusedRows;
   // persistent: a few tiles per resident workgroup; a multiple of 8 blocks, one share of the tile range per XCD
-  const unsigned grid = (unsigned)((std::min<int64_t>(tiles, 256 * (cb == 32 ? 8 : 4)) + 7) / 8 * 8);
-#define GEOTR_KPF(CC, WW, TT, MM, ...)                                                                                                  \
+  const unsigned grid = (unsigned)((std::min<int64_t>(tiles, 256 * (c_in == 32 ? 8 : 4)) + 7) / 8 * 8);
+#define GEOTR_KPF(CC, WW, TT)                                                                                                          \
   do {                                                                                                                             \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<CC, WW, TT, MM, ##__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kpconv_fused_kernel<CC, WW, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)lds) != hipSuccess)                                                                               \
       return fail(GEOTR_E_LAUNCH, "kpconv_fused: cannot reserve %zu B of LDS", lds);                                               \
-    kpconv_fused_kernel<CC, WW, TT, MM, ##__VA_ARGS__><<<dim3(grid), dim3(64 * WW), lds, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points,  \
-                                                                               pos_flag, m, ns, (int)h, sigma, (int)c_in, (int)c_out, KS, NT, bhi, \
-                                                                               blo, bias, order, out);                             \
+    kpconv_fused_kernel<CC, WW, TT><<<dim3(grid), dim3(64 * WW), lds, stream>>>(s_feats, q_points, s_points, neighbors, kernel_points, pos_flag, m, \
+                                                                               ns, (int)h, sigma, (int)c_out, KS, NT, bhi, blo, bias, order, out); \
   } while (0)
-  GEOTR_CHECK_ARG(bf16_operands >= 0 && bf16_operands <= 2, "kpconv_fused: arithmetic mode must be 0 (split-bf16), 1 (bf16) or 2 (fp32)");
   if (c_in == 32) {  // 8 waves in both widths: two resident workgroups at c_in = 32 give 4 waves per SIMD, the LDS tile allows no more
-    if (bf16_operands == 2) GEOTR_KPF(32, 8, 0, false);
-    else if (bf16_operands == 1) GEOTR_KPF(32, 8, 1, false);
-    else GEOTR_KPF(32, 8, 3, false);
-  } else if (c_in == 64) {
-    if (bf16_operands == 2) GEOTR_KPF(64, 8, 0, false);
-    else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1, false);
-    else GEOTR_KPF(64, 8, 3, false);
-  } else if (c_out <= 32 * waves) {  // several channel blocks of 64
-    if (bf16_operands == 2) GEOTR_KPF(64, 8, 0, true);
-    else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1, true);
-    else GEOTR_KPF(64, 8, 3, true);
-  } else {  // ... and two column tiles per wave (C_out = 512)
-    if (bf16_operands == 2) GEOTR_KPF(64, 8, 0, true, 2);
-    else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1, true, 2);
-    else GEOTR_KPF(64, 8, 3, true, 2);
+    if (bf16_operands == 2) GEOTR_KPF(32, 8, 0);
+    else if (bf16_operands == 1) GEOTR_KPF(32, 8, 1);
+    else GEOTR_KPF(32, 8, 3);
+  } else {
+    if (bf16_operands == 2) GEOTR_KPF(64, 8, 0);
+    else if (bf16_operands == 1) GEOTR_KPF(64, 8, 1);
+    else GEOTR_KPF(64, 8, 3);
   }
 #undef GEOTR_KPF
   GEOTR_CHECK_LAUNCH("kpconv_fused");

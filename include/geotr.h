@@ -34,7 +34,7 @@ extern "C" {
 const char* geotr_last_error(void);
 /* ABI version of this header; bumped on any signature change.  A host compares the macro it was compiled against with what the
  * loaded library reports. */
-#define GEOTR_ABI_VERSION 7
+#define GEOTR_ABI_VERSION 8
 int geotr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -233,10 +233,9 @@ int geotr_gemm_packed_bf16(const float* A, int64_t lda, const void* packed, floa
 /* K1 in one kernel (kpconv_fused.hip): geotr_kpconv_gather + the packed GEMM without the (m, 15 c_in) operand in HBM -- influences
  * and the neighbour contraction on the fp32 matrix pipe into an LDS tile, the kernel-point contraction on the bf16 matrix pipe against
  * `packed` = geotr_gemm_pack(weights viewed (15 c_in, c_out), b_is_kn = 1), epilogue / max(count, 1) + bias (kpconv/kpconv.py:79-121).
- * pos_flag (ns) as for geotr_kpconv_gather (required).  Shapes: geotr_kpconv_fused_supported(c_in, c_out, h) -- c_in = 32 or a multiple
- * of 64 (round 5: c_in >= 128 runs channel blocks of 64 through the same LDS tile), c_out a multiple of 32 (<= 256; 512 with c_in >= 128),
- * h <= 40; other layers use the two-kernel path.  The model executor fuses the c_in <= 64 layers only: for c_in >= 128 the fused form
- * measured 3.7 % slower end to end than gather -> packed GEMM (profiles/r05_ab_runs.md).  bf16_operands as geotr_gemm_packed_splitk.
+ * pos_flag (ns) as for geotr_kpconv_gather (required).  Shapes: geotr_kpconv_fused_supported(c_in, c_out, h) -- c_in = 32 or 64, c_out
+ * a multiple of 32 (<= 256), h <= 40; other layers use the two-kernel path (ABI 8: the c_in >= 128 form of ABI 6-7 measured 3.7 % slower
+ * end to end than gather -> packed GEMM, profiles/r05_ab_runs.md, and was removed).  bf16_operands as geotr_gemm_packed_splitk.
  * order (m int32, may be NULL = row order): the sequence in which the query rows are visited, 32 per workgroup tile -- pass the grid
  * order of the query stage (geotr_radius_grid_order / geotr_pyramid_buffers.order) so that a tile's rows share their neighbour rows in
  * L1 / L2 and each XCD works through one stretch of space.  Results land in their own rows and do not depend on the order. */

@@ -19,7 +19,12 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 python $ROOT/bench.py --detail $OUT/bench_n1_detail.json > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 echo "bench rc=$?"; head -c 200 $OUT/bench_n1.json; echo
 B="--no-cpu-baseline --no-sibling-mode"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 $B > $OUT/bench_under_rocprof.json 2>/dev/null
+for try in 1 2 3; do  # (rocprofv3 itself crashed once in round 6: "Segmentation fault" after the run, no stats written)
+  rm -rf $OUT/stats
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 $B > $OUT/bench_under_rocprof.json 2>/dev/null
+  [ -n "$(find $OUT/stats -name '*kernel_stats.csv' 2>/dev/null | head -1)" ] && break
+  echo "rocprofv3 four-lane trace failed (try $try)"
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_l1 -o bench -- python $ROOT/bench.py --steps 6 --warmup 2 --lanes 1 $B > $OUT/bench_l1_under_rocprof.json 2>/dev/null
 # HBM traffic: counters only (no trace domains besides --kernel-trace), one counter per pass; a launch covers 16 stacked pairs, as in the bench
 P="--steps 2 --warmup 1 --lanes 1 --stack 16 --batch 16 $B"

@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
     assert b'h <= 64' in lib.geotr_last_error()
     assert lib.geotr_kpconv_c1_fused(one, one, one, one, one, 8, 8, 38, 64, 14, 0.1, one, None, None, one, None) == -1
     assert b'15 kernel points' in lib.geotr_last_error()
-    assert lib.geotr_kpconv_fused_supported(32, 64, 38) == 1 and lib.geotr_kpconv_fused_supported(128, 128, 38) == 1 and lib.geotr_kpconv_fused_supported(96, 128, 38) == 0 and lib.geotr_kpconv_fused_supported(64, 512, 38) == 0
+    assert lib.geotr_kpconv_fused_supported(32, 64, 38) == 1 and lib.geotr_kpconv_fused_supported(64, 256, 38) == 1 and lib.geotr_kpconv_fused_supported(128, 128, 38) == 0 and lib.geotr_kpconv_fused_supported(96, 128, 38) == 0 and lib.geotr_kpconv_fused_supported(64, 512, 38) == 0
     assert lib.geotr_kpconv_fused_supported(64, 96, 38) == 0 and lib.geotr_kpconv_fused_supported(64, 64, 41) == 0
     assert lib.geotr_kpconv_fused(one, one, one, one, one, one, 8, 8, 38, 96, 128, 15, 0.1, one, None, 0, None, one, None) == -1
     assert b'unsupported shape' in lib.geotr_last_error()

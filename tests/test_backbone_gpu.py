@@ -70,8 +70,7 @@ def test_kpconv_layer_matches_oracle(C):
     assert _mse(got, want) <= 1e-8
 
 
-@pytest.mark.parametrize('C,CO,H', [(32, 32, 36), (64, 64, 36), (32, 64, 38), (64, 128, 24), (32, 128, 40), (64, 256, 33),
-                                    (128, 128, 36), (256, 256, 38), (128, 64, 24), (192, 256, 33), (512, 128, 40), (256, 512, 36)])  # (round 5) several channel blocks of 64
+@pytest.mark.parametrize('C,CO,H', [(32, 32, 36), (64, 64, 36), (32, 64, 38), (64, 128, 24), (32, 128, 40), (64, 256, 33)])
 def test_kpconv_fused_matches_oracle_and_the_two_kernel_path(C, CO, H, matrix_precision):
     """geotr_kpconv_fused (one kernel: fp32-MFMA neighbour contraction into LDS + split-bf16 kernel-point contraction) vs the
     oracle and vs gather -> packed GEMM, on a strided layer (queries = coarser cloud), with pad neighbours, rows of negative
