@@ -241,6 +241,7 @@ __global__ void rg_scatter_kernel(const float* __restrict__ s, int batch, const 
 // The number of queries and the pad index are read on the device (the lengths / the support clouds' headers): a pyramid stage whose size
 // only the device knows needs no host read (round 3).  nq_cap = row capacity of the query array.
 constexpr int kRgAhead = 4;  // candidate steps in flight per wave (rg_query_kernel, rg_query_quad_kernel)
+constexpr int kRgBucketMin = 64;  // rows of more hits than this are ranked bucket by bucket (rg_query_kernel)
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restrict__ hdr, const int* __restrict__ cell_start,
                                                        const float4* __restrict__ sorted, const float* __restrict__ q,
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
                                                        float r2, int width, int cap,
                                                        int64_t* __restrict__ out, int* __restrict__ counts,
                                                        int* __restrict__ max_count, int* __restrict__ overflow,
-                                                       const int* __restrict__ q_order) {
+                                                       const int* __restrict__ q_order, int bucketed) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t ns_total = rg_rows(hdr, batch);
@@ -291,13 +292,13 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
       }
     }
     const int inc = wave_inclusive_scan(seg_len);
-    const int total = __shfl(inc, 8, 64);
+    const int total = __builtin_amdgcn_readlane(inc, 8);  // (wave-uniform values live in SGPRs: v_readlane, not a ds_bpermute round trip each)
     // flat candidate index t -> sorted row t + off[k], k = the last run that starts at or before t (empty runs share their successor's start)
     int pre[9], off[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      pre[k] = __shfl(inc - seg_len, k, 64);
-      off[k] = __shfl(seg_start, k, 64) - pre[k];
+      pre[k] = __builtin_amdgcn_readlane(inc - seg_len, k);
+      off[k] = __builtin_amdgcn_readlane(seg_start, k) - pre[k];
     }
 
     // Round 6: kRgAhead steps of 64 candidates are LOADED before the first is judged -- the loop was one dependent L2 / MALL round trip per
@@ -348,11 +349,53 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     int64_t* row = out + qi * (int64_t)width;
-    for (int e = lane; e < count; e += 64) {
-      const unsigned long long mine = keys[e];
-      int rank = 0;
-      for (int j = 0; j < count; ++j) rank += keys[j] < mine;  // broadcast LDS reads
-      if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
+    if (count <= kRgBucketMin || 2 * count > cap || !bucketed) {  // (the grouped copy lives in the upper half of the wave's key row)
+      for (int e = lane; e < count; e += 64) {
+        const unsigned long long mine = keys[e];
+        int rank = 0;
+        for (int j = 0; j < count; ++j) rank += keys[j] < mine;  // broadcast LDS reads
+        if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
+      }
+    } else {
+      // Round 6: a dense row (KITTI: 100-300 hits for a table of 40) ranked every key against every key -- count^2 / 64 LDS reads per
+      // lane, the longest part of such a query.  Now the keys are first dealt into 64 buckets of equal d^2 width (lane b <-> bucket b: a
+      // surface's hits are uniform in d^2), a key's rank is (keys in lower buckets) + (smaller keys in its own bucket), and only buckets
+      // that start below `width` are ranked at all.  Same (d^2, index) order: the same rows, bit for bit.
+      unsigned long long* keys2 = keys + cap / 2;                  // the keys grouped by bucket: count <= cap / 2 keys in the row's lower half
+      int* hist = reinterpret_cast<int*>(lds_keys + (size_t)4 * cap) + w * 192;  // [64] bucket sizes, [64] bucket starts, [64] fill cursors
+      hist[lane] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const float to_bucket = 64.0f / r2;
+      for (int e = lane; e < count; e += 64)
+        atomicAdd(&hist[min(63, (int)(__uint_as_float((unsigned)(keys[e] >> 32)) * to_bucket))], 1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int mine_n = hist[lane];
+      const int mine_start = wave_inclusive_scan(mine_n) - mine_n;
+      hist[64 + lane] = mine_start, hist[128 + lane] = mine_start;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int e = lane; e < count; e += 64) {  // (the order inside a bucket is whatever the atomics give: the ranks below do not depend on it)
+        const unsigned long long k = keys[e];
+        keys2[atomicAdd(&hist[128 + min(63, (int)(__uint_as_float((unsigned)(k >> 32)) * to_bucket))], 1)] = k;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int e = lane; e < count; e += 64) {  // position e of the grouped keys
+        const unsigned long long mine = keys2[e];
+        const int b = min(63, (int)(__uint_as_float((unsigned)(mine >> 32)) * to_bucket));
+        const int start = hist[64 + b];
+        if (start >= width) continue;  // the whole bucket lies beyond the table
+        const int end = start + hist[b];
+        int rank = start;
+        for (int j = start; j < end; ++j) rank += keys2[j] < mine;
+        if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
+      }
     }
     for (int j = count + lane; j < width; j += 64) row[j] = ns_total;  // pad (radius_neighbors_cpu.cpp:85)
     // the next query of this wave overwrites the key row: every lane's reads above come first
@@ -371,6 +414,14 @@ __global__ __launch_bounds__(256) void rg_query_kernel(const CloudGrid* __restri
 // back to back and a quarter as many waves carry the same work.  Same arithmetic, same (d^2, index) order: bit-identical rows.  A query
 // with more than 128 hits is redone by the whole wave on the wave's 512 keys (= the one-query kernel's capacity).
 constexpr int kQuadKeys = 128;
+// inclusive scan inside every aligned group of 16 lanes: four DPP row shifts (lanes shifting in from outside the row read 0)
+__device__ __forceinline__ int row16_inclusive_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
+  return x;
+}
 
 // __launch_bounds__(256, 5): the register allocation is held to 5 waves per SIMD (96 VGPRs, nothing spilled; uncapped the kernel took 98
 // = 4 waves).  Measured on a 16-pair 3DMatch stack (scripts/abi_bench.bin pyramid, profiles/r05_ab_runs.md): the whole pyramid 150.3 ->
@@ -379,8 +430,9 @@ __global__ __launch_bounds__(256, 5) void rg_query_quad_kernel(const CloudGrid* 
                                                             const float4* __restrict__ sorted, const float* __restrict__ q,
                                                             const int64_t* __restrict__ q_len, const int* __restrict__ q_order, int batch,
                                                             float r2, int width, int cap, int64_t* __restrict__ out,
-                                                            int* __restrict__ overflow) {
+                                                            int* __restrict__ overflow, int bucketed) {
   __shared__ __attribute__((aligned(16))) unsigned long long quad_keys[4][4 * kQuadKeys];
+  __shared__ int quad_hist[4][4][48];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int grp = lane >> 4, l = lane & 15;
   unsigned long long* wave_keys = quad_keys[w];
@@ -422,12 +474,7 @@ __global__ __launch_bounds__(256, 5) void rg_query_quad_kernel(const CloudGrid* 
         seg_len = cell_start[row + x1 + 1] - seg_start;
       }
     }
-    int inc = seg_len;  // inclusive scan inside the 16-lane group
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      const int t = __shfl_up(inc, o, 16);
-      if (l >= o) inc += t;
-    }
+    const int inc = row16_inclusive_scan(seg_len);  // inclusive scan inside the 16-lane group
     const int total = __shfl(inc, 8, 16);
     int pre[9], off[9];  // flat candidate index t -> sorted row t + off[k] (see rg_query_kernel)
 #pragma unroll
@@ -468,15 +515,49 @@ __global__ __launch_bounds__(256, 5) void rg_query_quad_kernel(const CloudGrid* 
     const int count = base;
     const bool dense = has_q && count > kQuadKeys;
     wave_sync();
-    // ranking inside the group: lane l takes keys l, l + 16, ...; every key of the row is read as a broadcast within the group
+    // ranking inside the group.  Rows of 17 .. 64 hits (the usual case: ~38 on a 3DMatch surface) are first dealt into 16 buckets of equal
+    // d^2 width (lane l <-> bucket l), so a key is compared with its own bucket only -- see rg_query_kernel; the grouped copy lives in the
+    // upper half of the group's key row.  Other rows: lane l takes keys l, l + 16, ... against every key of the row (broadcast reads).
     int64_t* row = out + (int64_t)qi * width;
+    const bool by_bucket = bucketed && has_q && !dense && count > 16 && 2 * count <= kQuadKeys;
+    int* hist = quad_hist[w][grp];  // [16] bucket sizes, [16] bucket starts, [16] fill cursors
+    const float to_bucket = 16.0f / r2;
+    if (__any(by_bucket)) {  // (the four groups of the wave walk these steps together; a group that does not take part idles through them)
+      hist[l] = 0;
+      wave_sync();
+      if (by_bucket)
+        for (int e = l; e < count; e += 16) atomicAdd(&hist[min(15, (int)(__uint_as_float((unsigned)(keys[e] >> 32)) * to_bucket))], 1);
+      wave_sync();
+      const int mine_n = hist[l];
+      const int mine_start = row16_inclusive_scan(mine_n) - mine_n;
+      hist[16 + l] = mine_start, hist[32 + l] = mine_start;
+      wave_sync();
+      if (by_bucket)
+        for (int e = l; e < count; e += 16) {
+          const unsigned long long k = keys[e];
+          keys[kQuadKeys / 2 + atomicAdd(&hist[32 + min(15, (int)(__uint_as_float((unsigned)(k >> 32)) * to_bucket))], 1)] = k;
+        }
+      wave_sync();
+      if (by_bucket)
+        for (int e = l; e < count; e += 16) {  // position e of the grouped keys
+          const unsigned long long mine = keys[kQuadKeys / 2 + e];
+          const int b = min(15, (int)(__uint_as_float((unsigned)(mine >> 32)) * to_bucket));
+          const int start = hist[16 + b];
+          if (start >= width) continue;  // the whole bucket lies beyond the table
+          const int end = start + hist[b];
+          int rank = start;
+          for (int j = start; j < end; ++j) rank += keys[kQuadKeys / 2 + j] < mine;
+          if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
+        }
+    }
     if (has_q && !dense) {
-      for (int e = l; e < count; e += 16) {
-        const unsigned long long mine = keys[e];
-        int rank = 0;
-        for (int j = 0; j < count; ++j) rank += keys[j] < mine;
-        if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
-      }
+      if (!by_bucket)
+        for (int e = l; e < count; e += 16) {
+          const unsigned long long mine = keys[e];
+          int rank = 0;
+          for (int j = 0; j < count; ++j) rank += keys[j] < mine;
+          if (rank < width) row[rank] = (int64_t)(unsigned)(mine & 0xffffffffull) + g.s_start;
+        }
       for (int j = count + l; j < width; j += 16) row[j] = ns_total;  // pad (radius_neighbors_cpu.cpp:85)
     }
     wave_sync();
@@ -1235,6 +1316,10 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
     const char* e = std::getenv("GEOTR_RG_TILE");
     return e && e[0] == '1';
   }();
+  static const bool bucket_rank = [] {
+    const char* e = std::getenv("GEOTR_RG_BUCKETS");  // A/B switch: 0 = every row is ranked key against key
+    return !(e && e[0] == '0');
+  }();
   static const int quad_mode = [] {
     const char* e = std::getenv("GEOTR_RG_QUAD");  // A/B switch: 0 = one query per wave everywhere; 2 = quad in row order; 3 = quad even for dense searches
     return e ? std::atoi(e) : 1;
@@ -1247,7 +1332,7 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
     const int64_t quads = (expect + 3) / 4;
     const int* order = (quad_mode == 2 || quad_mode == 4) ? nullptr : q_order;
     rg_query_quad_kernel<<<dim3((unsigned)((quads + 3) / 4)), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, order, (int)batch, r2,
-                                                                                     (int)width, (int)cap, out, overflow);
+                                                                                     (int)width, (int)cap, out, overflow, bucket_rank ? 1 : 0);
     GEOTR_CHECK_LAUNCH("radius_query(quad)");
     return GEOTR_OK;
   }
@@ -1270,9 +1355,11 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
   }();
   if (count_only) {
     rg_query_kernel<true><<<dim3(nb), dim3(256), 0, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
-                                                             r2, 0, 0, nullptr, counts, max_count, nullptr, nullptr);
+                                                             r2, 0, 0, nullptr, counts, max_count, nullptr, nullptr, 0);
   } else {
-    const size_t lds = (size_t)cap * 4 * sizeof(unsigned long long);
+    const bool bucketed = bucket_rank && cap <= 512;
+    // per wave: the compacted keys (a row of <= cap / 2 hits is regrouped by bucket into its upper half); behind the four waves' rows: bucket sizes, starts, fill cursors
+    const size_t lds = (size_t)cap * 4 * sizeof(unsigned long long) + (bucketed ? 4 * 192 * sizeof(int) : 0);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rg_query_kernel<false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1280,7 +1367,7 @@ int radius_query_hinted(bool count_only, const void* grid_ws, const float* q, co
     }
     rg_query_kernel<false><<<dim3(nb), dim3(256), lds, stream>>>(L.hdr, L.cell_start, L.sorted, q, q_len, (int)batch, nq,
                                                                 r2, (int)width, (int)cap, out, nullptr,
-                                                                nullptr, overflow, dense_order ? q_order : nullptr);
+                                                                nullptr, overflow, dense_order ? q_order : nullptr, bucketed ? 1 : 0);
   }
   GEOTR_CHECK_LAUNCH("radius_query");
   return GEOTR_OK;
