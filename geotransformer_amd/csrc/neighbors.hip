@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256, 5) void rg_query_quad_kernel(const CloudGrid* 
                                                             float r2, int width, int cap, int64_t* __restrict__ out,
                                                             int* __restrict__ overflow, int bucketed) {
   __shared__ __attribute__((aligned(16))) unsigned long long quad_keys[4][4 * kQuadKeys];
-  __shared__ int quad_hist[4][4][48];
+  __shared__ __attribute__((aligned(16))) int quad_hist[4][4][48];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int grp = lane >> 4, l = lane & 15;
   unsigned long long* wave_keys = quad_keys[w];
@@ -475,13 +475,22 @@ __global__ __launch_bounds__(256, 5) void rg_query_quad_kernel(const CloudGrid* 
       }
     }
     const int inc = row16_inclusive_scan(seg_len);  // inclusive scan inside the 16-lane group
-    const int total = __shfl(inc, 8, 16);
+    // the group's run table through LDS: lanes 0 .. 8 park (start of run k in the flat candidate space, sorted row - that start), every lane
+    // reads the 18 words back with five 16-byte broadcast reads (was: 19 ds_bpermute round trips per quad)
+    int* runtab = quad_hist[w][grp];  // (free here: the ranking of the previous quad is behind a wave_sync) [0..8] pre, [9..17] off, [18] total
+    if (l < 9) runtab[l] = inc - seg_len, runtab[9 + l] = seg_start - (inc - seg_len);
+    if (l == 8) runtab[18] = inc;
+    wave_sync();
     int pre[9], off[9];  // flat candidate index t -> sorted row t + off[k] (see rg_query_kernel)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      pre[k] = __shfl(inc - seg_len, k, 16);
-      off[k] = __shfl(seg_start, k, 16) - pre[k];
+    int total;
+    {
+      const int4 q0 = *reinterpret_cast<const int4*>(runtab), q1 = *reinterpret_cast<const int4*>(runtab + 4), q2 = *reinterpret_cast<const int4*>(runtab + 8),
+                 q3 = *reinterpret_cast<const int4*>(runtab + 12), q4 = *reinterpret_cast<const int4*>(runtab + 16);
+      pre[0] = q0.x, pre[1] = q0.y, pre[2] = q0.z, pre[3] = q0.w, pre[4] = q1.x, pre[5] = q1.y, pre[6] = q1.z, pre[7] = q1.w, pre[8] = q2.x;
+      off[0] = q2.y, off[1] = q2.z, off[2] = q2.w, off[3] = q3.x, off[4] = q3.y, off[5] = q3.z, off[6] = q3.w, off[7] = q4.x, off[8] = q4.y;
+      total = q4.z;
     }
+    wave_sync();  // (the table's words are the ranking's bucket counters later in this quad)
     int most = total;  // the longest candidate list of the four
     most = max(most, __shfl_xor(most, 16, 64));
     most = max(most, __shfl_xor(most, 32, 64));
