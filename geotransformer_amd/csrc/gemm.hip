@@ -877,6 +877,148 @@ void gemm_packed_kernel(PackedArgs g) {
                                 g.partial + (int64_t)blockIdx.z * g.M * g.N, g.N);
 }
 
+// ---- round 6: K <= 64, exact fp32 -- a PERSISTENT block per CU that pipelines over ROW TILES ---------------------------
+// A launch like (640 000, 128, 32 | 64) has one or two 32-deep stages per 128-row tile: in gemm_packed_kernel every block pays the load
+// latency of its only stage(s) and the drain of its stores with just two blocks per CU to hide them, and re-reads the same 16-32 KB of
+// weight -- 157 / 207 us against HBM floors of 82 / 98 us (profiles/r06_ab_runs.md).  Here a block keeps the weight of its column block in
+// LDS for its whole life, walks the row tiles of its XCD share (column block fixed), and runs a three-slot ring of ACTIVATION stages across
+// tile boundaries: the DMA of stage s + 2 is issued before the MFMAs of stage s, so loads fly under two stages of matrix work and under the
+// epilogue of the tile in between; the epilogue (epilogue_lds: bias, statistics records, affine, residual, activation -- unchanged) has
+// its own slab, so stores drain while the next tile multiplies.  LDS: 2 x 16 KB weight + 3 x 16 KB ring + 70 KB slab = 150 KB, one block
+// per CU.  Same MFMA sequence per output element as gemm_packed_kernel<WM, WN, 0>: bit-identical results.
+// Synchronisation: a wave waits `vmcnt(4)` after the MFMAs of stage s -- at most its four newest vector-memory operations, the DMA of
+// stage s + 2 issued at the top of the iteration, may be outstanding; loads retire in order, so its share of stage s + 1 has landed --
+// then the block barrier publishes stage s + 1 and certifies that every wave has read stage s (its slot is the target of the next DMA).
+template <int WM, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void gemm_packed_smallk_kernel(PackedArgs g) {
+  constexpr int BM = 128, RING = 3;
+  constexpr int WAVES_M = BM / (32 * WM), WAVES_N = 4 / WAVES_M, NT_BLK = WN * WAVES_N;
+  constexpr int A_BYTES = BM * 128, B_BYTES = NT_BLK * 4 * 1024;  // one 32-deep stage: activation tile / the column block's weight
+  constexpr int B_PER_WAVE = NT_BLK;                                // 1 KB weight chunks per wave and stage (NT_BLK * 4 in all)
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+  unsigned char* wsm = psm;                              // [2][B_BYTES]
+  unsigned char* ring = psm + 2 * B_BYTES;               // [RING][A_BYTES]
+  float* slab_all = reinterpret_cast<float*>(psm + 2 * B_BYTES + RING * A_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xcd = (int)blockIdx.x & 7, nbx = (int)gridDim.x >> 3;
+  const int tile_end = min(g.nx * g.ny, (xcd + 1) * g.tiles_per_xcd);
+  const int tile0 = xcd * g.tiles_per_xcd + ((int)blockIdx.x >> 3);  // this block's tiles: tile0, tile0 + nbx, ... (nbx % nx == 0: one column block)
+  if (tile0 >= tile_end) return;                                     // (uniform per block: before any barrier)
+  const int my_tiles = (tile_end - tile0 + nbx - 1) / nbx;
+  const int nkt = g.KS / 2;                                          // 1 or 2 (host)
+  const int total_stages = my_tiles * nkt;
+  const int ct0 = (tile0 % g.nx) * NT_BLK;
+  const int wrow = (wave / WAVES_N) * 32 * WM, wctl = (wave % WAVES_N) * WN;
+  const int fr = lane & 31, fk = lane >> 5;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)psm;
+  struct Geo {
+    int by, m0, m_end, sgi;
+  };
+  auto geo_of = [&](int i) -> Geo {  // the i-th tile of this block
+    Geo q;
+    q.by = (tile0 + i * nbx) / g.nx;
+    q.m0 = q.by * BM, q.m_end = g.M, q.sgi = 0;
+    if (g.nseg > 0) {
+      while (q.sgi + 1 < g.nseg && q.by >= g.seg_tile0[q.sgi + 1]) ++q.sgi;
+      q.m0 = g.seg_row0[q.sgi] + (q.by - g.seg_tile0[q.sgi]) * BM;
+      q.m_end = g.seg_row0[q.sgi + 1];
+    }
+    return q;
+  };
+  auto issue_a = [&](int s_) {  // activation stage s_ (tile s_ / nkt, 32-deep step s_ % nkt) into its ring slot: four 1 KB DMAs per wave
+    const Geo q = geo_of(s_ / nkt);
+    unsigned char* st = ring + (s_ % RING) * A_BYTES;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = 8 * (4 * wave + t) + (lane >> 3);
+      const int c = (lane & 7) ^ (r & 7);
+      const int gm = min(q.m0 + r, q.m_end - 1);  // rows past the segment's end: any valid row (never stored)
+      const float* src = g.A + (int64_t)gm * g.lda + 4 * c + (s_ % nkt) * 32;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + (4 * wave + t) * 1024), 16, 0, 0);
+    }
+  };
+  // the column block's weight, once: chunk (ctl, q) of stage kt = 8-deep group q of the stage (packed by geotr_gemm_pack_f32)
+  for (int kt = 0; kt < nkt; ++kt)
+#pragma unroll
+    for (int t = 0; t < B_PER_WAVE; ++t) {
+      const int idx = wave + 4 * t, ctl = idx >> 2, q = idx & 3;
+      const int ct = min(ct0 + ctl, g.NT - 1);
+      const unsigned short* src = g.Bhi + (((int64_t)ct * 2 * g.KS + 4 * kt + q) * 64 + lane) * 8;  // 16 B per lane
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(wsm + kt * B_BYTES + idx * 1024), 16, 0, 0);
+    }
+  issue_a(0);
+  if (total_stages > 1) issue_a(1);
+  GEOTR_WAIT_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+  f32x16 acc[WM][WN];
+  u32x4 fb[2][2][2];  // [step of the stage][8-deep group of the step][column tile]
+  u32x4 fa[2][2][2];  // [step][row tile][8-deep group of the step]
+  for (int s_ = 0; s_ < total_stages; ++s_) {
+    const int kt = s_ % nkt;
+    if (kt == 0) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    const bool more = s_ + 2 < total_stages;
+    if (more) issue_a(s_ + 2);  // into the slot of stage s_ - 1: every wave has passed the barrier behind its reads
+    {  // fragment reads of both 16-deep steps, then the MFMAs (nothing touches a fragment register between its read and the wait)
+      const unsigned ast = lds_base + 2 * B_BYTES + (s_ % RING) * A_BYTES, wst = lds_base + kt * B_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const unsigned ab = wst + (wctl * 4 + 2 * ks) * 1024 + lane * 16;
+        lds_issue2<1024>(ab, fb[ks][0][0], fb[ks][1][0]);
+        if constexpr (WN == 2) lds_issue2<1024>(ab + 4096, fb[ks][0][1], fb[ks][1][1]);
+        const int r = wrow + fr, c0 = 4 * ks + fk;
+        const unsigned a0 = ast + (r * 8 + (c0 ^ (r & 7))) * 16, a1 = ast + (r * 8 + ((c0 + 2) ^ (r & 7))) * 16;
+        if constexpr (WM == 2) {
+          lds_issue2<4096>(a0, fa[ks][0][0], fa[ks][1][0]);
+          lds_issue2<4096>(a1, fa[ks][0][1], fa[ks][1][1]);
+        } else {
+          lds_issue1(a0, fa[ks][0][0]);
+          lds_issue1(a1, fa[ks][0][1]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (WM == 2) lds_wait(fa[ks][0][0], fa[ks][1][0], fa[ks][0][1], fa[ks][1][1]);
+        else lds_wait(fa[ks][0][0], fa[ks][0][1]);
+        if constexpr (WN == 2) lds_wait(fb[ks][0][0], fb[ks][1][0], fb[ks][0][1], fb[ks][1][1]);
+        else lds_wait(fb[ks][0][0], fb[ks][1][0]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+              for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[ks][i][c][e]), __uint_as_float(fb[ks][c][j][e]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) GEOTR_WAIT_VMCNT(4);
+    else GEOTR_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();  // stage s_ + 1 complete for every wave; every wave holds its stage-s_ fragments in registers
+    if (kt == nkt - 1) {           // the tile is finished: epilogue through this wave's own slab, stores drain under the next tile
+      const Geo q = geo_of(s_ / nkt);
+      float* slab = slab_all + wave * (32 * WM * (32 * WN + 4));
+      epilogue_lds<WM, WN>(acc, slab, lane, q.m0 + wrow, 32 * (ct0 + wctl), q.m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act, g.C,
+                           g.ldc, g.stats ? g.stats + ((int64_t)q.by * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr, g.gres,
+                           g.seg_affine ? g.seg_affine + (int64_t)q.sgi * 2 * g.N : nullptr);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the slab is this wave's alone: its next tile's writes stay behind these reads)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
 // out = act(alpha * (sum over z, in z order) partial[z] / row_div + bias + residual): the epilogue of a split-K launch.  One float4
 // per thread when N % 4 == 0 and everything is 16-byte aligned (the packed path's shapes), scalar otherwise.
 template <bool VEC>
@@ -1155,6 +1297,25 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   // 501 vs 959 pairs/s).  Variants of this launch that were built, measured within +-3 % and removed in round 5 (git history; numbers in
   // profiles/r04_ab_runs.md sections 6, 8, 11): a persistent multi-tile form, weight fragments straight from L2 (three blocks per CU),
   // a half-block start stagger of the second resident block, a two-slot ring for the deep launches.
+  // Round 6: K <= 64 in exact fp32 on the 128-wide tile, enough row tiles to give every block several: the persistent kernel
+  // (gemm_packed_smallk_kernel).  GEOTR_GEMM_SMALLK=0 keeps gemm_packed_kernel (measurement switch).
+  if constexpr (TERMS == 0) {
+    const char* smallk_env = std::getenv("GEOTR_GEMM_SMALLK");  // (read per launch: tests/test_gemm_gpu.py runs both kernels in one process)
+    const bool smallk = !(smallk_env && smallk_env[0] == '0');
+    const int nx = (int)((N + 127) / 128);
+    if (smallk && splits == 1 && nkt_all <= 2 && bn == 128 && tiles * nx >= 1024) {
+      constexpr int lds = 2 * 16384 + 3 * 16384 + 4 * 64 * 68 * 4;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_smallk_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+          hipSuccess)
+        return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);
+      g.nx = nx, g.ny = (int)gy, g.tiles_per_xcd = (int)(((int64_t)g.nx * g.ny + 7) / 8);
+      int nbx = 32 / nx * nx;  // blocks per XCD: one per CU, a multiple of the column blocks so that a block keeps ONE column block
+      if (nbx < nx) nbx = nx;
+      gemm_packed_smallk_kernel<2, 2><<<dim3((unsigned)(8 * nbx)), dim3(256), lds, stream>>>(g);
+      GEOTR_CHECK_LAUNCH("gemm_packed(small K)");
+      return GEOTR_OK;
+    }
+  }
   const bool deep = TERMS == 0 && g.kt_split >= 6 && bn == 64;
   if (bn == 64 && deep) GEOTR_PACKED(1, 2, 64, 3);
   else if (bn == 128) GEOTR_PACKED(2, 2, 128, 2);
