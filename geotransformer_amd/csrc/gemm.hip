@@ -877,253 +877,6 @@ void gemm_packed_kernel(PackedArgs g) {
                                 g.partial + (int64_t)blockIdx.z * g.M * g.N, g.N);
 }
 
-// The epilogue of the persistent kernel below: epilogue_lds's arithmetic for the launches that kernel takes (alpha, bias, activation,
-// statistics records; no row_div / residual / gathered rows / affine), with every slab access in inline asm.  An LDS DMA of a later
-// stage is in flight while this runs: the compiler would put `s_waitcnt vmcnt(0)` in front of the first ds_read it can see -- and in
-// front of the first use of an ordinary global load (the bias: held in registers by the caller) -- and drain it.
-__device__ __forceinline__ void lds_store1(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory"); }
-template <int WM, int WN>
-__device__ __forceinline__ void epilogue_lds_async(const f32x16 (&acc)[WM][WN], unsigned slab, int lane, int row0, int col0, int M, int N, float alpha,
-                                                   const float (&bv)[4], int act, float* __restrict__ C, int64_t ldc, float* __restrict__ stats_rec) {
-  constexpr int TW = 32 * WN, TS = TW + 4;
-  const int fr = lane & 31, fk = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) lds_store1(slab + ((32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk) * TS + 32 * j + fr) * 4, acc[i][j][r]);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  constexpr int V4 = TW / 4, RPI = 64 / V4;  // float4 per row, rows per wave instruction
-  const int cq = (lane % V4) * 4, rl = lane / V4;
-  const int gn = col0 + cq;
-  float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
-  // all row pieces of the wave are read back in one batch (one LDS round trip, not one per piece: with one wave per SIMD nothing else hides it)
-  constexpr int NP = 32 * WM / RPI;
-  u32x4 rawv[NP];
-#pragma unroll
-  for (int t = 0; t < NP; ++t) lds_issue1(slab + ((rl + RPI * t) * TS + cq) * 4, rawv[t]);
-#pragma unroll
-  for (int t = 0; t < NP; t += 4) lds_wait(rawv[t], rawv[t + 1], rawv[t + 2], rawv[t + 3]);
-#pragma unroll
-  for (int t = 0; t < NP; ++t) {
-    const int rs = rl + RPI * t;
-    const int gm = row0 + rs;
-    const u32x4 raw = rawv[t];
-    if (gm >= M || gn >= N) continue;
-    float x[4] = {__uint_as_float(raw.x) * alpha, __uint_as_float(raw.y) * alpha, __uint_as_float(raw.z) * alpha, __uint_as_float(raw.w) * alpha};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      x[e] += bv[e];
-      if (act == 1) x[e] = fmaxf(x[e], 0.f);
-      if (act == 2) x[e] = x[e] > 0.f ? x[e] : 0.1f * x[e];
-    }
-    if (C) *reinterpret_cast<float4*>(C + (int64_t)gm * ldc + gn) = make_float4(x[0], x[1], x[2], x[3]);
-    if (stats_rec) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        st_s[e] += x[e];
-        st_q[e] = fmaf(x[e], x[e], st_q[e]);
-      }
-    }
-  }
-  if (stats_rec) {  // (wave-uniform: every lane takes part in the shuffles)
-#pragma unroll
-    for (int o = V4; o < 64; o <<= 1)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        st_s[e] += __shfl_xor(st_s[e], o, 64);
-        st_q[e] += __shfl_xor(st_q[e], o, 64);
-      }
-    if (rl == 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        stats_rec[gn + e] = st_s[e];
-        stats_rec[N + gn + e] = st_q[e];
-      }
-    }
-  }
-}
-
-// ---- round 6: K <= 64, exact fp32 -- a PERSISTENT block per CU that pipelines over ROW TILES ---------------------------
-// A launch like (640 000, 128, 32 | 64) has one or two 32-deep stages per 128-row tile: in gemm_packed_kernel every block pays the load
-// latency of its only stage(s) and the drain of its stores with just two blocks per CU to hide them, and re-reads the same 16-32 KB of
-// weight -- 157 / 207 us against HBM floors of 82 / 98 us (profiles/r06_ab_runs.md).  Here a block keeps the weight of its column block in
-// LDS for its whole life, walks the row tiles of its XCD share (column block fixed), and runs a three-slot ring of ACTIVATION stages across
-// tile boundaries: the DMA of stage s + 2 is issued before the MFMAs of stage s, so loads fly under two stages of matrix work and under the
-// epilogue of the tile in between; the epilogue (epilogue_lds: bias, statistics records, affine, residual, activation -- unchanged) has
-// its own slab, so stores drain while the next tile multiplies.  LDS: 2 x 16 KB weight + 3 x 16 KB ring + 70 KB slab = 150 KB, one block
-// per CU.  Same MFMA sequence per output element as gemm_packed_kernel<WM, WN, 0>: bit-identical results.
-// Synchronisation: a wave waits `vmcnt(4)` after the MFMAs of stage s -- at most its four newest vector-memory operations, the DMA of
-// stage s + 2 issued at the top of the iteration, may be outstanding; loads retire in order, so its share of stage s + 1 has landed --
-// then the block barrier publishes stage s + 1 and certifies that every wave has read stage s (its slot is the target of the next DMA).
-template <int WM, int WN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void gemm_packed_smallk_kernel(PackedArgs g) {
-  constexpr int BM = 128, RING = 3;
-  constexpr int WAVES_M = BM / (32 * WM), WAVES_N = 4 / WAVES_M, NT_BLK = WN * WAVES_N;
-  constexpr int A_BYTES = BM * 128, B_BYTES = NT_BLK * 4 * 1024;  // one 32-deep stage: activation tile / the column block's weight
-  constexpr int B_PER_WAVE = NT_BLK;                                // 1 KB weight chunks per wave and stage (NT_BLK * 4 in all)
-  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
-  unsigned char* wsm = psm;                              // [2][B_BYTES]
-  unsigned char* ring = psm + 2 * B_BYTES;               // [RING][A_BYTES]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int xcd = (int)blockIdx.x & 7, nbx = (int)gridDim.x >> 3;
-  const int tile_end = min(g.nx * g.ny, (xcd + 1) * g.tiles_per_xcd);
-  const int tile0 = xcd * g.tiles_per_xcd + ((int)blockIdx.x >> 3);  // this block's tiles: tile0, tile0 + nbx, ... (nbx % nx == 0: one column block)
-  if (tile0 >= tile_end) return;                                     // (uniform per block: before any barrier)
-  const int my_tiles = (tile_end - tile0 + nbx - 1) / nbx;
-  const int nkt = g.KS / 2;                                          // 1 or 2 (host)
-  const int total_stages = my_tiles * nkt;
-  const int ct0 = (tile0 % g.nx) * NT_BLK;
-  const int wrow = (wave / WAVES_N) * 32 * WM, wctl = (wave % WAVES_N) * WN;
-  const int fr = lane & 31, fk = lane >> 5;
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)psm;
-  struct Geo {
-    int by, m0, m_end, sgi;
-  };
-  int sgi_hint = 0;  // (the tiles of a block ascend: the segment search resumes where the last one ended)
-  auto geo_of = [&](int i) -> Geo {  // the i-th tile of this block
-    Geo q;
-    q.by = (tile0 + i * nbx) / g.nx;
-    q.m0 = q.by * BM, q.m_end = g.M, q.sgi = 0;
-    if (g.nseg > 0) {
-      q.sgi = q.by >= g.seg_tile0[sgi_hint] ? sgi_hint : 0;
-      while (q.sgi + 1 < g.nseg && q.by >= g.seg_tile0[q.sgi + 1]) ++q.sgi;
-      sgi_hint = q.sgi;
-      q.m0 = g.seg_row0[q.sgi] + (q.by - g.seg_tile0[q.sgi]) * BM;
-      q.m_end = g.seg_row0[q.sgi + 1];
-    }
-    return q;
-  };
-  auto issue_a = [&](int s_) {  // activation stage s_ (tile s_ / nkt, 32-deep step s_ % nkt) into its ring slot: four 1 KB DMAs per wave
-    const Geo q = geo_of(s_ / nkt);
-    unsigned char* st = ring + (s_ % RING) * A_BYTES;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int r = 8 * (4 * wave + t) + (lane >> 3);
-      const int c = (lane & 7) ^ (r & 7);
-      const int gm = min(q.m0 + r, q.m_end - 1);  // rows past the segment's end: any valid row (never stored)
-      const float* src = g.A + (int64_t)gm * g.lda + 4 * c + (s_ % nkt) * 32;
-      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + (4 * wave + t) * 1024), 16, 0, 0);
-    }
-  };
-  // the column block's weight, once: chunk (ctl, q) of stage kt = 8-deep group q of the stage (packed by geotr_gemm_pack_f32)
-  for (int kt = 0; kt < nkt; ++kt)
-#pragma unroll
-    for (int t = 0; t < B_PER_WAVE; ++t) {
-      const int idx = wave + 4 * t, ctl = idx >> 2, q = idx & 3;
-      const int ct = min(ct0 + ctl, g.NT - 1);
-      const unsigned short* src = g.Bhi + (((int64_t)ct * 2 * g.KS + 4 * kt + q) * 64 + lane) * 8;  // 16 B per lane
-      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(wsm + kt * B_BYTES + idx * 1024), 16, 0, 0);
-    }
-  // the lane's four bias values (its columns are the same in every tile): loaded before any DMA is in flight
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  {
-    constexpr int V4 = 32 * WN / 4;
-    const int gn = 32 * (ct0 + wctl) + (lane % V4) * 4;
-    if (g.bias && gn + 3 < g.N) {
-      const float4 q4 = *reinterpret_cast<const float4*>(g.bias + gn);
-      bv[0] = q4.x, bv[1] = q4.y, bv[2] = q4.z, bv[3] = q4.w;
-    }
-  }
-  issue_a(0);
-  if (total_stages > 1) issue_a(1);
-  GEOTR_WAIT_VMCNT(0);
-  __builtin_amdgcn_s_barrier();
-  // vector-memory operations a wave issues per FULL tile's epilogue: 16 row stores (+ 8 statistics stores); a partly filled tile issues
-  // fewer, so the wait behind it is the conservative one
-  const int full_stores = (32 * WM) / (64 / (32 * WN / 4)) + (g.stats ? 8 : 0);
-  int stores_behind = -1;  // stores issued since the DMA the next wait is for (-1: unknown -> wait for everything but the newest DMA)
-  f32x16 acc[WM][WN];
-  u32x4 fb[2][2][2];  // [step of the stage][8-deep group of the step][column tile]
-  u32x4 fa[2][2][2];  // [step][row tile][8-deep group of the step]
-#ifdef GEOTR_SK_STAMPS
-  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
-#define SK_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp[i] += now_ - t_prev; t_prev = now_; } while (0)
-#else
-#define SK_STAMP(i) do {} while (0)
-#endif
-  for (int s_ = 0; s_ < total_stages; ++s_) {
-    const int kt = s_ % nkt;
-    if (kt == 0) {
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    }
-    const bool more = s_ + 2 < total_stages;
-    if (more) issue_a(s_ + 2);  // into the slot of stage s_ - 1: every wave has passed the barrier behind its reads
-    SK_STAMP(0);
-    {  // fragment reads of both 16-deep steps, then the MFMAs (nothing touches a fragment register between its read and the wait)
-      const unsigned ast = lds_base + 2 * B_BYTES + (s_ % RING) * A_BYTES, wst = lds_base + kt * B_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const unsigned ab = wst + (wctl * 4 + 2 * ks) * 1024 + lane * 16;
-        lds_issue2<1024>(ab, fb[ks][0][0], fb[ks][1][0]);
-        if constexpr (WN == 2) lds_issue2<1024>(ab + 4096, fb[ks][0][1], fb[ks][1][1]);
-        const int r = wrow + fr, c0 = 4 * ks + fk;
-        const unsigned a0 = ast + (r * 8 + (c0 ^ (r & 7))) * 16, a1 = ast + (r * 8 + ((c0 + 2) ^ (r & 7))) * 16;
-        if constexpr (WM == 2) {
-          lds_issue2<4096>(a0, fa[ks][0][0], fa[ks][1][0]);
-          lds_issue2<4096>(a1, fa[ks][0][1], fa[ks][1][1]);
-        } else {
-          lds_issue1(a0, fa[ks][0][0]);
-          lds_issue1(a1, fa[ks][0][1]);
-        }
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if constexpr (WM == 2) lds_wait(fa[ks][0][0], fa[ks][1][0], fa[ks][0][1], fa[ks][1][1]);
-        else lds_wait(fa[ks][0][0], fa[ks][0][1]);
-        if constexpr (WN == 2) lds_wait(fb[ks][0][0], fb[ks][1][0], fb[ks][0][1], fb[ks][1][1]);
-        else lds_wait(fb[ks][0][0], fb[ks][1][0]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-              for (int j = 0; j < WN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[ks][i][c][e]), __uint_as_float(fb[ks][c][j][e]), acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    SK_STAMP(1);
-    // wait for this wave's share of stage s_ + 1: the operations issued after it are (the previous epilogue's stores, if that tile ended between)
-    // + the 4 DMAs of stage s_ + 2; loads and stores retire in order, so an exact count leaves those stores in flight
-    if (!more) GEOTR_WAIT_VMCNT(0);
-    else if (stores_behind == 16) GEOTR_WAIT_VMCNT(20);
-    else if (stores_behind == 24) GEOTR_WAIT_VMCNT(28);
-    else if (stores_behind == 0) GEOTR_WAIT_VMCNT(4);
-    else GEOTR_WAIT_VMCNT(4);
-    stores_behind = 0;
-    SK_STAMP(2);
-    __builtin_amdgcn_s_barrier();  // stage s_ + 1 complete for every wave; every wave holds its stage-s_ fragments in registers
-    SK_STAMP(3);
-    if (kt == nkt - 1) {           // the tile is finished: epilogue through this wave's own slab, stores drain under the next tile
-      const Geo q = geo_of(s_ / nkt);
-      const unsigned slab = lds_base + 2 * B_BYTES + RING * A_BYTES + wave * (32 * WM * (32 * WN + 4)) * 4;
-      epilogue_lds_async<WM, WN>(acc, slab, lane, q.m0 + wrow, 32 * (ct0 + wctl), q.m_end, g.N, g.alpha, bv, g.act, g.C, g.ldc,
-                                 g.stats ? g.stats + ((int64_t)q.by * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr);
-      // (the slab is this wave's alone; its reads above were waited for one by one)
-      stores_behind = (q.m0 + wrow + 32 * WM <= q.m_end && g.C) ? full_stores : -1;
-      SK_STAMP(4);
-    }
-  }
-#ifdef GEOTR_SK_STAMPS
-  if (blockIdx.x == 8 && tid == 0)
-    printf("smallk stamps (wave 0 of block 8, %d tiles, nkt %d): issue %llu  reads+mfma %llu  vmcnt %llu  barrier %llu  epilogue %llu  (s_memtime ticks)\n", my_tiles, nkt,
-           stamp[0], stamp[1], stamp[2], stamp[3], stamp[4]);
-#endif
-}
-
 // out = act(alpha * (sum over z, in z order) partial[z] / row_div + bias + residual): the epilogue of a split-K launch.  One float4
 // per thread when N % 4 == 0 and everything is 16-byte aligned (the packed path's shapes), scalar otherwise.
 template <bool VEC>
@@ -1402,26 +1155,6 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   // 501 vs 959 pairs/s).  Variants of this launch that were built, measured within +-3 % and removed in round 5 (git history; numbers in
   // profiles/r04_ab_runs.md sections 6, 8, 11): a persistent multi-tile form, weight fragments straight from L2 (three blocks per CU),
   // a half-block start stagger of the second resident block, a two-slot ring for the deep launches.
-  // Round 6: K <= 64 in exact fp32 on the 128-wide tile, enough row tiles to give every block several: the persistent kernel
-  // (gemm_packed_smallk_kernel).  GEOTR_GEMM_SMALLK=0 keeps gemm_packed_kernel (measurement switch).
-  if constexpr (TERMS == 0) {
-    const char* smallk_env = std::getenv("GEOTR_GEMM_SMALLK");  // (read per launch: tests/test_gemm_gpu.py runs both kernels in one process)
-    const bool smallk = !(smallk_env && smallk_env[0] == '0');
-    const int nx = (int)((N + 127) / 128);
-    if (smallk && splits == 1 && nkt_all <= 2 && bn == 128 && tiles * nx >= 1024 && !row_div && !residual && !g.gres.src && !seg_affine && C && N % 128 == 0 &&
-        (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) {
-      constexpr int lds = 2 * 16384 + 3 * 16384 + 4 * 64 * 68 * 4;
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_packed_smallk_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-          hipSuccess)
-        return fail(GEOTR_E_LAUNCH, "gemm_packed: cannot reserve %d B of LDS", lds);
-      g.nx = nx, g.ny = (int)gy, g.tiles_per_xcd = (int)(((int64_t)g.nx * g.ny + 7) / 8);
-      int nbx = 32 / nx * nx;  // blocks per XCD: one per CU, a multiple of the column blocks so that a block keeps ONE column block
-      if (nbx < nx) nbx = nx;
-      gemm_packed_smallk_kernel<2, 2><<<dim3((unsigned)(8 * nbx)), dim3(256), lds, stream>>>(g);
-      GEOTR_CHECK_LAUNCH("gemm_packed(small K)");
-      return GEOTR_OK;
-    }
-  }
   const bool deep = TERMS == 0 && g.kt_split >= 6 && bn == 64;
   if (bn == 64 && deep) GEOTR_PACKED(1, 2, 64, 3);
   else if (bn == 128) GEOTR_PACKED(2, 2, 128, 2);

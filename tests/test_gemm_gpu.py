@@ -253,43 +253,6 @@ def test_group_norm_statistics_out_of_the_gemm_epilogue(N, K, segs, matrix_preci
     assert torch.equal(fused, two)
 
 
-@pytest.mark.parametrize('N,K,segs', [(128, 32, [70000, 61234, 127, 9000]), (128, 64, [150000]), (256, 64, [40001, 39999]), (160, 32, [131072 + 5])])
-def test_small_k_persistent_gemm_is_bitwise_the_tile_kernel(N, K, segs, monkeypatch):
-    """Round 6: exact-fp32 launches with K <= 64 and >= 1024 tiles of 128 x 128 take gemm_packed_smallk_kernel (one persistent block per
-    CU, weight resident in LDS, activation ring across row tiles).  Same MFMA sequence per output element: the product, the GroupNorm
-    statistics records, and the affine + residual + activation tail must be the bits of gemm_packed_kernel (GEOTR_GEMM_SMALLK=0)."""
-    from geotransformer_amd import kernels
-    prev = kernels.set_precision('fp32')
-    try:
-        g = torch.Generator().manual_seed(N + K + len(segs))
-        M = sum(segs)
-        a = (torch.randn(M, K, generator=g) * 1.5 + 0.3).cuda()
-        w = torch.randn(N, K, generator=g).cuda()
-        bias = torch.randn(N, generator=g).cuda()
-        x = torch.randn(M, N, generator=g).cuda()
-        g2, be2 = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
-        packed = kernels.gemm_pack(w)
-
-        def run():
-            plain = kernels.gemm_packed(a, packed, N, bias=bias, split_k=False)
-            act = kernels.gemm_packed(a, packed, N, bias=bias, residual=x, act='leaky', split_k=False)
-            y, stats, rpr = kernels.linear_gn(a, w, bias, seg_rows=segs)
-            tail = kernels.residual_tail(a, w, bias, (8, g2, be2, 1e-5), x, seg_rows=segs)
-            torch.cuda.synchronize()
-            return plain, act, y, stats, tail
-
-        monkeypatch.setenv('GEOTR_GEMM_SMALLK', '0')
-        want = run()
-        monkeypatch.setenv('GEOTR_GEMM_SMALLK', '1')
-        got = run()
-        for i, (p, q) in enumerate(zip(got, want)):
-            assert torch.equal(p, q), i
-        ref = (a.double() @ w.double().t() + bias.double()).float()
-        assert torch.allclose(got[0], ref, rtol=2e-5, atol=2e-4)
-    finally:
-        kernels.set_precision(prev)
-
-
 @pytest.mark.parametrize('lat_ch,skip_ch,n_out,nc,m,segs', [(512, 256, 256, 3000, 9000, [4000, 5000]), (1024, 512, 512, 1100, 4200, None),
                                                             (256, 128, 96, 2048, 2048, [1024, 1024])])
 def test_decoder_linear_without_the_concatenation(lat_ch, skip_ch, n_out, nc, m, segs, matrix_precision):
