@@ -286,7 +286,7 @@ def kernels_alone(workload_tag):
     if not found:
         return None
     rec = json.load(open(found[-1]))
-    if workload_tag and rec.get('workload') and str(rec['workload'])[:40] != str(workload_tag)[:40]:
+    if workload_tag and rec.get('workload') and not str(rec['workload']).startswith(str(workload_tag)):
         return None
     return {'us': rec.get('kernels_alone_us_per_pair'), 'file': os.path.basename(found[-1]), 'matrix_precision': rec.get('matrix_precision')}
 

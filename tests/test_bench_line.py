@@ -59,3 +59,24 @@ def test_dry_run_ends_stdout_with_one_parsable_line():
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     rec = json.loads(lines[-1])
     assert rec['dry_run'] is True and len(lines[-1]) < 4096
+
+
+def test_kernels_alone_figure_comes_from_the_committed_one_lane_trace_of_the_same_workload():
+    """Round 6: the line carries `kernels_alone_us_per_pair` -- kernel time per pair with one lane, from the latest
+    committed profiles/r*_kernels_alone.json (scripts/kernel_trace_summary.py) -- for the headline workload only."""
+    import glob
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    found = sorted(glob.glob(os.path.join(root, 'profiles', 'r*_kernels_alone.json')))
+    assert found, 'no committed one-lane trace summary'
+    rec = json.load(open(found[-1]))
+    got = bench.kernels_alone('BASELINE configs[1]')
+    assert got and got['us'] == rec['kernels_alone_us_per_pair'] and 500 < got['us'] < 3000
+    assert bench.kernels_alone('BASELINE configs[3]') is None  # another workload: not quoted
+    line = bench.compact_line({'metric': 'm', 'value': 1.0, 'unit': 'pairs/s', 'config': {}, 'kernels_alone_us_per_pair': got['us']})
+    assert line['kernels_alone_us_per_pair'] == got['us']
