@@ -66,7 +66,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
                                              float alpha, const float* __restrict__ bias, const int32_t* __restrict__ row_div,
                                              const float* __restrict__ residual, int64_t ldr, int act, float* __restrict__ C, int64_t ldc,
                                              float* __restrict__ stats_rec = nullptr, const GatherRes gr = GatherRes{nullptr, nullptr, 0, 0, 0},
-                                             const float* __restrict__ col_affine = nullptr) {
+                                             const float* __restrict__ col_affine = nullptr, int nt_store = 0) {
   constexpr int TW = 32 * WN, TS = TW + 4;
   const int fr = lane & 31, fk = lane >> 5;
   constexpr int PIECE = 32 * WM;  // the whole accumulator block travels through the slab of (32 * WM) x (32 * WN + 4) floats at once
@@ -158,7 +158,12 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WM][WN], float*
     if (C) {
       float* cp = C + (int64_t)gm * ldc + gn;
       if (full) {
-        *reinterpret_cast<float4*>(cp) = make_float4(x[0], x[1], x[2], x[3]);
+        if (nt_store) {  // (streaming stores that do not allocate in L2: PackedArgs.nt_store)
+          using nt_f32x4 = __attribute__((ext_vector_type(4))) float;
+          __builtin_nontemporal_store(nt_f32x4{x[0], x[1], x[2], x[3]}, reinterpret_cast<nt_f32x4*>(cp));
+        } else {
+          *reinterpret_cast<float4*>(cp) = make_float4(x[0], x[1], x[2], x[3]);
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -553,6 +558,7 @@ struct PackedArgs {
   int M, N, K, KS, NT;  // KS = padded K / 16, NT = padded N / 32
   float alpha;
   int act;
+  int nt_store;  // C is written with non-temporal stores (launches of >= 100 000 rows; GEOTR_GEMM_NT=0 switches it off)
   // split-K (gridDim.z > 1): block z contracts the 32-deep stages [z * kt_split, min((z + 1) * kt_split, KS / 2)) and stores its raw
   // fp32 partial tile to partial + z * M * N (row-major, ld = N); gemm_splitk_reduce_kernel sums the slices in z order and
   // applies the epilogue.  gridDim.z == 1: kt_split = KS / 2, partial unused -- the launch is exactly the unsplit kernel.
@@ -871,7 +877,7 @@ void gemm_packed_kernel(PackedArgs g) {
   if (gridDim.z == 1)
     epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, g.alpha, g.bias, g.row_div, g.residual, g.ldr, g.act,
                                 g.C, g.ldc, g.stats ? g.stats + ((int64_t)by * WAVES_M + wave / WAVES_N) * 2 * g.N : nullptr, g.gres,
-                                g.seg_affine ? g.seg_affine + (int64_t)sgi * 2 * g.N : nullptr);
+                                g.seg_affine ? g.seg_affine + (int64_t)sgi * 2 * g.N : nullptr, g.nt_store);
   else  // raw partial sums of this K slice; the epilogue runs in the reduce kernel
     epilogue_lds<WM, WN>(acc, slab, lane, m0 + wrow, 32 * (ct0 + wctl), m_end, g.N, 1.0f, nullptr, nullptr, nullptr, 0, 0,
                                 g.partial + (int64_t)blockIdx.z * g.M * g.N, g.N);
@@ -1105,6 +1111,16 @@ static int gemm_packed_launch(const float* A, int64_t lda, const void* packed, f
   g.lda = lda; g.ldc = ldc; g.ldr = residual ? ldr : 0;
   g.M = (int)M; g.N = (int)N; g.K = (int)K; g.KS = (int)(kp / 16); g.NT = (int)(np / 32); g.alpha = alpha; g.act = act;
   g.nseg = 0;
+  {
+    // Round 6: a tall launch streams its output (82 - 330 MB, read back from HBM by the GroupNorm pass either way): non-temporal stores do
+    // not allocate in L2 and retire sooner -- (640 000, 128, 32) 158 -> 139 us, (640 000, 128, 64) 208 -> 195, bench +1.3 %
+    // (profiles/r06_ab_runs.md section 10).  GEOTR_GEMM_NT=0: plain stores (measurement switch).
+    static const bool nt_on = [] {
+      const char* e = std::getenv("GEOTR_GEMM_NT");
+      return !(e && e[0] == '0');
+    }();
+    g.nt_store = (nt_on && M >= 100000) ? 1 : 0;
+  }
   g.stats = stats;
   g.gres = gres ? *gres : GatherRes{nullptr, nullptr, 0, 0, 0};
   g.seg_affine = seg_affine;

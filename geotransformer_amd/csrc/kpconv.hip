@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
 #pragma unroll
       for (int k = 0; k < kKP; ++k)
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) o[k * C + 64 * j] = acc[j][k >> 1][k & 1];
+        for (int j = 0; j < CPL; ++j) __builtin_nontemporal_store(acc[j][k >> 1][k & 1], o + k * C + 64 * j);  // (the (M, 15 C) operand is streamed: 0.1 - 0.4 GB per launch)
       if (cl == 0) nnum[m] = cnt[slot];
     }
     __builtin_amdgcn_wave_barrier();
@@ -380,7 +380,12 @@ __global__ __launch_bounds__(256) void gn_apply2_kernel(const float* __restrict_
       if (act == 2) r[k] = r[k] > 0.f ? r[k] : 0.1f * r[k];
       if (act == 1) r[k] = fmaxf(r[k], 0.f);
     }
-    *reinterpret_cast<float4*>(out + e) = make_float4(r[0], r[1], r[2], r[3]);
+    if (total >= (int64_t)(16 << 20)) {  // a tensor of >= 64 MB is streamed: non-temporal stores (its consumer reads it from HBM either way)
+      using nt_f32x4 = __attribute__((ext_vector_type(4))) float;
+      __builtin_nontemporal_store(nt_f32x4{r[0], r[1], r[2], r[3]}, reinterpret_cast<nt_f32x4*>(out + e));
+    } else {
+      *reinterpret_cast<float4*>(out + e) = make_float4(r[0], r[1], r[2], r[3]);
+    }
     if (flag) {
       const int lpr = C >> 2;  // lanes per row
       float sum = (r[0] + r[1]) + (r[2] + r[3]);

@@ -691,7 +691,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void g
     float r[V];
 #pragma unroll
     for (int c = 0; c < V; ++c) r[c] = (d[c] + (MEAN ? __fdiv_rn(m[c], (float)(S - 1)) : m[c])) + bias[c];
-    *reinterpret_cast<typename GseVec<V>::T*>(out + (p0 + e) * D + c0) = *reinterpret_cast<const typename GseVec<V>::T*>(r);
+    if constexpr (V == 4) {  // the (n, n, D) tensor is streamed (0.1 - 3 GB per launch, read back by later launches from HBM): non-temporal stores
+      using nt_f32x4 = __attribute__((ext_vector_type(4))) float;
+      __builtin_nontemporal_store(nt_f32x4{r[0], r[1], r[2], r[3]}, reinterpret_cast<nt_f32x4*>(out + (p0 + e) * D + c0));
+    } else {
+      *reinterpret_cast<typename GseVec<V>::T*>(out + (p0 + e) * D + c0) = *reinterpret_cast<const typename GseVec<V>::T*>(r);
+    }
     emit_pos(e, r);
   }
   while (slow) {  // exact direct evaluation (rare)
