@@ -793,6 +793,7 @@ __device__ __forceinline__ float wave_max_all(float x) {
   } while (0)
 
 constexpr int kSinkWavesPerBlock = 4;
+constexpr int kSinkRebases = 6;  // re-basings of E per patch pair (see the wave kernel)
 template <int K>
 constexpr int sink_wave_floats() {  // LDS floats per wave: S (aliasing the two gathered feature blocks) + u, v, exp(u), exp(v)
   return ((((K + 1) * (K + 1) > 2 * K * 33 ? (K + 1) * (K + 1) : 2 * K * 33) + 3) / 4 * 4) + 4 * ((K + 1 + 3) / 4 * 4);
@@ -912,29 +913,38 @@ __global__ __launch_bounds__(64 * kSinkWavesPerBlock, 2) void patch_sinkhorn_wav
   const float lmu = rm_l ? norm : -kSinkInf, lnu = sm_l ? norm : -kSinkInf;
   const float lmu_d = logf(nvc) + norm, lnu_d = logf(nvr) + norm;
   GEOTR_WAVE_SYNC();
-  // ---- E: lane i's row and column of exp(S - max), the dustbin row / column one entry per lane ----
+  // ---- E: lane i's row and column of exp(S + ub_i + vb_j - max), the dustbin row / column one entry per lane ----
+  // (ub, vb) = BASE potentials the matrix is built around, zero at the start.  When the scores span more than fp32's exp range (fine
+  // features are not normalised: |S| ~ 400 was seen on KITTI-shape pairs under random weights) exp(u) under- / overflows, the guard below
+  // sends the half-sweep to the max-shifted form, and at the end of that sweep the kernel RE-BASES: E is rebuilt around the current
+  // (u, v) -- S + u + v is the log of the current plan, bounded -- and the products run on exp(u - ub), exp(v - vb) from then on
+  // (the "absorption" step of stabilised Sinkhorn).  At most kSinkRebases times per patch pair; moderate scores never re-base.
   float Erow[K1], Ecol[K1];
-  float rmax = -3.4e38f, cmax = -3.4e38f;
-#pragma unroll
-  for (int j = 0; j < K1; ++j) {
-    Erow[j] = S[li * K1 + j], Ecol[j] = S[j * K1 + li];
-    rmax = fmaxf(rmax, Erow[j]), cmax = fmaxf(cmax, Ecol[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < K1; ++j) Erow[j] = __expf(Erow[j] - rmax), Ecol[j] = __expf(Ecol[j] - cmax);
+  float rmax = 0.f, cmax = 0.f, drmax = 0.f, dcmax = 0.f, Edr = 0.f, Edc = 0.f, Edr_c = 0.f, Edc_c = 0.f;
+  float my_ub = 0.f, my_vb = 0.f, ub_d = 0.f, vb_d = 0.f;
   const float corner = alpha;
-  const float dr = active ? S[K * K1 + li] : -3.4e38f, dc = active ? S[li * K1 + K] : -3.4e38f;
-  const float drmax = fmaxf(wave_max_all(dr), corner), dcmax = fmaxf(wave_max_all(dc), corner);
-  const float Edr = active ? __expf(dr - drmax) : 0.f, Edc = active ? __expf(dc - dcmax) : 0.f;
-  const float Edr_c = __expf(corner - drmax), Edc_c = __expf(corner - dcmax);
+  auto build_E = [&]() {  // u[], v[] in LDS hold the base potentials of every row / column (index K: the dustbin's)
+    rmax = -3.4e38f, cmax = -3.4e38f;
+#pragma unroll
+    for (int j = 0; j < K1; ++j) {
+      Erow[j] = (S[li * K1 + j] + my_ub) + v[j], Ecol[j] = (S[j * K1 + li] + u[j]) + my_vb;
+      rmax = fmaxf(rmax, Erow[j]), cmax = fmaxf(cmax, Ecol[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < K1; ++j) Erow[j] = __expf(Erow[j] - rmax), Ecol[j] = __expf(Ecol[j] - cmax);
+    const float cb = (corner + ub_d) + vb_d;
+    const float dr = active ? (S[K * K1 + li] + ub_d) + my_vb : -3.4e38f, dc = active ? (S[li * K1 + K] + my_ub) + vb_d : -3.4e38f;
+    drmax = fmaxf(wave_max_all(dr), cb), dcmax = fmaxf(wave_max_all(dc), cb);
+    Edr = active ? __expf(dr - drmax) : 0.f, Edc = active ? __expf(dc - dcmax) : 0.f;
+    Edr_c = __expf(cb - drmax), Edc_c = __expf(cb - dcmax);
+  };
   // ---- 100 x { u = log_mu - LSE_j(S + v);  v = log_nu - LSE_i(S + u) }  (:13-18) ----
   float my_u = 0.f, my_v = 0.f, u_d = 0.f, v_d = 0.f;      // the lane's own entries and the dustbin's (uniform)
-  float my_eu = 1.f, my_ev = 1.f, eu_d = 1.f, ev_d = 1.f;  // their exponentials
-  if (lane < VP) eu[lane] = lane < K1 ? 1.f : 0.f, ev[lane] = lane < K1 ? 1.f : 0.f;
-  if (VP > 64 && lane < VP - 64) eu[64 + lane] = 64 + lane < K1 ? 1.f : 0.f, ev[64 + lane] = 64 + lane < K1 ? 1.f : 0.f;
-  GEOTR_WAVE_SYNC();
-  // one half-sweep: `E` = the lane's row (half 0) or column (half 1) of E, `eo` = exp of the other potential in LDS
-  auto half_sweep = [&](const float (&E)[K1], float emax, float Ed, float Ed_c, float dmax, const float* eo, float my_eo, float eo_d,
+  float my_eu = 1.f, my_ev = 1.f, eu_d = 1.f, ev_d = 1.f;  // exp(u - ub), exp(v - vb)
+  bool fell = false;  // (wave-uniform) a half-sweep of the current sweep took the max-shifted form
+  // one half-sweep: `E` = the lane's row (half 0) or column (half 1) of E, `eo` = exp(other potential - its base) in LDS;
+  // eoff / doff = (max the line was built with) - (its own base potential)
+  auto half_sweep = [&](const float (&E)[K1], float eoff, float Ed, float Ed_c, float doff, const float* eo, float my_eo, float eo_d,
                         float* raw_o, float my_raw_o, float raw_o_d, bool rows, float lm, float lm_d, float& mine, float& mine_d) {
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -947,9 +957,10 @@ __global__ __launch_bounds__(64 * kSinkWavesPerBlock, 2) void patch_sinkhorn_wav
     }
     const float s = s0 + s1;
     const float sd = wave_sum_dpp(Ed * my_eo) + Ed_c * eo_d;
-    float lse = emax + __logf(s), lse_d = dmax + __logf(sd);
+    float lse = eoff + __logf(s), lse_d = doff + __logf(sd);
     const bool bad = (active && !(s > 1e-30f && s < 1e30f)) || !(sd > 1e-30f && sd < 1e30f);
     if (__any(bad) || force_exact) {  // (wave-uniform) the max-shifted form of the reference for this half-sweep
+      fell = true;
       if (active) raw_o[lane] = my_raw_o;
       if (lane == 0) raw_o[K] = raw_o_d;
       GEOTR_WAVE_SYNC();
@@ -973,17 +984,35 @@ __global__ __launch_bounds__(64 * kSinkWavesPerBlock, 2) void patch_sinkhorn_wav
     mine = lm - lse;
     mine_d = lm_d - lse_d;
   };
-  for (int it = 0; it < iters; ++it) {
-    half_sweep(Erow, rmax, Edr, Edr_c, drmax, ev, my_ev, ev_d, v, my_v, v_d, true, lmu, lmu_d, my_u, u_d);
-    my_eu = __expf(my_u), eu_d = __expf(u_d);
-    if (active) eu[lane] = my_eu;
-    if (lane == 0) eu[K] = eu_d;
+  int rebases = 0, it = 0;
+  while (it < iters) {  // one pass per base: the matrix is (re)built here, the sweeps below run until the next re-basing
+    if (active) u[lane] = my_ub, v[lane] = my_vb;
+    if (lane == 0) u[K] = ub_d, v[K] = vb_d;
+    if (lane < VP) eu[lane] = lane < K1 ? 1.f : 0.f, ev[lane] = lane < K1 ? 1.f : 0.f;
+    if (VP > 64 && lane < VP - 64) eu[64 + lane] = 64 + lane < K1 ? 1.f : 0.f, ev[64 + lane] = 64 + lane < K1 ? 1.f : 0.f;
     GEOTR_WAVE_SYNC();
-    half_sweep(Ecol, cmax, Edc, Edc_c, dcmax, eu, my_eu, eu_d, u, my_u, u_d, false, lnu, lnu_d, my_v, v_d);
-    my_ev = __expf(my_v), ev_d = __expf(v_d);
-    if (active) ev[lane] = my_ev;
-    if (lane == 0) ev[K] = ev_d;
-    GEOTR_WAVE_SYNC();
+    build_E();
+    my_eu = __expf(my_u - my_ub), eu_d = __expf(u_d - ub_d), my_ev = __expf(my_v - my_vb), ev_d = __expf(v_d - vb_d);  // (= 1: the bases are the potentials)
+    for (; it < iters;) {
+      half_sweep(Erow, rmax - my_ub, Edr, Edr_c, drmax - ub_d, ev, my_ev, ev_d, v, my_v, v_d, true, lmu, lmu_d, my_u, u_d);
+      my_eu = __expf(my_u - my_ub), eu_d = __expf(u_d - ub_d);
+      if (active) eu[lane] = my_eu;
+      if (lane == 0) eu[K] = eu_d;
+      GEOTR_WAVE_SYNC();
+      half_sweep(Ecol, cmax - my_vb, Edc, Edc_c, dcmax - vb_d, eu, my_eu, eu_d, u, my_u, u_d, false, lnu, lnu_d, my_v, v_d);
+      my_ev = __expf(my_v - my_vb), ev_d = __expf(v_d - vb_d);
+      if (active) ev[lane] = my_ev;
+      if (lane == 0) ev[K] = ev_d;
+      GEOTR_WAVE_SYNC();
+      ++it;
+      if (fell && rebases < kSinkRebases && !force_exact) {  // (wave-uniform) re-base E around the potentials this sweep ended with
+        fell = false;
+        ++rebases;
+        my_ub = my_u, ub_d = u_d, my_vb = my_v, vb_d = v_d;
+        break;
+      }
+      fell = false;
+    }
   }
   if (active) u[lane] = my_u, v[lane] = my_v;
   if (lane == 0) u[K] = u_d, v[K] = v_d;
@@ -1123,26 +1152,83 @@ __global__ __launch_bounds__(256, 2) void patch_sinkhorn_block128_kernel(
   const bool dust_wave = (wave & 1) == 0;                    // wave 0: dustbin row, wave 2: dustbin column
   for (int e = tid; e < VP; e += NT) u[e] = 0.f, v[e] = 0.f, eu[e] = e < K1 ? 1.f : 0.f, ev[e] = e < K1 ? 1.f : 0.f;
   __syncthreads();
-  // ---- E: the thread's row / column of exp(S - max); the dustbin line two entries per lane of its wave ----
-  float E[K1];
-  float emax = -3.4e38f;
-#pragma unroll
-  for (int j = 0; j < K1; ++j) {
-    E[j] = rows ? S[idx * K1 + j] : S[j * K1 + idx];
-    emax = fmaxf(emax, E[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < K1; ++j) E[j] = __expf(E[j] - emax);
-  const float corner = alpha;
-  const float d0 = rows ? S[K * K1 + lane] : S[lane * K1 + K], d1 = rows ? S[K * K1 + 64 + lane] : S[(64 + lane) * K1 + K];
-  const float dmax = fmaxf(wave_max_all(fmaxf(d0, d1)), corner);
-  const float Ed0 = __expf(d0 - dmax), Ed1 = __expf(d1 - dmax), Ed_c = __expf(corner - dmax);
-  // ---- 100 x { u = log_mu - LSE_j(S + v);  v = log_nu - LSE_i(S + u) }  (:13-18) ----
   float* mine_raw = rows ? u : v;
   float* mine_exp = rows ? eu : ev;
   float* other_raw = rows ? v : u;
   const float* other_exp = rows ? ev : eu;
-  for (int it = 0; it < 2 * iters; ++it) {
+  const float corner = alpha;
+  // one half-sweep of this wave's lines in the reference's max-shifted form: LSE over S + (the other side's raw potentials)
+  auto exact_half = [&](float& lse, float& lse_d) {
+    float mx = -3.4e38f, sum = 0.f;
+    for (int j = 0; j < K1; ++j) {
+      const float x = (rows ? S[idx * K1 + j] : S[j * K1 + idx]) + other_raw[j];
+      if (x > mx) {
+        sum = sum * __expf(mx - x) + 1.f;
+        mx = x;
+      } else {
+        sum += __expf(x - mx);
+      }
+    }
+    lse = mx + __logf(sum);
+    if (dust_wave) {
+      const float x0 = (rows ? S[K * K1 + lane] : S[lane * K1 + K]) + other_raw[lane];
+      const float x1 = (rows ? S[K * K1 + 64 + lane] : S[(64 + lane) * K1 + K]) + other_raw[64 + lane];
+      const float xc = corner + other_raw[K];
+      const float md = fmaxf(wave_max_all(fmaxf(x0, x1)), xc);
+      const float sde = wave_sum_dpp(__expf(x0 - md) + __expf(x1 - md)) + __expf(xc - md);
+      lse_d = md + __logf(sde);
+    }
+  };
+  // Scores that span more than ~30 in a row or a column (fine features are not normalised: |S| ~ 400 on KITTI-shape pairs under random
+  // weights) would push exp(u), exp(v) out of fp32's range on the first sweeps.  Such a patch pair runs its FIRST sweep in the max-shifted
+  // form and builds E around the potentials that sweep ends with -- S + u + v is then the log of a plan with exact column sums, bounded
+  // above -- so that the products below run on exp(u - ub), exp(v - vb) (patch_sinkhorn_wave_kernel re-bases the same way, any time).
+  float my_b = 0.f, b_d = 0.f;  // bases of this thread's own potential and of its side's dustbin potential
+  int it = 0;
+  {
+    float lo = 3.4e38f, hi = -3.4e38f;
+    for (int j = 0; j < K1; ++j) {
+      const float x = rows ? S[idx * K1 + j] : S[j * K1 + idx];
+      if (x > -1e11f) lo = fminf(lo, x), hi = fmaxf(hi, x);
+    }
+    if (__syncthreads_or(hi - lo > 30.f) && !force_exact) {
+      // ... max-shifted sweeps until no potential moves by more than 20 any more (at most 8): from there on exp(u - ub) stays in range
+      for (int pre = 0; pre < 8 && it + 2 <= 2 * iters; ++pre) {
+        float delta = 0.f;
+        for (int h = 0; h < 2; ++h, ++it) {
+          if ((h == 0) == rows) {
+            float lse, lse_d = 0.f;
+            exact_half(lse, lse_d);
+            const float mine = lm - lse;
+            delta = fabsf(mine - mine_raw[idx]);
+            mine_raw[idx] = mine;
+            if (dust_wave && lane == 0) mine_raw[K] = lm_d - lse_d;
+          }
+          __syncthreads();
+        }
+        if (!__syncthreads_or(delta > 20.f)) break;
+      }
+      my_b = mine_raw[idx], b_d = mine_raw[K];
+    }
+  }
+  // ---- E: the thread's row / column of exp(S + bases - max); the dustbin line two entries per lane of its wave ----
+  float E[K1];
+  float emax = -3.4e38f;
+#pragma unroll
+  for (int j = 0; j < K1; ++j) {
+    E[j] = ((rows ? S[idx * K1 + j] : S[j * K1 + idx]) + my_b) + other_raw[j];
+    emax = fmaxf(emax, E[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < K1; ++j) E[j] = __expf(E[j] - emax);
+  const float cb = (corner + b_d) + other_raw[K];
+  const float d0 = ((rows ? S[K * K1 + lane] : S[lane * K1 + K]) + b_d) + other_raw[lane];
+  const float d1 = ((rows ? S[K * K1 + 64 + lane] : S[(64 + lane) * K1 + K]) + b_d) + other_raw[64 + lane];
+  const float dmax = fmaxf(wave_max_all(fmaxf(d0, d1)), cb);
+  const float Ed0 = __expf(d0 - dmax), Ed1 = __expf(d1 - dmax), Ed_c = __expf(cb - dmax);
+  __syncthreads();  // the bases have been read: the raw arrays take the running potentials
+  // ---- 100 x { u = log_mu - LSE_j(S + v);  v = log_nu - LSE_i(S + u) }  (:13-18) ----
+  for (; it < 2 * iters; ++it) {
     if (((it & 1) == 0) == rows) {  // (wave-uniform) this wave's half-sweep
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -1154,39 +1240,21 @@ __global__ __launch_bounds__(256, 2) void patch_sinkhorn_block128_kernel(
         if (4 * q + 3 < K1) s1 = fmaf(E[4 * q + 3 < K1 ? 4 * q + 3 : 0], o.w, s1);
       }
       const float s = s0 + s1;
-      float lse = emax + __logf(s), lse_d = 0.f;
+      float lse = (emax - my_b) + __logf(s), lse_d = 0.f;
       bool bad = !(s > 1e-30f && s < 1e30f);
       if (dust_wave) {
         const float sd = wave_sum_dpp(fmaf(Ed1, other_exp[64 + lane], Ed0 * other_exp[lane])) + Ed_c * other_exp[K];
-        lse_d = dmax + __logf(sd);
+        lse_d = (dmax - b_d) + __logf(sd);
         bad = bad || !(sd > 1e-30f && sd < 1e30f);
       }
-      if (__any(bad) || force_exact) {  // (wave-uniform) the max-shifted form of the reference for this wave's lines
-        float mx = -3.4e38f, sum = 0.f;
-        for (int j = 0; j < K1; ++j) {
-          const float x = (rows ? S[idx * K1 + j] : S[j * K1 + idx]) + other_raw[j];
-          if (x > mx) {
-            sum = sum * __expf(mx - x) + 1.f;
-            mx = x;
-          } else {
-            sum += __expf(x - mx);
-          }
-        }
-        lse = mx + __logf(sum);
-        if (dust_wave) {
-          const float x0 = d0 + other_raw[lane], x1 = d1 + other_raw[64 + lane], xc = corner + other_raw[K];
-          const float md = fmaxf(wave_max_all(fmaxf(x0, x1)), xc);
-          const float sde = wave_sum_dpp(__expf(x0 - md) + __expf(x1 - md)) + __expf(xc - md);
-          lse_d = md + __logf(sde);
-        }
-      }
+      if (__any(bad) || force_exact) exact_half(lse, lse_d);  // (wave-uniform) the max-shifted form of the reference for this wave's lines
       const float mine = lm - lse;
       mine_raw[idx] = mine;
-      mine_exp[idx] = __expf(mine);
+      mine_exp[idx] = __expf(mine - my_b);
       if (dust_wave && lane == 0) {
         const float md = lm_d - lse_d;
         mine_raw[K] = md;
-        mine_exp[K] = __expf(md);
+        mine_exp[K] = __expf(md - b_d);
       }
     }
     __syncthreads();

@@ -488,11 +488,11 @@ static int run_embedding(int clouds, int n, int reps) {
 
 // S1 + S2 of one stack: `patches` patch pairs of k points, c channels (16 pairs x 256 coarse matches at the bench workload), 100 sweeps.
 // Prints the time per launch and a checksum of the output (to compare the kernel forms: GEOTR_SINKHORN_FORM=block | wave-exact | default).
-static int run_sinkhorn(int patches, int k, int c, int reps) {
+static int run_sinkhorn(int patches, int k, int c, int reps, float valid = 0.9f, int64_t n_rows = 40000) {
   std::mt19937 rng(9);
   std::normal_distribution<float> nrm(0.f, 1.f);
   std::uniform_real_distribution<float> u01(0.f, 1.f);
-  const int64_t n = 40000;
+  const int64_t n = n_rows;  // rows of each feature table (the model's fine level: 20 000 at 3DMatch, ~75 000 per KITTI cloud)
   std::vector<float> rf((size_t)n * c), sf((size_t)n * c);
   for (auto* f : {&rf, &sf})  // unit rows, as the model's fine features
     for (int64_t i = 0; i < n; ++i) {
@@ -503,7 +503,7 @@ static int run_sinkhorn(int patches, int k, int c, int reps) {
   std::vector<int64_t> ri((size_t)patches * k), si((size_t)patches * k);
   std::vector<uint8_t> rm((size_t)patches * k), sm((size_t)patches * k);
   for (size_t e = 0; e < ri.size(); ++e) {
-    rm[e] = u01(rng) < 0.9f, sm[e] = u01(rng) < 0.9f;
+    rm[e] = u01(rng) < valid, sm[e] = u01(rng) < valid;
     ri[e] = rm[e] ? (int64_t)(u01(rng) * (n - 1)) : n, si[e] = sm[e] ? (int64_t)(u01(rng) * (n - 1)) : n;
   }
   float *drf, *dsf, *dalpha, *dout;
@@ -597,9 +597,9 @@ int main(int argc, char** argv) {
     return run_kpconv(argc > 2 ? std::atoi(argv[2]) : 16, argc > 3 ? std::atoi(argv[3]) : 5, arithmetic(argc > 4 ? argv[4] : "fp32"));
   if (mode == "embedding")  // embedding [clouds=32] [superpoints=300] [reps=5]
     return run_embedding(argc > 2 ? std::atoi(argv[2]) : 32, argc > 3 ? std::atoi(argv[3]) : 300, argc > 4 ? std::atoi(argv[4]) : 5);
-  if (mode == "sinkhorn")  // sinkhorn [patches=4096] [k=64] [c=256] [reps=5]
+  if (mode == "sinkhorn")  // sinkhorn [patches=4096] [k=64] [c=256] [reps=5] [fraction of valid points per patch=0.9]
     return run_sinkhorn(argc > 2 ? std::atoi(argv[2]) : 4096, argc > 3 ? std::atoi(argv[3]) : 64, argc > 4 ? std::atoi(argv[4]) : 256,
-                        argc > 5 ? std::atoi(argv[5]) : 5);
+                        argc > 5 ? std::atoi(argv[5]) : 5, argc > 6 ? (float)std::atof(argv[6]) : 0.9f, argc > 7 ? std::atoll(argv[7]) : 40000);
   if (mode == "cloud") {  // cloud [3dmatch|kitti]: one synthetic cloud as text (to look at its density without a GPU)
     const bool kitti = argc > 2 && std::string(argv[2]) == "kitti";
     std::mt19937 rng(1000);
