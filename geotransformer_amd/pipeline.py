@@ -152,39 +152,6 @@ class RegistrationPipeline:
         return (outs, data) if return_pyramid else outs
 
 
-def _lane_streams(lanes, device):
-    """One HIP stream per lane.  GEOTR_LANE_CU_MASK (measurement switch, profiles/r06_ab_runs.md section 11) confines lane l to a share
-    of the compute units with hipExtStreamCreateWithCUMask: `slice` = the l-th share of EVERY XCD's CUs, `xcd` = the l-th share of the
-    XCDs (mask bit i is a CU of XCD i % 8: the driver deals the bits round-robin over the XCDs)."""
-    mode, _, parts = os.environ.get('GEOTR_LANE_CU_MASK', '').partition(':')
-    parts = int(parts) if parts else lanes  # `slice:2` = two shares, lane l on share l % 2
-    if mode not in ('slice', 'xcd') or lanes < 2:
-        return [torch.cuda.Stream(device=device) for _ in range(lanes)]
-    import ctypes
-    with open('/proc/self/maps') as maps:  # the HIP runtime this process already runs on (torch's), not a second copy
-        path = next(line.split()[-1] for line in maps if 'libamdhip64' in line)
-    hip = ctypes.CDLL(path)
-    cus = torch.cuda.get_device_properties(device).multi_processor_count
-    streams = []
-    with torch.cuda.device(device):
-        for lane in range(lanes):
-            part = lane % parts
-            if mode == 'slice':
-                bits = [part * cus // parts <= i < (part + 1) * cus // parts for i in range(cus)]
-            else:
-                bits = [(i % 8) * parts // 8 == part for i in range(cus)]
-            words = (ctypes.c_uint32 * ((cus + 31) // 32))()
-            for i, on in enumerate(bits):
-                if on:
-                    words[i // 32] |= 1 << (i % 32)
-            handle = ctypes.c_void_p()
-            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(len(words)), words)
-            if rc != 0 or not handle.value:
-                raise RuntimeError(f'hipExtStreamCreateWithCUMask failed ({rc})')
-            streams.append(torch.cuda.ExternalStream(handle.value, device=device))
-    return streams
-
-
 class ConcurrentRegistration:
     """Keeps several independent pairs in flight on one GPU: one persistent host thread + one HIP stream per lane.
 
@@ -209,7 +176,7 @@ class ConcurrentRegistration:
         self.lanes = max(1, int(lanes))
         self.stack = max(1, min(16, int(stack)))
         self.device = pipeline.device
-        self.streams = _lane_streams(self.lanes, self.device)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
         self._queue = queue.SimpleQueue()
         self._pending = 0
         self._cv = threading.Condition()
