@@ -946,10 +946,19 @@ __global__ __launch_bounds__(64 * kSinkWavesPerBlock, 2) void patch_sinkhorn_wav
   // eoff / doff = (max the line was built with) - (its own base potential)
   auto half_sweep = [&](const float (&E)[K1], float eoff, float Ed, float Ed_c, float doff, const float* eo, float my_eo, float eo_d,
                         float* raw_o, float my_raw_o, float raw_o_d, bool rows, float lm, float lm_d, float& mine, float& mine_d) {
+    // K = 64: all the broadcast reads of exp(other) first -- the compiler schedules the interleaved form with two reads in flight at a
+    // time, one LDS round trip per 8 FMAs (333 vs 360 us per 4 096 patch pairs).  K = 32 keeps the interleaved form: the 16 extra VGPRs
+    // of the hoisted one cost a wave per SIMD there (202 vs 173 us; profiles/r06_ab_runs.md section 13)
+    constexpr bool HOIST = K >= 64;
+    float4 oq[HOIST ? VP / 4 : 1];
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int q = 0; q < VP / 4; ++q) oq[q] = *reinterpret_cast<const float4*>(eo + 4 * q);
+    }
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int q = 0; q < VP / 4; ++q) {
-      const float4 o = *reinterpret_cast<const float4*>(eo + 4 * q);
+      const float4 o = HOIST ? oq[HOIST ? q : 0] : *reinterpret_cast<const float4*>(eo + 4 * q);
       if (4 * q < K1) s0 = fmaf(E[4 * q], o.x, s0);
       if (4 * q + 1 < K1) s1 = fmaf(E[4 * q + 1 < K1 ? 4 * q + 1 : 0], o.y, s1);
       if (4 * q + 2 < K1) s0 = fmaf(E[4 * q + 2 < K1 ? 4 * q + 2 : 0], o.z, s0);
@@ -1230,14 +1239,33 @@ __global__ __launch_bounds__(256, 2) void patch_sinkhorn_block128_kernel(
   // ---- 100 x { u = log_mu - LSE_j(S + v);  v = log_nu - LSE_i(S + u) }  (:13-18) ----
   for (; it < 2 * iters; ++it) {
     if (((it & 1) == 0) == rows) {  // (wave-uniform) this wave's half-sweep
-      float s0 = 0.f, s1 = 0.f;
+      // the broadcast reads of exp(other) in batches of seven, a batch ahead of the FMAs that consume it (one read in flight at a time
+      // -- what the compiler scheduled from the interleaved form -- made a half-sweep 33 LDS round trips long; deeper batches spill)
+      constexpr int NQ = VP / 4, QB = 7, NB = (NQ + QB - 1) / QB;
+      float4 oq[2][QB];
+      auto read_batch = [&](int b, float4 (&dst)[QB]) {
 #pragma unroll
-      for (int q = 0; q < VP / 4; ++q) {
-        const float4 o = *reinterpret_cast<const float4*>(other_exp + 4 * q);
-        if (4 * q < K1) s0 = fmaf(E[4 * q], o.x, s0);
-        if (4 * q + 1 < K1) s1 = fmaf(E[4 * q + 1 < K1 ? 4 * q + 1 : 0], o.y, s1);
-        if (4 * q + 2 < K1) s0 = fmaf(E[4 * q + 2 < K1 ? 4 * q + 2 : 0], o.z, s0);
-        if (4 * q + 3 < K1) s1 = fmaf(E[4 * q + 3 < K1 ? 4 * q + 3 : 0], o.w, s1);
+        for (int q = 0; q < QB; ++q)
+          if (b * QB + q < NQ) dst[q] = *reinterpret_cast<const float4*>(other_exp + 4 * (b * QB + q));
+      };
+      float s0 = 0.f, s1 = 0.f;
+      auto fma_batch = [&](int b, const float4 (&src)[QB]) {
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) {
+          const int q = b * QB + qq;
+          if (q >= NQ) continue;
+          const float4 o = src[qq];
+          if (4 * q < K1) s0 = fmaf(E[4 * q < K1 ? 4 * q : 0], o.x, s0);
+          if (4 * q + 1 < K1) s1 = fmaf(E[4 * q + 1 < K1 ? 4 * q + 1 : 0], o.y, s1);
+          if (4 * q + 2 < K1) s0 = fmaf(E[4 * q + 2 < K1 ? 4 * q + 2 : 0], o.z, s0);
+          if (4 * q + 3 < K1) s1 = fmaf(E[4 * q + 3 < K1 ? 4 * q + 3 : 0], o.w, s1);
+        }
+      };
+      read_batch(0, oq[0]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB) read_batch(b + 1, oq[(b + 1) & 1]);
+        fma_batch(b, oq[b & 1]);
       }
       const float s = s0 + s1;
       float lse = (emax - my_b) + __logf(s), lse_d = 0.f;
