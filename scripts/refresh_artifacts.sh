@@ -59,7 +59,7 @@ cd /tmp
 if [ "${OTHERS:-1}" = "1" ]; then
   timeout 400 python $ROOT/bench.py --config lomatch --precision bf16 --detail $OUT/bench_lomatch_bf16_detail.json > $OUT/bench_lomatch_bf16.json 2> $OUT/bench_lomatch_bf16.err; echo "lomatch bf16 rc=$?"
   timeout 300 python $ROOT/bench.py --config modelnet --detail $OUT/bench_modelnet_detail.json > $OUT/bench_modelnet.json 2> $OUT/bench_modelnet.err; echo "modelnet rc=$?"
-  timeout 400 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 8 --detail $OUT/bench_kitti_detail.json > $OUT/bench_kitti.json 2> $OUT/bench_kitti.err; echo "kitti rc=$?"
+  timeout 400 python $ROOT/bench.py --config kitti --steps 20 --warmup 2 --pairs 8 --detail $OUT/bench_kitti_detail.json > $OUT/bench_kitti.json 2> $OUT/bench_kitti.err; echo "kitti rc=$?"
   timeout 200 env GEOTR_SINKHORN_FORM=block GEOTR_RG_DENSE_ORDER=0 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 8 $B > $OUT/ab_kitti_r5_forms.json 2> $OUT/ab_kitti_r5_forms.err
   timeout 200 python $ROOT/bench.py --config kitti --steps 5 --warmup 1 --pairs 8 $B > $OUT/ab_kitti_default.json 2> $OUT/ab_kitti_default.err
   python -c "
