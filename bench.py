@@ -742,6 +742,9 @@ def main():
             edges = [t0 + elapsed * q / 4 for q in range(1, 5)]
             quarters = [sum(1 for a in arrivals if (edges[q - 1] if q else t0) <= a < edges[q]) for q in range(4)]
             note(f'rank {rank}: results handed back per quarter of the timed region: {quarters} (of {len(arrivals)})')
+            first = sorted(arrivals)[:4 * args.stack * args.lanes:args.stack]  # one arrival per stack of the first four rounds of stacks
+            note(f'rank {rank}: first stacks handed back at ms ' + ' '.join(f'{1e3 * (a - t0):.0f}' for a in first)
+                 + f'; last result at {1e3 * (max(arrivals) - t0):.0f} of {1e3 * elapsed:.0f} ms')
         if args.dump_shapes and rank == 0:
             acc = {}
             for sec, kind, work in events:

@@ -177,6 +177,15 @@ class ConcurrentRegistration:
         self.stack = max(1, min(16, int(stack)))
         self.device = pipeline.device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
+        # Cold starts (every lane idle, several stacks submitted at once -- the start of a drained region): lanes that begin together run
+        # the same phases of the forward at the same time and contend for the same units instead of filling each other's gaps: the first
+        # four stacks of a region came back after 63 / 63 / 103 / 104 ms where the steady state returns four per 57 ms
+        # (profiles/r06_ab_runs.md section 15).  The k-th lane to pick up a stack after a full idle therefore starts k / lanes of a
+        # steady-state stack cycle late (the cycle is measured: time between a busy lane's consecutive forward launches), which is the
+        # phase offset the lanes drift to anyway.  GEOTR_COLD_STAGGER=0 switches it off (A/B runs).
+        self._cold_stagger = os.environ.get('GEOTR_COLD_STAGGER', '1') != '0'
+        self._cycle_s = None   # steady-state seconds per stack of one lane (latest measurement)
+        self._cold_rank = 0    # lanes started since every lane was idle
         self._queue = queue.SimpleQueue()
         self._pending = 0
         self._cv = threading.Condition()
@@ -197,7 +206,17 @@ class ConcurrentRegistration:
                 self._error = self._error or exc
             self._pending -= len(job)
             if self._pending == 0:
+                self._cold_rank = 0  # everything submitted has been delivered: the next pick-ups are a cold start
                 self._cv.notify_all()
+
+    def _cold_start_delay(self):
+        """Seconds the calling lane (idle until now) waits before it begins the stack it has just taken from the queue."""
+        with self._cv:
+            k = self._cold_rank
+            self._cold_rank += 1
+        if not self._cold_stagger or k == 0 or k >= self.lanes or self._cycle_s is None:
+            return 0.0
+        return min(k * self._cycle_s / self.lanes, 0.25)
 
     def _begin(self, job, stream):
         """Enqueue the pyramid of a stacked job on the lane's stream -- no host synchronisation -- and record the event its sizes wait on."""
@@ -247,6 +266,7 @@ class ConcurrentRegistration:
         with torch.cuda.stream(stream), torch.no_grad():
             begun = None   # (job, plan, points, event): pyramid enqueued, its sizes not yet on the host
             flying = None  # (job, raw, data, counts): forward launched, its counts not yet on the host
+            last_launch = None  # host time of this lane's previous forward launch while it has been busy without a break
 
             def land():  # nothing else to overlap with: wait for the stack in flight and deliver it
                 nonlocal flying
@@ -262,14 +282,21 @@ class ConcurrentRegistration:
 
             while True:
                 if begun is None:
+                    cold = flying is None
                     try:
-                        job = self._queue.get() if flying is None else self._queue.get_nowait()
+                        job = self._queue.get() if cold else self._queue.get_nowait()
                     except queue.Empty:
                         land()
                         continue
                     if job is None:
                         land()
                         return
+                    if cold:
+                        last_launch = None
+                        if len(job) > 1:
+                            delay = self._cold_start_delay()
+                            if delay > 0.0:
+                                time.sleep(delay)
                     if len(job) == 1:  # a single pair: the one-pair entry point, synchronously
                         land()
                         index, ref, src, sink, ready = job[0]
@@ -302,6 +329,10 @@ class ConcurrentRegistration:
                     flying = None
                 try:
                     flying = self._launch(begun)
+                    now = time.perf_counter()
+                    if last_launch is not None:
+                        self._cycle_s = now - last_launch
+                    last_launch = now
                 except BaseException as exc:
                     self._job_done(job, exc)
                 begun = None

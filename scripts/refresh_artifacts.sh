@@ -2,7 +2,8 @@
 # Round artifacts on the GPU box: full GPU suite, bench line (fp32 headline + split-bf16 sibling, CPU baseline, 4-pair parity), rocprofv3
 # kernel stats of the same command (4 lanes and 1 lane), PMC passes (HBM traffic, fp32), per-instantiation GEMM traffic table,
 # the other BASELINE configurations.
-# usage (from the repo root, via gpurun): bash scripts/refresh_artifacts.sh r06   (SUITE=0 skips the GPU test suite, OTHERS=0 the other configs)
+# usage (from the repo root, via gpurun): bash scripts/refresh_artifacts.sh r06   (SUITE=0 skips the GPU test suite, OTHERS=0 the other configs,
+# PROF=0 the rocprofv3 passes)
 set -u
 TAG=${1:-r06}
 export ROUND=${TAG#r}
@@ -19,6 +20,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 python $ROOT/bench.py --detail $OUT/bench_n1_detail.json > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 echo "bench rc=$?"; head -c 200 $OUT/bench_n1.json; echo
 B="--no-cpu-baseline --no-sibling-mode"
+if [ "${PROF:-1}" = "1" ]; then  # (PROF=0: bench lines only -- host-side changes leave the kernel traces and the PMC passes of the previous call valid)
 for try in 1 2 3; do  # (rocprofv3 itself crashed once in round 6: "Segmentation fault" after the run, no stats written)
   rm -rf $OUT/stats
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 $B > $OUT/bench_under_rocprof.json 2>/dev/null
@@ -39,6 +41,7 @@ python $ROOT/scripts/kernel_trace_summary.py $OUT/kernel_trace.md $(find $OUT/st
   $(find $OUT/stats_l1 -name "*kernel_stats.csv" | head -1) $OUT/bench_l1_under_rocprof.json 2>&1 | tail -3
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 find $OUT -name "*counter_collection.csv" -size +8M -delete
+fi
 ab() { name=$1; shift; timeout 300 env "$@" python $ROOT/bench.py $B ${EXTRA:-} > $OUT/ab_$name.json 2> $OUT/ab_$name.err; python -c "
 import json
 try:

@@ -68,3 +68,23 @@ def test_an_overflowed_radius_search_raises_in_every_entry_point():
     with pytest.raises(RuntimeError, match='row capacity exceeded'):
         NativeModel.finalize(_stack(COUNTS)[0], overflow=flag)
     NativeModel.raise_on_overflow(0)  # no overflow: silent
+
+
+def test_cold_start_stagger_of_the_lanes():
+    """ConcurrentRegistration: the k-th lane to take a stack after every lane was idle starts k / lanes of a steady-state stack cycle late
+    (lanes that begin together run the same phases at the same time); no delay before a cycle has been measured, for the first lane, once
+    every lane has started, or with the switch off."""
+    import threading
+    import types
+    from geotransformer_amd.pipeline import ConcurrentRegistration
+    lane = types.SimpleNamespace(lanes=4, _cold_rank=0, _cold_stagger=True, _cycle_s=None, _cv=threading.Condition())
+    delay = lambda: ConcurrentRegistration._cold_start_delay(lane)  # noqa: E731
+    assert [delay() for _ in range(4)] == [0.0, 0.0, 0.0, 0.0]  # no cycle measured yet
+    lane._cold_rank, lane._cycle_s = 0, 0.056
+    got = [delay() for _ in range(6)]
+    assert got[0] == 0.0 and got[4:] == [0.0, 0.0]
+    assert got[1:4] == pytest.approx([0.014, 0.028, 0.042])
+    lane._cold_rank, lane._cycle_s = 0, 10.0  # a stale / absurd cycle is capped
+    assert [delay() for _ in range(3)] == [0.0, 0.25, 0.25]
+    lane._cold_rank, lane._cycle_s, lane._cold_stagger = 0, 0.056, False
+    assert [delay() for _ in range(4)] == [0.0, 0.0, 0.0, 0.0]
