@@ -216,7 +216,7 @@ class ConcurrentRegistration:
             self._cold_rank += 1
         if not self._cold_stagger or k == 0 or k >= self.lanes or self._cycle_s is None:
             return 0.0
-        return min(k * self._cycle_s / self.lanes, 0.25)
+        return min(k * self._cycle_s / self.lanes, 0.1)
 
     def _begin(self, job, stream):
         """Enqueue the pyramid of a stacked job on the lane's stream -- no host synchronisation -- and record the event its sizes wait on."""

@@ -85,6 +85,6 @@ def test_cold_start_stagger_of_the_lanes():
     assert got[0] == 0.0 and got[4:] == [0.0, 0.0]
     assert got[1:4] == pytest.approx([0.014, 0.028, 0.042])
     lane._cold_rank, lane._cycle_s = 0, 10.0  # a stale / absurd cycle is capped
-    assert [delay() for _ in range(3)] == [0.0, 0.25, 0.25]
+    assert [delay() for _ in range(3)] == [0.0, 0.1, 0.1]
     lane._cold_rank, lane._cycle_s, lane._cold_stagger = 0, 0.056, False
     assert [delay() for _ in range(4)] == [0.0, 0.0, 0.0, 0.0]
