@@ -184,6 +184,14 @@ class ConcurrentRegistration:
         # steady-state stack cycle late (the cycle is measured: time between a busy lane's consecutive forward launches), which is the
         # phase offset the lanes drift to anyway.  GEOTR_COLD_STAGGER=0 switches it off (A/B runs).
         self._cold_stagger = os.environ.get('GEOTR_COLD_STAGGER', '1') != '0'
+        # Consecutive forward launches of ANY two lanes are kept at least 0.75 x cycle / lanes apart (GEOTR_LAUNCH_SPACING=f sets the
+        # factor, 0 switches it off).  Lanes that launch together stay together -- their kernels slow each other down equally, nothing
+        # pulls them apart -- and a region with two lanes in lock-step runs 3-4 % slower than one with evenly spaced lanes: the two modes
+        # of the headline's run-to-run spread (1 091-1 099 vs 1 125-1 140 pairs/s; profiles/r06_ab_runs.md section 16).  The limit is 1.33 x
+        # the steady launch rate, so it only acts on launches that come too close; a cycle measured under the limit is at most the limit's
+        # own spacing x lanes = 0.75 x the previous estimate, so an over-estimate decays instead of throttling the lanes.
+        self._spacing = float(os.environ.get('GEOTR_LAUNCH_SPACING', '0.75') or 0)
+        self._last_any = 0.0   # host time reserved for the most recent forward launch of any lane
         self._cycle_s = None   # steady-state seconds per stack of one lane (latest measurement)
         self._cold_rank = 0    # lanes started since every lane was idle
         self._queue = queue.SimpleQueue()
@@ -328,6 +336,14 @@ class ConcurrentRegistration:
                         self._job_done(prev, exc)
                     flying = None
                 try:
+                    if self._spacing > 0.0 and self._cycle_s is not None:
+                        gap = min(self._spacing * self._cycle_s / self.lanes, 0.05)
+                        with self._cv:
+                            now = time.perf_counter()
+                            slot = max(now, self._last_any + gap)
+                            self._last_any = slot
+                        if slot > now:
+                            time.sleep(slot - now)
                     flying = self._launch(begun)
                     now = time.perf_counter()
                     if last_launch is not None:
