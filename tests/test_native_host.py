@@ -88,3 +88,70 @@ def test_cold_start_stagger_of_the_lanes():
     assert [delay() for _ in range(3)] == [0.0, 0.1, 0.1]
     lane._cold_rank, lane._cycle_s, lane._cold_stagger = 0, 0.056, False
     assert [delay() for _ in range(4)] == [0.0, 0.0, 0.0, 0.0]
+
+
+def test_lane_loop_spaces_the_launches_and_delivers_everything(monkeypatch):
+    """The pipelined lane loop itself (ConcurrentRegistration._lane_main_pipelined) on the CPU: the GPU work of a stack is replaced by
+    sleeps, the streams by stubs.  Every submitted stack must be delivered exactly once and the loop must terminate; with the limiter's
+    spacing pinned at its 50 ms cap (factor 100), no two lanes launch closer together than that once a stack cycle is known (the second
+    region: sleeps only ever lengthen a gap, so the check holds on a loaded host)."""
+    import contextlib
+    import queue
+    import threading
+    import time
+    from geotransformer_amd.pipeline import ConcurrentRegistration
+
+    class Stream:
+        def synchronize(self): pass
+        def wait_event(self, e): pass
+
+    class Event:
+        def synchronize(self): time.sleep(0.004)  # "the forward in flight + the next pyramid"
+
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda d: None)
+    monkeypatch.setattr(torch.cuda, 'stream', lambda s: contextlib.nullcontext())
+    r = object.__new__(ConcurrentRegistration)
+    r.lanes, r.stack, r.device, r.return_pyramid, r.pipelined = 3, 4, 'cpu', False, True
+    r.streams = [Stream() for _ in range(r.lanes)]
+    r._cold_stagger, r._spacing, r._last_any, r._cycle_s, r._cold_rank = True, 100.0, 0.0, None, 0
+    r._queue, r._pending, r._cv, r._error = queue.SimpleQueue(), 0, threading.Condition(), None
+    launches, delivered = [], []
+    lock = threading.Lock()
+    region = [0]
+    r._begin = lambda job, stream: (job, None, None, Event())
+
+    def launch(begun):
+        with lock:
+            launches.append((time.perf_counter(), region[0]))
+        return begun[0], None, None, None
+
+    def deliver(flying):
+        with lock:
+            delivered.extend(index for index, *_ in flying[0])
+
+    r._launch, r._deliver = launch, deliver
+    threads = [threading.Thread(target=r._lane_main_pipelined, args=(lane,), daemon=True) for lane in range(r.lanes)]
+    for t in threads:
+        t.start()
+    n_jobs = 9
+    for rnd in range(2):  # two regions with a full idle between them (the second starts with a measured cycle: staggered and spaced)
+        region[0] = rnd
+        with r._cv:
+            r._pending += n_jobs * r.stack
+        for j in range(n_jobs):
+            base = (rnd * n_jobs + j) * r.stack
+            r._queue.put([(base + k, None, None, None, None) for k in range(r.stack)])
+        with r._cv:
+            assert r._cv.wait_for(lambda: r._pending == 0, timeout=30), 'the lanes did not finish'
+        assert r._error is None and r._cycle_s is not None
+    for _ in threads:
+        r._queue.put(None)
+    for t in threads:
+        t.join(timeout=5)
+        assert not t.is_alive()
+    assert sorted(delivered) == list(range(2 * n_jobs * r.stack))
+    second = sorted(t for t, rnd in launches if rnd == 1)
+    assert len(second) == n_jobs
+    # slots are 50 ms apart; a launch happens at or after its slot (a late wake-up of the earlier lane can shorten one gap, never the span)
+    gaps = [b - a for a, b in zip(second, second[1:])]
+    assert min(gaps) >= 0.02 and second[-1] - second[0] >= 0.05 * (n_jobs - 1) - 0.05, gaps
